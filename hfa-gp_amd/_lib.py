@@ -1,0 +1,134 @@
+"""ctypes binding of ``libhfagp_hip.so`` (C ABI declared in ``include/hfagp.h``).
+
+The product path has NO fallback: if the shared library is missing or its ABI
+version differs, ``lib()`` raises ``RuntimeError`` (build it with
+``python -c "import __graft_entry__ as g; g.build()"`` or
+``bash hfa-gp_amd/csrc/build.sh``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhfagp_hip.so")
+ABI_VERSION = 1
+
+c_float_p = C.c_void_p  # device pointers travel as integers
+
+
+class RaymarchArgs(C.Structure):
+    _fields_ = [
+        ("planes", C.c_void_p), ("cam2world", C.c_void_p), ("intrinsics", C.c_void_p),
+        ("u_strat", C.c_void_p), ("u_imp", C.c_void_p),
+        ("dec_w0", C.c_void_p), ("dec_b0", C.c_void_p), ("dec_w1", C.c_void_p), ("dec_b1", C.c_void_p),
+        ("feat", C.c_void_p), ("depth", C.c_void_p), ("wsum", C.c_void_p), ("tminmax", C.c_void_p),
+        ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("res", C.c_int32),
+        ("Sc", C.c_int32), ("Sf", C.c_int32), ("plane_axes", C.c_int32), ("white_back", C.c_int32),
+        ("ray_start", C.c_double), ("ray_end", C.c_double),
+        ("box_warp", C.c_float), ("decoder_lr_mul", C.c_float),
+    ]
+
+
+class StyleArgs(C.Structure):
+    _fields_ = [
+        ("w", C.c_void_p), ("affine_w", C.c_void_p), ("affine_b", C.c_void_p), ("wsq", C.c_void_p),
+        ("styles", C.c_void_p), ("dcoef", C.c_void_p),
+        ("B", C.c_int32), ("w_dim", C.c_int32), ("w_stride", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32),
+        ("style_gain", C.c_float), ("eps", C.c_float),
+    ]
+
+
+class ModconvArgs(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("wt", C.c_void_p), ("styles", C.c_void_p), ("dcoef", C.c_void_p),
+        ("noise", C.c_void_p), ("bias", C.c_void_p), ("y", C.c_void_p), ("workspace", C.c_void_p),
+        ("x_batch_stride", C.c_int64),
+        ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32),
+        ("mode", C.c_int32), ("act", C.c_int32), ("ksplit", C.c_int32),
+        ("noise_strength", C.c_float), ("alpha", C.c_float), ("gain", C.c_float), ("clamp", C.c_float),
+    ]
+
+
+class UpfirEpilogueArgs(C.Structure):
+    _fields_ = [
+        ("yt", C.c_void_p), ("dcoef", C.c_void_p), ("noise", C.c_void_p), ("bias", C.c_void_p), ("y", C.c_void_p),
+        ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("act", C.c_int32),
+        ("noise_strength", C.c_float), ("alpha", C.c_float), ("gain", C.c_float), ("clamp", C.c_float),
+    ]
+
+
+class SkipArgs(C.Structure):
+    _fields_ = [
+        ("img_in", C.c_void_p), ("y", C.c_void_p), ("img_out", C.c_void_p),
+        ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("plane_major", C.c_int32),
+    ]
+
+
+class TorgbArgs(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("weight", C.c_void_p), ("styles", C.c_void_p), ("bias", C.c_void_p),
+        ("rgb_in", C.c_void_p), ("rgb_out", C.c_void_p),
+        ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32),
+        ("clamp", C.c_float),
+    ]
+
+
+# every symbol include/hfagp.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "hfagp_abi_version": (C.c_int, []),
+    "hfagp_last_error": (C.c_char_p, []),
+    "hfagp_raymarch_fwd": (C.c_int, [C.POINTER(RaymarchArgs), C.c_void_p]),
+    "hfagp_style_fwd": (C.c_int, [C.POINTER(StyleArgs), C.c_void_p]),
+    "hfagp_weight_prep": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "hfagp_modconv_workspace_bytes": (C.c_size_t, [C.POINTER(ModconvArgs)]),
+    "hfagp_modconv_fwd": (C.c_int, [C.POINTER(ModconvArgs), C.c_void_p]),
+    "hfagp_upfir_epilogue_fwd": (C.c_int, [C.POINTER(UpfirEpilogueArgs), C.c_void_p]),
+    "hfagp_skip_upsample_add": (C.c_int, [C.POINTER(SkipArgs), C.c_void_p]),
+    "hfagp_torgb_fwd": (C.c_int, [C.POINTER(TorgbArgs), C.c_void_p]),
+    "hfagp_upfirdn2d_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int32] * 12 + [C.c_float, C.c_void_p]),
+    "hfagp_bias_act_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64,
+                                     C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "hfagp_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p]),
+    "hfagp_nhwc_to_nchw": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the shared library; raise loudly if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"hfa_gp_amd: HIP library not found at {LIB_PATH}. There is no CPU fallback; build it with "
+                f"`bash {os.path.join(_HERE, 'csrc', 'build.sh')}` (hipcc --offload-arch=gfx950).")
+        try:
+            handle = C.CDLL(LIB_PATH)
+        except OSError as e:  # missing libamdhip64 etc.
+            raise RuntimeError(f"hfa_gp_amd: cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in SYMBOLS.items():
+            try:
+                fn = getattr(handle, name)
+            except AttributeError as e:
+                raise RuntimeError(f"hfa_gp_amd: {LIB_PATH} does not export {name}") from e
+            fn.restype = res
+            fn.argtypes = args
+        ver = handle.hfagp_abi_version()
+        if ver != ABI_VERSION:
+            raise RuntimeError(f"hfa_gp_amd: ABI version mismatch: library {ver}, binding {ABI_VERSION}")
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().hfagp_last_error()
+        raise RuntimeError(f"{what} failed (code {rc}): {msg.decode() if msg else 'unknown error'}")

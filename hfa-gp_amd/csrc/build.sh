@@ -1,0 +1,18 @@
+#!/usr/bin/env bash
+# Build libhfagp_hip.so for gfx950 (cross-compiles without a GPU).
+set -euo pipefail
+here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+out="${here}/../libhfagp_hip.so"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function)
+objs=()
+for src in elementwise modconv raymarch; do
+    obj="${here}/${src}.o"
+    if [[ ! -f "$obj" || "${here}/${src}.hip" -nt "$obj" || "${here}/common.h" -nt "$obj" || "${here}/../../include/hfagp.h" -nt "$obj" ]]; then
+        "$HIPCC" "${FLAGS[@]}" ${HFAGP_EXTRA_FLAGS:-} -c "${here}/${src}.hip" -o "$obj" &
+    fi
+    objs+=("$obj")
+done
+wait
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o "$out"
+echo "built $out"

@@ -1,0 +1,51 @@
+// Shared helpers for libhfagp_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdint>
+#include "../../include/hfagp.h"
+
+namespace hfagp {
+
+void set_error(const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: HIP launch failed: %s", what, hipGetErrorString(e));
+        return HFAGP_ELAUNCH;
+    }
+    return HFAGP_OK;
+}
+
+#define HFAGP_REQUIRE(cond, code, ...)            \
+    do {                                          \
+        if (!(cond)) {                            \
+            ::hfagp::set_error(__VA_ARGS__);      \
+            return (code);                        \
+        }                                         \
+    } while (0)
+
+constexpr int kWave = 64;          // gfx950 wavefront
+constexpr int kNumCU = 256;        // MI355X
+constexpr int kNumXCD = 8;
+
+__device__ __forceinline__ float lrelu_gain_clamp(float v, int act, float alpha, float gain, float clamp) {
+    if (act == HFAGP_ACT_LRELU) v = v < 0.f ? v * alpha : v;
+    v *= gain;
+    if (clamp >= 0.f) v = fminf(fmaxf(v, -clamp), clamp);
+    return v;
+}
+
+// XCD-aware bijective remap of a linear block id: blocks that land on the same
+// XCD (observed: id % 8) get a contiguous chunk of the logical index space so
+// that neighbouring tiles share that XCD's L2 (cdna_hip_programming.md T1).
+__device__ __forceinline__ unsigned xcd_remap(unsigned id, unsigned n) {
+    const unsigned q = n / kNumXCD, r = n % kNumXCD;
+    const unsigned xcd = id % kNumXCD, k = id / kNumXCD;
+    const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + k;
+}
+
+}  // namespace hfagp

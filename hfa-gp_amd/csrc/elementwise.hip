@@ -1,0 +1,396 @@
+// HBM-bound streaming ops of the EG3D synthesis path (gfx950).
+// Everything here is coalesced 16-byte-per-lane channels-last traffic; nothing is
+// reshaped into a GEMM.  See include/hfagp.h for the interfaces they replace.
+#include "common.h"
+
+namespace hfagp {
+
+// ---------------------------------------------------------------- error string
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ---------------------------------------------------------------- styles / demod
+// One wave per output element; 64 lanes stride the reduction dimension.
+__global__ void __launch_bounds__(256) style_kernel(const float* __restrict__ w, const float* __restrict__ A,
+                                                    const float* __restrict__ ab, float* __restrict__ styles,
+                                                    int B, int w_dim, int w_stride, int Cin, float wgain, float sgain) {
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (wave >= B * Cin) return;
+    const int b = wave / Cin, i = wave % Cin;
+    const float* wr = w + (size_t)b * w_stride;
+    const float* ar = A + (size_t)i * w_dim;
+    float acc = 0.f;
+    for (int k = lane * 4; k < w_dim; k += 256) {
+        const float4 x = *reinterpret_cast<const float4*>(wr + k);
+        const float4 y = *reinterpret_cast<const float4*>(ar + k);
+        acc += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) styles[wave] = (acc * wgain + ab[i]) * sgain;
+}
+
+__global__ void __launch_bounds__(256) demod_kernel(const float* __restrict__ styles, const float* __restrict__ wsq,
+                                                    float* __restrict__ dcoef, int B, int Cin, int Cout, float eps) {
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (wave >= B * Cout) return;
+    const int b = wave / Cout, o = wave % Cout;
+    const float* s = styles + (size_t)b * Cin;
+    const float* q = wsq + (size_t)o * Cin;
+    float acc = 0.f;
+    for (int k = lane; k < Cin; k += 64) acc += s[k] * s[k] * q[k];
+    for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m);
+    if (lane == 0) dcoef[wave] = rsqrtf(acc + eps);
+}
+
+// ---------------------------------------------------------------- weight prep
+__global__ void __launch_bounds__(256) weight_prep_kernel(const float* __restrict__ w, float* __restrict__ wt,
+                                                          float* __restrict__ wsq, int Cout, int Cin, int taps) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // over Cout*Cin
+    if (idx >= Cout * Cin) return;
+    const int co = idx / Cin, ci = idx % Cin;
+    const float* src = w + (size_t)idx * taps;
+    float sq = 0.f;
+    for (int t = 0; t < taps; ++t) {
+        const float v = src[t];
+        sq += v * v;
+        wt[(((size_t)t * (Cin >> 2) + (ci >> 2)) * Cout + co) * 4 + (ci & 3)] = v;
+    }
+    if (wsq) wsq[idx] = sq;
+}
+
+// ---------------------------------------------------------------- FIR + epilogue after the transposed conv
+// yt [B][2H+1][2W+1][C] -> y [B][2H][2W][C];  out = sum_{p,q} f[p] f[q] yt[Y+p-1][X+q-1],
+// f = [1,3,3,1]/4 per axis (= outer([1,3,3,1])/64 * gain 4).  Each thread owns 4 channels
+// of one output column and walks a vertical strip with a sliding window of
+// horizontally filtered rows, so every input row is read once per column.
+constexpr int kStrip = 8;
+
+__global__ void __launch_bounds__(256) upfir_epilogue_kernel(HfagpUpfirEpilogueArgs a) {
+    const int C4 = a.C >> 2;
+    const int Wo = 2 * a.W, Ho = 2 * a.H, Wi = 2 * a.W + 1, Hi = 2 * a.H + 1;
+    const int strips = (Ho + kStrip - 1) / kStrip;
+    const long long total = (long long)a.B * strips * Wo * C4;
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= total) return;
+    const int c4 = (int)(tid % C4);
+    const int X = (int)((tid / C4) % Wo);
+    const int st = (int)((tid / ((long long)C4 * Wo)) % strips);
+    const int b = (int)(tid / ((long long)C4 * Wo * strips));
+    const int Y0 = st * kStrip;
+    const float4* src = reinterpret_cast<const float4*>(a.yt) + (size_t)b * Hi * Wi * C4 + c4;
+    const float f0 = 0.25f, f1 = 0.75f;
+
+    auto hrow = [&](int yin) -> float4 {
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (yin < 0 || yin >= Hi) return r;
+        const float4* row = src + (size_t)yin * Wi * C4;
+        const float fw[4] = {f0, f1, f1, f0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int xin = X + q - 1;
+            if (xin >= 0 && xin < Wi) {
+                const float4 v = row[(size_t)xin * C4];
+                r.x += fw[q] * v.x; r.y += fw[q] * v.y; r.z += fw[q] * v.z; r.w += fw[q] * v.w;
+            }
+        }
+        return r;
+    };
+
+    float4 d = make_float4(1.f, 1.f, 1.f, 1.f), bs = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.dcoef) d = reinterpret_cast<const float4*>(a.dcoef + (size_t)b * a.C)[c4];
+    if (a.bias) bs = reinterpret_cast<const float4*>(a.bias)[c4];
+
+    float4 h0 = hrow(Y0 - 1), h1 = hrow(Y0), h2 = hrow(Y0 + 1);
+    float4* dst = reinterpret_cast<float4*>(a.y) + (size_t)b * Ho * Wo * C4 + c4;
+#pragma unroll
+    for (int k = 0; k < kStrip; ++k) {
+        const int Y = Y0 + k;
+        if (Y >= Ho) break;
+        const float4 h3 = hrow(Y + 2);
+        float4 o;
+        o.x = f0 * h0.x + f1 * h1.x + f1 * h2.x + f0 * h3.x;
+        o.y = f0 * h0.y + f1 * h1.y + f1 * h2.y + f0 * h3.y;
+        o.z = f0 * h0.z + f1 * h1.z + f1 * h2.z + f0 * h3.z;
+        o.w = f0 * h0.w + f1 * h1.w + f1 * h2.w + f0 * h3.w;
+        const float nz = a.noise ? a.noise[(size_t)Y * Wo + X] * a.noise_strength : 0.f;
+        o.x = lrelu_gain_clamp(o.x * d.x + nz + bs.x, a.act, a.alpha, a.gain, a.clamp);
+        o.y = lrelu_gain_clamp(o.y * d.y + nz + bs.y, a.act, a.alpha, a.gain, a.clamp);
+        o.z = lrelu_gain_clamp(o.z * d.z + nz + bs.z, a.act, a.alpha, a.gain, a.clamp);
+        o.w = lrelu_gain_clamp(o.w * d.w + nz + bs.w, a.act, a.alpha, a.gain, a.clamp);
+        dst[((size_t)Y * Wo + X) * C4] = o;
+        h0 = h1; h1 = h2; h2 = h3;
+    }
+}
+
+// ---------------------------------------------------------------- skip: img_out = upsample2d(img_in) + y
+// upsample2d = zero-insert x2, pad [2,1,2,1], FIR [1,3,3,1]^2/64, gain 4  ==  per axis
+//   out[2i]   = .25*in[i-1] + .75*in[i]
+//   out[2i+1] = .75*in[i]   + .25*in[i+1]          (out-of-range taps are zero)
+__device__ __forceinline__ void up2_taps(int Y, int& i0, int& i1, float& w0, float& w1) {
+    if (Y & 1) { i0 = (Y - 1) >> 1; i1 = i0 + 1; w0 = 0.75f; w1 = 0.25f; }
+    else       { i1 = Y >> 1; i0 = i1 - 1; w0 = 0.25f; w1 = 0.75f; }
+}
+
+__global__ void __launch_bounds__(256) skip_kernel(HfagpSkipArgs a) {
+    const int C4 = a.C >> 2;
+    const int Ho = a.img_in ? 2 * a.H : a.H, Wo = a.img_in ? 2 * a.W : a.W;
+    const long long total = (long long)a.B * Ho * Wo * C4;
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= total) return;
+    const int c4 = (int)(tid % C4);
+    const int X = (int)((tid / C4) % Wo);
+    const int Y = (int)((tid / ((long long)C4 * Wo)) % Ho);
+    const int b = (int)(tid / ((long long)C4 * Wo * Ho));
+    float4 o = reinterpret_cast<const float4*>(a.y)[tid];
+    if (a.img_in) {
+        int y0, y1, x0, x1; float wy0, wy1, wx0, wx1;
+        up2_taps(Y, y0, y1, wy0, wy1);
+        up2_taps(X, x0, x1, wx0, wx1);
+        const float4* src = reinterpret_cast<const float4*>(a.img_in) + (size_t)b * a.H * a.W * C4 + c4;
+        const int ys[2] = {y0, y1}, xs[2] = {x0, x1};
+        const float wy[2] = {wy0, wy1}, wx[2] = {wx0, wx1};
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                if (ys[p] >= 0 && ys[p] < a.H && xs[q] >= 0 && xs[q] < a.W) {
+                    const float4 v = src[((size_t)ys[p] * a.W + xs[q]) * C4];
+                    const float wgt = wy[p] * wx[q];
+                    o.x += wgt * v.x; o.y += wgt * v.y; o.z += wgt * v.z; o.w += wgt * v.w;
+                }
+    }
+    if (a.plane_major) {
+        const int Cp = a.C / 3;                     // channels per plane
+        const int c = c4 * 4, pl = c / Cp, ch = c % Cp;
+        float4* dst = reinterpret_cast<float4*>(a.img_out + ((((size_t)b * 3 + pl) * Ho + Y) * Wo + X) * Cp + ch);
+        *dst = o;
+    } else {
+        reinterpret_cast<float4*>(a.img_out)[tid] = o;
+    }
+}
+
+// ---------------------------------------------------------------- toRGB (few output channels) + skip
+// 8 lanes per pixel, each lane strides the input channels in float4 steps, so a wave
+// reads 8 full 128-byte-aligned runs per load instruction.
+constexpr int kTorgbMaxOut = 4;
+
+__global__ void __launch_bounds__(256) torgb_kernel(HfagpTorgbArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float wmod[];   // [Cout][Cin]
+    const int b = blockIdx.y;
+    for (int i = threadIdx.x; i < a.Cout * a.Cin; i += blockDim.x)
+        wmod[i] = a.weight[i] * a.styles[(size_t)b * a.Cin + (i % a.Cin)];
+    __syncthreads();
+    const int HW = a.H * a.W;
+    const int sub = threadIdx.x & 7;
+    const int pix = blockIdx.x * (blockDim.x >> 3) + (threadIdx.x >> 3);
+    if (pix >= HW) return;
+    const float4* xr = reinterpret_cast<const float4*>(a.x + ((size_t)b * HW + pix) * a.Cin);
+    float acc[kTorgbMaxOut] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = sub; k < (a.Cin >> 2); k += 8) {
+        const float4 v = xr[k];
+#pragma unroll
+        for (int c = 0; c < kTorgbMaxOut; ++c)
+            if (c < a.Cout) {
+                const float4 wv = reinterpret_cast<const float4*>(wmod + c * a.Cin)[k];
+                acc[c] += v.x * wv.x + v.y * wv.y + v.z * wv.z + v.w * wv.w;
+            }
+    }
+#pragma unroll
+    for (int c = 0; c < kTorgbMaxOut; ++c) {
+        acc[c] += __shfl_xor(acc[c], 1);
+        acc[c] += __shfl_xor(acc[c], 2);
+        acc[c] += __shfl_xor(acc[c], 4);
+    }
+    if (sub != 0) return;
+    const int Y = pix / a.W, X = pix % a.W;
+    for (int c = 0; c < a.Cout; ++c) {
+        float v = acc[c] + a.bias[c];
+        if (a.clamp >= 0.f) v = fminf(fmaxf(v, -a.clamp), a.clamp);
+        if (a.rgb_in) {
+            const int Hi = a.H >> 1, Wi = a.W >> 1;
+            int y0, y1, x0, x1; float wy0, wy1, wx0, wx1;
+            up2_taps(Y, y0, y1, wy0, wy1);
+            up2_taps(X, x0, x1, wx0, wx1);
+            const float* src = a.rgb_in + ((size_t)b * a.Cout + c) * Hi * Wi;
+            float u = 0.f;
+            if (y0 >= 0 && x0 >= 0) u += wy0 * wx0 * src[y0 * Wi + x0];
+            if (y0 >= 0 && x1 < Wi) u += wy0 * wx1 * src[y0 * Wi + x1];
+            if (y1 < Hi && x0 >= 0) u += wy1 * wx0 * src[y1 * Wi + x0];
+            if (y1 < Hi && x1 < Wi) u += wy1 * wx1 * src[y1 * Wi + x1];
+            v += u;
+        }
+        a.rgb_out[((size_t)b * a.Cout + c) * HW + pix] = v;
+    }
+}
+
+// ---------------------------------------------------------------- generic upfirdn2d (NCHW, test surface)
+__global__ void __launch_bounds__(256) upfirdn2d_kernel(const float* __restrict__ x, const float* __restrict__ f,
+                                                        float* __restrict__ y, int NC, int H, int W, int fh, int fw,
+                                                        int up, int down, int px0, int py0, int Ho, int Wo, float gain) {
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= (long long)NC * Ho * Wo) return;
+    const int ox = (int)(tid % Wo), oy = (int)((tid / Wo) % Ho);
+    const int nc = (int)(tid / ((long long)Wo * Ho));
+    const float* src = x + (size_t)nc * H * W;
+    float acc = 0.f;
+    // padded/upsampled coordinate of the window origin; correlate with the flipped filter
+    for (int p = 0; p < fh; ++p) {
+        const int uy = oy * down + p - py0;
+        if (uy < 0 || uy % up != 0) continue;
+        const int iy = uy / up;
+        if (iy >= H) continue;
+        for (int q = 0; q < fw; ++q) {
+            const int ux = ox * down + q - px0;
+            if (ux < 0 || ux % up != 0) continue;
+            const int ix = ux / up;
+            if (ix >= W) continue;
+            acc += f[(fh - 1 - p) * fw + (fw - 1 - q)] * src[(size_t)iy * W + ix];
+        }
+    }
+    y[tid] = acc * gain;
+}
+
+// ---------------------------------------------------------------- bias_act (test surface)
+__global__ void __launch_bounds__(256) bias_act_kernel(const float* __restrict__ x, const float* __restrict__ b,
+                                                       float* __restrict__ y, long long n, int C, long long inner,
+                                                       int act, float alpha, float gain, float clamp) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float v = x[i];
+        if (b) v += b[(i / inner) % C];
+        y[i] = lrelu_gain_clamp(v, act, alpha, gain, clamp);
+    }
+}
+
+// ---------------------------------------------------------------- layout transposes (32x33 LDS tile)
+__global__ void __launch_bounds__(256) transpose_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                        int rows, int cols) {
+    // x [batch][rows][cols] -> y [batch][cols][rows]
+    __shared__ float tile[32][33];
+    const size_t base = (size_t)blockIdx.z * rows * cols;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int k = ty; k < 32; k += 8) {
+        const int r = r0 + k, c = c0 + tx;
+        if (r < rows && c < cols) tile[k][tx] = x[base + (size_t)r * cols + c];
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int c = c0 + k, r = r0 + tx;
+        if (r < rows && c < cols) y[base + (size_t)c * rows + r] = tile[tx][k];
+    }
+}
+
+}  // namespace hfagp
+
+using namespace hfagp;
+
+extern "C" {
+
+int hfagp_abi_version(void) { return HFAGP_ABI_VERSION; }
+const char* hfagp_last_error(void) { return g_err; }
+
+int hfagp_style_fwd(const HfagpStyleArgs* a, void* stream) {
+    HFAGP_REQUIRE(a && a->w && a->affine_w && a->affine_b && a->styles, HFAGP_EBADARG, "style_fwd: null pointer");
+    HFAGP_REQUIRE(a->B > 0 && a->Cin > 0 && a->w_dim > 0 && a->w_dim % 4 == 0 && a->w_stride % 4 == 0,
+                  HFAGP_EBADARG, "style_fwd: bad dims B=%d Cin=%d w_dim=%d", a->B, a->Cin, a->w_dim);
+    hipStream_t s = (hipStream_t)stream;
+    const float wgain = 1.0f / sqrtf((float)a->w_dim);
+    int waves = a->B * a->Cin;
+    style_kernel<<<(waves + 3) / 4, 256, 0, s>>>(a->w, a->affine_w, a->affine_b, a->styles, a->B, a->w_dim,
+                                                 a->w_stride, a->Cin, wgain, a->style_gain);
+    if (a->dcoef) {
+        HFAGP_REQUIRE(a->wsq && a->Cout > 0, HFAGP_EBADARG, "style_fwd: dcoef requested without wsq");
+        waves = a->B * a->Cout;
+        demod_kernel<<<(waves + 3) / 4, 256, 0, s>>>(a->styles, a->wsq, a->dcoef, a->B, a->Cin, a->Cout, a->eps);
+    }
+    return check_launch("style_fwd");
+}
+
+int hfagp_weight_prep(const float* weight, float* wt, float* wsq, int32_t Cout, int32_t Cin, int32_t taps,
+                      void* stream) {
+    HFAGP_REQUIRE(weight && wt, HFAGP_EBADARG, "weight_prep: null pointer");
+    HFAGP_REQUIRE(Cin % 4 == 0 && Cout > 0 && (taps == 1 || taps == 9), HFAGP_EUNSUPPORTED,
+                  "weight_prep: Cin=%d must be a multiple of 4, taps=%d must be 1 or 9", Cin, taps);
+    const int n = Cout * Cin;
+    weight_prep_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(weight, wt, wsq, Cout, Cin, taps);
+    return check_launch("weight_prep");
+}
+
+int hfagp_upfir_epilogue_fwd(const HfagpUpfirEpilogueArgs* a, void* stream) {
+    HFAGP_REQUIRE(a && a->yt && a->y, HFAGP_EBADARG, "upfir_epilogue: null pointer");
+    HFAGP_REQUIRE(a->C % 4 == 0 && a->B > 0 && a->H > 0 && a->W > 0, HFAGP_EUNSUPPORTED,
+                  "upfir_epilogue: C=%d must be a multiple of 4", a->C);
+    const int strips = (2 * a->H + kStrip - 1) / kStrip;
+    const long long total = (long long)a->B * strips * 2 * a->W * (a->C / 4);
+    upfir_epilogue_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(*a);
+    return check_launch("upfir_epilogue");
+}
+
+int hfagp_skip_upsample_add(const HfagpSkipArgs* a, void* stream) {
+    HFAGP_REQUIRE(a && a->y && a->img_out, HFAGP_EBADARG, "skip_upsample_add: null pointer");
+    HFAGP_REQUIRE(a->C % 4 == 0 && (!a->plane_major || (a->C % 3 == 0 && (a->C / 3) % 4 == 0)), HFAGP_EUNSUPPORTED,
+                  "skip_upsample_add: unsupported channel count %d", a->C);
+    const int Ho = a->img_in ? 2 * a->H : a->H, Wo = a->img_in ? 2 * a->W : a->W;
+    const long long total = (long long)a->B * Ho * Wo * (a->C / 4);
+    skip_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(*a);
+    return check_launch("skip_upsample_add");
+}
+
+int hfagp_torgb_fwd(const HfagpTorgbArgs* a, void* stream) {
+    HFAGP_REQUIRE(a && a->x && a->weight && a->styles && a->bias && a->rgb_out, HFAGP_EBADARG, "torgb: null pointer");
+    HFAGP_REQUIRE(a->Cout >= 1 && a->Cout <= kTorgbMaxOut && a->Cin % 4 == 0 && a->H % 2 == 0 && a->W % 2 == 0,
+                  HFAGP_EUNSUPPORTED, "torgb: Cout=%d (max %d), Cin=%d", a->Cout, kTorgbMaxOut, a->Cin);
+    const int HW = a->H * a->W;
+    dim3 grid((HW + 31) / 32, a->B);
+    const size_t lds = (size_t)a->Cout * a->Cin * sizeof(float);
+    torgb_kernel<<<grid, 256, lds, (hipStream_t)stream>>>(*a);
+    return check_launch("torgb");
+}
+
+int hfagp_upfirdn2d_fwd(const float* x, const float* f, float* y, int32_t N, int32_t C, int32_t H, int32_t W,
+                        int32_t fh, int32_t fw, int32_t up, int32_t down, int32_t px0, int32_t px1, int32_t py0,
+                        int32_t py1, float gain, void* stream) {
+    HFAGP_REQUIRE(x && f && y, HFAGP_EBADARG, "upfirdn2d: null pointer");
+    HFAGP_REQUIRE(up >= 1 && down >= 1 && fh >= 1 && fw >= 1, HFAGP_EBADARG, "upfirdn2d: bad up/down/filter");
+    const int Ho = (H * up + py0 + py1 - fh) / down + 1, Wo = (W * up + px0 + px1 - fw) / down + 1;
+    HFAGP_REQUIRE(Ho > 0 && Wo > 0, HFAGP_EBADARG, "upfirdn2d: empty output");
+    const long long total = (long long)N * C * Ho * Wo;
+    upfirdn2d_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+        x, f, y, N * C, H, W, fh, fw, up, down, px0, py0, Ho, Wo, gain);
+    return check_launch("upfirdn2d");
+}
+
+int hfagp_bias_act_fwd(const float* x, const float* b, float* y, int64_t n, int32_t C, int64_t inner, int32_t act,
+                       float alpha, float gain, float clamp, void* stream) {
+    HFAGP_REQUIRE(x && y && n >= 0, HFAGP_EBADARG, "bias_act: null pointer");
+    HFAGP_REQUIRE(act == HFAGP_ACT_LINEAR || act == HFAGP_ACT_LRELU, HFAGP_EUNSUPPORTED, "bias_act: act %d", act);
+    if (n == 0) return HFAGP_OK;
+    const long long blocks = (n + 255) / 256;
+    bias_act_kernel<<<(unsigned)(blocks > 8192 ? 8192 : blocks), 256, 0, (hipStream_t)stream>>>(
+        x, b, y, n, C > 0 ? C : 1, inner > 0 ? inner : 1, act, alpha, gain, clamp);
+    return check_launch("bias_act");
+}
+
+int hfagp_nchw_to_nhwc(const float* x, float* y, int32_t B, int32_t C, int32_t H, int32_t W, void* stream) {
+    HFAGP_REQUIRE(x && y, HFAGP_EBADARG, "nchw_to_nhwc: null pointer");
+    dim3 grid((H * W + 31) / 32, (C + 31) / 32, B);
+    transpose_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, y, C, H * W);
+    return check_launch("nchw_to_nhwc");
+}
+
+int hfagp_nhwc_to_nchw(const float* x, float* y, int32_t B, int32_t C, int32_t H, int32_t W, void* stream) {
+    HFAGP_REQUIRE(x && y, HFAGP_EBADARG, "nhwc_to_nchw: null pointer");
+    dim3 grid((C + 31) / 32, (H * W + 31) / 32, B);
+    transpose_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, y, H * W, C);
+    return check_launch("nhwc_to_nchw");
+}
+
+}  // extern "C"

@@ -1,0 +1,389 @@
+// Modulated convolution as an implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32), gfx950.
+//
+//   M = output pixels of one 8x16 (or 4x16 ...) spatial patch, N = output channels, K = taps x Cin.
+//   x is channels-last; the patch (+halo) for an 8-channel K-chunk is staged in LDS once and
+//   re-read for every tap (9x reuse); the style modulation is applied on the way into LDS and the
+//   demodulation / noise / bias / leaky-ReLU / clamp in the epilogue, so the weights are shared by
+//   the whole batch (EG3D's "scale activations" form of modulated_conv2d).
+//   The up-sampling conv runs as the 4 output phases of the stride-2 transposed convolution
+//   (4+2+2+1 = 9 taps in total, i.e. no zero-insert FLOPs); its FIR is hfagp_upfir_epilogue_fwd.
+//
+//   K order inside a chunk is permuted so that each lane fetches its A and B operands for four
+//   consecutive MFMAs with one ds_read_b128 each:  MFMA step s uses channel 4*h + s for the lane
+//   half h = lane>>5  (A[i][k]: lane = 32*k + i,  B[k][j]: lane = 32*k + j).
+#include "common.h"
+
+namespace hfagp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int CK = 8;            // input channels per K-chunk
+constexpr int AS = 12;           // LDS pixel stride of the A patch in floats (8 + pad, 16-B aligned)
+constexpr int PW = 16;           // patch width in output positions
+constexpr int MAXTAPS = 9;
+
+struct Phase {
+    int ntaps;
+    int mh, mw;                  // extent of the (m, n) position grid of this phase
+    int sy, sx, oy0, ox0;        // output pixel = (sy*m + oy0, sx*n + ox0)
+    signed char dy[MAXTAPS], dx[MAXTAPS], widx[MAXTAPS];
+};
+
+struct ConvParams {
+    const float* x; const float* wt; const float* styles; const float* dcoef;
+    const float* noise; const float* bias;
+    float* out;                  // y, or the split-K workspace
+    long long x_batch_stride;
+    long long slab;              // elements per split-K slab (B*Ho*Wo*Cout)
+    int B, H, W, Cin, Cout, Ho, Wo;
+    int nphase, tiles_h, tiles_w, tiles_n, ksplit, nchunks;
+    int dymin, dxmin, ph, pw;    // patch origin offset and patch extent (pixels)
+    int fused;                   // 1: apply the epilogue here, 0: store raw accumulators
+    int act; float noise_strength, alpha, gain, clamp;
+    Phase phase[4];
+};
+
+template <int WM, int WN, int TM, int TN>
+__global__ void __launch_bounds__(256) modconv_kernel(const ConvParams p) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, PH = BM / PW;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* As = lds;                                   // [ph*pw][AS]
+    float* Bs = lds + ((PH + 2) * (PW + 2)) * AS;      // [ntaps][2][BN][4]
+
+    const Phase& ph = p.phase[blockIdx.y];
+    // ---- decode the block id: N tile fastest (neighbours share the input patch in L2)
+    unsigned id = blockIdx.x;
+    const int tn_blk = id % p.tiles_n; id /= p.tiles_n;
+    const int tw = id % p.tiles_w;     id /= p.tiles_w;
+    const int th = id % p.tiles_h;     id /= p.tiles_h;
+    const int b = id % p.B;            id /= p.B;
+    const int ks = id;
+    const int m0 = th * PH, n0 = tw * PW, co0 = tn_blk * BN;
+    if (m0 >= ph.mh || n0 >= ph.mw) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int h = lane >> 5, l31 = lane & 31;
+
+    const int c_begin = (int)(((long long)p.nchunks * ks) / p.ksplit);
+    const int c_end = (int)(((long long)p.nchunks * (ks + 1)) / p.ksplit);
+
+    // ---- staging assignment (register prefetch: global -> regs -> LDS)
+    const int npatch = p.ph * p.pw;
+    constexpr int A_PER_T = ((PH + 2) * (PW + 2) * 2 + 255) / 256;   // float4 per thread, A
+    constexpr int B_PER_T = (MAXTAPS * 2 * BN + 255) / 256;          // float4 per thread, B
+    float4 ra[A_PER_T], rb[B_PER_T];
+    const float* xb = p.x + (long long)b * p.x_batch_stride;
+    const float* sb = p.styles ? p.styles + (size_t)b * p.Cin : nullptr;
+    const int nB = ph.ntaps * 2 * BN;
+    const int cq = p.Cin >> 2;
+
+    // chunk-independent source offsets (-1 = zero fill)
+    long long aoff[A_PER_T], boff[B_PER_T];
+#pragma unroll
+    for (int k = 0; k < A_PER_T; ++k) {
+        const int idx = tid + k * 256;
+        aoff[k] = -1;
+        if (idx < npatch * 2) {
+            const int pix = idx >> 1, q = idx & 1;
+            const int iy = m0 + p.dymin + pix / p.pw, ix = n0 + p.dxmin + pix % p.pw;
+            if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) aoff[k] = ((long long)iy * p.W + ix) * p.Cin + 4 * q;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < B_PER_T; ++k) {
+        const int idx = tid + k * 256;
+        boff[k] = -1;
+        if (idx < nB) {
+            const int co = idx % BN, q = (idx / BN) & 1, t = idx / (2 * BN);
+            if (co0 + co < p.Cout) boff[k] = ((long long)ph.widx[t] * cq + q) * p.Cout + co0 + co;
+        }
+    }
+
+    auto load_regs = [&](int chunk) {
+        const int c0 = chunk * CK;
+#pragma unroll
+        for (int k = 0; k < A_PER_T; ++k) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (aoff[k] >= 0) {
+                v = *reinterpret_cast<const float4*>(xb + aoff[k] + c0);
+                if (sb) {
+                    const float4 s = *reinterpret_cast<const float4*>(sb + c0 + 4 * ((tid + k * 256) & 1));
+                    v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w;
+                }
+            }
+            ra[k] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < B_PER_T; ++k) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (boff[k] >= 0) v = reinterpret_cast<const float4*>(p.wt)[boff[k] + (long long)(c0 >> 2) * p.Cout];
+            rb[k] = v;
+        }
+    };
+    auto store_lds = [&]() {
+#pragma unroll
+        for (int k = 0; k < A_PER_T; ++k) {
+            const int idx = tid + k * 256;
+            if (idx < npatch * 2) *reinterpret_cast<float4*>(As + (idx >> 1) * AS + 4 * (idx & 1)) = ra[k];
+        }
+#pragma unroll
+        for (int k = 0; k < B_PER_T; ++k) {
+            const int idx = tid + k * 256;
+            if (idx < nB) reinterpret_cast<float4*>(Bs)[idx] = rb[k];
+        }
+    };
+
+    // ---- per-lane fragment addresses
+    int apix[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        const int pidx = (wm * TM + tm) * 32 + l31;
+        apix[tm] = ((pidx >> 4) * p.pw + (pidx & 15)) * AS + 4 * h;
+    }
+    int bcol[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) bcol[tn] = (h * BN + (wn * TN + tn) * 32 + l31) * 4;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+    if (c_begin < c_end) load_regs(c_begin);
+    for (int c = c_begin; c < c_end; ++c) {
+        store_lds();
+        __syncthreads();
+        if (c + 1 < c_end) load_regs(c + 1);
+        for (int t = 0; t < ph.ntaps; ++t) {
+            const int toff = ((ph.dy[t] - p.dymin) * p.pw + (ph.dx[t] - p.dxmin)) * AS;
+            float4 a4[TM], b4[TN];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) a4[tm] = *reinterpret_cast<const float4*>(As + apix[tm] + toff);
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) b4[tn] = *reinterpret_cast<const float4*>(Bs + t * 2 * BN * 4 + bcol[tn]);
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[tm].x, b4[tn].x, acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[tm].y, b4[tn].y, acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[tm].z, b4[tn].z, acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[tm].w, b4[tn].w, acc[tm][tn], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue.  C/D layout of 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    float* out = p.out + (size_t)ks * p.slab;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int co = co0 + (wn * TN + tn) * 32 + l31;
+        if (co >= p.Cout) continue;
+        float d = 1.f, bs = 0.f;
+        if (p.fused) {
+            if (p.dcoef) d = p.dcoef[(size_t)b * p.Cout + co];
+            if (p.bias) bs = p.bias[co];
+        }
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pidx = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int m = m0 + (pidx >> 4), n = n0 + (pidx & 15);
+                if (m >= ph.mh || n >= ph.mw) continue;
+                const int oy = ph.sy * m + ph.oy0, ox = ph.sx * n + ph.ox0;
+                float v = acc[tm][tn][r];
+                if (p.fused) {
+                    v = v * d + bs;
+                    if (p.noise) v += p.noise[(size_t)oy * p.Wo + ox] * p.noise_strength;
+                    v = lrelu_gain_clamp(v, p.act, p.alpha, p.gain, p.clamp);
+                }
+                out[(((size_t)b * p.Ho + oy) * p.Wo + ox) * p.Cout + co] = v;
+            }
+    }
+}
+
+// sum the split-K slabs and (optionally) apply the epilogue
+__global__ void __launch_bounds__(256) splitk_epilogue_kernel(const float* __restrict__ ws, float* __restrict__ y,
+                                                              const float* __restrict__ dcoef,
+                                                              const float* __restrict__ noise,
+                                                              const float* __restrict__ bias, long long slab,
+                                                              int ksplit, int HoWo, int Cout, int fused, int act,
+                                                              float noise_strength, float alpha, float gain,
+                                                              float clamp) {
+    const long long i4 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i4 * 4 >= slab) return;
+    float4 s = reinterpret_cast<const float4*>(ws)[i4];
+    for (int k = 1; k < ksplit; ++k) {
+        const float4 v = reinterpret_cast<const float4*>(ws + (size_t)k * slab)[i4];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (fused) {
+        const long long e = i4 * 4;
+        const int co = (int)(e % Cout);
+        const long long pix = e / Cout;
+        const int b = (int)(pix / HoWo);
+        float4 d = make_float4(1.f, 1.f, 1.f, 1.f), bs = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (dcoef) d = *reinterpret_cast<const float4*>(dcoef + (size_t)b * Cout + co);
+        if (bias) bs = *reinterpret_cast<const float4*>(bias + co);
+        const float nz = noise ? noise[pix % HoWo] * noise_strength : 0.f;
+        s.x = lrelu_gain_clamp(s.x * d.x + bs.x + nz, act, alpha, gain, clamp);
+        s.y = lrelu_gain_clamp(s.y * d.y + bs.y + nz, act, alpha, gain, clamp);
+        s.z = lrelu_gain_clamp(s.z * d.z + bs.z + nz, act, alpha, gain, clamp);
+        s.w = lrelu_gain_clamp(s.w * d.w + bs.w + nz, act, alpha, gain, clamp);
+    }
+    reinterpret_cast<float4*>(y)[i4] = s;
+}
+
+// ------------------------------------------------------------------ host side
+struct Plan {
+    ConvParams p;
+    int bn;           // N tile: 128, 96, 64 or 32
+    int bm;           // M tile: pixels per block
+    dim3 grid;
+    size_t lds_bytes;
+    size_t ws_bytes;
+};
+
+static void set_phase(Phase& ph, int ntaps, int mh, int mw, int sy, int sx, int oy0, int ox0,
+                      const int (*taps)[3]) {
+    ph.ntaps = ntaps; ph.mh = mh; ph.mw = mw; ph.sy = sy; ph.sx = sx; ph.oy0 = oy0; ph.ox0 = ox0;
+    for (int t = 0; t < ntaps; ++t) {
+        ph.dy[t] = (signed char)taps[t][0]; ph.dx[t] = (signed char)taps[t][1]; ph.widx[t] = (signed char)taps[t][2];
+    }
+}
+
+static int make_plan(const HfagpModconvArgs* a, Plan& pl) {
+    ConvParams& p = pl.p;
+    p = ConvParams{};
+    p.x = a->x; p.wt = a->wt; p.styles = a->styles; p.dcoef = a->dcoef; p.noise = a->noise; p.bias = a->bias;
+    p.x_batch_stride = a->x_batch_stride;
+    p.B = a->B; p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.Cout = a->Cout;
+    p.act = a->act; p.noise_strength = a->noise_strength; p.alpha = a->alpha; p.gain = a->gain; p.clamp = a->clamp;
+    p.nchunks = a->Cin / CK;
+
+    // N tile / wave arrangement
+    if (a->Cout % 128 == 0) pl.bn = 128;
+    else if (a->Cout % 96 == 0) pl.bn = 96;
+    else if (a->Cout % 64 == 0) pl.bn = 64;
+    else pl.bn = 32;
+    pl.bm = 128;
+    const int PH = pl.bm / PW;
+    p.tiles_n = (a->Cout + pl.bn - 1) / pl.bn;
+
+    int gh, gw;   // extent of the position grid that the tiles cover
+    if (a->mode == HFAGP_CONV3X3) {
+        static const int t9[9][3] = {{-1, -1, 0}, {-1, 0, 1}, {-1, 1, 2}, {0, -1, 3}, {0, 0, 4},
+                                     {0, 1, 5},   {1, -1, 6}, {1, 0, 7},  {1, 1, 8}};
+        p.nphase = 1; p.Ho = a->H; p.Wo = a->W;
+        set_phase(p.phase[0], 9, a->H, a->W, 1, 1, 0, 0, t9);
+        p.dymin = -1; p.dxmin = -1; p.ph = PH + 2; p.pw = PW + 2;
+        gh = a->H; gw = a->W; p.fused = 1;
+    } else if (a->mode == HFAGP_CONV1X1) {
+        static const int t1[1][3] = {{0, 0, 0}};
+        p.nphase = 1; p.Ho = a->H; p.Wo = a->W;
+        set_phase(p.phase[0], 1, a->H, a->W, 1, 1, 0, 0, t1);
+        p.dymin = 0; p.dxmin = 0; p.ph = PH; p.pw = PW;
+        gh = a->H; gw = a->W; p.fused = 1;
+    } else if (a->mode == HFAGP_CONVT3X3_UP2) {
+        // y_t[2i+ti][2j+tj] += x[i][j] * w[ti][tj]; output phase (a,b) collects ti = a (mod 2), tj = b (mod 2)
+        static const int t00[4][3] = {{0, 0, 0}, {-1, 0, 6}, {0, -1, 2}, {-1, -1, 8}};
+        static const int t01[2][3] = {{0, 0, 1}, {-1, 0, 7}};
+        static const int t10[2][3] = {{0, 0, 3}, {0, -1, 5}};
+        static const int t11[1][3] = {{0, 0, 4}};
+        p.nphase = 4; p.Ho = 2 * a->H + 1; p.Wo = 2 * a->W + 1;
+        set_phase(p.phase[0], 4, a->H + 1, a->W + 1, 2, 2, 0, 0, t00);
+        set_phase(p.phase[1], 2, a->H + 1, a->W, 2, 2, 0, 1, t01);
+        set_phase(p.phase[2], 2, a->H, a->W + 1, 2, 2, 1, 0, t10);
+        set_phase(p.phase[3], 1, a->H, a->W, 2, 2, 1, 1, t11);
+        p.dymin = -1; p.dxmin = -1; p.ph = PH + 1; p.pw = PW + 1;
+        gh = a->H + 1; gw = a->W + 1; p.fused = 0;
+    } else {
+        set_error("modconv: unknown mode %d", a->mode);
+        return HFAGP_EBADARG;
+    }
+    p.tiles_h = (gh + PH - 1) / PH;
+    p.tiles_w = (gw + PW - 1) / PW;
+    p.slab = (long long)a->B * p.Ho * p.Wo * a->Cout;
+
+    const long long base_blocks = (long long)p.tiles_h * p.tiles_w * a->B * p.tiles_n * p.nphase;
+    int ks = a->ksplit;
+    if (ks <= 0) {
+        ks = 1;
+        const long long target = 2 * kNumCU;
+        if (base_blocks < target) ks = (int)((target + base_blocks - 1) / base_blocks);
+        const int max_ks = p.nchunks / 2 > 0 ? p.nchunks / 2 : 1;   // at least 2 chunks per split
+        if (ks > max_ks) ks = max_ks;
+        if (ks > 64) ks = 64;
+    }
+    if (ks > p.nchunks) ks = p.nchunks;
+    p.ksplit = ks;
+    if (ks > 1) p.fused = 0;
+    pl.ws_bytes = ks > 1 ? (size_t)ks * p.slab * sizeof(float) : 0;
+    pl.grid = dim3((unsigned)(p.tiles_h * p.tiles_w * a->B * p.tiles_n * ks), (unsigned)p.nphase, 1);
+    pl.lds_bytes = ((size_t)(PH + 2) * (PW + 2) * AS + (size_t)MAXTAPS * 2 * pl.bn * 4) * sizeof(float);
+    return HFAGP_OK;
+}
+
+static int validate(const HfagpModconvArgs* a) {
+    HFAGP_REQUIRE(a && a->x && a->wt && a->y, HFAGP_EBADARG, "modconv: null pointer");
+    HFAGP_REQUIRE(a->B > 0 && a->H > 0 && a->W > 0 && a->Cin > 0 && a->Cout > 0, HFAGP_EBADARG, "modconv: bad dims");
+    HFAGP_REQUIRE(a->Cin % CK == 0, HFAGP_EUNSUPPORTED, "modconv: Cin=%d must be a multiple of %d", a->Cin, CK);
+    HFAGP_REQUIRE(a->Cout % 4 == 0, HFAGP_EUNSUPPORTED, "modconv: Cout=%d must be a multiple of 4", a->Cout);
+    HFAGP_REQUIRE(a->act == HFAGP_ACT_LINEAR || a->act == HFAGP_ACT_LRELU, HFAGP_EUNSUPPORTED, "modconv: act %d", a->act);
+    return HFAGP_OK;
+}
+
+}  // namespace hfagp
+
+using namespace hfagp;
+
+extern "C" {
+
+size_t hfagp_modconv_workspace_bytes(const HfagpModconvArgs* a) {
+    if (validate(a) != HFAGP_OK) return 0;
+    Plan pl;
+    if (make_plan(a, pl) != HFAGP_OK) return 0;
+    return pl.ws_bytes;
+}
+
+int hfagp_modconv_fwd(const HfagpModconvArgs* a, void* stream) {
+    int rc = validate(a);
+    if (rc != HFAGP_OK) return rc;
+    Plan pl;
+    rc = make_plan(a, pl);
+    if (rc != HFAGP_OK) return rc;
+    ConvParams& p = pl.p;
+    hipStream_t s = (hipStream_t)stream;
+    if (p.ksplit > 1) {
+        HFAGP_REQUIRE(a->workspace, HFAGP_EBADARG, "modconv: split-K (%d) needs a workspace of %zu bytes", p.ksplit,
+                      pl.ws_bytes);
+        p.out = a->workspace;
+    } else {
+        p.out = a->y;
+    }
+    switch (pl.bn) {
+        case 128: modconv_kernel<2, 2, 2, 2><<<pl.grid, 256, pl.lds_bytes, s>>>(p); break;
+        case 96:  modconv_kernel<4, 1, 1, 3><<<pl.grid, 256, pl.lds_bytes, s>>>(p); break;
+        case 64:  modconv_kernel<2, 2, 2, 1><<<pl.grid, 256, pl.lds_bytes, s>>>(p); break;
+        default:  modconv_kernel<4, 1, 1, 1><<<pl.grid, 256, pl.lds_bytes, s>>>(p); break;
+    }
+    rc = check_launch("modconv_fwd");
+    if (rc != HFAGP_OK) return rc;
+    if (p.ksplit > 1) {
+        const int fused = a->mode != HFAGP_CONVT3X3_UP2;
+        const long long n4 = p.slab / 4;
+        splitk_epilogue_kernel<<<(unsigned)((n4 + 255) / 256), 256, 0, s>>>(
+            a->workspace, a->y, a->dcoef, a->noise, a->bias, p.slab, p.ksplit, p.Ho * p.Wo, a->Cout, fused, a->act,
+            a->noise_strength, a->alpha, a->gain, a->clamp);
+        rc = check_launch("modconv_fwd/splitk");
+    }
+    return rc;
+}
+
+}  // extern "C"

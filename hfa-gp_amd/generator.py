@@ -1,0 +1,302 @@
+"""TriPlaneGenerator: the object HFA-GP holds as ``self.generator``.
+
+Drop-in surface: ``synthesis(ws, c, noise_mode='const') ->
+{'image','image_raw','image_depth'}``, ``parameters()``, ``requires_grad_``,
+``to()``, ``state_dict()`` with EG3D key names (``backbone.synthesis.b8.conv0.weight``
+...), exactly what ``load_G_official`` (/root/reference/code/networks/headnerf.py:31-38)
+hands to ``HeadNeRF_*`` and what ``trainer_rgb.py:59-60,70-71,143-151`` touch.
+
+The arithmetic runs in libhfagp_hip.so (see ops.py).  There is no PyTorch
+fallback: calling ``synthesis`` with CPU tensors or without the library raises.
+
+The renderer's random draws (EG3D uses ``torch.rand_like`` / ``torch.rand``
+inside ``ImportanceRenderer`` even in eval mode) are drawn here from the torch
+device generator, or passed in as ``u_strat`` / ``u_imp`` for reproducible parity.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+from torch import nn
+
+from . import ops
+from .config import GeneratorConfig, ffhq512_128
+
+
+# --------------------------------------------------------------------------- parameter containers
+class _Affine(nn.Module):
+    def __init__(self, w_dim: int, cin: int, gen: torch.Generator):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(cin, w_dim, generator=gen))
+        self.bias = nn.Parameter(torch.ones(cin))           # bias_init = 1
+
+
+class _SynthesisLayer(nn.Module):
+    def __init__(self, cin, cout, w_dim, resolution, up, taps, gen, use_noise=True):
+        super().__init__()
+        self.up, self.resolution = up, resolution
+        self.affine = _Affine(w_dim, cin, gen)
+        self.weight = nn.Parameter(torch.randn(cout, cin, 3, 3, generator=gen))
+        if use_noise:
+            self.register_buffer("noise_const", torch.randn(resolution, resolution, generator=gen))
+            self.noise_strength = nn.Parameter(torch.zeros([]))
+        self.bias = nn.Parameter(torch.zeros(cout))
+        self.register_buffer("resample_filter", _fir(taps))
+
+
+class _ToRGB(nn.Module):
+    def __init__(self, cin, cout, w_dim, gen):
+        super().__init__()
+        self.affine = _Affine(w_dim, cin, gen)
+        self.weight = nn.Parameter(torch.randn(cout, cin, 1, 1, generator=gen))
+        self.bias = nn.Parameter(torch.zeros(cout))
+
+
+class _SynthesisBlock(nn.Module):
+    def __init__(self, cin, cout, w_dim, resolution, img_channels, taps, gen):
+        super().__init__()
+        self.in_channels, self.out_channels, self.resolution = cin, cout, resolution
+        if cin == 0:
+            self.const = nn.Parameter(torch.randn(cout, resolution, resolution, generator=gen))
+        else:
+            self.conv0 = _SynthesisLayer(cin, cout, w_dim, resolution, 2, taps, gen)
+        self.conv1 = _SynthesisLayer(cout, cout, w_dim, resolution, 1, taps, gen)
+        self.torgb = _ToRGB(cout, img_channels, w_dim, gen)
+        self.register_buffer("resample_filter", _fir(taps))
+
+
+class _FC(nn.Module):
+    def __init__(self, fin, fout, gen, lr_mul=1.0, bias_init=0.0):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(fout, fin, generator=gen) / lr_mul)
+        self.bias = nn.Parameter(torch.full([fout], float(bias_init)))
+
+
+def _fir(taps) -> torch.Tensor:
+    k = torch.tensor(list(taps), dtype=torch.float32)
+    k = torch.outer(k, k)
+    return k / k.sum()
+
+
+class _Synthesis(nn.Module):
+    pass
+
+
+class _Backbone(nn.Module):
+    pass
+
+
+class _Mapping(nn.Module):
+    pass
+
+
+class _SuperRes(nn.Module):
+    pass
+
+
+class _Decoder(nn.Module):
+    pass
+
+
+# --------------------------------------------------------------------------- the generator
+class TriPlaneGenerator(nn.Module):
+    def __init__(self, cfg: Optional[GeneratorConfig] = None, seed: int = 0):
+        super().__init__()
+        self.cfg = cfg = cfg or ffhq512_128()
+        cfg.validate()
+        if tuple(cfg.resample_filter) != (1, 3, 3, 1):
+            raise ValueError("the fused up-sampling kernels are written for resample_filter [1,3,3,1]")
+        gen = torch.Generator().manual_seed(seed)
+        taps = cfg.resample_filter
+        # EG3D attribute names (for state_dict compatibility)
+        self.z_dim, self.c_dim, self.w_dim = cfg.z_dim, cfg.c_dim, cfg.w_dim
+        self.img_resolution, self.img_channels = cfg.img_resolution, cfg.img_channels
+        self.neural_rendering_resolution = cfg.neural_rendering_resolution
+
+        self.backbone = _Backbone()
+        syn = _Synthesis()
+        for res in cfg.block_resolutions:
+            cin = cfg.channels(res // 2) if res > 4 else 0
+            setattr(syn, f"b{res}", _SynthesisBlock(cin, cfg.channels(res), cfg.w_dim, res,
+                                                    cfg.backbone_img_channels, taps, gen))
+        self.backbone.synthesis = syn
+        mp = _Mapping()
+        mp.embed = _FC(cfg.c_dim, cfg.w_dim, gen)
+        for i in range(cfg.mapping_layers):
+            setattr(mp, f"fc{i}", _FC(2 * cfg.w_dim if i == 0 else cfg.w_dim, cfg.w_dim, gen, cfg.mapping_lr_mul))
+        mp.register_buffer("w_avg", torch.zeros(cfg.w_dim))
+        self.backbone.mapping = mp
+
+        sr = _SuperRes()
+        r0, r1 = cfg.sr_resolutions
+        sr.block0 = _SynthesisBlock(cfg.plane_channels, cfg.sr_channels[0], cfg.w_dim, r0, cfg.img_channels, taps, gen)
+        sr.block1 = _SynthesisBlock(cfg.sr_channels[0], cfg.sr_channels[1], cfg.w_dim, r1, cfg.img_channels, taps, gen)
+        self.superresolution = sr
+
+        dec = _Decoder()
+        dec.net = nn.ModuleDict({
+            "0": _FC(cfg.plane_channels, cfg.decoder_hidden, gen, cfg.decoder_lr_mul),
+            "2": _FC(cfg.decoder_hidden, 1 + cfg.plane_channels, gen, cfg.decoder_lr_mul),
+        })
+        self.decoder = dec
+        self._prep: Dict[int, tuple] = {}        # id(param) -> (version, data_ptr, wt, wsq)
+        self._scalars: Dict[int, tuple] = {}     # id(param) -> (version, data_ptr, python float)
+        self._const_nhwc: Optional[tuple] = None
+
+    # ----------------------------------------------------------------- caches
+    def _prepared(self, weight: torch.Tensor):
+        key = id(weight)
+        hit = self._prep.get(key)
+        if hit is not None and hit[0] == weight._version and hit[1] == weight.data_ptr():
+            return hit[2], hit[3]
+        wt, wsq = ops.weight_prep(weight.detach().contiguous())
+        self._prep[key] = (weight._version, weight.data_ptr(), wt, wsq)
+        return wt, wsq
+
+    def _scalar(self, t: torch.Tensor) -> float:
+        """Host copy of a 0-d parameter (noise_strength), cached so steady state has no device sync."""
+        hit = self._scalars.get(id(t))
+        if hit is not None and hit[0] == t._version and hit[1] == t.data_ptr():
+            return hit[2]
+        v = float(t.detach())
+        self._scalars[id(t)] = (t._version, t.data_ptr(), v)
+        return v
+
+    def _const(self, const: torch.Tensor) -> torch.Tensor:
+        hit = self._const_nhwc
+        if hit is not None and hit[0] == const._version and hit[1] == const.data_ptr():
+            return hit[2]
+        x = ops.nchw_to_nhwc(const.detach()[None].contiguous())
+        self._const_nhwc = (const._version, const.data_ptr(), x)
+        return x
+
+    # ----------------------------------------------------------------- layers
+    def _layer(self, x, layer: _SynthesisLayer, w, batch, noise_mode, conv_clamp):
+        cfg = self.cfg
+        wt, wsq = self._prepared(layer.weight)
+        styles, dcoef = ops.styles_demod(w, layer.affine.weight, layer.affine.bias, wsq, 1.0, cfg.demod_eps)
+        noise, ns = None, 0.0
+        if noise_mode == "const":
+            noise, ns = layer.noise_const, self._scalar(layer.noise_strength)
+        elif noise_mode != "none":
+            raise NotImplementedError("noise_mode must be 'const' or 'none' (HFA-GP passes 'const', headnerf.py:112)")
+        cout = layer.weight.shape[0]
+        gain = math.sqrt(2.0)
+        if layer.up == 2:
+            yt = ops.modconv(x, wt, cout, ops.CONVT3X3_UP2, styles=styles, batch=batch)
+            return ops.upfir_epilogue(yt, dcoef, noise, ns, layer.bias, "lrelu", cfg.lrelu_alpha, gain, conv_clamp)
+        return ops.modconv(x, wt, cout, ops.CONV3X3, styles=styles, dcoef=dcoef, noise=noise, noise_strength=ns,
+                           bias=layer.bias, act="lrelu", alpha=cfg.lrelu_alpha, gain=gain, clamp=conv_clamp,
+                           batch=batch)
+
+    def _block(self, x, img, blk: _SynthesisBlock, ws3, batch, noise_mode, conv_clamp, small_rgb, last):
+        i = 0
+        if blk.in_channels == 0:
+            x = self._layer(self._const(blk.const), blk.conv1, ws3[:, 0], batch, noise_mode, conv_clamp)
+            i = 1
+        else:
+            x = self._layer(x, blk.conv0, ws3[:, 0], batch, noise_mode, conv_clamp)
+            x = self._layer(x, blk.conv1, ws3[:, 1], batch, noise_mode, conv_clamp)
+            i = 2
+        tr = blk.torgb
+        cin = tr.weight.shape[1]
+        styles, _ = ops.styles_demod(ws3[:, i], tr.affine.weight, tr.affine.bias, None, 1.0 / math.sqrt(cin))
+        if small_rgb:
+            img = ops.torgb_small(x, tr.weight.detach().reshape(tr.weight.shape[0], cin), styles, tr.bias, img,
+                                  conv_clamp)
+        else:
+            wt, _ = self._prepared(tr.weight)
+            y = ops.modconv(x, wt, tr.weight.shape[0], ops.CONV1X1, styles=styles, bias=tr.bias, act="linear",
+                            gain=1.0, clamp=conv_clamp, batch=batch)
+            img = ops.skip_upsample_add(img, y, plane_major=last)
+        return x, img
+
+    # ----------------------------------------------------------------- public API
+    def backbone_planes(self, ws: torch.Tensor) -> torch.Tensor:
+        """ws [B, num_ws, 512] → tri-plane volume [B, 3, R, R, 32] (plane-major, channels-last)."""
+        cfg = self.cfg
+        syn = self.backbone.synthesis
+        b = ws.shape[0]
+        x = img = None
+        idx = 0
+        for res in cfg.block_resolutions:
+            blk = getattr(syn, f"b{res}")
+            n_conv = 1 if res == 4 else 2
+            x, img = self._block(x, img, blk, ws[:, idx: idx + n_conv + 1], b, cfg.backbone_noise_mode,
+                                 cfg.backbone_conv_clamp, False, res == cfg.plane_resolution)
+            idx += n_conv
+        return img
+
+    def render(self, planes: torch.Tensor, c: torch.Tensor, u_strat=None, u_imp=None):
+        cfg = self.cfg
+        b = planes.shape[0]
+        res = cfg.neural_rendering_resolution
+        r = res * res
+        dev = planes.device
+        if u_strat is None:
+            u_strat = torch.rand(b, r, cfg.depth_resolution, device=dev)
+        if u_imp is None:
+            u_imp = torch.rand(b * r, cfg.depth_resolution_importance, device=dev)
+        c2w = c[:, :16].contiguous()
+        intr = c[:, 16:25].contiguous()
+        net = self.decoder.net
+        return ops.raymarch(planes, c2w, intr, u_strat.reshape(b, r, -1).contiguous(), u_imp.contiguous(),
+                            net["0"].weight, net["0"].bias, net["2"].weight, net["2"].bias, res,
+                            cfg.ray_start, cfg.ray_end, cfg.box_warp, cfg.decoder_lr_mul,
+                            0 if cfg.plane_axes == "eg3d_original" else 1, cfg.white_back)
+
+    def superres(self, rgb_raw: torch.Tensor, feat_img: torch.Tensor, ws: torch.Tensor) -> torch.Tensor:
+        cfg = self.cfg
+        b = ws.shape[0]
+        w_last = ws[:, -1:, :].expand(-1, 3, -1)
+        sr = self.superresolution
+        x, rgb = self._block(feat_img, rgb_raw, sr.block0, w_last, b, cfg.sr_noise_mode, cfg.sr_conv_clamp, True, False)
+        x, rgb = self._block(x, rgb, sr.block1, w_last, b, cfg.sr_noise_mode, cfg.sr_conv_clamp, True, False)
+        return rgb
+
+    @torch.no_grad()
+    def synthesis(self, ws: torch.Tensor, c: torch.Tensor, noise_mode: str = "const",
+                  u_strat: Optional[torch.Tensor] = None, u_imp: Optional[torch.Tensor] = None,
+                  return_planes: bool = False, **_unused) -> Dict[str, torch.Tensor]:
+        cfg = self.cfg
+        if not ws.is_cuda:
+            raise RuntimeError("TriPlaneGenerator.synthesis: the MI355X path needs CUDA/ROCm tensors; "
+                               "there is no CPU fallback (oracle/ is test infrastructure only)")
+        if noise_mode != "const":
+            raise NotImplementedError("HFA-GP always passes noise_mode='const' (headnerf.py:112)")
+        if ws.shape[1:] != (cfg.num_ws, cfg.w_dim) or c.shape[1] != cfg.c_dim:
+            raise ValueError(f"expected ws [B,{cfg.num_ws},{cfg.w_dim}] and c [B,{cfg.c_dim}], got "
+                             f"{tuple(ws.shape)} and {tuple(c.shape)}")
+        ws = ws.detach().float().contiguous()
+        c = c.detach().float().contiguous()
+        b = ws.shape[0]
+        res = cfg.neural_rendering_resolution
+        planes = self.backbone_planes(ws)
+        feat, depth, wsum, tmm = self.render(planes, c, u_strat, u_imp)
+        # MipRayMarcher2 clamps the expected depth to the GLOBAL min/max sample depth of the batch
+        depth = torch.clamp(depth, tmm[..., 0].min(), tmm[..., 1].max())
+        feat_img = feat.view(b, res, res, 32)                             # channels-last
+        rgb_raw = feat_img[..., :3].permute(0, 3, 1, 2).contiguous()      # NCHW, 'image_raw'
+        img = self.superres(rgb_raw, feat_img, ws)
+        out = {"image": img, "image_raw": rgb_raw, "image_depth": depth.view(b, 1, res, res)}
+        if return_planes:
+            out["planes"] = planes
+            out["feature_image"] = feat_img
+        return out
+
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError("HFA-GP only calls generator.synthesis (headnerf.py:112); mapping is in mapping()")
+
+
+def load_G_official(args=None, device="cuda", cfg: Optional[GeneratorConfig] = None, seed: int = 0,
+                    weights: Optional[str] = None) -> TriPlaneGenerator:
+    """Counterpart of headnerf.py:31-38.  The EG3D pickle is not shipped with the reference, so the
+    generator is random-initialised from ``seed`` (EG3D init) or loaded from a safetensors file with
+    EG3D key names; it comes back frozen, as the reference does (``requires_grad_(False)``)."""
+    g = TriPlaneGenerator(cfg, seed=seed)
+    if weights is not None:
+        from safetensors.torch import load_file
+        g.load_state_dict(load_file(weights), strict=True)
+    return g.requires_grad_(False).to(device)

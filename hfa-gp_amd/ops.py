@@ -1,0 +1,242 @@
+"""Operator layer: the EG3D op API of the hot path, backed by libhfagp_hip.so.
+
+Mirrors (names and argument meaning) the operators the reference's generator
+reaches below ``generator.synthesis`` (headnerf.py:112): ``bias_act``,
+``upfirdn2d`` / ``upsample2d``, ``modulated_conv2d`` (+ fused ``bias_act``),
+and the renderer.  Every function takes CUDA (ROCm) fp32 tensors, enqueues on
+``torch.cuda.current_stream()`` and never falls back to PyTorch math.
+Activations are channels-last ``[B, H, W, C]`` unless a name says ``nchw``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib as L
+
+CONV3X3, CONVT3X3_UP2, CONV1X1 = 0, 1, 2
+ACT_LINEAR, ACT_LRELU = 0, 1
+_ACT = {"linear": ACT_LINEAR, "lrelu": ACT_LRELU}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def _chk(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a CUDA/ROCm tensor (the HIP path has no CPU fallback)")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name}: expected float32, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name}: expected a contiguous tensor")
+    return t
+
+
+# ----------------------------------------------------------------------------- weights
+def weight_prep(weight: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """weight [Cout, Cin, k, k] → (wt [k*k, Cin/4, Cout, 4], wsq [Cout, Cin])."""
+    _chk(weight, "weight")
+    co, ci, kh, kw = weight.shape
+    wt = torch.empty(kh * kw, ci // 4, co, 4, device=weight.device, dtype=torch.float32)
+    wsq = torch.empty(co, ci, device=weight.device, dtype=torch.float32)
+    L.check(L.lib().hfagp_weight_prep(_ptr(weight), _ptr(wt), _ptr(wsq), co, ci, kh * kw, _stream()), "weight_prep")
+    return wt, wsq
+
+
+def styles_demod(w: torch.Tensor, affine_w: torch.Tensor, affine_b: torch.Tensor,
+                 wsq: Optional[torch.Tensor], style_gain: float = 1.0, eps: float = 1e-8):
+    """w [B, w_dim] (may be a strided row view of ws) → styles [B, Cin], dcoef [B, Cout] | None."""
+    if w.dtype != torch.float32 or not w.is_cuda or w.stride(-1) != 1:
+        raise RuntimeError("styles_demod: w must be a CUDA fp32 tensor with unit inner stride")
+    b, wd = w.shape
+    cin = affine_w.shape[0]
+    styles = torch.empty(b, cin, device=w.device, dtype=torch.float32)
+    dcoef = None
+    a = L.StyleArgs()
+    a.w, a.affine_w, a.affine_b = _ptr(w), _ptr(_chk(affine_w, "affine_w")), _ptr(_chk(affine_b, "affine_b"))
+    a.styles = _ptr(styles)
+    a.B, a.w_dim, a.w_stride, a.Cin = b, wd, w.stride(0), cin
+    a.style_gain, a.eps = style_gain, eps
+    if wsq is not None:
+        dcoef = torch.empty(b, wsq.shape[0], device=w.device, dtype=torch.float32)
+        a.wsq, a.dcoef, a.Cout = _ptr(_chk(wsq, "wsq")), _ptr(dcoef), wsq.shape[0]
+    L.check(L.lib().hfagp_style_fwd(C.byref(a), _stream()), "style_fwd")
+    return styles, dcoef
+
+
+# ----------------------------------------------------------------------------- modulated conv
+def modconv(x: torch.Tensor, wt: torch.Tensor, cout: int, mode: int, styles: Optional[torch.Tensor] = None,
+            dcoef: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None,
+            noise_strength: float = 0.0, bias: Optional[torch.Tensor] = None, act: str = "linear",
+            alpha: float = 0.2, gain: float = 1.0, clamp: Optional[float] = None, batch: Optional[int] = None,
+            ksplit: int = 0) -> torch.Tensor:
+    """x [B|1, H, W, Cin] channels-last.  mode CONV3X3 / CONV1X1: fused epilogue, returns [B,H,W,Cout];
+    mode CONVT3X3_UP2: returns the RAW transposed-conv result [B, 2H+1, 2W+1, Cout]."""
+    _chk(x, "x")
+    xb, h, w, cin = x.shape
+    b = batch if batch is not None else xb
+    a = L.ModconvArgs()
+    a.x, a.wt = _ptr(x), _ptr(_chk(wt, "wt"))
+    a.styles, a.dcoef, a.noise, a.bias = _ptr(styles), _ptr(dcoef), _ptr(noise), _ptr(bias)
+    a.x_batch_stride = 0 if (xb == 1 and b > 1) else h * w * cin
+    a.B, a.H, a.W, a.Cin, a.Cout = b, h, w, cin, cout
+    a.mode, a.act, a.ksplit = mode, _ACT[act], ksplit
+    a.noise_strength, a.alpha, a.gain = noise_strength, alpha, gain
+    a.clamp = -1.0 if clamp is None else float(clamp)
+    if mode == CONVT3X3_UP2:
+        y = torch.empty(b, 2 * h + 1, 2 * w + 1, cout, device=x.device, dtype=torch.float32)
+    else:
+        y = torch.empty(b, h, w, cout, device=x.device, dtype=torch.float32)
+    a.y = _ptr(y)
+    nbytes = L.lib().hfagp_modconv_workspace_bytes(C.byref(a))
+    ws = None
+    if nbytes:
+        ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
+        a.workspace = _ptr(ws)
+    L.check(L.lib().hfagp_modconv_fwd(C.byref(a), _stream()), "modconv_fwd")
+    return y
+
+
+def upfir_epilogue(yt: torch.Tensor, dcoef: Optional[torch.Tensor], noise: Optional[torch.Tensor],
+                   noise_strength: float, bias: Optional[torch.Tensor], act: str = "lrelu", alpha: float = 0.2,
+                   gain: float = math.sqrt(2.0), clamp: Optional[float] = None) -> torch.Tensor:
+    """yt [B, 2H+1, 2W+1, C] raw transposed conv → FIR(pad 1, gain 4) → demod/noise/bias/act → [B,2H,2W,C]."""
+    _chk(yt, "yt")
+    b, hi, wi, c = yt.shape
+    h, w = (hi - 1) // 2, (wi - 1) // 2
+    y = torch.empty(b, 2 * h, 2 * w, c, device=yt.device, dtype=torch.float32)
+    a = L.UpfirEpilogueArgs()
+    a.yt, a.dcoef, a.noise, a.bias, a.y = _ptr(yt), _ptr(dcoef), _ptr(noise), _ptr(bias), _ptr(y)
+    a.B, a.H, a.W, a.C, a.act = b, h, w, c, _ACT[act]
+    a.noise_strength, a.alpha, a.gain = noise_strength, alpha, gain
+    a.clamp = -1.0 if clamp is None else float(clamp)
+    L.check(L.lib().hfagp_upfir_epilogue_fwd(C.byref(a), _stream()), "upfir_epilogue_fwd")
+    return y
+
+
+def skip_upsample_add(img: Optional[torch.Tensor], y: torch.Tensor, plane_major: bool = False) -> torch.Tensor:
+    """SynthesisBlock 'skip': upsample2d(img) + y (channels-last).  plane_major → [B,3,H,W,C/3]."""
+    _chk(y, "y")
+    b, ho, wo, c = y.shape
+    a = L.SkipArgs()
+    if img is not None:
+        _chk(img, "img")
+        a.img_in, a.H, a.W = _ptr(img), img.shape[1], img.shape[2]
+    else:
+        a.H, a.W = ho, wo
+    out = torch.empty((b, 3, ho, wo, c // 3) if plane_major else (b, ho, wo, c), device=y.device,
+                      dtype=torch.float32)
+    a.y, a.img_out, a.B, a.C, a.plane_major = _ptr(y), _ptr(out), b, c, int(plane_major)
+    L.check(L.lib().hfagp_skip_upsample_add(C.byref(a), _stream()), "skip_upsample_add")
+    return out
+
+
+def torgb_small(x: torch.Tensor, weight: torch.Tensor, styles: torch.Tensor, bias: torch.Tensor,
+                rgb_in: Optional[torch.Tensor], clamp: Optional[float]) -> torch.Tensor:
+    """ToRGBLayer with ≤4 output channels + skip add; x channels-last, rgb NCHW."""
+    _chk(x, "x")
+    b, h, w, cin = x.shape
+    cout = weight.shape[0]
+    out = torch.empty(b, cout, h, w, device=x.device, dtype=torch.float32)
+    a = L.TorgbArgs()
+    a.x, a.weight, a.styles, a.bias = _ptr(x), _ptr(_chk(weight, "weight")), _ptr(_chk(styles, "styles")), _ptr(bias)
+    a.rgb_in = _ptr(_chk(rgb_in, "rgb_in")) if rgb_in is not None else None
+    a.rgb_out = _ptr(out)
+    a.B, a.H, a.W, a.Cin, a.Cout = b, h, w, cin, cout
+    a.clamp = -1.0 if clamp is None else float(clamp)
+    L.check(L.lib().hfagp_torgb_fwd(C.byref(a), _stream()), "torgb_fwd")
+    return out
+
+
+# ----------------------------------------------------------------------------- renderer
+def raymarch(planes: torch.Tensor, cam2world: torch.Tensor, intrinsics: torch.Tensor, u_strat: torch.Tensor,
+             u_imp: torch.Tensor, dec_w0: torch.Tensor, dec_b0: torch.Tensor, dec_w1: torch.Tensor,
+             dec_b1: torch.Tensor, res: int, ray_start: float, ray_end: float, box_warp: float,
+             decoder_lr_mul: float = 1.0, plane_axes: int = 0, white_back: bool = False):
+    """planes [B,3,H,W,32] → feat [B,R,32], depth [B,R] (unclamped), wsum [B,R], tminmax [B,R,2]."""
+    _chk(planes, "planes")
+    b, three, h, w, ch = planes.shape
+    if three != 3 or ch != 32:
+        raise RuntimeError("raymarch: planes must be [B, 3, H, W, 32]")
+    r = res * res
+    sc, sf = u_strat.shape[-1], u_imp.shape[-1]
+    if u_strat.numel() != b * r * sc or u_imp.numel() != b * r * sf:
+        raise RuntimeError("raymarch: u_strat / u_imp have the wrong number of elements")
+    dev = planes.device
+    feat = torch.empty(b, r, 32, device=dev, dtype=torch.float32)
+    depth = torch.empty(b, r, device=dev, dtype=torch.float32)
+    wsum = torch.empty(b, r, device=dev, dtype=torch.float32)
+    tmm = torch.empty(b, r, 2, device=dev, dtype=torch.float32)
+    a = L.RaymarchArgs()
+    a.planes, a.cam2world, a.intrinsics = _ptr(planes), _ptr(_chk(cam2world, "cam2world")), _ptr(_chk(intrinsics, "intrinsics"))
+    a.u_strat, a.u_imp = _ptr(_chk(u_strat, "u_strat")), _ptr(_chk(u_imp, "u_imp"))
+    a.dec_w0, a.dec_b0 = _ptr(_chk(dec_w0, "dec_w0")), _ptr(_chk(dec_b0, "dec_b0"))
+    a.dec_w1, a.dec_b1 = _ptr(_chk(dec_w1, "dec_w1")), _ptr(_chk(dec_b1, "dec_b1"))
+    a.feat, a.depth, a.wsum, a.tminmax = _ptr(feat), _ptr(depth), _ptr(wsum), _ptr(tmm)
+    a.B, a.H, a.W, a.res, a.Sc, a.Sf = b, h, w, res, sc, sf
+    a.plane_axes, a.white_back = plane_axes, int(white_back)
+    a.ray_start, a.ray_end, a.box_warp, a.decoder_lr_mul = ray_start, ray_end, box_warp, decoder_lr_mul
+    L.check(L.lib().hfagp_raymarch_fwd(C.byref(a), _stream()), "raymarch_fwd")
+    return feat, depth, wsum, tmm
+
+
+# ----------------------------------------------------------------------------- standalone ops (NCHW)
+def upfirdn2d(x: torch.Tensor, f: torch.Tensor, up: int = 1, down: int = 1,
+              padding=(0, 0, 0, 0), gain: float = 1.0) -> torch.Tensor:
+    """EG3D upfirdn2d(x, f, up, down, padding=[px0,px1,py0,py1], gain) on NCHW fp32."""
+    _chk(x, "x")
+    _chk(f, "f")
+    n, c, h, w = x.shape
+    fh, fw = f.shape
+    px0, px1, py0, py1 = padding
+    ho = (h * up + py0 + py1 - fh) // down + 1
+    wo = (w * up + px0 + px1 - fw) // down + 1
+    y = torch.empty(n, c, ho, wo, device=x.device, dtype=torch.float32)
+    L.check(L.lib().hfagp_upfirdn2d_fwd(_ptr(x), _ptr(f), _ptr(y), n, c, h, w, fh, fw, up, down,
+                                        px0, px1, py0, py1, gain, _stream()), "upfirdn2d_fwd")
+    return y
+
+
+def upsample2d(x: torch.Tensor, f: torch.Tensor) -> torch.Tensor:
+    return upfirdn2d(x, f, up=2, padding=(2, 1, 2, 1), gain=4.0)
+
+
+def bias_act(x: torch.Tensor, b: Optional[torch.Tensor] = None, dim: int = 1, act: str = "linear",
+             alpha: float = 0.2, gain: Optional[float] = None, clamp: Optional[float] = None) -> torch.Tensor:
+    """EG3D bias_act.bias_act(x, b, dim, act, alpha, gain, clamp)."""
+    _chk(x, "x")
+    if gain is None:
+        gain = math.sqrt(2.0) if act == "lrelu" else 1.0
+    y = torch.empty_like(x)
+    inner = 1
+    for s in x.shape[dim + 1:]:
+        inner *= s
+    L.check(L.lib().hfagp_bias_act_fwd(_ptr(x), _ptr(b), _ptr(y), x.numel(), x.shape[dim], inner, _ACT[act],
+                                       alpha, gain, -1.0 if clamp is None else float(clamp), _stream()), "bias_act_fwd")
+    return y
+
+
+def nchw_to_nhwc(x: torch.Tensor) -> torch.Tensor:
+    _chk(x, "x")
+    b, c, h, w = x.shape
+    y = torch.empty(b, h, w, c, device=x.device, dtype=torch.float32)
+    L.check(L.lib().hfagp_nchw_to_nhwc(_ptr(x), _ptr(y), b, c, h, w, _stream()), "nchw_to_nhwc")
+    return y
+
+
+def nhwc_to_nchw(x: torch.Tensor) -> torch.Tensor:
+    _chk(x, "x")
+    b, h, w, c = x.shape
+    y = torch.empty(b, c, h, w, device=x.device, dtype=torch.float32)
+    L.check(L.lib().hfagp_nhwc_to_nchw(_ptr(x), _ptr(y), b, c, h, w, _stream()), "nhwc_to_nchw")
+    return y

@@ -1,0 +1,8 @@
+"""Import alias: the package sources live in ``hfa-gp_amd/`` (not an importable name)."""
+import os as _os
+
+_real = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "hfa-gp_amd")
+__path__[:] = [_real]
+with open(_os.path.join(_real, "__init__.py")) as _f:
+    exec(compile(_f.read(), _os.path.join(_real, "__init__.py"), "exec"))
+del _os, _f

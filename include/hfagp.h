@@ -1,0 +1,188 @@
+/*
+ * hfagp.h — C ABI of libhfagp_hip.so: the MI355X (gfx950) implementation of the
+ * EG3D tri-plane generator hot path that HFA-GP calls as
+ *   generator.synthesis(ws, c=label, noise_mode='const')['image']
+ * (/root/reference/code/networks/headnerf.py:112,118,133,207,218,267,277).
+ *
+ * The reference has no FFI of its own (it is pure Python).  The
+ * interfaces these entry points replace are the EG3D operator API one level
+ * below that call (NVlabs/eg3d, not shipped in the reference tree):
+ *   hfagp_raymarch_fwd      <- ImportanceRenderer.forward + RaySampler + OSGDecoder + MipRayMarcher2
+ *   hfagp_modconv_fwd       <- modulated_conv2d(...) + bias_act(...) (SynthesisLayer / ToRGBLayer)
+ *   hfagp_style_fwd         <- FullyConnectedLayer affine + demodulation coefficients
+ *   hfagp_upfir_epilogue_fwd<- upfirdn2d(pad [1,1,1,1], gain 4) after the transposed conv + bias_act
+ *   hfagp_upfirdn2d_fwd     <- upfirdn2d.upfirdn2d(x, f, up, down, padding, gain)
+ *                              (in-repo twin: upfirdn2d_native, code/networks/encoder3d.py:23-45)
+ *   hfagp_bias_act_fwd      <- bias_act.bias_act(x, b, act, alpha, gain, clamp)
+ *                              (in-repo twin: fused_leaky_relu, code/networks/encoder3d.py:7-8)
+ *   hfagp_torgb_fwd         <- ToRGBLayer for img_channels=3 + upsample2d(img) skip add
+ *   hfagp_skip_upsample_add <- img = upsample2d(img, resample_filter) + y   (SynthesisBlock 'skip')
+ *
+ * Contract:
+ *   - plain pointers and sizes only; all pointers are DEVICE pointers owned by the caller;
+ *     the library never allocates, frees or retains them past the call;
+ *   - all work is enqueued asynchronously on the hipStream_t passed in (void* here so that
+ *     callers need no HIP headers); no internal synchronisation;
+ *   - return 0 on success, <0 on error: -1 bad arguments, -2 unsupported shape/dtype,
+ *     -3 HIP launch failure; hfagp_last_error() returns a thread-local message;
+ *   - never aborts, never throws across the boundary.
+ *
+ * Activation layout inside the path is channels-last fp32:  x[b][y][x][c].
+ * The tri-plane volume is plane-major channels-last:        planes[b][plane][y][x][32].
+ */
+#ifndef HFAGP_H_
+#define HFAGP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HFAGP_ABI_VERSION 1
+
+enum { HFAGP_OK = 0, HFAGP_EBADARG = -1, HFAGP_EUNSUPPORTED = -2, HFAGP_ELAUNCH = -3 };
+
+int hfagp_abi_version(void);
+const char* hfagp_last_error(void);
+
+/* ------------------------------------------------------------------ ray march
+ * One launch: ray generation -> stratified depths -> tri-plane bilinear gather
+ * -> decoder MLP -> coarse compositing -> importance re-sampling -> second
+ * gather+MLP -> depth merge -> final compositing.                              */
+typedef struct {
+    const float* planes;      /* [B][3][H][W][32] fp32                                        */
+    const float* cam2world;   /* [B][16] row-major 4x4 (label[:, :16])                        */
+    const float* intrinsics;  /* [B][9]  row-major 3x3 (label[:, 16:25])                      */
+    const float* u_strat;     /* [B][R][Sc]  uniforms of the stratified jitter                */
+    const float* u_imp;       /* [B][R][Sf]  uniforms of the inverse-CDF draw                 */
+    const float* dec_w0;      /* decoder.net.0.weight [64][32]  (raw parameter)               */
+    const float* dec_b0;      /* decoder.net.0.bias   [64]                                    */
+    const float* dec_w1;      /* decoder.net.2.weight [33][64]                                */
+    const float* dec_b1;      /* decoder.net.2.bias   [33]                                    */
+    float*       feat;        /* out [B][R][32]  composited features, scaled to (-1,1)        */
+    float*       depth;       /* out [B][R]      expected depth, NaN->inf, NOT yet clamped    */
+    float*       wsum;        /* out [B][R]      sum of weights                               */
+    float*       tminmax;     /* out [B][R][2]   per-ray min / max sample depth               */
+    int32_t B, H, W;          /* plane height/width                                           */
+    int32_t res;              /* rays per side; R = res*res                                   */
+    int32_t Sc, Sf;           /* coarse / importance samples per ray: 16,32 or 48 each        */
+    int32_t plane_axes;       /* 0: (x,y),(x,z),(z,x) [eg3d original]; 1: third = (z,y)       */
+    int32_t white_back;
+    double ray_start, ray_end;/* python floats of rendering_kwargs (kept double: linspace/delta rounding) */
+    float box_warp, decoder_lr_mul;
+} HfagpRaymarchArgs;
+
+int hfagp_raymarch_fwd(const HfagpRaymarchArgs* a, void* stream);
+
+/* ------------------------------------------------------------------ styles
+ * styles[b][i] = (w[b] . A[i]) / sqrt(w_dim) * 1 + bias[i]   (then * style_gain)
+ * dcoef[b][o]  = rsqrt( sum_i styles[b][i]^2 * wsq[o][i] + eps )   if wsq != NULL */
+typedef struct {
+    const float* w;           /* [B][w_stride] one latent row per sample                      */
+    const float* affine_w;    /* [Cin][w_dim]                                                 */
+    const float* affine_b;    /* [Cin]                                                        */
+    const float* wsq;         /* [Cout][Cin] = sum_k weight[o][i][k]^2, or NULL (no demod)    */
+    float*       styles;      /* out [B][Cin]                                                 */
+    float*       dcoef;       /* out [B][Cout] or NULL                                        */
+    int32_t B, w_dim, w_stride, Cin, Cout;
+    float style_gain, eps;
+} HfagpStyleArgs;
+
+int hfagp_style_fwd(const HfagpStyleArgs* a, void* stream);
+
+/* weight preparation (cached by the host while the generator is frozen)
+ *   wt  [taps][Cin/4][Cout][4]  <- weight [Cout][Cin][kh][kw]      (MFMA B-operand image)
+ *   wsq [Cout][Cin]             <- sum over taps of weight^2                           */
+int hfagp_weight_prep(const float* weight, float* wt, float* wsq,
+                      int32_t Cout, int32_t Cin, int32_t taps, void* stream);
+
+/* ------------------------------------------------------------------ modulated conv
+ * Implicit-GEMM on v_mfma_f32_32x32x2_f32 (exact fp32).  Input is scaled by
+ * styles on the way into LDS; demodulation, noise, bias, leaky-ReLU, gain and
+ * clamp are applied in the epilogue (mode 0/2) or by hfagp_upfir_epilogue_fwd
+ * (mode 1, which writes the raw transposed-conv result).                          */
+enum { HFAGP_CONV3X3 = 0, HFAGP_CONVT3X3_UP2 = 1, HFAGP_CONV1X1 = 2 };
+enum { HFAGP_ACT_LINEAR = 0, HFAGP_ACT_LRELU = 1 };
+
+typedef struct {
+    const float* x;           /* [B][H][W][Cin]; x_batch_stride (elements) may be 0 (const)   */
+    const float* wt;          /* from hfagp_weight_prep                                       */
+    const float* styles;      /* [B][Cin] or NULL                                             */
+    const float* dcoef;       /* [B][Cout] or NULL                                            */
+    const float* noise;       /* [Ho][Wo] or NULL                                             */
+    const float* bias;        /* [Cout] or NULL                                               */
+    float*       y;           /* mode 0/2: [B][H][W][Cout]; mode 1: [B][2H+1][2W+1][Cout] raw */
+    float*       workspace;   /* split-K partials, >= hfagp_modconv_workspace_bytes()          */
+    int64_t x_batch_stride;
+    int32_t B, H, W, Cin, Cout;
+    int32_t mode, act;
+    int32_t ksplit;           /* 0 = let the library choose                                   */
+    float noise_strength, alpha, gain, clamp;   /* clamp < 0: none                            */
+} HfagpModconvArgs;
+
+size_t hfagp_modconv_workspace_bytes(const HfagpModconvArgs* a);
+int hfagp_modconv_fwd(const HfagpModconvArgs* a, void* stream);
+
+/* FIR (4x4 [1,3,3,1]^2/64, pad [1,1,1,1], gain 4) over the raw transposed-conv
+ * output + demod + noise + bias + act.  yt [B][2H+1][2W+1][C] -> y [B][2H][2W][C] */
+typedef struct {
+    const float* yt;
+    const float* dcoef;       /* [B][C] or NULL */
+    const float* noise;       /* [2H][2W] or NULL */
+    const float* bias;        /* [C] or NULL */
+    float*       y;
+    int32_t B, H, W, C;       /* H, W = INPUT resolution of the up-conv */
+    int32_t act;
+    float noise_strength, alpha, gain, clamp;
+} HfagpUpfirEpilogueArgs;
+
+int hfagp_upfir_epilogue_fwd(const HfagpUpfirEpilogueArgs* a, void* stream);
+
+/* skip connection: img_out = upsample2d(img_in) + y  (both channels-last, C channels;
+ * img_in may be NULL -> img_out = y).  Optional plane-major output for the last block:
+ * planes_out [B][3][2H][2W][C/3] when plane_major != 0.                              */
+typedef struct {
+    const float* img_in;      /* [B][H][W][C] or NULL */
+    const float* y;           /* [B][2H][2W][C] (or [B][H][W][C] when img_in is NULL) */
+    float*       img_out;
+    int32_t B, H, W, C;       /* H, W = resolution of img_in */
+    int32_t plane_major;
+} HfagpSkipArgs;
+
+int hfagp_skip_upsample_add(const HfagpSkipArgs* a, void* stream);
+
+/* toRGB with few output channels (super-resolution, img_channels = 3):
+ * rgb_out[b][c][y][x] (NCHW) = sum_i x[b][y][x][i]*styles[b][i]*w[c][i] + bias[c]
+ *                              (clamped) + upsample2d(rgb_in)[b][c][y][x]           */
+typedef struct {
+    const float* x;           /* [B][H][W][Cin] channels-last */
+    const float* weight;      /* [Cout][Cin] (1x1) */
+    const float* styles;      /* [B][Cin] (already * 1/sqrt(Cin)) */
+    const float* bias;        /* [Cout] */
+    const float* rgb_in;      /* NCHW [B][Cout][H/2][W/2] or NULL */
+    float*       rgb_out;     /* NCHW [B][Cout][H][W] */
+    int32_t B, H, W, Cin, Cout;
+    float clamp;
+} HfagpTorgbArgs;
+
+int hfagp_torgb_fwd(const HfagpTorgbArgs* a, void* stream);
+
+/* ------------------------------------------------------------------ standalone ops (NCHW, test surface) */
+int hfagp_upfirdn2d_fwd(const float* x, const float* f, float* y,
+                        int32_t N, int32_t C, int32_t H, int32_t W, int32_t fh, int32_t fw,
+                        int32_t up, int32_t down, int32_t px0, int32_t px1, int32_t py0, int32_t py1,
+                        float gain, void* stream);
+
+int hfagp_bias_act_fwd(const float* x, const float* b, float* y, int64_t n, int32_t C, int64_t inner,
+                       int32_t act, float alpha, float gain, float clamp, void* stream);
+
+/* layout helpers */
+int hfagp_nchw_to_nhwc(const float* x, float* y, int32_t B, int32_t C, int32_t H, int32_t W, void* stream);
+int hfagp_nhwc_to_nchw(const float* x, float* y, int32_t B, int32_t C, int32_t H, int32_t W, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HFAGP_H_ */
