@@ -1,0 +1,152 @@
+#!/usr/bin/env python
+"""bench.py — rendered 512^2 frames/s at 96 depth samples (BASELINE.json metric, config 2).
+
+One "step" = one pass of the hot path over one batch of synthetic input:
+``generator.synthesis(ws[B,14,512], c[B,25], noise_mode='const')`` for the
+``ffhq512_128`` preset (random-init EG3D weights, random latents + gaussian cameras,
+explicit sampling uniforms), forward only, inputs resident in HBM before the
+timed region.  N>1: one process per GPU, frames are independent → weak scaling,
+no data-path collective; only the timing is reduced (MAX).
+
+Prints ONE JSON line on rank 0 (see the contract in the task description).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32 dense peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4, help="frames per step per GPU")
+    ap.add_argument("--preset", default="ffhq512_128")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-runs", type=int, default=2)
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, state, runs: int):
+    """Oracle (kind 'port') timed on this box's host cores: B=1 synthesis, same workload."""
+    from oracle import eg3d_oracle as O
+    from tests.util import make_inputs
+    ws, c, us, ui = make_inputs(cfg, 1, seed=10)
+    with torch.no_grad():
+        O.synthesis(state, cfg, ws, c, us, ui)          # warm-up
+        t = time.perf_counter()
+        for _ in range(runs):
+            O.synthesis(state, cfg, ws, c, us, ui)
+        dt = (time.perf_counter() - t) / runs
+    return {"value": 1.0 / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{runs} x synthesis(B=1) of the {cfg.name} workload with the fp32 PyTorch-CPU oracle, "
+                      f"{dt:.2f} s/frame"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from hfa_gp_amd.config import PRESETS
+    from hfa_gp_amd.generator import TriPlaneGenerator
+    from tests.util import make_inputs, state_cpu
+
+    cfg = PRESETS[args.preset]()
+    gen = TriPlaneGenerator(cfg, seed=0).requires_grad_(False)
+    state = state_cpu(gen) if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+    gen = gen.to(dev)
+    B = args.batch
+    # each rank renders its own frames (frame-parallel): different seed per rank
+    ws, c, us, ui = make_inputs(cfg, B, seed=10 + rank)
+    ws, c, us, ui = ws.to(dev), c.to(dev), us.to(dev), ui.to(dev)
+
+    def step():
+        return gen.synthesis(ws, c, noise_mode="const", u_strat=us, u_imp=ui)["image"]
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    gen.timing = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        img = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    timing, gen.timing = gen.timing, None
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(img).all()
+
+    def agg(key):
+        evs = timing.get(key, [])
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in evs)
+        units = sum(u for _, _, u in evs)
+        return ms, units, len(evs)
+
+    if rank == 0:
+        frames = world * B * args.steps
+        rm_ms, rm_bytes, rm_n = agg("raymarch")
+        mc_ms, mc_flops, mc_n = agg("modconv")
+        rm_gbs = rm_bytes / (rm_ms * 1e-3) / 1e9
+        mc_tf = mc_flops / (mc_ms * 1e-3) / 1e12
+        out = {
+            "metric": "rendered 512^2 frames/sec (96 depth samples), whole job",
+            "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{cfg.name}: synthesis(ws[B,14,512], c[B,25]) forward, 512x512 out, 128^2 rays x "
+                                   f"(48+48) samples, random-init weights, random latents+cameras",
+                       "frames_per_step_per_gpu": B, "parallelism": f"frame-parallel x{world}"},
+            # dominant kernel by time: the fp32 MFMA modulated-conv implicit GEMM (all 17 conv launches per frame)
+            "roofline": {"bound": "mfma", "kernel": "modconv_kernel (v_mfma_f32_32x32x2_f32)",
+                         "achieved": mc_tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": mc_tf / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                         "avg_launch_ms": mc_ms / max(mc_n, 1), "launches": mc_n},
+            # the kernel north_star sets the HBM target on
+            "roofline_raymarch": {"bound": "hbm", "kernel": "raymarch_kernel<3,3>", "achieved": rm_gbs,
+                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rm_gbs / HBM_PEAK_GBS,
+                                  "traffic": None, "avg_launch_ms": rm_ms / max(rm_n, 1), "launches": rm_n,
+                                  "algorithmic_bytes_per_launch": rm_bytes / max(rm_n, 1)},
+        }
+        if state is not None:
+            out["cpu_baseline"] = cpu_baseline(cfg, state, args.cpu_runs)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

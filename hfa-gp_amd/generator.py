@@ -144,6 +144,18 @@ class TriPlaneGenerator(nn.Module):
         self._prep: Dict[int, tuple] = {}        # id(param) -> (version, data_ptr, wt, wsq)
         self._scalars: Dict[int, tuple] = {}     # id(param) -> (version, data_ptr, python float)
         self._const_nhwc: Optional[tuple] = None
+        self.timing: Optional[Dict[str, list]] = None   # bench.py: {'raymarch': [(ev0, ev1, units)], 'modconv': [...]}
+
+    def _timed(self, key: str, units: float, fn, *args, **kwargs):
+        """Run ``fn`` bracketed by HIP events on the current stream when bench.py enabled timing."""
+        if self.timing is None:
+            return fn(*args, **kwargs)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn(*args, **kwargs)
+        e1.record()
+        self.timing.setdefault(key, []).append((e0, e1, units))
+        return out
 
     # ----------------------------------------------------------------- caches
     def _prepared(self, weight: torch.Tensor):
@@ -184,12 +196,15 @@ class TriPlaneGenerator(nn.Module):
             raise NotImplementedError("noise_mode must be 'const' or 'none' (HFA-GP passes 'const', headnerf.py:112)")
         cout = layer.weight.shape[0]
         gain = math.sqrt(2.0)
+        # algorithmic FLOPs: 2 * B * H_in * W_in * Cin * Cout * 9 (the up-conv is counted in its
+        # polyphase / transposed form at INPUT resolution)
+        flops = 2.0 * batch * x.shape[1] * x.shape[2] * x.shape[3] * cout * 9
         if layer.up == 2:
-            yt = ops.modconv(x, wt, cout, ops.CONVT3X3_UP2, styles=styles, batch=batch)
+            yt = self._timed("modconv", flops, ops.modconv, x, wt, cout, ops.CONVT3X3_UP2, styles=styles, batch=batch)
             return ops.upfir_epilogue(yt, dcoef, noise, ns, layer.bias, "lrelu", cfg.lrelu_alpha, gain, conv_clamp)
-        return ops.modconv(x, wt, cout, ops.CONV3X3, styles=styles, dcoef=dcoef, noise=noise, noise_strength=ns,
-                           bias=layer.bias, act="lrelu", alpha=cfg.lrelu_alpha, gain=gain, clamp=conv_clamp,
-                           batch=batch)
+        return self._timed("modconv", flops, ops.modconv, x, wt, cout, ops.CONV3X3, styles=styles, dcoef=dcoef,
+                           noise=noise, noise_strength=ns, bias=layer.bias, act="lrelu", alpha=cfg.lrelu_alpha,
+                           gain=gain, clamp=conv_clamp, batch=batch)
 
     def _block(self, x, img, blk: _SynthesisBlock, ws3, batch, noise_mode, conv_clamp, small_rgb, last):
         i = 0
@@ -242,7 +257,11 @@ class TriPlaneGenerator(nn.Module):
         c2w = c[:, :16].contiguous()
         intr = c[:, 16:25].contiguous()
         net = self.decoder.net
-        return ops.raymarch(planes, c2w, intr, u_strat.reshape(b, r, -1).contiguous(), u_imp.contiguous(),
+        # algorithmic bytes per frame: samples * 3 planes * 4 taps * 32 ch * 4 B
+        # + outputs R*(32+1+1)*4 + uniforms R*(Sc+Sf)*4
+        s_tot = cfg.depth_resolution + cfg.depth_resolution_importance
+        nbytes = float(b) * r * (s_tot * 3 * 4 * 32 * 4 + 34 * 4 + s_tot * 4)
+        return self._timed("raymarch", nbytes, ops.raymarch, planes, c2w, intr, u_strat.reshape(b, r, -1).contiguous(), u_imp.contiguous(),
                             net["0"].weight, net["0"].bias, net["2"].weight, net["2"].bias, res,
                             cfg.ray_start, cfg.ray_end, cfg.box_warp, cfg.decoder_lr_mul,
                             0 if cfg.plane_axes == "eg3d_original" else 1, cfg.white_back)

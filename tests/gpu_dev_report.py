@@ -1,11 +1,12 @@
 """Developer report (run on the GPU box): per-stage error of the HIP path vs the CPU oracle.
 Not a test; prints max-abs / rms errors so tolerances in test_gpu_parity.py are set from measurement."""
+import os
 import sys
 import time
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests.util import make_inputs, perturb_state, state_cpu  # noqa: E402
 from hfa_gp_amd import ops  # noqa: E402
 from hfa_gp_amd.config import PRESETS  # noqa: E402
