@@ -314,6 +314,11 @@ def load_G_official(args=None, device="cuda", cfg: Optional[GeneratorConfig] = N
     """Counterpart of headnerf.py:31-38.  The EG3D pickle is not shipped with the reference, so the
     generator is random-initialised from ``seed`` (EG3D init) or loaded from a safetensors file with
     EG3D key names; it comes back frozen, as the reference does (``requires_grad_(False)``)."""
+    if cfg is None and getattr(args, "generator_preset", None):
+        from .config import PRESETS
+        cfg = PRESETS[args.generator_preset]()
+    seed = getattr(args, "generator_seed", seed)
+    weights = weights or getattr(args, "generator_weights", None)
     g = TriPlaneGenerator(cfg, seed=seed)
     if weights is not None:
         from safetensors.torch import load_file

@@ -1,0 +1,206 @@
+"""Avatar modules — the L3 drop-in boundary of HFA-GP.
+
+Counterparts of /root/reference/code/networks/headnerf.py:
+  HeadNeRF_final :44-134   HeadNeRF_3DMM :162-219   HeadNeRF_Audio :222-279
+  Weights_3DMM   :138-158  AudioAttNet   :284-314   AudioNet       :319-349
+Same class names, constructor signatures, method names (`get_weights`, `get_latent`, `get_image`,
+`forward`, `get_delta`), parameter names (`bases`, `delta`, `bases_2`, `delta_2`, `encoder.*`,
+`weights_3dmm.fc.N.*`, `generator.*`) and side effects (the IN-PLACE label flip of columns
+[1,2,5,6,9,10] on the caller's tensor).  `self.generator` is the MI355X `TriPlaneGenerator`
+(generator.py) instead of an unpickled EG3D network.
+
+Latent-basis layer: Q = qr((bases + 1e-8)^T), ws = (alpha @ Q^T).view(B,14,512) + delta.  The QR stays
+on PyTorch-ROCm (rocSOLVER); when `bases` does not require grad the factor is cached (the reference
+re-factorises on every call, headnerf.py:91).
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional
+
+import torch
+from torch import nn
+
+from .encoder3d import Encoder, EqualLinear
+from .generator import load_G_official
+
+FLIP_COLUMNS = [1, 2, 5, 6, 9, 10]      # headnerf.py:108,132,201,214,261,274
+NUM_WS = 14                               # headnerf.py:55
+
+
+def load_bases(device, base_dir, dim_shape):
+    """PTI pivot initialisation (headnerf.py:12-23): one `<dir>/0.pt` latent per basis vector."""
+    bases = torch.randn(dim_shape, 18, 512)
+    dirs = os.listdir(base_dir)
+    for i in range(dim_shape):
+        bases[i] = torch.load(base_dir + dirs[i] + "/0.pt").squeeze(0).detach()
+    return bases.to(device)
+
+
+def toogle_grad(model, flag=True):
+    for p in model.parameters():
+        p.requires_grad = flag
+
+
+class _LatentBasis(nn.Module):
+    """Shared implementation of the K-dimensional W+ subspace (rows A1-A3 of SURVEY.md §8a)."""
+
+    def _init_basis(self, device, dim, dim_shape):
+        self.dim, self.dim_shape = dim, dim_shape
+        bases = torch.randn(dim_shape, NUM_WS * dim).to(device)
+        self.bases = nn.Parameter(bases, requires_grad=True)
+        self.delta = nn.Parameter(bases.mean(dim=0), requires_grad=True)
+        self._q_cache = None
+
+    def _select(self, person_2: bool):
+        return self.bases, self.delta
+
+    def _orthonormal(self, bases: torch.Tensor) -> torch.Tensor:
+        if not (bases.requires_grad and torch.is_grad_enabled()):
+            key = (id(bases), bases._version, bases.data_ptr())
+            if self._q_cache is not None and self._q_cache[0] == key:
+                return self._q_cache[1]
+            q = torch.linalg.qr((bases.detach() + 1e-8).T, mode="reduced")[0]
+            self._q_cache = (key, q)
+            return q
+        return torch.linalg.qr((bases + 1e-8).T, mode="reduced")[0]
+
+    def get_latent(self, weights: Optional[torch.Tensor], person_2: bool = False):
+        bases, delta = self._select(person_2)
+        q = self._orthonormal(bases)                     # [14*dim, K]
+        if weights is None:
+            return q
+        out = weights @ q.T                              # == sum_k diag(alpha) Q^T  (headnerf.py:96-98)
+        return out.view(weights.shape[0], -1, self.dim) + delta.view(-1, self.dim)
+
+    def get_image(self, latent: torch.Tensor, label: torch.Tensor) -> torch.Tensor:
+        label[:, FLIP_COLUMNS] *= -1                     # in place, on the caller's tensor
+        return self.generator.synthesis(latent, c=label, noise_mode="const")["image"]
+
+
+class HeadNeRF_final(_LatentBasis):
+    """RGB-driven avatar (headnerf.py:44-134)."""
+
+    def __init__(self, args, size, device, dim=512, dim_shape=20, run_id="nerface2",
+                 emb_dir="./PTI/embeddings/", use_softmax=False):
+        super().__init__()
+        self.base_dir = emb_dir + run_id
+        self.device = device
+        self.encoder = Encoder(size, dim, dim_shape, use_softmax, args.out_pose)
+        self.args = args
+        self.out_pose = args.out_pose
+        self._init_basis(device, dim, dim_shape)
+        if getattr(args, "person_2", False):
+            if getattr(args, "init", False):
+                bases_2 = load_bases(device, emb_dir + args.run_id_2 + "/PTI/", dim_shape).view(dim_shape, -1)
+            else:
+                bases_2 = torch.randn(dim_shape, NUM_WS * dim).to(device)
+            if not args.same_bases:
+                self.bases_2 = nn.Parameter(bases_2, requires_grad=True)
+            self.delta_2 = nn.Parameter(bases_2.mean(dim=0), requires_grad=True)
+        self.generator = load_G_official(args, device)
+
+    def _select(self, person_2: bool):
+        if not person_2:
+            return self.bases, self.delta
+        return (self.bases if self.args.same_bases else self.bases_2), self.delta_2
+
+    def get_delta(self, person_2=False):
+        return (self.delta_2 if person_2 else self.delta).view(-1, self.dim)
+
+    def get_weights(self, image):
+        return self.encoder(image)          # (weights, pose) when out_pose
+
+    def forward(self, image, label, person_2=False):
+        label[:, FLIP_COLUMNS] *= -1
+        if self.out_pose:
+            weights, pose = self.encoder(image)
+        else:
+            weights, pose = self.encoder(image), None
+        latent = self.get_latent(weights, person_2)
+        img = self.generator.synthesis(latent, c=label, noise_mode="const")["image"]
+        return (img, pose) if self.out_pose else img
+
+
+class Weights_3DMM(nn.Module):
+    """Seven activation-less EqualLinear layers: expression coefficients → basis coordinates (:138-158)."""
+
+    def __init__(self, input_dim=76, dim=512, dim_shape=50, use_softmax=False):
+        super().__init__()
+        dims = [input_dim] + [dim] * 6 + [dim_shape]
+        self.fc = nn.Sequential(*[EqualLinear(a, b) for a, b in zip(dims[:-1], dims[1:])])
+        self.softmax = nn.Softmax(dim=1)
+        self.use_softmax = use_softmax
+
+    def forward(self, x):
+        w = self.fc(x)
+        return self.softmax(w) if self.use_softmax else w
+
+
+class _ParamDriven(_LatentBasis):
+    def __init__(self, args, size, device, dim=512, dim_shape=20, run_id="nerface2",
+                 emb_dir="./PTI/embeddings/", use_softmax=False):
+        super().__init__()
+        self.base_dir = emb_dir + run_id
+        self.device = device
+        self.weights_3dmm = Weights_3DMM(input_dim=args.params_len, dim=dim, dim_shape=dim_shape,
+                                         use_softmax=use_softmax)
+        self._init_basis(device, dim, dim_shape)
+        self.generator = load_G_official(args, device)
+
+    def get_weights(self, params):
+        return self.weights_3dmm(params)
+
+    def forward(self, params, label, person_2=False):
+        label[:, FLIP_COLUMNS] *= -1
+        latent = self.get_latent(self.weights_3dmm(params), person_2)
+        return self.generator.synthesis(latent, c=label, noise_mode="const")["image"]
+
+
+class HeadNeRF_3DMM(_ParamDriven):
+    """3DMM-expression-driven avatar (headnerf.py:162-219)."""
+
+
+class HeadNeRF_Audio(_ParamDriven):
+    """Audio-feature-driven avatar (headnerf.py:222-279)."""
+
+
+class AudioAttNet(nn.Module):
+    """Attention over a window of per-frame audio features (:284-314): scores from the first `dim_aud`
+    dims, weighted sum over all dims."""
+
+    def __init__(self, dim_aud=32, seq_len=8):
+        super().__init__()
+        self.seq_len, self.dim_aud = seq_len, dim_aud
+        chans = [dim_aud, 16, 8, 4, 2, 1]
+        layers = []
+        for a, b in zip(chans[:-1], chans[1:]):
+            layers += [nn.Conv1d(a, b, kernel_size=3, stride=1, padding=1, bias=True), nn.LeakyReLU(0.02, True)]
+        self.attentionConvNet = nn.Sequential(*layers)
+        self.attentionNet = nn.Sequential(nn.Linear(seq_len, seq_len, bias=True), nn.Softmax(dim=1))
+
+    def forward(self, x):
+        y = x[..., :self.dim_aud].permute(1, 0).unsqueeze(0)
+        y = self.attentionConvNet(y)
+        y = self.attentionNet(y.view(1, self.seq_len)).view(self.seq_len, 1)
+        return torch.sum(y * x, dim=0)
+
+
+class AudioNet(nn.Module):
+    """DeepSpeech window [N,16,29] → per-frame audio feature [N, dim_aud] (:319-349)."""
+
+    def __init__(self, dim_aud=76, win_size=16):
+        super().__init__()
+        self.win_size, self.dim_aud = win_size, dim_aud
+        chans = [29, 32, 32, 64, 64]
+        layers = []
+        for a, b in zip(chans[:-1], chans[1:]):
+            layers += [nn.Conv1d(a, b, kernel_size=3, stride=2, padding=1, bias=True), nn.LeakyReLU(0.02, True)]
+        self.encoder_conv = nn.Sequential(*layers)
+        self.encoder_fc1 = nn.Sequential(nn.Linear(64, 64), nn.LeakyReLU(0.02, True), nn.Linear(64, dim_aud))
+
+    def forward(self, x):
+        half = int(self.win_size / 2)
+        x = x[:, 8 - half: 8 + half, :].permute(0, 2, 1)
+        x = self.encoder_conv(x).squeeze(-1)
+        return self.encoder_fc1(x).squeeze()

@@ -1,0 +1,311 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the reference-generated
+golden vectors.  Needs an MI355X:  python -m pytest tests -m gpu
+
+Tolerances.  The path computes in fp32 (exact-f32 MFMA).  north_star's bar is MSE <= 1e-3 on [-1,1]
+images; the internal bar used here is max-abs <= 1e-4 — measured errors are ~5e-6,
+the slack covers fp32 summation-order differences (MFMA k-order, split-K, wave scans vs cumprod)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import ROOT, look_at_label, make_inputs, perturb_state, state_cpu
+
+pytestmark = pytest.mark.gpu
+
+ATOL = 1e-4          # internal fp32 bar (max abs)
+MSE_BAR = 1e-3       # north_star bar on the final image
+
+G = np.load(os.path.join(ROOT, "tests", "golden", "reference_vectors.npz"), allow_pickle=False)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("the -m gpu tests need an MI355X")
+    from hfa_gp_amd import _lib
+    _lib.lib()      # fail loudly if the HIP library is missing
+    return torch.device("cuda:0")
+
+
+def close(a, b, atol=ATOL, rtol=1e-5):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = (a - b).abs()
+    assert torch.isfinite(a).all()
+    assert bool((err <= atol + rtol * b.abs()).all()), f"max err {err.max().item():.3e}"
+
+
+# ----------------------------------------------------------------------------- standalone ops
+def test_upfirdn2d_golden_and_ragged(dev):
+    from hfa_gp_amd import ops
+    from oracle import eg3d_oracle as O
+    x, k = torch.from_numpy(G["fir_x"]).to(dev), torch.from_numpy(G["fir_k"]).to(dev)
+    for name, (up, down, pad) in {"u1d1p21": (1, 1, (2, 1)), "u1d1p11": (1, 1, (1, 1)), "u2d1p21": (2, 1, (2, 1)),
+                                   "u1d2p11": (1, 2, (1, 1)), "u2d2p21": (2, 2, (2, 1)),
+                                   "u1d1p0m1": (1, 1, (0, -1))}.items():
+        y = ops.upfirdn2d(x, k, up=up, down=down, padding=(pad[0], pad[1], pad[0], pad[1]))
+        close(y, torch.from_numpy(G["fir_" + name]), atol=1e-6)
+    close(ops.upsample2d(x, k), torch.from_numpy(G["fir_up2gain4"]), atol=1e-6)
+    g = torch.Generator().manual_seed(0)
+    for shape in [(1, 1, 1, 1), (2, 3, 5, 7), (1, 2, 17, 4)]:
+        xr = torch.randn(shape, generator=g)
+        f = torch.randn(3, 4, generator=g)
+        want = O.upfirdn2d(xr, f, up=2, down=1, padding=(3, 2, 1, 2), gain=1.5)
+        close(ops.upfirdn2d(xr.to(dev), f.to(dev), up=2, down=1, padding=(3, 2, 1, 2), gain=1.5), want, atol=1e-5)
+
+
+def test_bias_act_golden(dev):
+    from hfa_gp_amd import ops
+    x = torch.from_numpy(G["fir_x"]).to(dev)
+    b = torch.from_numpy(G["flrelu_b"]).reshape(-1).to(dev)
+    close(ops.bias_act(x, b, act="lrelu"), torch.from_numpy(G["flrelu_y"]), atol=1e-6)
+    y = ops.bias_act(x, b, act="lrelu", gain=3.0, clamp=0.5)
+    assert float(y.abs().max()) <= 0.5 + 1e-7
+    close(ops.bias_act(x, None, act="linear"), x, atol=0)
+    empty = torch.empty(0, 4, 2, 2, device=dev)
+    assert ops.bias_act(empty, b).numel() == 0
+
+
+def test_layout_round_trip(dev):
+    from hfa_gp_amd import ops
+    x = torch.randn(2, 37, 5, 9, device=dev)
+    y = ops.nchw_to_nhwc(x)
+    assert torch.equal(y, x.permute(0, 2, 3, 1).contiguous())
+    assert torch.equal(ops.nhwc_to_nchw(y), x)
+
+
+# ----------------------------------------------------------------------------- modulated conv
+def _layer_state(cin, cout, res, seed):
+    g = torch.Generator().manual_seed(seed)
+    return {"L.weight": torch.randn(cout, cin, 3, 3, generator=g), "L.bias": 0.3 * torch.randn(cout, generator=g),
+            "L.affine.weight": torch.randn(cin, 64, generator=g), "L.affine.bias": torch.ones(cin),
+            "L.noise_const": torch.randn(res, res, generator=g), "L.noise_strength": torch.tensor(0.37)}
+
+
+@pytest.mark.parametrize("b,h,cin,cout,up,ksplit,clamp", [
+    (1, 4, 8, 32, 1, 0, None), (2, 5, 24, 96, 1, 1, None), (3, 17, 16, 128, 1, 2, 0.8), (1, 33, 8, 64, 1, 0, None),
+    (2, 4, 8, 32, 2, 0, None), (1, 9, 16, 128, 2, 1, 0.9), (2, 16, 32, 96, 2, 3, None), (1, 1, 8, 4, 1, 0, None)])
+def test_synthesis_layer(dev, b, h, cin, cout, up, ksplit, clamp):
+    """SynthesisLayer = affine -> modulated 3x3 conv (plain or up-2) -> noise -> bias -> lrelu*sqrt2 -> clamp."""
+    from hfa_gp_amd import ops
+    from oracle import eg3d_oracle as O
+    res = h * up
+    P = _layer_state(cin, cout, res, seed=b * 100 + h)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(b, cin, h, h, generator=g)
+    w = torch.randn(b, 64, generator=g)
+    want = O.synthesis_layer(x, w, P, "L", up, O.fir_kernel(), "const", clamp, 0.2, True, 1e-8)
+    D = {k: v.to(dev) for k, v in P.items()}
+    wt, wsq = ops.weight_prep(D["L.weight"])
+    styles, dcoef = ops.styles_demod(w.to(dev), D["L.affine.weight"], D["L.affine.bias"], wsq)
+    xh = ops.nchw_to_nhwc(x.to(dev))
+    if up == 2:
+        yt = ops.modconv(xh, wt, cout, ops.CONVT3X3_UP2, styles=styles, ksplit=ksplit)
+        y = ops.upfir_epilogue(yt, dcoef, D["L.noise_const"], 0.37, D["L.bias"], clamp=clamp)
+    else:
+        y = ops.modconv(xh, wt, cout, ops.CONV3X3, styles=styles, dcoef=dcoef, noise=D["L.noise_const"],
+                        noise_strength=0.37, bias=D["L.bias"], act="lrelu", gain=math.sqrt(2), clamp=clamp,
+                        ksplit=ksplit)
+    close(ops.nhwc_to_nchw(y), want, atol=2e-5)
+
+
+def test_const_input_broadcast_and_torgb(dev):
+    """b4: the learned constant is shared by the batch (batch stride 0); toRGB: 1x1, no demod, linear."""
+    from hfa_gp_amd import ops
+    from oracle import eg3d_oracle as O
+    g = torch.Generator().manual_seed(9)
+    const = torch.randn(16, 4, 4, generator=g)
+    wgt = torch.randn(96, 16, 1, 1, generator=g)
+    P = {"T.weight": wgt, "T.bias": torch.randn(96, generator=g), "T.affine.weight": torch.randn(16, 64, generator=g),
+         "T.affine.bias": torch.ones(16)}
+    w = torch.randn(3, 64, generator=g)
+    want = O.torgb_layer(const[None].repeat(3, 1, 1, 1), w, P, "T", None, True)
+    D = {k: v.to(dev) for k, v in P.items()}
+    wt, _ = ops.weight_prep(D["T.weight"])
+    styles, _ = ops.styles_demod(w.to(dev), D["T.affine.weight"], D["T.affine.bias"], None, 1 / math.sqrt(16))
+    xh = ops.nchw_to_nhwc(const[None].to(dev))
+    y = ops.modconv(xh, wt, 96, ops.CONV1X1, styles=styles, bias=D["T.bias"], batch=3)
+    close(ops.nhwc_to_nchw(y), want, atol=2e-5)
+    # skip connection: upsample2d(img) + y, plain and plane-major
+    img = torch.randn(3, 96, 2, 2, generator=g)
+    want2 = O.upsample2d(img, O.fir_kernel()) + want
+    out = ops.skip_upsample_add(ops.nchw_to_nhwc(img.to(dev)), y)
+    close(ops.nhwc_to_nchw(out), want2, atol=2e-5)
+    pm = ops.skip_upsample_add(ops.nchw_to_nhwc(img.to(dev)), y, plane_major=True)       # [B,3,H,W,32]
+    close(pm.permute(0, 1, 4, 2, 3).reshape(3, 96, 4, 4), want2, atol=2e-5)
+
+
+def test_torgb_small_with_skip(dev):
+    from hfa_gp_amd import ops
+    from oracle import eg3d_oracle as O
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 24, 6, 10, generator=g)
+    P = {"T.weight": torch.randn(3, 24, 1, 1, generator=g), "T.bias": torch.randn(3, generator=g),
+         "T.affine.weight": torch.randn(24, 64, generator=g), "T.affine.bias": torch.ones(24)}
+    w = torch.randn(2, 64, generator=g)
+    rgb_in = torch.randn(2, 3, 3, 5, generator=g)
+    want = O.upsample2d(rgb_in, O.fir_kernel()) + O.torgb_layer(x, w, P, "T", 0.7, True)
+    D = {k: v.to(dev) for k, v in P.items()}
+    styles, _ = ops.styles_demod(w.to(dev), D["T.affine.weight"], D["T.affine.bias"], None, 1 / math.sqrt(24))
+    y = ops.torgb_small(ops.nchw_to_nhwc(x.to(dev)), D["T.weight"].reshape(3, 24), styles, D["T.bias"],
+                        rgb_in.to(dev), 0.7)
+    close(y, want, atol=2e-5)
+
+
+# ----------------------------------------------------------------------------- renderer
+def _render_case(dev, cfg, c, seed=0, planes_scale=1.0, u_edge=None, batch=None):
+    from hfa_gp_amd.generator import TriPlaneGenerator
+    from oracle import eg3d_oracle as O
+    b = c.shape[0]
+    gen = perturb_state(TriPlaneGenerator(cfg, seed=seed))
+    P = state_cpu(gen)
+    gen = gen.to(dev)
+    g = torch.Generator().manual_seed(seed + 1)
+    hw = 24
+    planes = planes_scale * torch.randn(b, 3, 32, hw, hw, generator=g)
+    res = cfg.neural_rendering_resolution
+    r = res * res
+    us = torch.rand(b, r, cfg.depth_resolution, 1, generator=g)
+    ui = torch.rand(b * r, cfg.depth_resolution_importance, generator=g)
+    if u_edge is not None:
+        us[:, ::3] = u_edge
+        ui[::5] = u_edge
+    o, d = O.ray_sampler(c[:, :16].reshape(-1, 4, 4), c[:, 16:].reshape(-1, 3, 3), res)
+    want = O.importance_renderer(P, cfg, planes, o, d, us, ui)
+    pl = planes.permute(0, 1, 3, 4, 2).contiguous().to(dev)
+    feat, depth, wsum, tmm = gen.render(pl, c.to(dev), us.to(dev), ui.to(dev))
+    depth = torch.clamp(depth, tmm[..., 0].min(), tmm[..., 1].max())
+    close(feat, want[0], atol=2e-5)
+    close(depth, want[1].squeeze(-1), atol=2e-5)
+    close(wsum, want[2].squeeze(-1), atol=2e-5)
+
+
+@pytest.mark.parametrize("preset", ["tiny64", "small128", "ffhq512_128"])
+def test_raymarch_vs_oracle(dev, preset):
+    """16+16, 32+32 and 48+48 samples; cameras inside the usual pose range."""
+    import dataclasses
+    from hfa_gp_amd.config import PRESETS
+    cfg = dataclasses.replace(PRESETS[preset](), neural_rendering_resolution=12, img_resolution=48)
+    c = look_at_label(torch.tensor([1.2, 1.9]), torch.tensor([1.4, 1.75]))
+    _render_case(dev, cfg, c)
+
+
+def test_raymarch_edge_cases(dev):
+    import dataclasses
+    from hfa_gp_amd.config import tiny64
+    cfg = dataclasses.replace(tiny64(), neural_rendering_resolution=8, img_resolution=32)
+    frontal = look_at_label(torch.tensor([math.pi / 2]), torch.tensor([math.pi / 2]))
+    # rays that miss the volume entirely (camera looks away: the un-flipped label) -> zero-padding taps only
+    away = look_at_label(torch.tensor([math.pi / 2]), torch.tensor([math.pi / 2]), flipped=False)
+    _render_case(dev, cfg, away)
+    # uniforms at the ends of [0,1): jitter 0 and importance draws at the first / last CDF cell
+    _render_case(dev, cfg, frontal, u_edge=0.0)
+    _render_case(dev, cfg, frontal, u_edge=1.0 - 2.0 ** -24)
+    # zero planes: decoder bias everywhere, importance pdf driven by constant density
+    _render_case(dev, cfg, frontal, planes_scale=0.0)
+    # large features: saturated sigmoid / dense medium (weights collapse onto the first samples)
+    _render_case(dev, cfg, frontal, planes_scale=30.0)
+    # alternative third plane axis and white background
+    _render_case(dev, dataclasses.replace(cfg, plane_axes="eg3d_fixed", white_back=True), frontal)
+    # wider box / different ray range
+    _render_case(dev, dataclasses.replace(cfg, box_warp=2.0, ray_start=2.0, ray_end=3.6), frontal)
+
+
+# ----------------------------------------------------------------------------- end to end
+@pytest.mark.parametrize("preset,batch", [("tiny64", 1), ("tiny64", 3), ("small128", 2), ("ffhq512_128", 1)])
+def test_synthesis_vs_oracle(dev, preset, batch):
+    """BASELINE configs 1 (tiny64 plumbing case) and 2 (512^2, 96 samples) against the oracle."""
+    from hfa_gp_amd.config import PRESETS
+    from hfa_gp_amd.generator import TriPlaneGenerator
+    from oracle import eg3d_oracle as O
+    cfg = PRESETS[preset]()
+    gen = perturb_state(TriPlaneGenerator(cfg, seed=0))
+    P = state_cpu(gen)
+    gen = gen.to(dev)
+    ws, c, us, ui = make_inputs(cfg, batch)
+    ref = O.synthesis(P, cfg, ws, c, us, ui, return_planes=True)
+    out = gen.synthesis(ws.to(dev), c.to(dev), noise_mode="const", u_strat=us.to(dev), u_imp=ui.to(dev),
+                        return_planes=True)
+    r = cfg.plane_resolution
+    close(out["planes"].permute(0, 1, 4, 2, 3).reshape(batch, 96, r, r), ref["planes"])
+    close(out["image_raw"], ref["image_raw"])
+    close(out["image_depth"], ref["image_depth"])
+    close(out["image"], ref["image"])
+    mse = (out["image"].cpu() - ref["image"]).pow(2).mean().item()
+    assert mse <= MSE_BAR
+    # the oracle's "scale activations" (training-mode) form of modulated conv must agree as well
+    ref2 = O.synthesis(P, cfg, ws, c, us, ui, fused=False)
+    close(out["image"], ref2["image"])
+
+
+def test_full_size_properties(dev):
+    """Size-independent properties at BASELINE config 2 size: per-sample independence, run-to-run
+    determinism, output ranges, and the depth clamp."""
+    from hfa_gp_amd.config import ffhq512_128
+    from hfa_gp_amd.generator import TriPlaneGenerator
+    cfg = ffhq512_128()
+    gen = TriPlaneGenerator(cfg, seed=1).to(dev)
+    ws, c, us, ui = [t.to(dev) for t in make_inputs(cfg, 3, seed=77)]
+    r = cfg.neural_rendering_resolution ** 2
+    a = gen.synthesis(ws, c, u_strat=us, u_imp=ui)
+    b = gen.synthesis(ws, c, u_strat=us, u_imp=ui)
+    assert torch.equal(a["image"], b["image"]), "no atomics / fixed reduction order -> bitwise repeatable"
+    one = gen.synthesis(ws[2:], c[2:], u_strat=us[2:], u_imp=ui[2 * r:])
+    assert torch.equal(one["image"], a["image"][2:]) and torch.equal(one["image_raw"], a["image_raw"][2:])
+    assert a["image"].shape == (3, 3, 512, 512) and a["image_raw"].shape == (3, 3, 128, 128)
+    assert a["image_depth"].shape == (3, 1, 128, 128)
+    assert torch.isfinite(a["image"]).all()
+    assert float(a["image_raw"].min()) >= -1.002 - 1e-5 and float(a["image_raw"].max()) <= 1.002 + 1e-5
+    lo, hi = cfg.ray_start, cfg.ray_end + (cfg.ray_end - cfg.ray_start) / (cfg.depth_resolution - 1)
+    assert float(a["image_depth"].min()) >= lo - 1e-5 and float(a["image_depth"].max()) <= hi + 1e-5
+    # EG3D draws fresh uniforms on every call: without explicit uniforms two calls differ
+    x = gen.synthesis(ws[:1], c[:1])["image"]
+    y = gen.synthesis(ws[:1], c[:1])["image"]
+    assert not torch.equal(x, y)
+
+
+def test_state_dict_round_trip_and_headnerf_boundary(dev, tmp_path):
+    """EG3D-named state dict survives safetensors; HeadNeRF_3DMM on the GPU calls the HIP generator and
+    flips the caller's label in place."""
+    from safetensors.torch import load_file, save_file
+    from hfa_gp_amd import headnerf
+    from hfa_gp_amd.config import tiny64
+    from hfa_gp_amd.generator import TriPlaneGenerator, load_G_official
+    from oracle import eg3d_oracle as O
+    cfg = tiny64()
+    g1 = perturb_state(TriPlaneGenerator(cfg, seed=3))
+    path = str(tmp_path / "g.safetensors")
+    save_file({k: v.contiguous() for k, v in g1.state_dict().items()}, path)
+    g2 = load_G_official(None, dev, cfg=cfg, seed=99, weights=path)
+    assert all(not p.requires_grad for p in g2.parameters())
+    assert sorted(load_file(path)) == sorted(g2.state_dict())
+
+    class Args:
+        out_pose = False
+        person_2 = False
+        params_len = 76
+        generator_preset = "tiny64"
+        generator_weights = path
+
+    torch.manual_seed(0)
+    m = headnerf.HeadNeRF_3DMM(Args(), 64, dev, 512, 8).to(dev)
+    params = torch.randn(2, 76, device=dev)
+    label = look_at_label(torch.tensor([1.5, 1.7]), torch.tensor([1.6, 1.5]), flipped=False).to(dev)
+    before = label.clone()
+    torch.manual_seed(5)
+    img = m(params, label)
+    assert img.shape == (2, 3, 64, 64)
+    flipped = before.clone()
+    flipped[:, headnerf.FLIP_COLUMNS] *= -1
+    assert torch.equal(label, flipped)
+    # same frame through the oracle (uniforms re-drawn with the same device seed)
+    torch.manual_seed(5)
+    r = cfg.neural_rendering_resolution ** 2
+    us = torch.rand(2, r, cfg.depth_resolution, device=dev)
+    ui = torch.rand(2 * r, cfg.depth_resolution_importance, device=dev)
+    ws = m.get_latent(m.get_weights(params))
+    ref = O.synthesis(state_cpu(g1), cfg, ws.cpu(), flipped.cpu(), us.cpu()[..., None], ui.cpu())["image"]
+    close(img, ref)

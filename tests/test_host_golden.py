@@ -1,0 +1,192 @@
+"""Host-side mirror of the reference's module API (cam_utils, encoder3d, headnerf) against golden vectors
+captured from the reference itself (tests/golden/make_golden.py)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from hfa_gp_amd import cam_utils, encoder3d, headnerf
+from tests.util import ROOT
+
+G = np.load(os.path.join(ROOT, "tests", "golden", "reference_vectors.npz"), allow_pickle=False)
+
+
+def T(name):
+    return torch.from_numpy(G[name])
+
+
+class Args:
+    out_pose = False
+    person_2 = False
+    params_len = 76
+    generator_preset = "tiny64"      # keep the CPU-side construction small; the basis layer ignores it
+
+
+class StubGenerator(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.calls = []
+
+    def synthesis(self, ws, c=None, noise_mode=None):
+        self.calls.append((ws.detach().clone(), c.detach().clone(), noise_mode))
+        return {"image": ws.mean(dim=(1, 2)).view(-1, 1, 1, 1).expand(-1, 3, 4, 4)}
+
+
+# ----------------------------------------------------------------------------- cam_utils
+def test_cam2world_fixed_angles():
+    for i, (h, v) in enumerate(G["cam_hv"]):
+        p, phi, theta = cam_utils.sample_camera_positions("cpu", n=1, r=2.7, horizontal_mean=float(h),
+                                                          vertical_mean=float(v), mode=None)
+        assert torch.allclose(p, T("cam_points")[i: i + 1], atol=1e-6)
+        m = cam_utils.create_cam2world_matrix(-p, p, device="cpu")
+        assert torch.allclose(m, T("cam_c2w")[i: i + 1], atol=1e-6)
+
+
+def test_frontal_camera_is_identity_rotation_at_radius():
+    p, _, _ = cam_utils.sample_camera_positions("cpu", n=1, r=2.7, mode=None)
+    m = cam_utils.create_cam2world_matrix(-p, p, device="cpu")[0]
+    want = torch.eye(4)
+    want[2, 3] = 2.7
+    assert torch.allclose(m, want, atol=1e-6)
+
+
+def test_gaussian_sampling_consumes_rng_like_reference():
+    torch.manual_seed(20)
+    p, phi, theta = cam_utils.sample_camera_positions("cpu", n=6, r=2.7, horizontal_stddev=0.3,
+                                                      vertical_stddev=0.155, mode="gaussian")
+    assert torch.allclose(p, T("cam_gauss_points"), atol=1e-6)
+    assert torch.allclose(phi, T("cam_gauss_phi"), atol=1e-6) and torch.allclose(theta, T("cam_gauss_theta"), atol=1e-6)
+    assert torch.allclose(cam_utils.create_cam2world_matrix(-p, p, device="cpu"), T("cam_gauss_c2w"), atol=1e-6)
+    torch.manual_seed(20)
+    lab = cam_utils.cam_sampler(6, "cpu")
+    assert lab.shape == (6, 25) and torch.allclose(lab[:, :16], T("cam_gauss_c2w").reshape(6, 16), atol=1e-6)
+    assert torch.allclose(lab[0, 16:], torch.tensor(cam_utils.FFHQ_INTRINSICS))
+
+
+# ----------------------------------------------------------------------------- encoder3d
+@pytest.mark.parametrize("name,up,down,pad", [
+    ("u1d1p21", 1, 1, (2, 1)), ("u1d1p11", 1, 1, (1, 1)), ("u2d1p21", 2, 1, (2, 1)),
+    ("u1d2p11", 1, 2, (1, 1)), ("u2d2p21", 2, 2, (2, 1)), ("u1d1p0m1", 1, 1, (0, -1))])
+def test_upfirdn2d(name, up, down, pad):
+    y = encoder3d.upfirdn2d(T("fir_x"), T("fir_k"), up=up, down=down, pad=pad)
+    assert torch.allclose(y, T("fir_" + name), atol=1e-6)
+
+
+def test_small_layers():
+    assert torch.allclose(encoder3d.make_kernel([1, 3, 3, 1]), T("fir_k"))
+    assert torch.allclose(encoder3d.fused_leaky_relu(T("fir_x"), T("flrelu_b")), T("flrelu_y"), atol=1e-6)
+    lin = encoder3d.EqualLinear(16, 8, lr_mul=0.5, bias_init=0.3)
+    with torch.no_grad():
+        lin.weight.copy_(T("eqlin_w")); lin.bias.copy_(T("eqlin_b"))
+        assert torch.allclose(lin(T("eqlin_x")), T("eqlin_y"), atol=1e-6)
+        conv = encoder3d.EqualConv2d(4, 6, 3, stride=1, padding=1)
+        conv.weight.copy_(T("eqconv_w")); conv.bias.copy_(T("eqconv_b"))
+        assert torch.allclose(conv(T("fir_x")), T("eqconv_y"), atol=1e-5)
+
+
+def test_resblock_state_dict_and_output():
+    rb = encoder3d.ResBlock(8, 16)
+    sd = {k[len("resblock_sd/"):]: T(k) for k in G.files if k.startswith("resblock_sd/")}
+    assert sorted(sd) == sorted(rb.state_dict())
+    rb.load_state_dict(sd, strict=True)
+    with torch.no_grad():
+        assert torch.allclose(rb(T("resblock_x")), T("resblock_y"), atol=1e-5)
+
+
+def test_encoder_keys_seeded_init_and_output():
+    torch.manual_seed(int(G["enc64_seed"][0]))
+    enc = encoder3d.Encoder(64, 512, 50, False, False)
+    sd = enc.state_dict()
+    assert list(sd.keys()) == [str(k) for k in G["enc64_keys"]]
+    assert [str(tuple(v.shape)) for v in sd.values()] == [str(s) for s in G["enc64_shapes"]]
+    assert torch.allclose(sd["net_app.convs.1.conv1.0.weight"].flatten()[:16], T("enc64_w_probe"))
+    x = torch.randn(2, 3, 64, 64, generator=torch.Generator().manual_seed(int(G["enc64_seed"][1])))
+    with torch.no_grad():
+        y = enc(x)
+    assert torch.allclose(y, T("enc64_y"), atol=2e-4, rtol=1e-4)
+
+
+# ----------------------------------------------------------------------------- driver nets
+def test_weights_3dmm():
+    torch.manual_seed(6)
+    m = headnerf.Weights_3DMM(76, 512, 50)
+    assert list(m.state_dict()) == [str(k) for k in G["w3dmm_keys"]]
+    x = torch.randn(3, 76, generator=torch.Generator().manual_seed(7))
+    with torch.no_grad():
+        assert torch.allclose(m(x), T("w3dmm_y"), atol=1e-4, rtol=1e-4)
+
+
+def test_audio_nets():
+    torch.manual_seed(8)
+    an = headnerf.AudioNet(64, 16)
+    assert list(an.state_dict()) == [str(k) for k in G["audnet_keys"]]
+    x = torch.randn(8, 16, 29, generator=torch.Generator().manual_seed(9))
+    with torch.no_grad():
+        assert torch.allclose(an(x), T("audnet_y"), atol=1e-5)
+    torch.manual_seed(10)
+    aa = headnerf.AudioAttNet()
+    assert list(aa.state_dict()) == [str(k) for k in G["audatt_keys"]]
+    x = torch.randn(8, 64, generator=torch.Generator().manual_seed(11))
+    with torch.no_grad():
+        assert torch.allclose(aa(x), T("audatt_y"), atol=1e-5)
+
+
+# ----------------------------------------------------------------------------- latent-basis layer
+@pytest.mark.parametrize("K", [8, 50])
+def test_get_latent_forward_backward(K):
+    torch.manual_seed(12)
+    m = headnerf.HeadNeRF_3DMM(Args(), 64, "cpu", 512, K)
+    keys = [k for k in m.state_dict() if not k.startswith("generator.")]
+    assert keys == [str(k) for k in G[f"hn{K}_keys"] if not str(k).startswith("generator.")]
+    assert any(k.startswith("generator.backbone.synthesis.b4.") for k in m.state_dict())
+    if K == 8:
+        assert torch.allclose(m.bases.detach(), T("hn8_bases")) and torch.allclose(m.delta.detach(), T("hn8_delta"))
+    else:
+        assert torch.allclose(m.bases.detach()[:, :8], T("hn50_bases_probe"))
+    alpha = T(f"hn{K}_alpha").clone().requires_grad_(True)
+    ws = m.get_latent(alpha)
+    assert ws.shape == (2, 14, 512)
+    got = ws.detach() if K == 8 else ws.detach()[:, :, :16]
+    assert torch.allclose(got, T(f"hn{K}_ws"), atol=2e-5)
+    up = torch.randn(ws.shape, generator=torch.Generator().manual_seed(14))
+    (ws * up).sum().backward()
+    assert torch.allclose(alpha.grad, T(f"hn{K}_dalpha"), atol=2e-4, rtol=1e-4)
+    dd = m.delta.grad if K == 8 else m.delta.grad[:64]
+    db = m.bases.grad if K == 8 else m.bases.grad[:, :64]
+    assert torch.allclose(dd, T(f"hn{K}_ddelta"), atol=1e-6)
+    assert torch.allclose(db, T(f"hn{K}_dbases"), atol=2e-4, rtol=1e-3)
+    # frozen basis → cached orthonormal factor, identical values
+    m.bases.requires_grad_(False)
+    with torch.no_grad():
+        a = m.get_latent(alpha.detach())
+        q1 = m._q_cache[1]
+        b = m.get_latent(alpha.detach())
+        assert m._q_cache[1] is q1 and torch.equal(a, b)
+        assert torch.allclose(a, ws.detach(), atol=1e-6)
+        assert float((q1.T @ q1 - torch.eye(K)).abs().max()) < 1e-5
+
+
+def test_label_flip_in_place_and_alternation():
+    torch.manual_seed(15)
+    m = headnerf.HeadNeRF_3DMM(Args(), 64, "cpu", 512, 8)
+    m.generator = StubGenerator()
+    label = T("flip_label_before").clone()
+    m.get_image(torch.ones(2, 14, 512), label)
+    assert torch.equal(label, T("flip_label_after1"))                      # caller's tensor mutated
+    assert torch.equal(m.generator.calls[-1][1], T("flip_seen_by_generator1"))
+    assert m.generator.calls[-1][2] == str(G["flip_noise_mode"])
+    m.get_image(torch.ones(2, 14, 512), label)
+    assert torch.equal(label, T("flip_label_after2")) and torch.equal(label, T("flip_label_before"))
+    label3 = label.clone()
+    m(T("fwd_params"), label3)
+    assert torch.equal(label3, T("fwd_label_after"))
+    assert torch.allclose(m.generator.calls[-1][0][:, :, :8], T("fwd_ws_seen"), atol=2e-5)
+
+
+def test_layout_grid_quantisation_formula():
+    """(img * 127.5 + 128).clamp(0, 255).uint8 on a [-1.2, 1.2] ramp, tiled 1 x 2 (run_recon_video_rgb.py:28-42)."""
+    from hfa_gp_amd.render import layout_grid
+    out = layout_grid(T("grid_in"), grid_w=2, grid_h=1)
+    assert out.dtype == np.uint8 and np.array_equal(out, G["grid_out"])

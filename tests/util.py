@@ -14,9 +14,14 @@ if ROOT not in sys.path:
 INTRINSICS = [4.2647, 0, 0.5, 0, 4.2647, 0.5, 0, 0, 1]   # /root/reference/code/trainer_rgb.py:32
 
 
-def look_at_label(h: torch.Tensor, v: torch.Tensor, r: float = 2.7) -> torch.Tensor:
-    """25-float labels for cameras on a sphere of radius r looking at the origin
-    (same geometry as cam_utils.sample_camera_positions + create_cam2world_matrix)."""
+FLIP_COLUMNS = [1, 2, 5, 6, 9, 10]                        # /root/reference/code/networks/headnerf.py:132
+
+
+def look_at_label(h: torch.Tensor, v: torch.Tensor, r: float = 2.7, flipped: bool = True) -> torch.Tensor:
+    """25-float labels for cameras on a sphere of radius r looking at the origin (same geometry as
+    cam_utils.sample_camera_positions + create_cam2world_matrix).  cam_utils labels have the camera
+    z axis pointing AWAY from the origin; HeadNeRF.get_image negates columns [1,2,5,6,9,10] before the
+    generator sees them (headnerf.py:132).  flipped=True returns what the GENERATOR is fed."""
     n = h.shape[0]
     pos = torch.stack([r * torch.sin(v) * torch.cos(h), r * torch.cos(v), r * torch.sin(v) * torch.sin(h)], -1)
     fwd = torch.nn.functional.normalize(-pos, dim=-1)
@@ -26,7 +31,10 @@ def look_at_label(h: torch.Tensor, v: torch.Tensor, r: float = 2.7) -> torch.Ten
     m = torch.eye(4).repeat(n, 1, 1)
     m[:, :3, :3] = torch.stack((-left, up, -fwd), dim=-1)
     m[:, :3, 3] = pos
-    return torch.cat([m.reshape(n, 16), torch.tensor(INTRINSICS).repeat(n, 1)], -1)
+    label = torch.cat([m.reshape(n, 16), torch.tensor(INTRINSICS).repeat(n, 1)], -1)
+    if flipped:
+        label[:, FLIP_COLUMNS] *= -1
+    return label
 
 
 def make_inputs(cfg, batch: int, seed: int = 10):
