@@ -120,4 +120,14 @@ def small128() -> GeneratorConfig:
         sr_channels=(64, 32), name="small128")
 
 
-PRESETS = {"ffhq512_128": ffhq512_128, "tiny64": tiny64, "small128": small128}
+def tiny14() -> GeneratorConfig:
+    """Smallest preset that keeps HFA-GP's 14-row W+ latent (plane resolution 256 -> 7 blocks):
+    used to test the HeadNeRF_* boundary, which hard-codes 14 x 512 (headnerf.py:55)."""
+    return GeneratorConfig(
+        plane_resolution=256, channel_base=2048, channel_max=32,
+        neural_rendering_resolution=16, depth_resolution=16,
+        depth_resolution_importance=16, img_resolution=64,
+        sr_channels=(32, 16), name="tiny14")
+
+
+PRESETS = {"ffhq512_128": ffhq512_128, "tiny64": tiny64, "small128": small128, "tiny14": tiny14}

@@ -370,9 +370,9 @@ int hfagp_upfirdn2d_fwd(const float* x, const float* f, float* y, int32_t N, int
 
 int hfagp_bias_act_fwd(const float* x, const float* b, float* y, int64_t n, int32_t C, int64_t inner, int32_t act,
                        float alpha, float gain, float clamp, void* stream) {
-    HFAGP_REQUIRE(x && y && n >= 0, HFAGP_EBADARG, "bias_act: null pointer");
     HFAGP_REQUIRE(act == HFAGP_ACT_LINEAR || act == HFAGP_ACT_LRELU, HFAGP_EUNSUPPORTED, "bias_act: act %d", act);
-    if (n == 0) return HFAGP_OK;
+    if (n == 0) return HFAGP_OK;                       // empty input: nothing to do (pointers may be null)
+    HFAGP_REQUIRE(x && y && n > 0, HFAGP_EBADARG, "bias_act: null pointer");
     const long long blocks = (n + 255) / 256;
     bias_act_kernel<<<(unsigned)(blocks > 8192 ? 8192 : blocks), 256, 0, (hipStream_t)stream>>>(
         x, b, y, n, C > 0 ? C : 1, inner > 0 ? inner : 1, act, alpha, gain, clamp);

@@ -215,7 +215,8 @@ def test_raymarch_edge_cases(dev):
 
 
 # ----------------------------------------------------------------------------- end to end
-@pytest.mark.parametrize("preset,batch", [("tiny64", 1), ("tiny64", 3), ("small128", 2), ("ffhq512_128", 1)])
+@pytest.mark.parametrize("preset,batch", [("tiny64", 1), ("tiny64", 3), ("tiny14", 2), ("small128", 2),
+                                          ("ffhq512_128", 1)])
 def test_synthesis_vs_oracle(dev, preset, batch):
     """BASELINE configs 1 (tiny64 plumbing case) and 2 (512^2, 96 samples) against the oracle."""
     from hfa_gp_amd.config import PRESETS
@@ -254,7 +255,10 @@ def test_full_size_properties(dev):
     b = gen.synthesis(ws, c, u_strat=us, u_imp=ui)
     assert torch.equal(a["image"], b["image"]), "no atomics / fixed reduction order -> bitwise repeatable"
     one = gen.synthesis(ws[2:], c[2:], u_strat=us[2:], u_imp=ui[2 * r:])
-    assert torch.equal(one["image"], a["image"][2:]) and torch.equal(one["image_raw"], a["image_raw"][2:])
+    # the split-K factor of the small layers depends on the batch size, so this is equal to fp32
+    # summation order, not bitwise
+    close(one["image"], a["image"][2:], atol=2e-5)
+    close(one["image_raw"], a["image_raw"][2:], atol=2e-5)
     assert a["image"].shape == (3, 3, 512, 512) and a["image_raw"].shape == (3, 3, 128, 128)
     assert a["image_depth"].shape == (3, 1, 128, 128)
     assert torch.isfinite(a["image"]).all()
@@ -272,10 +276,10 @@ def test_state_dict_round_trip_and_headnerf_boundary(dev, tmp_path):
     flips the caller's label in place."""
     from safetensors.torch import load_file, save_file
     from hfa_gp_amd import headnerf
-    from hfa_gp_amd.config import tiny64
+    from hfa_gp_amd.config import tiny14
     from hfa_gp_amd.generator import TriPlaneGenerator, load_G_official
     from oracle import eg3d_oracle as O
-    cfg = tiny64()
+    cfg = tiny14()
     g1 = perturb_state(TriPlaneGenerator(cfg, seed=3))
     path = str(tmp_path / "g.safetensors")
     save_file({k: v.contiguous() for k, v in g1.state_dict().items()}, path)
@@ -287,7 +291,7 @@ def test_state_dict_round_trip_and_headnerf_boundary(dev, tmp_path):
         out_pose = False
         person_2 = False
         params_len = 76
-        generator_preset = "tiny64"
+        generator_preset = "tiny14"
         generator_weights = path
 
     torch.manual_seed(0)
