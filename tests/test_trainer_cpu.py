@@ -1,0 +1,201 @@
+"""Host logic of the optimisation step (BASELINE config 1: plumbing on CPU) and the N>1 path on gloo.
+
+The product generator has no CPU path, so these tests plug a TEST-ONLY oracle-backed generator
+(autograd through the PyTorch oracle) behind the same `synthesis` interface; what is under test is the
+host side: HeadNeRF_* wiring, label flip, loss, optimiser ordering, checkpoint round trip and the
+flattened all-reduce of the shared gradients."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+from torch import nn
+
+from hfa_gp_amd import headnerf
+from hfa_gp_amd.config import tiny14
+from hfa_gp_amd.generator import TriPlaneGenerator
+from hfa_gp_amd.trainer import Trainer, allreduce_shared_grads
+from oracle import eg3d_oracle as O
+from tests.util import look_at_label
+
+
+class OracleGenerator(TriPlaneGenerator):
+    """TEST INFRASTRUCTURE: a TriPlaneGenerator (same parameters / state_dict keys) whose synthesis runs
+    the CPU oracle with autograd.  Instances are made by re-classing an existing generator."""
+
+    @classmethod
+    def adopt(cls, gen, seed=0):
+        gen.__class__ = cls
+        gen.seed = seed
+        gen.labels_seen = []
+        return gen
+
+    def synthesis(self, ws, c=None, noise_mode="const", **_):
+        assert noise_mode == "const"
+        self.labels_seen.append(c.detach().clone())
+        P = dict(self.named_parameters())
+        P.update(dict(self.named_buffers()))
+        g = torch.Generator().manual_seed(self.seed)
+        b, r = ws.shape[0], self.cfg.neural_rendering_resolution ** 2
+        us = torch.rand(b, r, self.cfg.depth_resolution, 1, generator=g)
+        ui = torch.rand(b * r, self.cfg.depth_resolution_importance, generator=g)
+        return O.synthesis(P, self.cfg, ws, c, us, ui)
+
+
+class Args:
+    out_pose = False
+    person_2 = False
+    params_len = 76
+    size = 32
+    batch_size = 1
+    lr = 3e-4
+    latent_dim_style = 512
+    latent_dim_shape = 8
+    generator_preset = "tiny14"
+    generator_seed = 0
+
+
+def make_trainer(seed=0, world_size=1, rank=0):
+    torch.manual_seed(seed)
+    gen = headnerf.HeadNeRF_3DMM(Args(), Args.size, "cpu", 512, Args.latent_dim_shape)
+    OracleGenerator.adopt(gen.generator)
+    return Trainer(Args(), "cpu", rank=rank, world_size=world_size, mode="3dmm", gen=gen)
+
+
+def frame(seed):
+    g = torch.Generator().manual_seed(seed)
+    real = (0.5 * torch.randn(1, 3, 32, 32, generator=g)).clamp(-1, 1)
+    params = torch.randn(1, 76, generator=g)
+    label = look_at_label(torch.tensor([1.5]), torch.tensor([1.6]), flipped=False)
+    return real, label, params
+
+
+def test_gen_update_config1_plumbing():
+    tr = make_trainer()
+    g0 = {k: v.clone() for k, v in tr.gen.generator.state_dict().items()}
+    b0 = tr.gen.bases.detach().clone()
+    real, label, params = frame(2)
+    before = label.clone()
+    l2, lp, img = tr.gen_update(real, label, params)
+    assert torch.isfinite(l2) and float(lp) == 0.0 and img.shape == (1, 3, 32, 32)
+    flipped = before.clone()
+    flipped[:, headnerf.FLIP_COLUMNS] *= -1
+    assert torch.equal(label, flipped)                               # in-place flip reaches the caller
+    assert tr.gen.bases.grad.abs().sum() > 0 and tr.gen.delta.grad.abs().sum() > 0
+    assert all(p.grad is not None and p.grad.abs().sum() > 0 for p in tr.gen.weights_3dmm.parameters())
+    assert not torch.equal(tr.gen.bases.detach(), b0)                # Adam stepped the shared basis
+    assert all(torch.equal(v, g0[k]) for k, v in tr.gen.generator.state_dict().items())   # generator frozen
+    # after tune_generator() the SAME optimiser starts moving the generator (trainer_rgb.py:58-60,69-71)
+    tr.tune_generator()
+    real, label, params = frame(3)
+    tr.gen_update(real, label, params)
+    moved = [k for k, v in tr.gen.generator.state_dict().items() if not torch.equal(v, g0[k])]
+    assert any(k.endswith("conv1.weight") for k in moved)
+
+
+def test_loss_decreases_on_one_frame():
+    tr = make_trainer(seed=1)
+    tr.g_optim = torch.optim.Adam([p for p in tr.gen.parameters() if p.requires_grad], lr=1e-2)
+    real, label0, params = frame(5)
+    losses = []
+    for _ in range(6):
+        losses.append(float(tr.gen_update(real, label0.clone(), params)[0]))
+    assert losses[-1] < losses[0]
+
+
+def test_checkpoint_round_trip(tmp_path):
+    tr = make_trainer(seed=2)
+    real, label, params = frame(7)
+    tr.gen_update(real, label, params)
+    path = tr.save(12, str(tmp_path))
+    assert os.path.basename(path) == "000012.pt"
+    sd = torch.load(path, weights_only=False)
+    assert set(sd) == {"gen", "g_optim", "args"}
+    assert "bases" in sd["gen"] and "delta" in sd["gen"] and "weights_3dmm.fc.0.weight" in sd["gen"]
+    assert any(k.startswith("generator.") for k in sd["gen"])
+    tr2 = make_trainer(seed=99)
+    assert tr2.resume(path) == 12
+    assert torch.equal(tr2.gen.bases.detach(), tr.gen.bases.detach())
+    a = tr.sample(None, frame(8)[1], frame(8)[2])
+    b = tr2.sample(None, frame(8)[1], frame(8)[2])
+    assert torch.allclose(a, b, atol=1e-6)
+
+
+def test_sample_bases_alternates_label_flip():
+    tr = make_trainer(seed=3)
+    imgs = tr.sample_bases()
+    assert len(imgs) == Args.latent_dim_shape and imgs[0].shape == (1, 3, 64, 64)
+    seen = tr.gen.generator.labels_seen
+    assert torch.equal(seen[0], seen[2]) and not torch.equal(seen[0], seen[1])      # reference quirk 2
+    assert torch.equal(seen[0][:, headnerf.FLIP_COLUMNS], -seen[1][:, headnerf.FLIP_COLUMNS])
+
+
+# ----------------------------------------------------------------------------- N > 1 (gloo, world_size 2)
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    try:
+        # different initial seeds per rank: the constructor must broadcast rank 0's parameters
+        tr = make_trainer(seed=10 + rank, world_size=world, rank=rank)
+        start = tr.gen.bases.detach().clone()
+        real, label, params = frame(20 + rank)              # each rank owns its own frame
+        tr.gen_update(real, label, params)
+        out[rank] = {"start": start, "bases": tr.gen.bases.detach().clone(),
+                     "grad": tr.gen.bases.grad.detach().clone(),
+                     "fc0": tr.gen.weights_3dmm.fc[0].weight.detach().clone()}
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_allreduce_shared_grads():
+    world, port = 2, _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+        r0, r1 = out[0], out[1]
+        assert torch.equal(r0["start"], r1["start"])                      # broadcast from rank 0
+        assert torch.equal(r0["grad"], r1["grad"])                        # one flattened all-reduce
+        assert torch.equal(r0["bases"], r1["bases"]) and torch.equal(r0["fc0"], r1["fc0"])
+    # the synchronised gradient is the MEAN of the two per-frame gradients
+    grads = []
+    for rank in range(2):
+        tr = make_trainer(seed=10, world_size=1)
+        real, label, params = frame(20 + rank)
+        tr.g_optim = torch.optim.SGD(tr.gen.parameters(), lr=0.0)
+        tr.gen_update(real, label, params)
+        grads.append(tr.gen.bases.grad.detach().clone())
+    assert torch.allclose(r0["grad"], 0.5 * (grads[0] + grads[1]), atol=1e-7, rtol=1e-4)
+
+
+def _flat_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        a = torch.nn.Parameter(torch.zeros(3, 4))
+        b = torch.nn.Parameter(torch.zeros(5))
+        c = torch.nn.Parameter(torch.zeros(2), requires_grad=False)
+        a.grad = torch.full((3, 4), float(rank + 1))
+        n = allreduce_shared_grads([a, b, c], world)        # b has no grad yet -> treated as zeros
+        out[rank] = (n, a.grad.clone(), b.grad.clone())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_flat_allreduce_numerics():
+    world, port = 2, _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_flat_worker, args=(world, port, out), nprocs=world, join=True)
+        for rank in range(world):
+            n, ga, gb = out[rank]
+            assert n == 17 and torch.equal(ga, torch.full((3, 4), 1.5)) and torch.equal(gb, torch.zeros(5))
