@@ -1,0 +1,58 @@
+"""Condense the rocprofv3 CSVs written by run_profile.sh into a small markdown summary."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def find(root, pat):
+    hits = sorted(glob.glob(os.path.join(root, "**", pat), recursive=True))
+    return hits[0] if hits else None
+
+
+def short(name):
+    name = name.replace("hfagp::", "").replace("void ", "")
+    return name.split("(")[0][:60]
+
+
+def main():
+    out, tag = sys.argv[1], sys.argv[2]
+    print(f"# rocprofv3 summary {tag}\n")
+    js = os.path.join(out, "bench_unprofiled.log")
+    if os.path.exists(js):
+        for line in open(js):
+            if line.startswith("{"):
+                d = json.loads(line)
+                print(f"bench (un-profiled): {d['value']:.1f} {d['unit']}, {d['ms_per_step']:.2f} ms/step, "
+                      f"B={d['config']['frames_per_step_per_gpu']}; modconv {d['roofline']['achieved']:.1f} TFLOP/s "
+                      f"({d['roofline']['frac']:.3f} of fp32 MFMA peak); raymarch "
+                      f"{d['roofline_raymarch']['achieved']:.0f} GB/s algorithmic ({d['roofline_raymarch']['frac']:.3f} of 8 TB/s), "
+                      f"{d['roofline_raymarch']['avg_launch_ms']:.3f} ms/launch\n")
+    stats = find(os.path.join(out, "trace"), "*kernel_stats.csv")
+    if stats:
+        print("## kernel stats (rocprofv3 --kernel-trace --stats), bench command\n")
+        print("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|")
+        for r in csv.DictReader(open(stats)):
+            print(f"| {short(r['Name'])} | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.3f} | "
+                  f"{float(r['AverageNs'])/1e3:.1f} | {float(r['Percentage']):.2f} |")
+    for kind, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+        f = find(os.path.join(out, kind), "*counter_collection.csv")
+        if not f:
+            continue
+        agg = defaultdict(lambda: [0, 0.0])
+        for r in csv.DictReader(open(f)):
+            if r.get("Counter_Name") != counter:
+                continue
+            a = agg[short(r["Kernel_Name"])]
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
+        print(f"\n## {counter} per launch (KiB as reported; gfx950: FETCH_SIZE under-reports wide reads 2x, see MI355X_MICROARCH.md)\n")
+        print("| kernel | launches | avg per launch (MB, raw) |\n|---|---|---|")
+        for k, (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            print(f"| {k} | {n} | {v / n * 1024 / 1e6:.2f} |")
+
+
+if __name__ == "__main__":
+    main()
