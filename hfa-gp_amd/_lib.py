@@ -69,10 +69,28 @@ class SkipArgs(C.Structure):
 class TorgbArgs(C.Structure):
     _fields_ = [
         ("x", C.c_void_p), ("weight", C.c_void_p), ("styles", C.c_void_p), ("bias", C.c_void_p),
-        ("rgb_in", C.c_void_p), ("rgb_out", C.c_void_p),
+        ("rgb_in", C.c_void_p), ("rgb_out", C.c_void_p), ("y_pre", C.c_void_p),
         ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32),
         ("clamp", C.c_float),
     ]
+
+
+class PointwiseBwdArgs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "dxs_conv", "s_conv", "dxs_rgb", "s_rgb", "g_rgb_small", "w_rgb_small", "s_small", "g_direct", "x",
+        "dcoef_p", "bias_p", "noise_p", "g_out", "partial", "sums")] + \
+        [(n, C.c_int32) for n in ("B", "H", "W", "C", "Co", "nchunks", "has_producer", "act_p")] + \
+        [(n, C.c_float) for n in ("noise_strength_p", "alpha", "gain", "clamp")]
+
+
+class StyleBwdArgs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("ds", "dd", "styles", "dcoef", "wsq", "affine_w", "dstot", "dw")] + \
+        [(n, C.c_int32) for n in ("B", "Cin", "Cout", "w_dim", "dw_stride", "accumulate")] + \
+        [("style_gain", C.c_float)]
+
+
+class RaymarchBwdArgs(C.Structure):
+    _fields_ = [("fwd", RaymarchArgs), ("g_feat", C.c_void_p), ("d_planes", C.c_void_p), ("rec", C.c_void_p)]
 
 
 # every symbol include/hfagp.h declares: name -> (restype, argtypes)
@@ -87,6 +105,12 @@ SYMBOLS = {
     "hfagp_upfir_epilogue_fwd": (C.c_int, [C.POINTER(UpfirEpilogueArgs), C.c_void_p]),
     "hfagp_skip_upsample_add": (C.c_int, [C.POINTER(SkipArgs), C.c_void_p]),
     "hfagp_torgb_fwd": (C.c_int, [C.POINTER(TorgbArgs), C.c_void_p]),
+    "hfagp_pointwise_bwd": (C.c_int, [C.POINTER(PointwiseBwdArgs), C.c_void_p]),
+    "hfagp_upfir_bwd": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p]),
+    "hfagp_upsample2d_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "hfagp_planes_to_nhwc": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p]),
+    "hfagp_style_bwd": (C.c_int, [C.POINTER(StyleBwdArgs), C.c_void_p]),
+    "hfagp_raymarch_bwd": (C.c_int, [C.POINTER(RaymarchBwdArgs), C.c_void_p]),
     "hfagp_upfirdn2d_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int32] * 12 + [C.c_float, C.c_void_p]),
     "hfagp_bias_act_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64,
                                      C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p]),

@@ -1,0 +1,163 @@
+"""Backward pass of ``TriPlaneGenerator.synthesis`` w.r.t. the latent ``ws`` (generator frozen) —
+what HFA-GP's fitting step needs for its first ``tune_iter`` iterations
+(/root/reference/code/trainer_rgb.py:59-60,73-98: ``g_loss.backward()`` flows through
+``generator.synthesis`` into ``bases`` / ``delta`` / the driver net).
+
+All arithmetic is HIP (ops.py); this file only walks the tape in reverse:
+
+  image ── toRGB/skip adjoints ──► SR block1 ──► SR block0 ──► feature image ──► ray-march backward
+        ──► d planes ──► backbone blocks 256 … 4 ──► per-layer style gradients ──► d ws
+
+Per activation tensor X one fused ``pointwise_bwd`` pass sums the input gradients of X's consumers, reduces
+their style gradients and pushes the result through the producer's clamp / leaky-ReLU / demodulation; the
+GEMM-shaped adjoints (conv bwd-data) run on the forward MFMA kernel with transposed weights.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import torch
+
+from . import ops
+
+
+def _masked(g: torch.Tensor, y: Optional[torch.Tensor], clamp: Optional[float]) -> torch.Tensor:
+    """Gradient through bias_act's clamp: zero where the (pre-clamp) output reached the limit."""
+    if clamp is None or y is None:
+        return g
+    return g * (y.abs() < clamp)
+
+
+class _Backward:
+    def __init__(self, gen, tape, d_ws: torch.Tensor):
+        self.gen, self.tape, self.d_ws = gen, tape, d_ws
+        self._wt_t = {}
+
+    # transposed-weight images for the bwd-data GEMMs (cached on the generator like the forward ones)
+    def wt_t(self, weight: torch.Tensor) -> torch.Tensor:
+        key = ("T", id(weight))
+        hit = self.gen._prep.get(key)
+        if hit is not None and hit[0] == weight._version and hit[1] == weight.data_ptr():
+            return hit[2]
+        wt, _ = ops.weight_prep(weight.detach().transpose(0, 1).contiguous())
+        self.gen._prep[key] = (weight._version, weight.data_ptr(), wt, None)
+        return wt
+
+    def style_grad(self, rec_layer: dict, ds: torch.Tensor, dd: Optional[torch.Tensor], style_gain: float = 1.0,
+                   affine=None, wsq=None, dcoef=None):
+        affine = affine if affine is not None else rec_layer["layer"].affine
+        ops.style_bwd(ds, dd, rec_layer["styles"], dcoef, wsq, affine.weight, self.d_ws[:, rec_layer["row"]],
+                      style_gain, accumulate=True)
+
+    # ------------------------------------------------------------------ one SynthesisBlock, in reverse
+    def block(self, rec: dict, g_img, dxs_next: Optional[torch.Tensor], s_next: Optional[torch.Tensor],
+              next_layer_rec: Optional[dict]):
+        """g_img: gradient of the block's output skip image (NCHW small / NHWC 96-ch).
+        dxs_next / s_next: raw bwd-data of the NEXT block's conv0 w.r.t. (x*s) and its styles (or None).
+        Returns (dxs of this block's conv0 w.r.t. its modulated input | None, conv0 rec | None, g_img_prev)."""
+        rgb, c1, c0 = rec["rgb"], rec["conv1"], rec["conv0"]
+        tr = rgb["torgb"]
+        cin = tr.weight.shape[1]
+        x1 = c1["out"]
+        # ---- toRGB + skip
+        g_img_prev = None
+        if rec["img_in"] is not None:
+            g_img_prev = ops.upsample2d_bwd(g_img, channels_last=not rgb["small"])
+        kw = {}
+        if rgb["small"]:
+            g_y = _masked(g_img, rgb["y_pre"], rgb["clamp"]).contiguous()
+            kw = dict(g_rgb_small=g_y, w_rgb_small=tr.weight.detach().reshape(tr.weight.shape[0], cin),
+                      s_small=rgb["styles"])
+        else:
+            g_y = _masked(g_img, rgb["y"], rgb["clamp"]).contiguous()
+            dxs_rgb = ops.modconv(g_y, self.wt_t(tr.weight), cin, ops.CONV1X1)
+            kw = dict(dxs_rgb=dxs_rgb, s_rgb=rgb["styles"])
+        # ---- X = conv1 output: consumers = next conv0 (+) toRGB; producer = conv1
+        g_conv1, sums = ops.pointwise_bwd(x1, dxs_conv=dxs_next, s_conv=s_next, producer=c1["producer"], **kw)
+        if next_layer_rec is not None:
+            next_layer_rec["ds"] = sums[:, 0]
+        ds_rgb = sums[:, 2] if rgb["small"] else sums[:, 1]
+        ops.style_bwd(ds_rgb, None, rgb["styles"], None, None, tr.affine.weight, self.d_ws[:, rgb["row"]],
+                      1.0 / math.sqrt(cin), accumulate=True)
+        c1["dd"] = sums[:, 3]
+        # ---- conv1 bwd-data
+        c1_cin = c1["layer"].weight.shape[1]
+        dxs1 = ops.modconv(g_conv1, self.wt_t(c1["layer"].weight), c1_cin, ops.CONV3X3_BWD)
+        if c0 is None:
+            # b4: the input is the learned constant (broadcast over the batch): only the style gradient is needed
+            xc = c1["x"].expand(dxs1.shape[0], -1, -1, -1).contiguous()
+            _, s0 = ops.pointwise_bwd(xc, dxs_conv=dxs1, s_conv=c1["styles"])
+            c1["ds"] = s0[:, 0]
+            self.finish_layer(c1)
+            return None, None, g_img_prev
+        # ---- X = conv0 output: consumer = conv1; producer = conv0 (up-sampling layer)
+        g_conv0, s0 = ops.pointwise_bwd(c0["out"], dxs_conv=dxs1, s_conv=c1["styles"], producer=c0["producer"])
+        c1["ds"] = s0[:, 0]
+        c0["dd"] = s0[:, 3]
+        self.finish_layer(c1)
+        gph = ops.upfir_bwd(g_conv0)
+        c0_cin = c0["layer"].weight.shape[1]
+        dxs0 = ops.modconv(gph, self.wt_t(c0["layer"].weight), c0_cin, ops.CONVS2_BWD)
+        return dxs0, c0, g_img_prev
+
+    def finish_layer(self, rec: dict):
+        """ds (from the pass over the layer's input) and dd (from the pass over its output) are both known."""
+        ops.style_bwd(rec["ds"], rec["dd"], rec["styles"], rec["dcoef"], rec["wsq"], rec["layer"].affine.weight,
+                      self.d_ws[:, rec["row"]], 1.0, accumulate=True)
+
+
+class SynthesisFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ws, c, u_strat, u_imp, gen):
+        tape = {}
+        with torch.no_grad():
+            img, rgb_raw, depth, _, _ = gen._forward_impl(ws.detach().float().contiguous(),
+                                                         c.detach().float().contiguous(), u_strat, u_imp, tape)
+        ctx.gen, ctx.tape = gen, tape
+        ctx.ws_shape = ws.shape
+        ctx.mark_non_differentiable(depth)
+        return img, rgb_raw, depth
+
+    @staticmethod
+    @torch.no_grad()
+    def backward(ctx, g_img, g_raw, _g_depth):
+        gen, tape = ctx.gen, ctx.tape
+        cfg = gen.cfg
+        b = tape["batch"]
+        dev = tape["planes"].device
+        d_ws = torch.zeros(ctx.ws_shape, device=dev, dtype=torch.float32)
+        bw = _Backward(gen, tape, d_ws)
+        if g_img is None:
+            g_img = torch.zeros(b, cfg.img_channels, cfg.img_resolution, cfg.img_resolution, device=dev)
+        g_img = g_img.float().contiguous()
+
+        # ---- super-resolution, block1 then block0
+        sr1, sr0 = tape["sr"][1], tape["sr"][0]
+        dxs, c0rec, g_rgb = bw.block(sr1, g_img, None, None, None)
+        dxs, c0rec0, g_rgb_raw = bw.block(sr0, g_rgb, dxs, c0rec["styles"], c0rec)
+        bw.finish_layer(c0rec)
+        # ---- feature image: consumer = SR block0.conv0, plus the first 3 channels through image_raw
+        feat_img = tape["feat_img"]
+        g_direct = torch.zeros_like(feat_img)
+        g_direct[..., :3] = g_rgb_raw.permute(0, 2, 3, 1)
+        if g_raw is not None:
+            g_direct[..., :3] += g_raw.permute(0, 2, 3, 1)
+        g_feat, s = ops.pointwise_bwd(feat_img.contiguous(), dxs_conv=dxs, s_conv=c0rec0["styles"], g_direct=g_direct)
+        c0rec0["ds"] = s[:, 0]
+        bw.finish_layer(c0rec0)
+        # ---- renderer
+        res = cfg.neural_rendering_resolution
+        d_planes = ops.raymarch_bwd(g_feat.view(b, res * res, 32), tape["planes"], u_strat=tape["u_strat"],
+                                    u_imp=tape["u_imp"], **gen._render_args(tape["c"]))
+        # ---- backbone, last block first
+        g_img_b = ops.planes_to_nhwc(d_planes)
+        dxs, nxt = None, None
+        for rec in reversed(tape["backbone"]):
+            s_next = nxt["styles"] if nxt is not None else None
+            dxs_new, c0, g_img_b = bw.block(rec, g_img_b, dxs, s_next, nxt)
+            if nxt is not None:
+                bw.finish_layer(nxt)
+            dxs, nxt = dxs_new, c0
+        ctx.tape = None
+        return d_ws, None, None, None, None

@@ -1,0 +1,302 @@
+// Streaming kernels of the backward pass of the synthesis path (gfx950).  HBM-bound, channels-last,
+// 16 bytes per lane.  The GEMM-shaped parts of the backward pass (conv bwd-data) reuse modconv_kernel
+// with transposed weights (modes HFAGP_CONV3X3_BWD / HFAGP_CONVS2_BWD / HFAGP_CONV1X1).
+//
+// Gradient bookkeeping of one SynthesisLayer P (out = clamp(lrelu(d*conv(x*s, W) + noise + bias) * gain)):
+//   g_pre  = g_out * gain * lrelu'(out) * [|out| < clamp]          (EG3D bias_act backward uses `out`)
+//   g_conv = g_pre * d            -> input of P's bwd-data GEMM (adjoint of conv w.r.t. x*s)
+//   dd[b,o] = sum_pix g_pre * conv,   conv = (pre - bias - noise) / d,  pre = lrelu^-1(out / gain)
+//   dxs    = bwd-data(g_conv)     -> dx = dxs * s,   ds[b,i] = sum_pix dxs * x
+// One fused pass per activation tensor X does the "dx of the consumers" and the "g_conv of the producer".
+#include "common.h"
+
+namespace hfagp {
+
+constexpr int kRed = 4;      // reductions per channel: ds_conv, ds_rgb, ds_small, dd_p
+
+__global__ void __launch_bounds__(256) pointwise_bwd_kernel(const HfagpPointwiseBwdArgs a, int rows_per_block) {
+    // block = (chunk of pixel rows, sample b); thread = (pixel lane, 4-channel group)
+    extern __shared__ __attribute__((aligned(16))) float red[];      // [256/C4][kRed][C]
+    const int C4 = a.C >> 2;
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int c4 = threadIdx.x % C4, pl = threadIdx.x / C4, npl = 256 / C4;
+    const int HW = a.H * a.W;
+    const int p_begin = chunk * rows_per_block, p_end = min(HW, p_begin + rows_per_block);
+    const size_t base = (size_t)b * HW * C4;
+
+    float4 s_c = make_float4(0, 0, 0, 0), s_r = s_c, d_p = make_float4(1, 1, 1, 1), b_p = s_c;
+    if (a.s_conv) s_c = reinterpret_cast<const float4*>(a.s_conv + (size_t)b * a.C)[c4];
+    if (a.s_rgb) s_r = reinterpret_cast<const float4*>(a.s_rgb + (size_t)b * a.C)[c4];
+    if (a.dcoef_p) d_p = reinterpret_cast<const float4*>(a.dcoef_p + (size_t)b * a.C)[c4];
+    if (a.bias_p) b_p = reinterpret_cast<const float4*>(a.bias_p)[c4];
+    float4 wsm[4];                       // small toRGB: w[c][i] * s_small[b][i]
+    float4 s_sm = make_float4(0, 0, 0, 0);
+    if (a.g_rgb_small) {
+        s_sm = reinterpret_cast<const float4*>(a.s_small + (size_t)b * a.C)[c4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            wsm[c] = c < a.Co ? reinterpret_cast<const float4*>(a.w_rgb_small + (size_t)c * a.C)[c4] : make_float4(0, 0, 0, 0);
+    }
+    float acc[kRed][4];
+#pragma unroll
+    for (int r = 0; r < kRed; ++r)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[r][k] = 0.f;
+
+    const bool pvalid = pl < npl;        // 256 % C4 != 0 leaves idle threads
+    if (pvalid && c4 < C4)
+        for (int p = p_begin + pl; p < p_end; p += npl) {
+            const size_t e = base + (size_t)p * C4 + c4;
+            const float4 x = reinterpret_cast<const float4*>(a.x)[e];
+            float gx[4] = {0, 0, 0, 0};
+            const float xv[4] = {x.x, x.y, x.z, x.w};
+            if (a.dxs_conv) {
+                const float4 g = reinterpret_cast<const float4*>(a.dxs_conv)[e];
+                const float gv[4] = {g.x, g.y, g.z, g.w}, sv[4] = {s_c.x, s_c.y, s_c.z, s_c.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { gx[k] += gv[k] * sv[k]; acc[0][k] += gv[k] * xv[k]; }
+            }
+            if (a.dxs_rgb) {
+                const float4 g = reinterpret_cast<const float4*>(a.dxs_rgb)[e];
+                const float gv[4] = {g.x, g.y, g.z, g.w}, sv[4] = {s_r.x, s_r.y, s_r.z, s_r.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { gx[k] += gv[k] * sv[k]; acc[1][k] += gv[k] * xv[k]; }
+            }
+            if (a.g_rgb_small) {
+                float t[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (c < a.Co) {
+                        const float g = a.g_rgb_small[((size_t)b * a.Co + c) * HW + p];
+                        t[0] += g * wsm[c].x; t[1] += g * wsm[c].y; t[2] += g * wsm[c].z; t[3] += g * wsm[c].w;
+                    }
+                const float sv[4] = {s_sm.x, s_sm.y, s_sm.z, s_sm.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { gx[k] += t[k] * sv[k]; acc[2][k] += t[k] * xv[k]; }
+            }
+            if (a.g_direct) {
+                const float4 g = reinterpret_cast<const float4*>(a.g_direct)[e];
+                gx[0] += g.x; gx[1] += g.y; gx[2] += g.z; gx[3] += g.w;
+            }
+            // producer layer P: through clamp / gain / leaky-ReLU, then the demodulation
+            const float nz = a.noise_p ? a.noise_p[p] * a.noise_strength_p : 0.f;
+            const float dv[4] = {d_p.x, d_p.y, d_p.z, d_p.w}, bv[4] = {b_p.x, b_p.y, b_p.z, b_p.w};
+            float go[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float g = gx[k];
+                float pre = xv[k];
+                if (a.has_producer) {
+                    if (a.clamp >= 0.f && fabsf(xv[k]) >= a.clamp) g = 0.f;
+                    g *= a.gain;
+                    pre = xv[k] / a.gain;
+                    if (a.act_p == HFAGP_ACT_LRELU && xv[k] < 0.f) { g *= a.alpha; pre /= a.alpha; }
+                    acc[3][k] += g * (pre - bv[k] - nz) / dv[k];
+                    g *= dv[k];
+                }
+                go[k] = g;
+            }
+            reinterpret_cast<float4*>(a.g_out)[e] = make_float4(go[0], go[1], go[2], go[3]);
+        }
+    // ---- block reduction over the pixel lanes, then one deterministic partial per (b, chunk)
+    float* mine = red + ((size_t)pl * kRed) * a.C + c4 * 4;
+#pragma unroll
+    for (int r = 0; r < kRed; ++r)
+        if (pvalid) *reinterpret_cast<float4*>(mine + r * a.C) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
+    __syncthreads();
+    for (int i = threadIdx.x; i < kRed * a.C; i += 256) {
+        float s = 0.f;
+        for (int q = 0; q < npl; ++q) s += red[(size_t)q * kRed * a.C + i];
+        a.partial[(((size_t)b * gridDim.x + chunk) * kRed) * a.C + i] = s;
+    }
+}
+
+// sums[b][r][c] = sum over chunks of partial[b][chunk][r][c]
+__global__ void __launch_bounds__(256) reduce_partials_kernel(const float* __restrict__ partial,
+                                                              float* __restrict__ sums, int B, int nchunks, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // over B * n
+    if (i >= B * n) return;
+    const int b = i / n, k = i % n;
+    float s = 0.f;
+    for (int q = 0; q < nchunks; ++q) s += partial[((size_t)b * nchunks + q) * n + k];
+    sums[i] = s;
+}
+
+// ---------------------------------------------------------------- adjoint of (FIR pad 1 gain 4) + parity split
+// g_y [B][2H][2W][C] -> gph [2][2][B][H+1][W+1][C],  gph[a][b][m][n] = g_yt[2m+a][2n+b],
+// g_yt[Y][X] = sum_{p,q} f[p] f[q] g_y[Y-p+1][X-q+1],  f = [1,3,3,1]/4.
+__global__ void __launch_bounds__(256) upfir_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gph,
+                                                        int B, int H, int W, int C) {
+    const int C4 = C >> 2;
+    const long long per = (long long)B * (H + 1) * (W + 1) * C4;
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= 4 * per) return;
+    const int phase = (int)(tid / per);
+    long long r = tid % per;
+    const int c4 = (int)(r % C4); r /= C4;
+    const int n = (int)(r % (W + 1)); r /= (W + 1);
+    const int m = (int)(r % (H + 1));
+    const int b = (int)(r / (H + 1));
+    const int Y = 2 * m + (phase >> 1), X = 2 * n + (phase & 1);
+    const int Ho = 2 * H, Wo = 2 * W;
+    const float f[4] = {0.25f, 0.75f, 0.75f, 0.25f};
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (Y <= Ho && X <= Wo) {
+        const float4* src = reinterpret_cast<const float4*>(gy) + (size_t)b * Ho * Wo * C4 + c4;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int y = Y - p + 1;
+            if (y < 0 || y >= Ho) continue;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int x = X - q + 1;
+                if (x < 0 || x >= Wo) continue;
+                const float4 v = src[((size_t)y * Wo + x) * C4];
+                const float wgt = f[p] * f[q];
+                o.x += wgt * v.x; o.y += wgt * v.y; o.z += wgt * v.z; o.w += wgt * v.w;
+            }
+        }
+    }
+    reinterpret_cast<float4*>(gph)[tid] = o;
+}
+
+// ---------------------------------------------------------------- adjoint of upsample2d (skip images)
+// g_in[i][j] = sum_{p,q} k[p] k[q] g[2i-1+p][2j-1+q],  k = [.25,.75,.75,.25]; generic strides so that the same
+// kernel serves channels-last (inner = C) and NCHW (inner = 1) tensors.
+__global__ void __launch_bounds__(256) upsample2d_bwd_kernel(const float* __restrict__ g, float* __restrict__ gin,
+                                                             long long outer, int H, int W, int inner) {
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= outer * H * W * inner) return;
+    const int c = (int)(tid % inner);
+    const int j = (int)((tid / inner) % W);
+    const int i = (int)((tid / ((long long)inner * W)) % H);
+    const long long o = tid / ((long long)inner * W * H);
+    const int Ho = 2 * H, Wo = 2 * W;
+    const float k[4] = {0.25f, 0.75f, 0.75f, 0.25f};
+    const float* src = g + (size_t)o * Ho * Wo * inner + c;
+    float acc = 0.f;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int y = 2 * i - 1 + p;
+        if (y < 0 || y >= Ho) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int x = 2 * j - 1 + q;
+            if (x < 0 || x >= Wo) continue;
+            acc += k[p] * k[q] * src[((size_t)y * Wo + x) * inner];
+        }
+    }
+    gin[tid] = acc;
+}
+
+// plane-major [B][3][H][W][Cp] -> channels-last [B][H][W][3*Cp] (gradient of the tri-plane volume back
+// into the layout of the backbone's skip image)
+__global__ void __launch_bounds__(256) planes_to_nhwc_kernel(const float* __restrict__ pm, float* __restrict__ y,
+                                                             int B, int H, int W, int Cp) {
+    const int C4 = (3 * Cp) >> 2;
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= (long long)B * H * W * C4) return;
+    const int c4 = (int)(tid % C4);
+    const long long pix = tid / C4;
+    const int x = (int)(pix % W), yy = (int)((pix / W) % H), b = (int)(pix / ((long long)W * H));
+    const int c = c4 * 4, pl = c / Cp, ch = c % Cp;
+    reinterpret_cast<float4*>(y)[tid] =
+        *reinterpret_cast<const float4*>(pm + ((((size_t)b * 3 + pl) * H + yy) * W + x) * Cp + ch);
+}
+
+// ---------------------------------------------------------------- styles -> latent
+// dstot[b][i] = gain * ( ds[b][i] - s[b][i]/gain... ) see host comment; wave per (b, i)
+__global__ void __launch_bounds__(256) style_bwd_ds_kernel(const float* __restrict__ ds, const float* __restrict__ dd,
+                                                           const float* __restrict__ styles,
+                                                           const float* __restrict__ dcoef,
+                                                           const float* __restrict__ wsq, float* __restrict__ dstot,
+                                                           int B, int Cin, int Cout, float style_gain) {
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= B * Cin) return;
+    const int b = wave / Cin, i = wave % Cin;
+    float acc = 0.f;
+    if (dd)   // d = rsqrt(sum_i s_i^2 wsq[o][i] + eps)  ->  dd/ds_i = -d^3 s_i wsq[o][i]
+        for (int o = lane; o < Cout; o += 64) {
+            const float d = dcoef[(size_t)b * Cout + o];
+            acc += dd[(size_t)b * Cout + o] * d * d * d * wsq[(size_t)o * Cin + i];
+        }
+    for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m);
+    if (lane == 0) dstot[wave] = (ds[wave] - styles[wave] * acc) * style_gain;
+}
+
+// dw[b][k] (+)= wgain * sum_i dstot[b][i] * A[i][k]
+__global__ void __launch_bounds__(256) style_bwd_dw_kernel(const float* __restrict__ dstot, const float* __restrict__ A,
+                                                           float* __restrict__ dw, int B, int Cin, int w_dim,
+                                                           int dw_stride, float wgain, int accumulate) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * w_dim) return;
+    const int b = idx / w_dim, k = idx % w_dim;
+    float acc = 0.f;
+    for (int i = 0; i < Cin; ++i) acc += dstot[(size_t)b * Cin + i] * A[(size_t)i * w_dim + k];
+    float* dst = dw + (size_t)b * dw_stride + k;
+    *dst = accumulate ? *dst + acc * wgain : acc * wgain;
+}
+
+}  // namespace hfagp
+
+using namespace hfagp;
+
+extern "C" {
+
+int hfagp_pointwise_bwd(const HfagpPointwiseBwdArgs* a, void* stream) {
+    HFAGP_REQUIRE(a && a->x && a->g_out && a->partial && a->sums, HFAGP_EBADARG, "pointwise_bwd: null pointer");
+    HFAGP_REQUIRE(a->C % 4 == 0 && a->C / 4 <= 256 && a->B > 0 && a->H > 0 && a->W > 0, HFAGP_EUNSUPPORTED,
+                  "pointwise_bwd: C=%d must be a multiple of 4 and <= 1024", a->C);
+    HFAGP_REQUIRE(!a->g_rgb_small || (a->Co >= 1 && a->Co <= 4 && a->w_rgb_small && a->s_small), HFAGP_EBADARG,
+                  "pointwise_bwd: small toRGB needs 1..4 channels, weights and styles");
+    HFAGP_REQUIRE(a->nchunks >= 1, HFAGP_EBADARG, "pointwise_bwd: nchunks");
+    const int HW = a->H * a->W;
+    const int rows = (HW + a->nchunks - 1) / a->nchunks;
+    const int npl = 256 / (a->C / 4);
+    const size_t lds = (size_t)npl * kRed * a->C * sizeof(float);
+    HFAGP_REQUIRE(lds <= 64 * 1024, HFAGP_EUNSUPPORTED, "pointwise_bwd: LDS %zu", lds);
+    hipStream_t s = (hipStream_t)stream;
+    pointwise_bwd_kernel<<<dim3(a->nchunks, a->B), 256, lds, s>>>(*a, rows);
+    const int n = kRed * a->C;
+    reduce_partials_kernel<<<(a->B * n + 255) / 256, 256, 0, s>>>(a->partial, a->sums, a->B, a->nchunks, n);
+    return check_launch("pointwise_bwd");
+}
+
+int hfagp_upfir_bwd(const float* gy, float* gph, int32_t B, int32_t H, int32_t W, int32_t C, void* stream) {
+    HFAGP_REQUIRE(gy && gph, HFAGP_EBADARG, "upfir_bwd: null pointer");
+    HFAGP_REQUIRE(C % 4 == 0 && B > 0 && H > 0 && W > 0, HFAGP_EUNSUPPORTED, "upfir_bwd: C=%d", C);
+    const long long total = 4ll * B * (H + 1) * (W + 1) * (C / 4);
+    upfir_bwd_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(gy, gph, B, H, W, C);
+    return check_launch("upfir_bwd");
+}
+
+int hfagp_upsample2d_bwd(const float* g, float* gin, int64_t outer, int32_t H, int32_t W, int32_t inner, void* stream) {
+    HFAGP_REQUIRE(g && gin, HFAGP_EBADARG, "upsample2d_bwd: null pointer");
+    HFAGP_REQUIRE(outer > 0 && H > 0 && W > 0 && inner > 0, HFAGP_EBADARG, "upsample2d_bwd: bad dims");
+    const long long total = outer * H * W * inner;
+    upsample2d_bwd_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(g, gin, outer, H, W, inner);
+    return check_launch("upsample2d_bwd");
+}
+
+int hfagp_planes_to_nhwc(const float* pm, float* y, int32_t B, int32_t H, int32_t W, int32_t Cp, void* stream) {
+    HFAGP_REQUIRE(pm && y, HFAGP_EBADARG, "planes_to_nhwc: null pointer");
+    HFAGP_REQUIRE(Cp % 4 == 0, HFAGP_EUNSUPPORTED, "planes_to_nhwc: Cp=%d", Cp);
+    const long long total = (long long)B * H * W * (3 * Cp / 4);
+    planes_to_nhwc_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(pm, y, B, H, W, Cp);
+    return check_launch("planes_to_nhwc");
+}
+
+int hfagp_style_bwd(const HfagpStyleBwdArgs* a, void* stream) {
+    HFAGP_REQUIRE(a && a->ds && a->styles && a->affine_w && a->dstot && a->dw, HFAGP_EBADARG, "style_bwd: null pointer");
+    HFAGP_REQUIRE(!a->dd || (a->dcoef && a->wsq && a->Cout > 0), HFAGP_EBADARG, "style_bwd: dd needs dcoef and wsq");
+    hipStream_t s = (hipStream_t)stream;
+    const int waves = a->B * a->Cin;
+    style_bwd_ds_kernel<<<(waves + 3) / 4, 256, 0, s>>>(a->ds, a->dd, a->styles, a->dcoef, a->wsq, a->dstot, a->B,
+                                                       a->Cin, a->Cout, a->style_gain);
+    const int n = a->B * a->w_dim;
+    style_bwd_dw_kernel<<<(n + 255) / 256, 256, 0, s>>>(a->dstot, a->affine_w, a->dw, a->B, a->Cin, a->w_dim,
+                                                       a->dw_stride, 1.0f / sqrtf((float)a->w_dim), a->accumulate);
+    return check_launch("style_bwd");
+}
+
+}  // extern "C"

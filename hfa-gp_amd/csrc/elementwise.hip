@@ -212,6 +212,7 @@ __global__ void __launch_bounds__(256) torgb_kernel(HfagpTorgbArgs a) {
     const int Y = pix / a.W, X = pix % a.W;
     for (int c = 0; c < a.Cout; ++c) {
         float v = acc[c] + a.bias[c];
+        if (a.y_pre) a.y_pre[((size_t)b * a.Cout + c) * HW + pix] = v;      // before the clamp: backward mask
         if (a.clamp >= 0.f) v = fminf(fmaxf(v, -a.clamp), a.clamp);
         if (a.rgb_in) {
             const int Hi = a.H >> 1, Wi = a.W >> 1;

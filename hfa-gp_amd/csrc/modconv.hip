@@ -26,6 +26,8 @@ struct Phase {
     int ntaps;
     int mh, mw;                  // extent of the (m, n) position grid of this phase
     int sy, sx, oy0, ox0;        // output pixel = (sy*m + oy0, sx*n + ox0)
+    int slab;                    // output slab of this phase (phases that ACCUMULATE into the same pixels)
+    long long in_off;            // element offset of this phase's input image inside x
     signed char dy[MAXTAPS], dx[MAXTAPS], widx[MAXTAPS];
 };
 
@@ -36,7 +38,8 @@ struct ConvParams {
     long long x_batch_stride;
     long long slab;              // elements per split-K slab (B*Ho*Wo*Cout)
     int B, H, W, Cin, Cout, Ho, Wo;
-    int nphase, tiles_h, tiles_w, tiles_n, ksplit, nchunks;
+    int in_h, in_w;              // extent of the input image(s) (differs from H, W for the parity images)
+    int nphase, nslab, tiles_h, tiles_w, tiles_n, ksplit, nchunks;
     int dymin, dxmin, ph, pw;    // patch origin offset and patch extent (pixels)
     int fused;                   // 1: apply the epilogue here, 0: store raw accumulators
     int act; float noise_strength, alpha, gain, clamp;
@@ -73,7 +76,7 @@ __global__ void __launch_bounds__(256) modconv_kernel(const ConvParams p) {
     constexpr int A_PER_T = ((PH + 2) * (PW + 2) * 2 + 255) / 256;   // float4 per thread, A
     constexpr int B_PER_T = (MAXTAPS * 2 * BN + 255) / 256;          // float4 per thread, B
     float4 ra[A_PER_T], rb[B_PER_T];
-    const float* xb = p.x + (long long)b * p.x_batch_stride;
+    const float* xb = p.x + ph.in_off + (long long)b * p.x_batch_stride;
     const float* sb = p.styles ? p.styles + (size_t)b * p.Cin : nullptr;
     const int nB = ph.ntaps * 2 * BN;
     const int cq = p.Cin >> 2;
@@ -87,7 +90,7 @@ __global__ void __launch_bounds__(256) modconv_kernel(const ConvParams p) {
         if (idx < npatch * 2) {
             const int pix = idx >> 1, q = idx & 1;
             const int iy = m0 + p.dymin + pix / p.pw, ix = n0 + p.dxmin + pix % p.pw;
-            if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) aoff[k] = ((long long)iy * p.W + ix) * p.Cin + 4 * q;
+            if (iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w) aoff[k] = ((long long)iy * p.in_w + ix) * p.Cin + 4 * q;
         }
     }
 #pragma unroll
@@ -179,7 +182,7 @@ __global__ void __launch_bounds__(256) modconv_kernel(const ConvParams p) {
     }
 
     // ---- epilogue.  C/D layout of 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    float* out = p.out + (size_t)ks * p.slab;
+    float* out = p.out + (size_t)(ks * p.nslab + ph.slab) * p.slab;
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
         const int co = co0 + (wn * TN + tn) * 32 + l31;
@@ -251,8 +254,9 @@ struct Plan {
 };
 
 static void set_phase(Phase& ph, int ntaps, int mh, int mw, int sy, int sx, int oy0, int ox0,
-                      const int (*taps)[3]) {
+                      const int (*taps)[3], int slab = 0, long long in_off = 0) {
     ph.ntaps = ntaps; ph.mh = mh; ph.mw = mw; ph.sy = sy; ph.sx = sx; ph.oy0 = oy0; ph.ox0 = ox0;
+    ph.slab = slab; ph.in_off = in_off;
     for (int t = 0; t < ntaps; ++t) {
         ph.dy[t] = (signed char)taps[t][0]; ph.dx[t] = (signed char)taps[t][1]; ph.widx[t] = (signed char)taps[t][2];
     }
@@ -266,6 +270,8 @@ static int make_plan(const HfagpModconvArgs* a, Plan& pl) {
     p.B = a->B; p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.Cout = a->Cout;
     p.act = a->act; p.noise_strength = a->noise_strength; p.alpha = a->alpha; p.gain = a->gain; p.clamp = a->clamp;
     p.nchunks = a->Cin / CK;
+    p.nslab = 1;
+    int in_h = a->H, in_w = a->W;      // extent of the image(s) the patches are read from
 
     // N tile / wave arrangement
     if (a->Cout % 128 == 0) pl.bn = 128;
@@ -303,10 +309,36 @@ static int make_plan(const HfagpModconvArgs* a, Plan& pl) {
         set_phase(p.phase[3], 1, a->H, a->W, 2, 2, 1, 1, t11);
         p.dymin = -1; p.dxmin = -1; p.ph = PH + 1; p.pw = PW + 1;
         gh = a->H + 1; gw = a->W + 1; p.fused = 0;
+    } else if (a->mode == HFAGP_CONV3X3_BWD) {
+        // adjoint of mode 0 w.r.t. its input: dx[p][q] = sum_t g[p - dy_t][q - dx_t] . W_t^T  (taps mirrored)
+        static const int t9[9][3] = {{1, 1, 0}, {1, 0, 1}, {1, -1, 2}, {0, 1, 3}, {0, 0, 4},
+                                     {0, -1, 5}, {-1, 1, 6}, {-1, 0, 7}, {-1, -1, 8}};
+        p.nphase = 1; p.Ho = a->H; p.Wo = a->W;
+        set_phase(p.phase[0], 9, a->H, a->W, 1, 1, 0, 0, t9);
+        p.dymin = -1; p.dxmin = -1; p.ph = PH + 2; p.pw = PW + 2;
+        gh = a->H; gw = a->W; p.fused = 1;
+    } else if (a->mode == HFAGP_CONVS2_BWD) {
+        // adjoint of mode 1 w.r.t. its input: dx[i][j] = sum_{ti,tj} g_yt[2i+ti][2j+tj] . W_{ti,tj}^T.
+        // x holds the four parity images of g_yt: x[a][b] [B][H+1][W+1][Cin], (a,b) = (ti&1, tj&1);
+        // each parity is one phase accumulating into its own slab (summed by the split-K reducer).
+        static const int t00[4][3] = {{0, 0, 0}, {1, 0, 6}, {0, 1, 2}, {1, 1, 8}};
+        static const int t01[2][3] = {{0, 0, 1}, {1, 0, 7}};
+        static const int t10[2][3] = {{0, 0, 3}, {0, 1, 5}};
+        static const int t11[1][3] = {{0, 0, 4}};
+        const long long img = (long long)a->B * (a->H + 1) * (a->W + 1) * a->Cin;
+        p.nphase = 4; p.nslab = 4; p.Ho = a->H; p.Wo = a->W;
+        set_phase(p.phase[0], 4, a->H, a->W, 1, 1, 0, 0, t00, 0, 0);
+        set_phase(p.phase[1], 2, a->H, a->W, 1, 1, 0, 0, t01, 1, img);
+        set_phase(p.phase[2], 2, a->H, a->W, 1, 1, 0, 0, t10, 2, 2 * img);
+        set_phase(p.phase[3], 1, a->H, a->W, 1, 1, 0, 0, t11, 3, 3 * img);
+        p.dymin = 0; p.dxmin = 0; p.ph = PH + 1; p.pw = PW + 1;
+        in_h = a->H + 1; in_w = a->W + 1;
+        gh = a->H; gw = a->W; p.fused = 0;
     } else {
         set_error("modconv: unknown mode %d", a->mode);
         return HFAGP_EBADARG;
     }
+    p.in_h = in_h; p.in_w = in_w;
     p.tiles_h = (gh + PH - 1) / PH;
     p.tiles_w = (gw + PW - 1) / PW;
     p.slab = (long long)a->B * p.Ho * p.Wo * a->Cout;
@@ -323,8 +355,8 @@ static int make_plan(const HfagpModconvArgs* a, Plan& pl) {
     }
     if (ks > p.nchunks) ks = p.nchunks;
     p.ksplit = ks;
-    if (ks > 1) p.fused = 0;
-    pl.ws_bytes = ks > 1 ? (size_t)ks * p.slab * sizeof(float) : 0;
+    if (ks * p.nslab > 1) p.fused = 0;
+    pl.ws_bytes = ks * p.nslab > 1 ? (size_t)ks * p.nslab * p.slab * sizeof(float) : 0;
     pl.grid = dim3((unsigned)(p.tiles_h * p.tiles_w * a->B * p.tiles_n * ks), (unsigned)p.nphase, 1);
     pl.lds_bytes = ((size_t)(PH + 2) * (PW + 2) * AS + (size_t)MAXTAPS * 2 * pl.bn * 4) * sizeof(float);
     return HFAGP_OK;
@@ -360,8 +392,9 @@ int hfagp_modconv_fwd(const HfagpModconvArgs* a, void* stream) {
     if (rc != HFAGP_OK) return rc;
     ConvParams& p = pl.p;
     hipStream_t s = (hipStream_t)stream;
-    if (p.ksplit > 1) {
-        HFAGP_REQUIRE(a->workspace, HFAGP_EBADARG, "modconv: split-K (%d) needs a workspace of %zu bytes", p.ksplit,
+    const int nslabs = p.ksplit * p.nslab;
+    if (nslabs > 1) {
+        HFAGP_REQUIRE(a->workspace, HFAGP_EBADARG, "modconv: split-K (%d slabs) needs a workspace of %zu bytes", nslabs,
                       pl.ws_bytes);
         p.out = a->workspace;
     } else {
@@ -375,11 +408,11 @@ int hfagp_modconv_fwd(const HfagpModconvArgs* a, void* stream) {
     }
     rc = check_launch("modconv_fwd");
     if (rc != HFAGP_OK) return rc;
-    if (p.ksplit > 1) {
-        const int fused = a->mode != HFAGP_CONVT3X3_UP2;
+    if (nslabs > 1) {
+        const int fused = a->mode != HFAGP_CONVT3X3_UP2 && a->mode != HFAGP_CONVS2_BWD;
         const long long n4 = p.slab / 4;
         splitk_epilogue_kernel<<<(unsigned)((n4 + 255) / 256), 256, 0, s>>>(
-            a->workspace, a->y, a->dcoef, a->noise, a->bias, p.slab, p.ksplit, p.Ho * p.Wo, a->Cout, fused, a->act,
+            a->workspace, a->y, a->dcoef, a->noise, a->bias, p.slab, nslabs, p.Ho * p.Wo, a->Cout, fused, a->act,
             a->noise_strength, a->alpha, a->gain, a->clamp);
         rc = check_launch("modconv_fwd/splitk");
     }

@@ -1,0 +1,250 @@
+// Device code shared by the forward ray marcher (raymarch.hip) and its backward pass (raymarch_bwd.hip):
+// ray generation, tri-plane bilinear gather in the MFMA B-operand layout, and the decoder MLP on
+// v_mfma_f32_16x16x4_f32.  See raymarch.hip for the mapping of lanes to samples / channels.
+#pragma once
+#include "common.h"
+
+namespace hfagp {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int CS = 36;   // LDS colour row stride in floats (32 + pad: conflict-free b128 writes)
+
+struct RayParams {
+    HfagpRaymarchArgs a;
+    float lin_step;      // (float(end) - float(start)) / (Sc - 1)   [torch.linspace, fp32]
+    float delta;         // float( (end - start) / (Sc - 1) )        [python double -> fp32]
+    float coord_scale;   // 2 / box_warp
+    int total_rays;
+    const float* g_feat; // backward only: [B][R][32]
+    float* rec;          // backward only: per-sample records [B*R][S][4] = (depth, omega, d sigma, -)
+};
+
+inline int fill_ray_params(const HfagpRaymarchArgs* a, RayParams& p, const char* who) {
+    HFAGP_REQUIRE(a->planes && a->cam2world && a->intrinsics && a->u_strat && a->u_imp && a->dec_w0 && a->dec_b0 &&
+                      a->dec_w1 && a->dec_b1,
+                  HFAGP_EBADARG, "%s: null pointer", who);
+    HFAGP_REQUIRE(a->B > 0 && a->H > 1 && a->W > 1 && a->res > 0, HFAGP_EBADARG, "%s: bad dims", who);
+    HFAGP_REQUIRE(a->box_warp > 0.f && a->ray_end > a->ray_start, HFAGP_EBADARG, "%s: bad ray range", who);
+    HFAGP_REQUIRE(a->Sc == a->Sf && (a->Sc == 16 || a->Sc == 32 || a->Sc == 48), HFAGP_EUNSUPPORTED,
+                  "%s: unsupported sample counts Sc=%d Sf=%d (supported: 16+16, 32+32, 48+48)", who, a->Sc, a->Sf);
+    p.a = *a;
+    p.lin_step = ((float)a->ray_end - (float)a->ray_start) / (float)(a->Sc - 1);
+    p.delta = (float)((a->ray_end - a->ray_start) / (double)(a->Sc - 1));
+    p.coord_scale = (float)(2.0 / (double)a->box_warp);
+    const long long total = (long long)a->B * a->res * a->res;
+    HFAGP_REQUIRE(total < (1ll << 31), HFAGP_EUNSUPPORTED, "%s: too many rays", who);
+    p.total_rays = (int)total;
+    p.g_feat = nullptr;
+    p.rec = nullptr;
+    return HFAGP_OK;
+}
+
+int launch_raymarch(const RayParams& p, bool grads, hipStream_t s);   // raymarch.hip
+
+// Waves of a workgroup are independent here; LDS hand-offs between lanes of ONE wave only need the
+// compiler not to reorder the accesses (the LDS executes a wave's DS instructions in order).
+#define WAVE_SYNC()                                            \
+    do {                                                       \
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                       \
+    } while (0)
+
+// Transcendentals on the hardware units (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1 ulp each).  The libm
+// forms (expf / log1pf / IEEE division) cost ~55 VALU instructions per softplus and made the kernel
+// VALU-bound (17 k VALU instructions per ray, rocprofv3 SQ_INSTS_VALU); these cost ~8.
+//   softplus(x) = max(x, 0) + log(1 + exp(-|x|))   (argument of log in (1, 2]: abs error ~1e-7;
+//                                                   equals x for x > 20 like torch's threshold form)
+__device__ __forceinline__ float exp_f(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+__device__ __forceinline__ float log_f(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
+__device__ __forceinline__ float softplus_f(float x) { return fmaxf(x, 0.f) + log_f(1.f + exp_f(-fabsf(x))); }
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.f + exp_f(-x)); }
+
+__device__ __forceinline__ float wave_scan_mul(float v, int lane) {   // inclusive product scan, 64 lanes
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float u = __shfl_up(v, o);
+        if (lane >= o) v *= u;
+    }
+    return v;
+}
+__device__ __forceinline__ float wave_scan_add(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float u = __shfl_up(v, o);
+        if (lane >= o) v += u;
+    }
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ---------------------------------------------------------------- ray generation (RaySampler.forward)
+__device__ __forceinline__ void ray_setup(const HfagpRaymarchArgs& a, int b, int pi, int pj, float o3[3], float d3[3]) {
+    const float* M = a.cam2world + b * 16;
+    const float* K = a.intrinsics + b * 9;
+    const float fx = K[0], sk = K[1], cx = K[2], fy = K[4], cy = K[5];
+    const float inv_res = 1.0f / (float)a.res, half_res = 0.5f / (float)a.res;
+    const float xc = __fadd_rn(__fmul_rn((float)pj, inv_res), half_res);
+    const float yc = __fadd_rn(__fmul_rn((float)pi, inv_res), half_res);
+    const float xl = __fdiv_rn(__fsub_rn(__fadd_rn(__fsub_rn(xc, cx), __fdiv_rn(__fmul_rn(cy, sk), fy)),
+                                         __fdiv_rn(__fmul_rn(sk, yc), fy)), fx);
+    const float yl = __fdiv_rn(__fsub_rn(yc, cy), fy);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float wv = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(M[4 * k], xl), __fmul_rn(M[4 * k + 1], yl)),
+                                             M[4 * k + 2]), M[4 * k + 3]);
+        o3[k] = M[4 * k + 3];
+        d3[k] = __fsub_rn(wv, o3[k]);
+    }
+    const float nrm = fmaxf(__fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(d3[0], d3[0]), __fmul_rn(d3[1], d3[1])),
+                                                 __fmul_rn(d3[2], d3[2]))), 1e-12f);
+    d3[0] = __fdiv_rn(d3[0], nrm); d3[1] = __fdiv_rn(d3[1], nrm); d3[2] = __fdiv_rn(d3[2], nrm);
+}
+
+// ---------------------------------------------------------------- tri-plane gather
+struct PlaneTaps {            // the 4 bilinear taps of one plane: texel index (y*W + x) and weight (0 if outside)
+    int idx[4];
+    float w[4];
+};
+
+// F.grid_sample(bilinear, zeros, align_corners=False) as ATen's CPU kernel computes it:
+// pixel = (g + 1) * (size / 2) - 0.5;  weights nw = (1-fy)(1-fx), ne = (1-fy)fx, sw = fy(1-fx), se = fy fx
+__device__ __forceinline__ void plane_taps(const HfagpRaymarchArgs& a, float gx, float gy, PlaneTaps& t) {
+    const float fW = (float)a.W, fH = (float)a.H;
+    const float ix = __fsub_rn(__fmul_rn(__fadd_rn(gx, 1.f), fW * 0.5f), 0.5f);
+    const float iy = __fsub_rn(__fmul_rn(__fadd_rn(gy, 1.f), fH * 0.5f), 0.5f);
+    const float fx0 = floorf(ix), fy0 = floorf(iy);
+    const float we = __fsub_rn(ix, fx0), ww = __fsub_rn(1.f, we);
+    const float ws_ = __fsub_rn(iy, fy0), wn = __fsub_rn(1.f, ws_);
+    // clamp before the int conversion so far-away coordinates stay defined
+    const int x0 = (int)fminf(fmaxf(fx0, -2.f), fW + 1.f), y0 = (int)fminf(fmaxf(fy0, -2.f), fH + 1.f);
+    const int x1 = x0 + 1, y1 = y0 + 1;
+    const bool vx0 = x0 >= 0 && x0 < a.W, vx1 = x1 >= 0 && x1 < a.W;
+    const bool vy0 = y0 >= 0 && y0 < a.H, vy1 = y1 >= 0 && y1 < a.H;
+    const int cx0 = min(max(x0, 0), a.W - 1), cx1 = min(max(x1, 0), a.W - 1);
+    const int cy0 = min(max(y0, 0), a.H - 1), cy1 = min(max(y1, 0), a.H - 1);
+    t.w[0] = (vx0 && vy0) ? __fmul_rn(wn, ww) : 0.f;
+    t.w[1] = (vx1 && vy0) ? __fmul_rn(wn, we) : 0.f;
+    t.w[2] = (vx0 && vy1) ? __fmul_rn(ws_, ww) : 0.f;
+    t.w[3] = (vx1 && vy1) ? __fmul_rn(ws_, we) : 0.f;
+    t.idx[0] = cy0 * a.W + cx0; t.idx[1] = cy0 * a.W + cx1;
+    t.idx[2] = cy1 * a.W + cx0; t.idx[3] = cy1 * a.W + cx1;
+}
+
+// sample position -> the three plane projections: (x,y), (x,z), (z,x) [eg3d original] or (z,y) [fixed]
+__device__ __forceinline__ void sample_taps(const RayParams& p, const float o3[3], const float d3[3], float tz,
+                                            PlaneTaps taps[3]) {
+    float q[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) q[k] = __fmul_rn(p.coord_scale, __fadd_rn(o3[k], __fmul_rn(tz, d3[k])));
+    plane_taps(p.a, q[0], q[1], taps[0]);
+    plane_taps(p.a, q[0], q[2], taps[1]);
+    plane_taps(p.a, q[2], p.a.plane_axes == 0 ? q[0] : q[1], taps[2]);
+}
+
+// lane (j, g) accumulates channels 8g..8g+7 of the mean over the 3 planes of the bilinear samples
+__device__ __forceinline__ void gather8(const HfagpRaymarchArgs& a, int b, int g, const PlaneTaps taps[3], float f[8]) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) f[c] = 0.f;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+        const float* base = a.planes + ((size_t)(b * 3 + pl) * a.H * a.W) * 32 + 8 * g;
+        float4 v0[4], v1[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float4* ptr = reinterpret_cast<const float4*>(base + (size_t)taps[pl].idx[k] * 32);
+            v0[k] = ptr[0];
+            v1[k] = ptr[1];
+        }
+        const float v[4][8] = {{v0[0].x, v0[0].y, v0[0].z, v0[0].w, v1[0].x, v1[0].y, v1[0].z, v1[0].w},
+                               {v0[1].x, v0[1].y, v0[1].z, v0[1].w, v1[1].x, v1[1].y, v1[1].z, v1[1].w},
+                               {v0[2].x, v0[2].y, v0[2].z, v0[2].w, v1[2].x, v1[2].y, v1[2].z, v1[2].w},
+                               {v0[3].x, v0[3].y, v0[3].z, v0[3].w, v1[3].x, v1[3].y, v1[3].z, v1[3].w}};
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float acc = v[0][c] * taps[pl].w[0];
+            acc = fmaf(v[1][c], taps[pl].w[1], acc);
+            acc = fmaf(v[2][c], taps[pl].w[2], acc);
+            acc = fmaf(v[3][c], taps[pl].w[3], acc);
+            f[c] += acc;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) f[c] *= 0.3333333333333333f;   // mean over the 3 planes
+}
+
+// ---------------------------------------------------------------- decoder (OSGDecoder) on the matrix core
+// Effective weights W * lr_mul / sqrt(fan_in) as MFMA A-operand registers of lane (j = lane&15, g = lane>>4):
+//   w0a[mt][t]      = W0[16mt + j][8g + t]            layer 1, K step t uses channel 8g + t
+//   w1a[ot][4mt+r]  = W1[1 + 16ot + j][16mt + 4g + r] layer 2, K step (mt, r) uses hidden 16mt + 4g + r
+//   wsig[mt][r]     = W1[0][16mt + 4g + r]            sigma row, VALU
+struct DecoderRegs {
+    float w0a[4][8], b0c[4][4], wsig[4][4], w1a[2][16], b1c[2][4];
+    float bsig;
+};
+
+__device__ __forceinline__ void load_decoder(const HfagpRaymarchArgs& a, int j, int g, DecoderRegs& w) {
+    const float g0 = a.decoder_lr_mul * 0.17677669529663687f;   // 1/sqrt(32)
+    const float g1 = a.decoder_lr_mul * 0.125f;                 // 1/sqrt(64)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) w.w0a[mt][t] = a.dec_w0[(16 * mt + j) * 32 + 8 * g + t] * g0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            w.b0c[mt][r] = a.dec_b0[16 * mt + 4 * g + r] * a.decoder_lr_mul;
+            w.wsig[mt][r] = a.dec_w1[16 * mt + 4 * g + r] * g1;
+        }
+    }
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                w.w1a[ot][mt * 4 + r] = a.dec_w1[(1 + 16 * ot + j) * 64 + 16 * mt + 4 * g + r] * g1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w.b1c[ot][r] = a.dec_b1[1 + 16 * ot + 4 * g + r] * a.decoder_lr_mul;
+    }
+    w.bsig = a.dec_b1[0] * a.decoder_lr_mul;
+}
+
+// f[8] (B operand) -> hidden pre-activations hp, softplus values h (C layout: lane (j,g), rows 4g+r of tile mt),
+// sigma (all four g lanes of a sample hold it), colour logits o[2] (rows 4g+r of colour tile ot).
+template <bool KEEP_PRE>
+__device__ __forceinline__ void decoder_fwd(const DecoderRegs& w, const float f[8], f32x4 hp[4], f32x4 h[4],
+                                            float& sigma, f32x4 o[2]) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        h[mt] = f32x4{w.b0c[mt][0], w.b0c[mt][1], w.b0c[mt][2], w.b0c[mt][3]};
+#pragma unroll
+        for (int t = 0; t < 8; ++t) h[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w0a[mt][t], f[t], h[mt], 0, 0, 0);
+    }
+    float sg = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (KEEP_PRE) hp[mt][r] = h[mt][r];
+            h[mt][r] = softplus_f(h[mt][r]);
+            sg = fmaf(h[mt][r], w.wsig[mt][r], sg);
+        }
+    sg += __shfl_xor(sg, 16);
+    sg += __shfl_xor(sg, 32);
+    sigma = sg + w.bsig;
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot) {
+        o[ot] = f32x4{w.b1c[ot][0], w.b1c[ot][1], w.b1c[ot][2], w.b1c[ot][3]};
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                o[ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w1a[ot][mt * 4 + r], h[mt][r], o[ot], 0, 0, 0);
+    }
+}
+
+}  // namespace hfagp

@@ -185,7 +185,7 @@ class TriPlaneGenerator(nn.Module):
         return x
 
     # ----------------------------------------------------------------- layers
-    def _layer(self, x, layer: _SynthesisLayer, w, batch, noise_mode, conv_clamp):
+    def _layer(self, x, layer: _SynthesisLayer, w, row, batch, noise_mode, conv_clamp, tape):
         cfg = self.cfg
         wt, wsq = self._prepared(layer.weight)
         styles, dcoef = ops.styles_demod(w, layer.affine.weight, layer.affine.bias, wsq, 1.0, cfg.demod_eps)
@@ -201,35 +201,50 @@ class TriPlaneGenerator(nn.Module):
         flops = 2.0 * batch * x.shape[1] * x.shape[2] * x.shape[3] * cout * 9
         if layer.up == 2:
             yt = self._timed("modconv", flops, ops.modconv, x, wt, cout, ops.CONVT3X3_UP2, styles=styles, batch=batch)
-            return ops.upfir_epilogue(yt, dcoef, noise, ns, layer.bias, "lrelu", cfg.lrelu_alpha, gain, conv_clamp)
-        return self._timed("modconv", flops, ops.modconv, x, wt, cout, ops.CONV3X3, styles=styles, dcoef=dcoef,
-                           noise=noise, noise_strength=ns, bias=layer.bias, act="lrelu", alpha=cfg.lrelu_alpha,
-                           gain=gain, clamp=conv_clamp, batch=batch)
-
-    def _block(self, x, img, blk: _SynthesisBlock, ws3, batch, noise_mode, conv_clamp, small_rgb, last):
-        i = 0
-        if blk.in_channels == 0:
-            x = self._layer(self._const(blk.const), blk.conv1, ws3[:, 0], batch, noise_mode, conv_clamp)
-            i = 1
+            out = ops.upfir_epilogue(yt, dcoef, noise, ns, layer.bias, "lrelu", cfg.lrelu_alpha, gain, conv_clamp)
         else:
-            x = self._layer(x, blk.conv0, ws3[:, 0], batch, noise_mode, conv_clamp)
-            x = self._layer(x, blk.conv1, ws3[:, 1], batch, noise_mode, conv_clamp)
-            i = 2
+            out = self._timed("modconv", flops, ops.modconv, x, wt, cout, ops.CONV3X3, styles=styles, dcoef=dcoef,
+                              noise=noise, noise_strength=ns, bias=layer.bias, act="lrelu", alpha=cfg.lrelu_alpha,
+                              gain=gain, clamp=conv_clamp, batch=batch)
+        rec = None
+        if tape is not None:
+            rec = dict(layer=layer, x=x, styles=styles, dcoef=dcoef, out=out, row=row, up=layer.up, wsq=wsq,
+                       producer=dict(dcoef=dcoef, bias=layer.bias, noise=noise, noise_strength=ns, act="lrelu",
+                                     alpha=cfg.lrelu_alpha, gain=gain, clamp=conv_clamp))
+        return out, rec
+
+    def _block(self, x, img, blk: _SynthesisBlock, ws, rows, batch, noise_mode, conv_clamp, small_rgb, last, tape):
+        """rows = the ws row of (conv0,) conv1, torgb."""
+        rec = dict(conv0=None, first=blk.in_channels == 0, img_in=img)
+        if blk.in_channels == 0:
+            x, rec["conv1"] = self._layer(self._const(blk.const), blk.conv1, ws[:, rows[0]], rows[0], batch,
+                                          noise_mode, conv_clamp, tape)
+        else:
+            x, rec["conv0"] = self._layer(x, blk.conv0, ws[:, rows[0]], rows[0], batch, noise_mode, conv_clamp, tape)
+            x, rec["conv1"] = self._layer(x, blk.conv1, ws[:, rows[1]], rows[1], batch, noise_mode, conv_clamp, tape)
         tr = blk.torgb
         cin = tr.weight.shape[1]
-        styles, _ = ops.styles_demod(ws3[:, i], tr.affine.weight, tr.affine.bias, None, 1.0 / math.sqrt(cin))
+        row = rows[-1]
+        styles, _ = ops.styles_demod(ws[:, row], tr.affine.weight, tr.affine.bias, None, 1.0 / math.sqrt(cin))
+        y = y_pre = None
         if small_rgb:
+            if tape is not None and conv_clamp is not None:
+                y_pre = torch.empty(batch, tr.weight.shape[0], x.shape[1], x.shape[2], device=x.device)
             img = ops.torgb_small(x, tr.weight.detach().reshape(tr.weight.shape[0], cin), styles, tr.bias, img,
-                                  conv_clamp)
+                                  conv_clamp, y_pre)
         else:
             wt, _ = self._prepared(tr.weight)
             y = ops.modconv(x, wt, tr.weight.shape[0], ops.CONV1X1, styles=styles, bias=tr.bias, act="linear",
                             gain=1.0, clamp=conv_clamp, batch=batch)
             img = ops.skip_upsample_add(img, y, plane_major=last)
+        if tape is not None:
+            rec["rgb"] = dict(torgb=tr, x=x, styles=styles, row=row, small=small_rgb, clamp=conv_clamp,
+                              y=y if conv_clamp is not None else None, y_pre=y_pre)
+            tape.append(rec)
         return x, img
 
     # ----------------------------------------------------------------- public API
-    def backbone_planes(self, ws: torch.Tensor) -> torch.Tensor:
+    def backbone_planes(self, ws: torch.Tensor, tape=None) -> torch.Tensor:
         """ws [B, num_ws, 512] → tri-plane volume [B, 3, R, R, 32] (plane-major, channels-last)."""
         cfg = self.cfg
         syn = self.backbone.synthesis
@@ -239,46 +254,54 @@ class TriPlaneGenerator(nn.Module):
         for res in cfg.block_resolutions:
             blk = getattr(syn, f"b{res}")
             n_conv = 1 if res == 4 else 2
-            x, img = self._block(x, img, blk, ws[:, idx: idx + n_conv + 1], b, cfg.backbone_noise_mode,
-                                 cfg.backbone_conv_clamp, False, res == cfg.plane_resolution)
+            rows = list(range(idx, idx + n_conv + 1))
+            x, img = self._block(x, img, blk, ws, rows, b, cfg.backbone_noise_mode, cfg.backbone_conv_clamp, False,
+                                 res == cfg.plane_resolution, tape)
             idx += n_conv
         return img
 
-    def render(self, planes: torch.Tensor, c: torch.Tensor, u_strat=None, u_imp=None):
+    def _render_args(self, c: torch.Tensor):
         cfg = self.cfg
-        b = planes.shape[0]
-        res = cfg.neural_rendering_resolution
-        r = res * res
-        dev = planes.device
+        net = self.decoder.net
+        return dict(cam2world=c[:, :16].contiguous(), intrinsics=c[:, 16:25].contiguous(),
+                    dec_w0=net["0"].weight, dec_b0=net["0"].bias, dec_w1=net["2"].weight, dec_b1=net["2"].bias,
+                    res=cfg.neural_rendering_resolution, ray_start=cfg.ray_start, ray_end=cfg.ray_end,
+                    box_warp=cfg.box_warp, decoder_lr_mul=cfg.decoder_lr_mul,
+                    plane_axes=0 if cfg.plane_axes == "eg3d_original" else 1, white_back=cfg.white_back)
+
+    def _uniforms(self, b: int, dev, u_strat, u_imp):
+        cfg = self.cfg
+        r = cfg.neural_rendering_resolution ** 2
         if u_strat is None:
             u_strat = torch.rand(b, r, cfg.depth_resolution, device=dev)
         if u_imp is None:
             u_imp = torch.rand(b * r, cfg.depth_resolution_importance, device=dev)
-        c2w = c[:, :16].contiguous()
-        intr = c[:, 16:25].contiguous()
-        net = self.decoder.net
+        return u_strat.reshape(b, r, -1).contiguous(), u_imp.contiguous()
+
+    def render(self, planes: torch.Tensor, c: torch.Tensor, u_strat=None, u_imp=None):
+        cfg = self.cfg
+        b = planes.shape[0]
+        r = cfg.neural_rendering_resolution ** 2
+        u_strat, u_imp = self._uniforms(b, planes.device, u_strat, u_imp)
         # algorithmic bytes per frame: samples * 3 planes * 4 taps * 32 ch * 4 B
         # + outputs R*(32+1+1)*4 + uniforms R*(Sc+Sf)*4
         s_tot = cfg.depth_resolution + cfg.depth_resolution_importance
         nbytes = float(b) * r * (s_tot * 3 * 4 * 32 * 4 + 34 * 4 + s_tot * 4)
-        return self._timed("raymarch", nbytes, ops.raymarch, planes, c2w, intr, u_strat.reshape(b, r, -1).contiguous(), u_imp.contiguous(),
-                            net["0"].weight, net["0"].bias, net["2"].weight, net["2"].bias, res,
-                            cfg.ray_start, cfg.ray_end, cfg.box_warp, cfg.decoder_lr_mul,
-                            0 if cfg.plane_axes == "eg3d_original" else 1, cfg.white_back)
+        return self._timed("raymarch", nbytes, ops.raymarch, planes, u_strat=u_strat, u_imp=u_imp,
+                           **self._render_args(c))
 
-    def superres(self, rgb_raw: torch.Tensor, feat_img: torch.Tensor, ws: torch.Tensor) -> torch.Tensor:
+    def superres(self, rgb_raw: torch.Tensor, feat_img: torch.Tensor, ws: torch.Tensor, tape=None) -> torch.Tensor:
         cfg = self.cfg
         b = ws.shape[0]
-        w_last = ws[:, -1:, :].expand(-1, 3, -1)
+        last = cfg.num_ws - 1
         sr = self.superresolution
-        x, rgb = self._block(feat_img, rgb_raw, sr.block0, w_last, b, cfg.sr_noise_mode, cfg.sr_conv_clamp, True, False)
-        x, rgb = self._block(x, rgb, sr.block1, w_last, b, cfg.sr_noise_mode, cfg.sr_conv_clamp, True, False)
+        x, rgb = self._block(feat_img, rgb_raw, sr.block0, ws, [last] * 3, b, cfg.sr_noise_mode, cfg.sr_conv_clamp,
+                             True, False, tape)
+        x, rgb = self._block(x, rgb, sr.block1, ws, [last] * 3, b, cfg.sr_noise_mode, cfg.sr_conv_clamp, True, False,
+                             tape)
         return rgb
 
-    @torch.no_grad()
-    def synthesis(self, ws: torch.Tensor, c: torch.Tensor, noise_mode: str = "const",
-                  u_strat: Optional[torch.Tensor] = None, u_imp: Optional[torch.Tensor] = None,
-                  return_planes: bool = False, **_unused) -> Dict[str, torch.Tensor]:
+    def _check_inputs(self, ws, c, noise_mode):
         cfg = self.cfg
         if not ws.is_cuda:
             raise RuntimeError("TriPlaneGenerator.synthesis: the MI355X path needs CUDA/ROCm tensors; "
@@ -288,18 +311,47 @@ class TriPlaneGenerator(nn.Module):
         if ws.shape[1:] != (cfg.num_ws, cfg.w_dim) or c.shape[1] != cfg.c_dim:
             raise ValueError(f"expected ws [B,{cfg.num_ws},{cfg.w_dim}] and c [B,{cfg.c_dim}], got "
                              f"{tuple(ws.shape)} and {tuple(c.shape)}")
-        ws = ws.detach().float().contiguous()
-        c = c.detach().float().contiguous()
+
+    def _forward_impl(self, ws, c, u_strat, u_imp, tape):
+        """ws, c: detached contiguous fp32 CUDA tensors.  Returns image, image_raw, depth, planes, feat_img;
+        when `tape` is a dict it is filled with everything the backward pass needs."""
+        cfg = self.cfg
         b = ws.shape[0]
         res = cfg.neural_rendering_resolution
-        planes = self.backbone_planes(ws)
+        bb_tape = [] if tape is not None else None
+        sr_tape = [] if tape is not None else None
+        planes = self.backbone_planes(ws, bb_tape)
+        u_strat, u_imp = self._uniforms(b, ws.device, u_strat, u_imp)
         feat, depth, wsum, tmm = self.render(planes, c, u_strat, u_imp)
         # MipRayMarcher2 clamps the expected depth to the GLOBAL min/max sample depth of the batch
         depth = torch.clamp(depth, tmm[..., 0].min(), tmm[..., 1].max())
         feat_img = feat.view(b, res, res, 32)                             # channels-last
         rgb_raw = feat_img[..., :3].permute(0, 3, 1, 2).contiguous()      # NCHW, 'image_raw'
-        img = self.superres(rgb_raw, feat_img, ws)
-        out = {"image": img, "image_raw": rgb_raw, "image_depth": depth.view(b, 1, res, res)}
+        img = self.superres(rgb_raw, feat_img, ws, sr_tape)
+        if tape is not None:
+            tape.update(backbone=bb_tape, sr=sr_tape, planes=planes, c=c, u_strat=u_strat, u_imp=u_imp,
+                        feat_img=feat_img, batch=b)
+        return img, rgb_raw, depth.view(b, 1, res, res), planes, feat_img
+
+    def synthesis(self, ws: torch.Tensor, c: torch.Tensor, noise_mode: str = "const",
+                  u_strat: Optional[torch.Tensor] = None, u_imp: Optional[torch.Tensor] = None,
+                  return_planes: bool = False, **_unused) -> Dict[str, torch.Tensor]:
+        """Drop-in for EG3D's TriPlaneGenerator.synthesis.  Differentiable w.r.t. `ws` (the latent-basis
+        fitting of HFA-GP); generator parameters must be frozen (backward w.r.t. weights: not built yet)."""
+        self._check_inputs(ws, c, noise_mode)
+        need_grad = torch.is_grad_enabled() and ws.requires_grad
+        if need_grad:
+            if any(p.requires_grad for p in self.parameters()):
+                raise NotImplementedError(
+                    "gradients w.r.t. the generator weights (tune_generator, trainer_rgb.py:69-71) are not built "
+                    "yet on the MI355X path; keep the generator frozen (requires_grad_(False))")
+            from .autograd import SynthesisFn
+            img, rgb_raw, depth = SynthesisFn.apply(ws, c.detach(), u_strat, u_imp, self)
+            return {"image": img, "image_raw": rgb_raw, "image_depth": depth}
+        with torch.no_grad():
+            img, rgb_raw, depth, planes, feat_img = self._forward_impl(
+                ws.detach().float().contiguous(), c.detach().float().contiguous(), u_strat, u_imp, None)
+        out = {"image": img, "image_raw": rgb_raw, "image_depth": depth}
         if return_planes:
             out["planes"] = planes
             out["feature_image"] = feat_img

@@ -17,7 +17,7 @@ import torch
 
 from . import _lib as L
 
-CONV3X3, CONVT3X3_UP2, CONV1X1 = 0, 1, 2
+CONV3X3, CONVT3X3_UP2, CONV1X1, CONV3X3_BWD, CONVS2_BWD = 0, 1, 2, 3, 4
 ACT_LINEAR, ACT_LRELU = 0, 1
 _ACT = {"linear": ACT_LINEAR, "lrelu": ACT_LRELU}
 
@@ -83,12 +83,16 @@ def modconv(x: torch.Tensor, wt: torch.Tensor, cout: int, mode: int, styles: Opt
     """x [B|1, H, W, Cin] channels-last.  mode CONV3X3 / CONV1X1: fused epilogue, returns [B,H,W,Cout];
     mode CONVT3X3_UP2: returns the RAW transposed-conv result [B, 2H+1, 2W+1, Cout]."""
     _chk(x, "x")
-    xb, h, w, cin = x.shape
+    if mode == CONVS2_BWD:                      # x = four parity images [2,2,B,H+1,W+1,Cin]
+        _, _, xb, h, w, cin = x.shape
+        h, w = h - 1, w - 1
+    else:
+        xb, h, w, cin = x.shape
     b = batch if batch is not None else xb
     a = L.ModconvArgs()
     a.x, a.wt = _ptr(x), _ptr(_chk(wt, "wt"))
     a.styles, a.dcoef, a.noise, a.bias = _ptr(styles), _ptr(dcoef), _ptr(noise), _ptr(bias)
-    a.x_batch_stride = 0 if (xb == 1 and b > 1) else h * w * cin
+    a.x_batch_stride = 0 if (xb == 1 and b > 1) else x.shape[-3] * x.shape[-2] * cin
     a.B, a.H, a.W, a.Cin, a.Cout = b, h, w, cin, cout
     a.mode, a.act, a.ksplit = mode, _ACT[act], ksplit
     a.noise_strength, a.alpha, a.gain = noise_strength, alpha, gain
@@ -142,13 +146,15 @@ def skip_upsample_add(img: Optional[torch.Tensor], y: torch.Tensor, plane_major:
 
 
 def torgb_small(x: torch.Tensor, weight: torch.Tensor, styles: torch.Tensor, bias: torch.Tensor,
-                rgb_in: Optional[torch.Tensor], clamp: Optional[float]) -> torch.Tensor:
-    """ToRGBLayer with ≤4 output channels + skip add; x channels-last, rgb NCHW."""
+                rgb_in: Optional[torch.Tensor], clamp: Optional[float], y_pre: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """ToRGBLayer with ≤4 output channels + skip add; x channels-last, rgb NCHW.  `y_pre` (optional,
+    [B,Cout,H,W]) receives the toRGB output before clamp and skip add (backward needs the clamp mask)."""
     _chk(x, "x")
     b, h, w, cin = x.shape
     cout = weight.shape[0]
     out = torch.empty(b, cout, h, w, device=x.device, dtype=torch.float32)
     a = L.TorgbArgs()
+    a.y_pre = _ptr(y_pre)
     a.x, a.weight, a.styles, a.bias = _ptr(x), _ptr(_chk(weight, "weight")), _ptr(_chk(styles, "styles")), _ptr(bias)
     a.rgb_in = _ptr(_chk(rgb_in, "rgb_in")) if rgb_in is not None else None
     a.rgb_out = _ptr(out)
@@ -240,3 +246,111 @@ def nhwc_to_nchw(x: torch.Tensor) -> torch.Tensor:
     y = torch.empty(b, c, h, w, device=x.device, dtype=torch.float32)
     L.check(L.lib().hfagp_nhwc_to_nchw(_ptr(x), _ptr(y), b, c, h, w, _stream()), "nhwc_to_nchw")
     return y
+
+
+# ----------------------------------------------------------------------------- backward pass
+def pointwise_bwd(x: torch.Tensor, dxs_conv=None, s_conv=None, dxs_rgb=None, s_rgb=None, g_rgb_small=None,
+                  w_rgb_small=None, s_small=None, g_direct=None, producer: Optional[dict] = None):
+    """Fused streaming pass over the saved activation x [B,H,W,C] (see include/hfagp.h).  `producer` =
+    dict(dcoef, bias, noise, noise_strength, act, alpha, gain, clamp) of the layer that produced x, or None.
+    Returns (g_out [B,H,W,C], sums [B,4,C])."""
+    _chk(x, "x")
+    b, h, w, c = x.shape
+    nchunks = max(1, min(256, (h * w) // 64))
+    a = L.PointwiseBwdArgs()
+    g_out = torch.empty_like(x)
+    partial = torch.empty(b, nchunks, 4, c, device=x.device, dtype=torch.float32)
+    sums = torch.empty(b, 4, c, device=x.device, dtype=torch.float32)
+    a.x, a.g_out, a.partial, a.sums = _ptr(x), _ptr(g_out), _ptr(partial), _ptr(sums)
+    a.dxs_conv, a.s_conv, a.dxs_rgb, a.s_rgb = _ptr(dxs_conv), _ptr(s_conv), _ptr(dxs_rgb), _ptr(s_rgb)
+    a.g_rgb_small, a.w_rgb_small, a.s_small, a.g_direct = _ptr(g_rgb_small), _ptr(w_rgb_small), _ptr(s_small), _ptr(g_direct)
+    a.B, a.H, a.W, a.C, a.nchunks = b, h, w, c, nchunks
+    a.Co = g_rgb_small.shape[1] if g_rgb_small is not None else 0
+    a.clamp = -1.0
+    if producer is not None:
+        a.has_producer = 1
+        a.dcoef_p, a.bias_p, a.noise_p = _ptr(producer.get("dcoef")), _ptr(producer.get("bias")), _ptr(producer.get("noise"))
+        a.noise_strength_p = producer.get("noise_strength", 0.0)
+        a.act_p = _ACT[producer.get("act", "lrelu")]
+        a.alpha, a.gain = producer.get("alpha", 0.2), producer.get("gain", math.sqrt(2.0))
+        clamp = producer.get("clamp")
+        a.clamp = -1.0 if clamp is None else float(clamp)
+    L.check(L.lib().hfagp_pointwise_bwd(C.byref(a), _stream()), "pointwise_bwd")
+    return g_out, sums
+
+
+def upfir_bwd(g_y: torch.Tensor) -> torch.Tensor:
+    """g_y [B,2H,2W,C] → parity images of the y_t gradient [2,2,B,H+1,W+1,C]."""
+    _chk(g_y, "g_y")
+    b, ho, wo, c = g_y.shape
+    h, w = ho // 2, wo // 2
+    gph = torch.empty(2, 2, b, h + 1, w + 1, c, device=g_y.device, dtype=torch.float32)
+    L.check(L.lib().hfagp_upfir_bwd(_ptr(g_y), _ptr(gph), b, h, w, c, _stream()), "upfir_bwd")
+    return gph
+
+
+def upsample2d_bwd(g: torch.Tensor, channels_last: bool) -> torch.Tensor:
+    """Adjoint of upsample2d: [B,2H,2W,C] → [B,H,W,C] (channels_last) or [B,C,2H,2W] → [B,C,H,W]."""
+    _chk(g, "g")
+    if channels_last:
+        b, ho, wo, c = g.shape
+        out = torch.empty(b, ho // 2, wo // 2, c, device=g.device, dtype=torch.float32)
+        outer, inner = b, c
+    else:
+        b, c, ho, wo = g.shape
+        out = torch.empty(b, c, ho // 2, wo // 2, device=g.device, dtype=torch.float32)
+        outer, inner = b * c, 1
+    L.check(L.lib().hfagp_upsample2d_bwd(_ptr(g), _ptr(out), outer, ho // 2, wo // 2, inner, _stream()), "upsample2d_bwd")
+    return out
+
+
+def planes_to_nhwc(pm: torch.Tensor) -> torch.Tensor:
+    _chk(pm, "planes")
+    b, three, h, w, cp = pm.shape
+    y = torch.empty(b, h, w, 3 * cp, device=pm.device, dtype=torch.float32)
+    L.check(L.lib().hfagp_planes_to_nhwc(_ptr(pm), _ptr(y), b, h, w, cp, _stream()), "planes_to_nhwc")
+    return y
+
+
+def style_bwd(ds: torch.Tensor, dd: Optional[torch.Tensor], styles: torch.Tensor, dcoef: Optional[torch.Tensor],
+              wsq: Optional[torch.Tensor], affine_w: torch.Tensor, dw: torch.Tensor, style_gain: float = 1.0,
+              accumulate: bool = True) -> None:
+    """Accumulate d ws for one layer into the row view dw [B, w_dim] (strided view of d_ws)."""
+    b, cin = styles.shape
+    a = L.StyleBwdArgs()
+    dstot = torch.empty(b, cin, device=styles.device, dtype=torch.float32)
+    if not ds.is_contiguous():
+        ds = ds.contiguous()
+    if dd is not None and not dd.is_contiguous():
+        dd = dd.contiguous()
+    a.ds, a.dd, a.styles, a.dcoef, a.wsq = _ptr(ds), _ptr(dd), _ptr(styles), _ptr(dcoef), _ptr(wsq)
+    a.affine_w, a.dstot, a.dw = _ptr(affine_w), _ptr(dstot), dw.data_ptr()
+    a.B, a.Cin, a.Cout = b, cin, (dd.shape[1] if dd is not None else 0)
+    a.w_dim, a.dw_stride, a.accumulate = affine_w.shape[1], dw.stride(0), int(accumulate)
+    a.style_gain = style_gain
+    L.check(L.lib().hfagp_style_bwd(C.byref(a), _stream()), "style_bwd")
+
+
+def raymarch_bwd(g_feat: torch.Tensor, planes: torch.Tensor, cam2world, intrinsics, u_strat, u_imp, dec_w0, dec_b0,
+                 dec_w1, dec_b1, res: int, ray_start: float, ray_end: float, box_warp: float,
+                 decoder_lr_mul: float = 1.0, plane_axes: int = 0, white_back: bool = False,
+                 return_rec: bool = False):
+    """g_feat [B,R,32] → d planes [B,3,H,W,32] (fp32 atomics into a zero-initialised buffer)."""
+    _chk(planes, "planes")
+    _chk(g_feat, "g_feat")
+    b, _, h, w, _ = planes.shape
+    r = res * res
+    sc, sf = u_strat.shape[-1], u_imp.shape[-1]
+    d_planes = torch.zeros_like(planes)
+    rec = torch.empty(b, r, sc + sf, 4, device=planes.device, dtype=torch.float32)
+    a = L.RaymarchBwdArgs()
+    f = a.fwd
+    f.planes, f.cam2world, f.intrinsics = _ptr(planes), _ptr(_chk(cam2world, "cam2world")), _ptr(_chk(intrinsics, "intrinsics"))
+    f.u_strat, f.u_imp = _ptr(_chk(u_strat, "u_strat")), _ptr(_chk(u_imp, "u_imp"))
+    f.dec_w0, f.dec_b0, f.dec_w1, f.dec_b1 = _ptr(dec_w0), _ptr(dec_b0), _ptr(dec_w1), _ptr(dec_b1)
+    f.B, f.H, f.W, f.res, f.Sc, f.Sf = b, h, w, res, sc, sf
+    f.plane_axes, f.white_back = plane_axes, int(white_back)
+    f.ray_start, f.ray_end, f.box_warp, f.decoder_lr_mul = ray_start, ray_end, box_warp, decoder_lr_mul
+    a.g_feat, a.d_planes, a.rec = _ptr(g_feat), _ptr(d_planes), _ptr(rec)
+    L.check(L.lib().hfagp_raymarch_bwd(C.byref(a), _stream()), "raymarch_bwd")
+    return (d_planes, rec) if return_rec else d_planes

@@ -103,7 +103,15 @@ int hfagp_weight_prep(const float* weight, float* wt, float* wsq,
  * styles on the way into LDS; demodulation, noise, bias, leaky-ReLU, gain and
  * clamp are applied in the epilogue (mode 0/2) or by hfagp_upfir_epilogue_fwd
  * (mode 1, which writes the raw transposed-conv result).                          */
-enum { HFAGP_CONV3X3 = 0, HFAGP_CONVT3X3_UP2 = 1, HFAGP_CONV1X1 = 2 };
+enum {
+    HFAGP_CONV3X3 = 0,      /* y = corr3x3(x*s, W), padding 1, fused epilogue                               */
+    HFAGP_CONVT3X3_UP2 = 1, /* y_t = conv_transpose2d(x*s, W, stride 2): RAW [B][2H+1][2W+1][Cout]          */
+    HFAGP_CONV1X1 = 2,      /* y = x*s . W (toRGB with many output channels), fused epilogue               */
+    HFAGP_CONV3X3_BWD = 3,  /* adjoint of mode 0 w.r.t. (x*s): x = grad [B][H][W][Cout_fwd], wt = prep of   */
+                            /* weight^T (Cin/Cout swapped), Cin = Cout_fwd, Cout = Cin_fwd                  */
+    HFAGP_CONVS2_BWD = 4    /* adjoint of mode 1 w.r.t. (x*s): x = 4 parity images of the y_t gradient      */
+                            /* [2][2][B][H+1][W+1][Cin] (hfagp_upfir_bwd), H, W = resolution of dx          */
+};
 enum { HFAGP_ACT_LINEAR = 0, HFAGP_ACT_LRELU = 1 };
 
 typedef struct {
@@ -163,11 +171,83 @@ typedef struct {
     const float* bias;        /* [Cout] */
     const float* rgb_in;      /* NCHW [B][Cout][H/2][W/2] or NULL */
     float*       rgb_out;     /* NCHW [B][Cout][H][W] */
+    float*       y_pre;       /* optional NCHW [B][Cout][H][W]: toRGB output before the skip add (for backward) */
     int32_t B, H, W, Cin, Cout;
     float clamp;
 } HfagpTorgbArgs;
 
 int hfagp_torgb_fwd(const HfagpTorgbArgs* a, void* stream);
+
+/* ------------------------------------------------------------------ backward pass (generator frozen: d/d ws)
+ * GEMM-shaped parts reuse hfagp_modconv_fwd (modes 3, 4 and 2 with transposed weights).               */
+
+/* One fused streaming pass per activation tensor X [B][H][W][C] (output of layer P, input of its
+ * consumers): sums the consumers' input gradients, reduces their style gradients, and pushes the result
+ * through P's clamp / gain / leaky-ReLU / demodulation.
+ *   gX      = dxs_conv*s_conv + dxs_rgb*s_rgb + s_small * (w_rgb_small^T g_rgb_small) + g_direct
+ *   g_out   = has_producer ? gX * gain * lrelu'(X) * [|X|<clamp] * dcoef_p : gX
+ *   sums[b][0] = sum_pix dxs_conv*X   sums[b][1] = sum_pix dxs_rgb*X   sums[b][2] = sum_pix (w^T g)*X
+ *   sums[b][3] = sum_pix g_pre * conv_p      (gradient of P's demodulation coefficients)              */
+typedef struct {
+    const float* dxs_conv;    /* [B][H][W][C] or NULL */
+    const float* s_conv;      /* [B][C] */
+    const float* dxs_rgb;     /* [B][H][W][C] or NULL */
+    const float* s_rgb;       /* [B][C] */
+    const float* g_rgb_small; /* NCHW [B][Co][H][W] (already clamp-masked) or NULL */
+    const float* w_rgb_small; /* [Co][C] */
+    const float* s_small;     /* [B][C] */
+    const float* g_direct;    /* [B][H][W][C] extra gradient added as is, or NULL */
+    const float* x;           /* [B][H][W][C] saved activation */
+    const float* dcoef_p;     /* [B][C] or NULL */
+    const float* bias_p;      /* [C] or NULL */
+    const float* noise_p;     /* [H][W] or NULL */
+    float*       g_out;       /* [B][H][W][C] */
+    float*       partial;     /* workspace [B][nchunks][4][C] */
+    float*       sums;        /* out [B][4][C] */
+    int32_t B, H, W, C, Co, nchunks, has_producer, act_p;
+    float noise_strength_p, alpha, gain, clamp;
+} HfagpPointwiseBwdArgs;
+
+int hfagp_pointwise_bwd(const HfagpPointwiseBwdArgs* a, void* stream);
+
+/* adjoint of hfagp_upfir_epilogue_fwd's FIR: g_y [B][2H][2W][C] -> four parity images of the y_t gradient,
+ * gph [2][2][B][H+1][W+1][C] (input of hfagp_modconv_fwd mode HFAGP_CONVS2_BWD)                          */
+int hfagp_upfir_bwd(const float* gy, float* gph, int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
+
+/* adjoint of upsample2d: g [outer][2H][2W][inner] -> gin [outer][H][W][inner] (inner = C for channels-last,
+ * 1 for NCHW with outer = B*C)                                                                           */
+int hfagp_upsample2d_bwd(const float* g, float* gin, int64_t outer, int32_t H, int32_t W, int32_t inner, void* stream);
+
+/* plane-major [B][3][H][W][Cp] -> channels-last [B][H][W][3*Cp] */
+int hfagp_planes_to_nhwc(const float* pm, float* y, int32_t B, int32_t H, int32_t W, int32_t Cp, void* stream);
+
+/* styles -> latent: dstot = (ds - styles * sum_o dd_o d_o^3 wsq[o][i]) * style_gain;
+ * dw[b][:] (+)= dstot[b] . affine_w / sqrt(w_dim)                                                         */
+typedef struct {
+    const float* ds;          /* [B][Cin] gradient w.r.t. the styles (data path) */
+    const float* dd;          /* [B][Cout] gradient w.r.t. the demod coefficients, or NULL */
+    const float* styles;      /* [B][Cin] */
+    const float* dcoef;       /* [B][Cout] */
+    const float* wsq;         /* [Cout][Cin] */
+    const float* affine_w;    /* [Cin][w_dim] */
+    float*       dstot;       /* workspace [B][Cin] */
+    float*       dw;          /* [B][dw_stride] row of d ws */
+    int32_t B, Cin, Cout, w_dim, dw_stride, accumulate;
+    float style_gain;
+} HfagpStyleBwdArgs;
+
+int hfagp_style_bwd(const HfagpStyleBwdArgs* a, void* stream);
+
+/* backward of hfagp_raymarch_fwd w.r.t. the tri-plane volume: recomputes the forward per ray, then
+ * scatters d feat -> d planes with fp32 atomics (d_planes must be zero-initialised by the caller).      */
+typedef struct {
+    HfagpRaymarchArgs fwd;    /* same inputs as the forward call (feat/depth/wsum/tminmax unused) */
+    const float* g_feat;      /* [B][R][32] gradient of the composited features */
+    float*       d_planes;    /* [B][3][H][W][32], accumulated into */
+    float*       rec;         /* workspace [B][R][Sc+Sf][4] floats (per-sample depth, omega, d sigma) */
+} HfagpRaymarchBwdArgs;
+
+int hfagp_raymarch_bwd(const HfagpRaymarchBwdArgs* a, void* stream);
 
 /* ------------------------------------------------------------------ standalone ops (NCHW, test surface) */
 int hfagp_upfirdn2d_fwd(const float* x, const float* f, float* y,

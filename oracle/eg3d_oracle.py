@@ -320,15 +320,18 @@ def sample_pdf(bins: Tensor, weights: Tensor, u: Tensor, eps: float = 1e-5) -> T
 
 
 def sample_importance(z: Tensor, weights: Tensor, u_imp: Tensor) -> Tensor:
-    b, r, s, _ = z.shape
-    z = z.reshape(b * r, s)
-    w = weights.reshape(b * r, -1)
-    w = F.max_pool1d(w[:, None].float(), 2, 1, padding=1)
-    w = F.avg_pool1d(w, 2, 1).squeeze(1)
-    w = w + 0.01
-    z_mid = 0.5 * (z[:, :-1] + z[:, 1:])
-    out = sample_pdf(z_mid, w[:, 1:-1], u_imp.reshape(b * r, -1))
-    return out.reshape(b, r, -1, 1)
+    """EG3D runs this under torch.no_grad() and detaches the result: the importance depths carry no
+    gradient (neither to the densities nor to the planes)."""
+    with torch.no_grad():
+        b, r, s, _ = z.shape
+        z = z.reshape(b * r, s)
+        w = weights.reshape(b * r, -1)
+        w = F.max_pool1d(w[:, None].float(), 2, 1, padding=1)
+        w = F.avg_pool1d(w, 2, 1).squeeze(1)
+        w = w + 0.01
+        z_mid = 0.5 * (z[:, :-1] + z[:, 1:])
+        out = sample_pdf(z_mid, w[:, 1:-1], u_imp.reshape(b * r, -1))
+    return out.detach().reshape(b, r, -1, 1)
 
 
 def importance_renderer(P: Dict[str, Tensor], cfg, planes: Tensor, origins: Tensor, dirs: Tensor,

@@ -1,0 +1,48 @@
+"""Developer micro-benchmark of one modulated-conv layer (run on the GPU box).
+usage: bench_conv.py B H Cin Cout up [ksplit] [iters]"""
+import math
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hfa_gp_amd import ops  # noqa: E402
+
+
+def main():
+    B, H, cin, cout, up = [int(v) for v in sys.argv[1:6]]
+    ksplit = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+    iters = int(sys.argv[7]) if len(sys.argv) > 7 else 10
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(0)
+    x = torch.randn(B, H, H, cin, device=dev, generator=g)
+    w = torch.randn(cout, cin, 3, 3, device=dev, generator=g)
+    wt, wsq = ops.weight_prep(w)
+    styles = torch.randn(B, cin, device=dev, generator=g)
+    dcoef = torch.rand(B, cout, device=dev, generator=g)
+    bias = torch.randn(cout, device=dev, generator=g)
+    mode = ops.CONVT3X3_UP2 if up == 2 else ops.CONV3X3
+
+    def run():
+        if up == 2:
+            return ops.modconv(x, wt, cout, mode, styles=styles, ksplit=ksplit)
+        return ops.modconv(x, wt, cout, mode, styles=styles, dcoef=dcoef, bias=bias, act="lrelu",
+                           gain=math.sqrt(2), ksplit=ksplit)
+    for _ in range(2):
+        run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        y = run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    flops = 2.0 * B * H * H * cin * cout * 9
+    print(f"conv B={B} H={H} {cin}->{cout} up={up} ksplit={ksplit}: {ms*1e3:.1f} us, {flops/ms/1e9:.1f} TFLOP/s "
+          f"({flops/ms/1e9/157.3:.3f} of fp32 MFMA peak)")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,49 @@
+"""Developer debug: per-sample records of the ray-march backward vs oracle autograd (GPU box)."""
+import dataclasses, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tests.util import look_at_label, perturb_state, state_cpu
+from hfa_gp_amd import ops
+from hfa_gp_amd.config import tiny64
+from hfa_gp_amd.generator import TriPlaneGenerator
+from oracle import eg3d_oracle as O
+
+dev = torch.device("cuda:0")
+cfg = dataclasses.replace(tiny64(), neural_rendering_resolution=4, img_resolution=16)
+gen = perturb_state(TriPlaneGenerator(cfg, seed=0)); P = state_cpu(gen); gen = gen.to(dev)
+c = look_at_label(torch.tensor([1.3]), torch.tensor([1.5]))
+g = torch.Generator().manual_seed(4)
+b, hw, res = 1, 20, 4; r = res * res
+planes = torch.randn(b, 3, 32, hw, hw, generator=g)
+us = torch.rand(b, r, 16, 1, generator=g); ui = torch.rand(b * r, 16, generator=g)
+g_feat = torch.randn(b, r, 32, generator=g)
+o, d = O.ray_sampler(c[:, :16].reshape(-1, 4, 4), c[:, 16:].reshape(-1, 3, 3), res)
+axes = O.plane_axes(cfg.plane_axes)
+def run(depths):
+    xyz = (o[:, :, None] + depths * d[:, :, None]).reshape(b, -1, 3)
+    feats = O.sample_from_planes(axes, planes, xyz, cfg.box_warp)
+    rgb, sigma = O.osg_decoder(P, feats, 1.0)
+    k = depths.shape[2]
+    return rgb.reshape(b, r, k, -1), sigma.reshape(b, r, k, 1)
+d_c = O.sample_stratified(b, r, cfg.ray_start, cfg.ray_end, 16, us)
+c_c, s_c = run(d_c)
+_, _, w = O.ray_march(c_c, s_c, d_c)
+d_f = O.sample_importance(d_c, w, ui)
+c_f, s_f = run(d_f)
+d_all = torch.cat([d_c, d_f], -2)
+c_all = torch.cat([c_c, c_f], -2).detach().requires_grad_(True)
+s_all = torch.cat([s_c, s_f], -2).detach().requires_grad_(True)
+_, idx = torch.sort(d_all, dim=-2)
+ds = torch.gather(d_all, -2, idx); cs = torch.gather(c_all, -2, idx.expand(-1, -1, -1, 32)); ss = torch.gather(s_all, -2, idx)
+rgb, _, _ = O.ray_march(cs, ss, ds)
+(rgb * g_feat).sum().backward()
+pl = planes.permute(0, 1, 3, 4, 2).contiguous().to(dev)
+u_s, u_i = gen._uniforms(b, dev, us.to(dev), ui.to(dev))
+dpl, rec = ops.raymarch_bwd(g_feat.to(dev), pl, u_strat=u_s, u_imp=u_i, return_rec=True, **gen._render_args(c.to(dev)))
+rec = rec.cpu()[0]   # [R, S, 4]
+print("depth err", (rec[..., 0] - d_all[0, ..., 0]).abs().max().item())
+# dL/dc_j = omega_j * 2 g  -> omega = (dL/dc . g) / (2 g.g)
+om_ref = (c_all.grad[0] * g_feat[0][:, None, :]).sum(-1) / (2 * (g_feat[0] ** 2).sum(-1))[:, None]
+print("omega err", (rec[..., 1] - om_ref).abs().max().item(), "max", om_ref.abs().max().item())
+print("dsigma err", (rec[..., 2] - s_all.grad[0, ..., 0]).abs().max().item(), "max", s_all.grad.abs().max().item())
+print(rec[0, :6, 2], s_all.grad[0, 0, :6, 0])

@@ -1,0 +1,162 @@
+"""Backward pass of the HIP path (d/d ws with the generator frozen) against autograd through the CPU oracle.
+Needs an MI355X:  python -m pytest tests -m gpu"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.util import look_at_label, make_inputs, perturb_state, state_cpu
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("the -m gpu tests need an MI355X")
+    from hfa_gp_amd import _lib
+    _lib.lib()
+    return torch.device("cuda:0")
+
+
+def close(a, b, atol, rtol=1e-4):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = (a - b).abs()
+    assert torch.isfinite(a).all()
+    assert bool((err <= atol + rtol * b.abs()).all()), f"max err {err.max().item():.3e} (ref max {b.abs().max().item():.3e})"
+
+
+@pytest.mark.parametrize("b,h,cin,cout", [(1, 4, 8, 32), (2, 9, 16, 24), (1, 17, 32, 128)])
+def test_conv3x3_bwd_data(dev, b, h, cin, cout):
+    """mode CONV3X3_BWD with transposed weights == autograd of F.conv2d w.r.t. its input."""
+    from hfa_gp_amd import ops
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(b, cin, h, h, generator=g, requires_grad=True)
+    w = torch.randn(cout, cin, 3, 3, generator=g)
+    gy = torch.randn(b, cout, h, h, generator=g)
+    F.conv2d(x, w, padding=1).backward(gy)
+    wt_t, _ = ops.weight_prep(w.to(dev).transpose(0, 1).contiguous())
+    dx = ops.modconv(ops.nchw_to_nhwc(gy.to(dev)), wt_t, cin, ops.CONV3X3_BWD)
+    close(ops.nhwc_to_nchw(dx), x.grad, atol=2e-5)
+
+
+@pytest.mark.parametrize("b,h,cin,cout", [(1, 4, 8, 32), (2, 7, 16, 24), (1, 16, 32, 64)])
+def test_upconv_bwd_data(dev, b, h, cin, cout):
+    """upfir_bwd + mode CONVS2_BWD == autograd of (conv_transpose2d stride 2 -> FIR pad 1 gain 4) w.r.t. input."""
+    from hfa_gp_amd import ops
+    from oracle import eg3d_oracle as O
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(b, cin, h, h, generator=g, requires_grad=True)
+    w = torch.randn(cout, cin, 3, 3, generator=g)
+    gy = torch.randn(b, cout, 2 * h, 2 * h, generator=g)
+    O._conv_up2(x, w, O.fir_kernel()).backward(gy)
+    wt_t, _ = ops.weight_prep(w.to(dev).transpose(0, 1).contiguous())
+    gph = ops.upfir_bwd(ops.nchw_to_nhwc(gy.to(dev)))
+    dx = ops.modconv(gph, wt_t, cin, ops.CONVS2_BWD)
+    close(ops.nhwc_to_nchw(dx), x.grad, atol=5e-5)
+
+
+def test_upsample2d_bwd(dev):
+    from hfa_gp_amd import ops
+    from oracle import eg3d_oracle as O
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 8, 5, 7, generator=g, requires_grad=True)
+    gy = torch.randn(2, 8, 10, 14, generator=g)
+    O.upsample2d(x, O.fir_kernel()).backward(gy)
+    close(ops.upsample2d_bwd(gy.to(dev), channels_last=False), x.grad, atol=1e-5)
+    gh = ops.nchw_to_nhwc(gy.to(dev))
+    close(ops.nhwc_to_nchw(ops.upsample2d_bwd(gh, channels_last=True)), x.grad, atol=1e-5)
+
+
+@pytest.mark.parametrize("preset", ["tiny64", "small128", "ffhq512_128"])
+def test_raymarch_bwd_vs_oracle_autograd(dev, preset):
+    """d planes of the fused renderer vs autograd through the oracle's ImportanceRenderer."""
+    import dataclasses
+    from hfa_gp_amd import ops
+    from hfa_gp_amd.config import PRESETS
+    from hfa_gp_amd.generator import TriPlaneGenerator
+    from oracle import eg3d_oracle as O
+    cfg = dataclasses.replace(PRESETS[preset](), neural_rendering_resolution=10, img_resolution=40)
+    gen = perturb_state(TriPlaneGenerator(cfg, seed=0))
+    P = state_cpu(gen)
+    gen = gen.to(dev)
+    c = look_at_label(torch.tensor([1.3, 1.8]), torch.tensor([1.5, 1.7]))
+    g = torch.Generator().manual_seed(4)
+    b, hw, res = 2, 20, cfg.neural_rendering_resolution
+    r = res * res
+    planes = torch.randn(b, 3, 32, hw, hw, generator=g, requires_grad=True)
+    us = torch.rand(b, r, cfg.depth_resolution, 1, generator=g)
+    ui = torch.rand(b * r, cfg.depth_resolution_importance, generator=g)
+    g_feat = torch.randn(b, r, 32, generator=g)
+    o, d = O.ray_sampler(c[:, :16].reshape(-1, 4, 4), c[:, 16:].reshape(-1, 3, 3), res)
+    feat, _, _ = O.importance_renderer(P, cfg, planes, o, d, us, ui)
+    feat.backward(g_feat)
+    pl = planes.detach().permute(0, 1, 3, 4, 2).contiguous().to(dev)
+    u_s, u_i = gen._uniforms(b, dev, us.to(dev), ui.to(dev))
+    dpl = ops.raymarch_bwd(g_feat.to(dev), pl, u_strat=u_s, u_imp=u_i, **gen._render_args(c.to(dev)))
+    close(dpl.permute(0, 1, 4, 2, 3), planes.grad, atol=2e-5, rtol=1e-3)
+
+
+@pytest.mark.parametrize("preset,batch", [("tiny64", 2), ("tiny14", 1), ("small128", 2)])
+def test_synthesis_backward_vs_oracle_autograd(dev, preset, batch):
+    """dL/d ws for L = <image, G> + <image_raw, G_raw>, generator frozen (BASELINE config 3 mechanics)."""
+    from hfa_gp_amd.config import PRESETS
+    from hfa_gp_amd.generator import TriPlaneGenerator
+    from oracle import eg3d_oracle as O
+    cfg = PRESETS[preset]()
+    gen = perturb_state(TriPlaneGenerator(cfg, seed=0)).requires_grad_(False)
+    P = state_cpu(gen)
+    gen = gen.to(dev)
+    ws, c, us, ui = make_inputs(cfg, batch)
+    g = torch.Generator().manual_seed(6)
+    G = torch.randn(batch, 3, cfg.img_resolution, cfg.img_resolution, generator=g) / cfg.img_resolution
+    G_raw = torch.randn(batch, 3, cfg.neural_rendering_resolution, cfg.neural_rendering_resolution, generator=g) / 64
+    ws_ref = ws.clone().requires_grad_(True)
+    ref = O.synthesis(P, cfg, ws_ref, c, us, ui)
+    ((ref["image"] * G).sum() + (ref["image_raw"] * G_raw).sum()).backward()
+    ws_d = ws.to(dev).requires_grad_(True)
+    out = gen.synthesis(ws_d, c.to(dev), noise_mode="const", u_strat=us.to(dev), u_imp=ui.to(dev))
+    close(out["image"], ref["image"], atol=1e-4)
+    ((out["image"] * G.to(dev)).sum() + (out["image_raw"] * G_raw.to(dev)).sum()).backward()
+    scale = ws_ref.grad.abs().max().item()
+    close(ws_d.grad, ws_ref.grad, atol=2e-4 * scale, rtol=2e-3)
+
+
+def test_trainer_step_on_gpu_matches_oracle_step(dev):
+    """One `gen_update` (3DMM-driven, L2 only) on the MI355X vs the same step through the oracle on CPU:
+    same loss, same gradients of bases / delta / driver net."""
+    from hfa_gp_amd import headnerf
+    from hfa_gp_amd.trainer import Trainer
+    from tests.test_trainer_cpu import Args, OracleGenerator, frame
+
+    def build(device, oracle):
+        torch.manual_seed(0)
+        gen = headnerf.HeadNeRF_3DMM(Args(), Args.size, device, 512, Args.latent_dim_shape)
+        if oracle:
+            OracleGenerator.adopt(gen.generator)
+        tr = Trainer(Args(), device, mode="3dmm", gen=gen)
+        tr.g_optim = torch.optim.SGD(tr.gen.parameters(), lr=0.0)      # compare gradients, not Adam's first step
+        return tr
+
+    real, label, params = frame(2)
+    cpu = build("cpu", True)
+    l2_cpu, _, _ = cpu.gen_update(real, label.clone(), params)
+    gpu = build(dev, False)
+    # same renderer uniforms as OracleGenerator draws (seed 0)
+    cfg = gpu.gen.generator.cfg
+    g = torch.Generator().manual_seed(0)
+    r = cfg.neural_rendering_resolution ** 2
+    us = torch.rand(1, r, cfg.depth_resolution, 1, generator=g).to(dev)
+    ui = torch.rand(r, cfg.depth_resolution_importance, generator=g).to(dev)
+    inner = gpu.gen.generator.synthesis
+    gpu.gen.generator.synthesis = lambda ws, c=None, noise_mode="const": inner(ws, c, noise_mode, u_strat=us, u_imp=ui)
+    l2_gpu, _, _ = gpu.gen_update(real.to(dev), label.clone().to(dev), params.to(dev))
+    assert abs(float(l2_gpu) - float(l2_cpu)) < 1e-5
+    for name in ("bases", "delta"):
+        a, bref = getattr(gpu.gen, name).grad, getattr(cpu.gen, name).grad
+        close(a, bref, atol=2e-4 * bref.abs().max().item(), rtol=2e-3)
+    a = gpu.gen.weights_3dmm.fc[0].weight.grad
+    bref = cpu.gen.weights_3dmm.fc[0].weight.grad
+    close(a, bref, atol=2e-4 * bref.abs().max().item(), rtol=2e-3)
