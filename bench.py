@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -35,6 +36,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=4, help="frames per step per GPU")
     ap.add_argument("--preset", default="ffhq512_128")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the fitting-step leg (train_step_ms)")
+    ap.add_argument("--train-batch", type=int, default=2, help="frames per fitting step per GPU")
+    ap.add_argument("--train-steps", type=int, default=6)
     ap.add_argument("--cpu-runs", type=int, default=2)
     return ap.parse_args()
 
@@ -53,6 +57,57 @@ def cpu_baseline(cfg, state, runs: int):
     return {"value": 1.0 / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{runs} x synthesis(B=1) of the {cfg.name} workload with the fp32 PyTorch-CPU oracle, "
                       f"{dt:.2f} s/frame"}
+
+
+class _FitArgs:
+    """Flags of code/train_3dmm.py that reach the step."""
+    out_pose = False
+    person_2 = False
+    params_len = 76
+    size = 256
+    batch_size = 1
+    lr = 3e-4
+    latent_dim_style = 512
+    latent_dim_shape = 50
+    generator_seed = 0
+
+
+def train_leg(args, cfg_name, dev, rank, world, dist):
+    """BASELINE config 3/4 mechanics: 3DMM-driven latent-basis fitting, generator frozen, L2 loss at 256^2
+    (LPIPS weights are not available offline), Adam 3e-4; frames sharded over ranks, ONE flattened
+    all-reduce of the shared gradients per step.  Returns max-over-ranks ms per step."""
+    from hfa_gp_amd.trainer import Trainer
+    from tests.util import look_at_label
+    fa = _FitArgs()
+    fa.generator_preset = cfg_name
+    torch.manual_seed(0)
+    tr = Trainer(fa, dev, rank=rank, world_size=world, mode="3dmm")
+    g = torch.Generator().manual_seed(40 + rank)
+    B = args.train_batch
+    real = (0.5 * torch.randn(B, 3, fa.size, fa.size, generator=g)).clamp(-1, 1).to(dev)
+    params = torch.randn(B, fa.params_len, generator=g).to(dev)
+    label = look_at_label(math.pi / 2 + 0.3 * torch.randn(B, generator=g),
+                          math.pi / 2 + 0.155 * torch.randn(B, generator=g), flipped=False).to(dev)
+    for _ in range(2):
+        tr.gen_update(real, label.clone(), params)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.train_steps):
+        l2, _, _ = tr.gen_update(real, label.clone(), params)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(l2)
+    return dt / args.train_steps * 1e3, B
 
 
 def main():
@@ -116,6 +171,12 @@ def main():
         units = sum(u for _, _, u in evs)
         return ms, units, len(evs)
 
+    train_ms = train_B = None
+    if not args.no_train:
+        del img
+        torch.cuda.empty_cache()
+        train_ms, train_B = train_leg(args, args.preset, dev, rank, world, dist)
+
     if rank == 0:
         frames = world * B * args.steps
         rm_ms, rm_bytes, rm_n = agg("raymarch")
@@ -141,6 +202,12 @@ def main():
                                   "traffic": None, "avg_launch_ms": rm_ms / max(rm_n, 1), "launches": rm_n,
                                   "algorithmic_bytes_per_launch": rm_bytes / max(rm_n, 1)},
         }
+        if train_ms is not None:
+            out["train_step_ms"] = train_ms
+            out["train_config"] = {"workload": "3DMM-driven latent-basis fitting step (fwd + bwd + Adam), K=50, "
+                                               "generator frozen, L2 at 256^2, synthetic frames",
+                                   "frames_per_step_per_gpu": train_B,
+                                   "collective": "one flattened all-reduce of shared grads per step" if world > 1 else None}
         if state is not None:
             out["cpu_baseline"] = cpu_baseline(cfg, state, args.cpu_runs)
         print(json.dumps(out), flush=True)

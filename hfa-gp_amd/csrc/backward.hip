@@ -224,17 +224,22 @@ __global__ void __launch_bounds__(256) style_bwd_ds_kernel(const float* __restri
     if (lane == 0) dstot[wave] = (ds[wave] - styles[wave] * acc) * style_gain;
 }
 
-// dw[b][k] (+)= wgain * sum_i dstot[b][i] * A[i][k]
+// dw[b][k] (+)= wgain * sum_i dstot[b][i] * A[i][k].  Block = 64 columns k x 4 row groups; coalesced rows of A.
 __global__ void __launch_bounds__(256) style_bwd_dw_kernel(const float* __restrict__ dstot, const float* __restrict__ A,
                                                            float* __restrict__ dw, int B, int Cin, int w_dim,
                                                            int dw_stride, float wgain, int accumulate) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= B * w_dim) return;
-    const int b = idx / w_dim, k = idx % w_dim;
+    __shared__ float red[4][64];
+    const int b = blockIdx.y, k = blockIdx.x * 64 + (threadIdx.x & 63), ig = threadIdx.x >> 6;
     float acc = 0.f;
-    for (int i = 0; i < Cin; ++i) acc += dstot[(size_t)b * Cin + i] * A[(size_t)i * w_dim + k];
-    float* dst = dw + (size_t)b * dw_stride + k;
-    *dst = accumulate ? *dst + acc * wgain : acc * wgain;
+    if (k < w_dim)
+        for (int i = ig; i < Cin; i += 4) acc += dstot[(size_t)b * Cin + i] * A[(size_t)i * w_dim + k];
+    red[ig][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (ig == 0 && k < w_dim) {
+        const float v = (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) * wgain;
+        float* dst = dw + (size_t)b * dw_stride + k;
+        *dst = accumulate ? *dst + v : v;
+    }
 }
 
 }  // namespace hfagp
@@ -293,8 +298,7 @@ int hfagp_style_bwd(const HfagpStyleBwdArgs* a, void* stream) {
     const int waves = a->B * a->Cin;
     style_bwd_ds_kernel<<<(waves + 3) / 4, 256, 0, s>>>(a->ds, a->dd, a->styles, a->dcoef, a->wsq, a->dstot, a->B,
                                                        a->Cin, a->Cout, a->style_gain);
-    const int n = a->B * a->w_dim;
-    style_bwd_dw_kernel<<<(n + 255) / 256, 256, 0, s>>>(a->dstot, a->affine_w, a->dw, a->B, a->Cin, a->w_dim,
+    style_bwd_dw_kernel<<<dim3((a->w_dim + 63) / 64, a->B), 256, 0, s>>>(a->dstot, a->affine_w, a->dw, a->B, a->Cin, a->w_dim,
                                                        a->dw_stride, 1.0f / sqrtf((float)a->w_dim), a->accumulate);
     return check_launch("style_bwd");
 }

@@ -1,0 +1,38 @@
+"""Developer timing of one fitting step (BASELINE config 3 mechanics) on the GPU box."""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hfa_gp_amd import headnerf
+from hfa_gp_amd.trainer import Trainer
+from tests.util import look_at_label
+
+
+class Args:
+    out_pose = False; person_2 = False; params_len = 76; size = 256; batch_size = 1; lr = 3e-4
+    latent_dim_style = 512; latent_dim_shape = 50; generator_preset = "ffhq512_128"; generator_seed = 0
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    tr = Trainer(Args(), dev, mode="3dmm")
+    g = torch.Generator().manual_seed(1)
+    real = (0.5 * torch.randn(B, 3, 256, 256, generator=g)).clamp(-1, 1).to(dev)
+    params = torch.randn(B, 76, generator=g).to(dev)
+    label0 = look_at_label(1.57 + 0.3 * torch.randn(B, generator=g), 1.57 + 0.15 * torch.randn(B, generator=g), flipped=False).to(dev)
+    for _ in range(2):
+        tr.gen_update(real, label0.clone(), params)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(iters):
+        l2, _, _ = tr.gen_update(real, label0.clone(), params)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / iters
+    print(f"train step B={B}: {dt*1e3:.2f} ms/step ({dt/B*1e3:.2f} ms/frame), l2={float(l2):.4f}, "
+          f"mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB")
+
+
+if __name__ == "__main__":
+    main()
