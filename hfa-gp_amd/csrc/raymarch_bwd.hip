@@ -23,6 +23,12 @@ struct TileLds {
 template <int S>
 __global__ void __launch_bounds__(256, 2) raymarch_bwd_tiles_kernel(const RayParams p, float* __restrict__ d_planes) {
     __shared__ TileLds lds_all[4];
+    // A operands of the two backward products, lane-linear ([step][lane]: conflict-free ds_read_b32), shared by
+    // the 4 waves:  w1t[mt][ot*4+r][lane] = W1[1 + 16ot + 4g + r][16mt + j] * g1
+    //               w0t[ft][mt*4+r][lane] = W0[16mt + 4g + r][16ft + j] * g0
+    __shared__ float w1t[4 * 8 * 64];
+    __shared__ float w0t[2 * 16 * 64];
+    __shared__ float wfwd[kDecLdsRows * 64];       // forward A operands (DecoderRegs image)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     TileLds& lds = lds_all[wave];
     const HfagpRaymarchArgs& a = p.a;
@@ -30,9 +36,23 @@ __global__ void __launch_bounds__(256, 2) raymarch_bwd_tiles_kernel(const RayPar
     const int R = a.res * a.res;
     constexpr int NT = S / 16;
 
-    DecoderRegs dec;
-    load_decoder(a, j, g, dec);
-    const float g0 = a.decoder_lr_mul * 0.17677669529663687f, g1 = a.decoder_lr_mul * 0.125f;
+    if (wave == 0) {
+        DecoderRegs dec;
+        load_decoder(a, j, g, dec);
+        store_decoder_lds(dec, wfwd, lane);
+    }
+    {
+        const float g0 = a.decoder_lr_mul * 0.17677669529663687f, g1 = a.decoder_lr_mul * 0.125f;
+        for (int i = threadIdx.x; i < 4 * 8 * 64; i += 256) {
+            const int l = i & 63, st = (i >> 6) & 7, mt = i >> 9, jj = l & 15, gg = l >> 4;
+            w1t[i] = a.dec_w1[(1 + 16 * (st >> 2) + 4 * gg + (st & 3)) * 64 + 16 * mt + jj] * g1;
+        }
+        for (int i = threadIdx.x; i < 2 * 16 * 64; i += 256) {
+            const int l = i & 63, st = (i >> 6) & 15, ft = i >> 10, jj = l & 15, gg = l >> 4;
+            w0t[i] = a.dec_w0[(16 * (st >> 2) + 4 * gg + (st & 3)) * 32 + 16 * ft + jj] * g0;
+        }
+        __syncthreads();
+    }
 
     const long long ntiles = (long long)p.total_rays * NT;
     for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long long)gridDim.x * 4) {
@@ -48,7 +68,7 @@ __global__ void __launch_bounds__(256, 2) raymarch_bwd_tiles_kernel(const RayPar
         gather8(a, b, g, taps, f);
         f32x4 hp[4], h[4], o[2];
         float sigma;
-        decoder_fwd<true>(dec, f, hp, h, sigma, o);
+        decoder_fwd_lds<true>(wfwd, lane, f, hp, h, sigma, o);
 
         // dL/do (colour logits) in the C layout: lane (j, g), register r of tile ot -> channel 16ot + 4g + r
         //   colour = sigmoid(o) * 1.002 - 0.001,  dL/dcolour = omega * 2 dL/dfeat
@@ -67,13 +87,13 @@ __global__ void __launch_bounds__(256, 2) raymarch_bwd_tiles_kernel(const RayPar
         f32x4 dH[4];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-            dH[mt] = f32x4{dec.wsig[mt][0] * rec.z, dec.wsig[mt][1] * rec.z, dec.wsig[mt][2] * rec.z,
-                           dec.wsig[mt][3] * rec.z};
+            const float* ws_ = wfwd + (48 + mt * 4) * 64 + lane;
+            dH[mt] = f32x4{ws_[0] * rec.z, ws_[64] * rec.z, ws_[128] * rec.z, ws_[192] * rec.z};
 #pragma unroll
             for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float wA = a.dec_w1[(1 + 16 * ot + 4 * g + r) * 64 + 16 * mt + j] * g1;
+                    const float wA = w1t[(mt * 8 + ot * 4 + r) * 64 + lane];
                     dH[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wA, dO[ot][r], dH[mt], 0, 0, 0);
                 }
 #pragma unroll
@@ -88,20 +108,22 @@ __global__ void __launch_bounds__(256, 2) raymarch_bwd_tiles_kernel(const RayPar
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float wA = a.dec_w0[(16 * mt + 4 * g + r) * 32 + 16 * ft + j] * g0;
+                    const float wA = w0t[(ft * 16 + mt * 4 + r) * 64 + lane];
                     dF[ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(wA, dH[mt][r], dF[ft], 0, 0, 0);
                 }
             // lane (j, g), register r -> feature channel 16ft + 4g + r of sample j
             *reinterpret_cast<float4*>(&lds.df[j * 32 + 16 * ft + 4 * g]) =
                 make_float4(dF[ft][0], dF[ft][1], dF[ft][2], dF[ft][3]);
         }
-        if (g < 3) {                                   // lane (j, g<3) publishes plane g's taps of sample j
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                lds.idx[j * 12 + g * 4 + k] = taps[g].idx[k];
-                lds.wgt[j * 12 + g * 4 + k] = taps[g].w[k] * 0.3333333333333333f;
+        for (int pl = 0; pl < 3; ++pl)                 // lane (j, g = pl) publishes plane pl's taps of sample j
+            if (g == pl) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    lds.idx[j * 12 + pl * 4 + k] = taps[pl].idx[k];
+                    lds.wgt[j * 12 + pl * 4 + k] = taps[pl].w[k] * 0.3333333333333333f;
+                }
             }
-        }
         WAVE_SYNC();
         // ---- scatter: half-wave hf handles samples hf, hf+2, ...; lane = channel
         {
@@ -114,7 +136,11 @@ __global__ void __launch_bounds__(256, 2) raymarch_bwd_tiles_kernel(const RayPar
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const float wgt = lds.wgt[sm * 12 + pl * 4 + k];
+#ifndef HFAGP_NO_ATOMICS
                         if (wgt != 0.f)
+#else
+                        if (wgt == 12345.f)
+#endif
                             unsafeAtomicAdd(base + ((size_t)pl * a.H * a.W + lds.idx[sm * 12 + pl * 4 + k]) * 32, v * wgt);
                     }
             }

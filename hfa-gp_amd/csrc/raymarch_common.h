@@ -247,4 +247,62 @@ __device__ __forceinline__ void decoder_fwd(const DecoderRegs& w, const float f[
     }
 }
 
+// The same decoder with the A operands read from an LDS image [105][64] of DecoderRegs (lane-linear, so every
+// ds_read_b32 is conflict-free): used where the registers are needed for the backward products.
+constexpr int kDecLdsRows = 105;
+__device__ __forceinline__ void store_decoder_lds(const DecoderRegs& w, float* img, int lane) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) img[(mt * 8 + t) * 64 + lane] = w.w0a[mt][t];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            img[(32 + mt * 4 + r) * 64 + lane] = w.b0c[mt][r];
+            img[(48 + mt * 4 + r) * 64 + lane] = w.wsig[mt][r];
+        }
+    }
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) img[(64 + ot * 16 + k) * 64 + lane] = w.w1a[ot][k];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) img[(96 + ot * 4 + r) * 64 + lane] = w.b1c[ot][r];
+    }
+    img[104 * 64 + lane] = w.bsig;
+}
+
+template <bool KEEP_PRE>
+__device__ __forceinline__ void decoder_fwd_lds(const float* img, int lane, const float f[8], f32x4 hp[4], f32x4 h[4],
+                                                float& sigma, f32x4 o[2]) {
+    const float* W = img + lane;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        h[mt] = f32x4{W[(32 + mt * 4) * 64], W[(33 + mt * 4) * 64], W[(34 + mt * 4) * 64], W[(35 + mt * 4) * 64]};
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+            h[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[(mt * 8 + t) * 64], f[t], h[mt], 0, 0, 0);
+    }
+    float sg = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (KEEP_PRE) hp[mt][r] = h[mt][r];
+            h[mt][r] = softplus_f(h[mt][r]);
+            sg = fmaf(h[mt][r], W[(48 + mt * 4 + r) * 64], sg);
+        }
+    sg += __shfl_xor(sg, 16);
+    sg += __shfl_xor(sg, 32);
+    sigma = sg + W[104 * 64];
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot) {
+        o[ot] = f32x4{W[(96 + ot * 4) * 64], W[(97 + ot * 4) * 64], W[(98 + ot * 4) * 64], W[(99 + ot * 4) * 64]};
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                o[ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[(64 + ot * 16 + mt * 4 + r) * 64], h[mt][r], o[ot], 0, 0, 0);
+    }
+}
+
 }  // namespace hfagp
