@@ -117,9 +117,15 @@ __global__ void __launch_bounds__(256) reduce_partials_kernel(const float* __res
     const int i = blockIdx.x * blockDim.x + threadIdx.x;   // over B * n
     if (i >= B * n) return;
     const int b = i / n, k = i % n;
-    float s = 0.f;
-    for (int q = 0; q < nchunks; ++q) s += partial[((size_t)b * nchunks + q) * n + k];
-    sums[i] = s;
+    const float* src = partial + (size_t)b * nchunks * n + k;
+    float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};          // fixed order -> deterministic
+    int q = 0;
+    for (; q + 8 <= nchunks; q += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) part[u] += src[(size_t)(q + u) * n];
+    }
+    for (; q < nchunks; ++q) part[0] += src[(size_t)q * n];
+    sums[i] = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
 }
 
 // ---------------------------------------------------------------- adjoint of (FIR pad 1 gain 4) + parity split
@@ -231,8 +237,17 @@ __global__ void __launch_bounds__(256) style_bwd_dw_kernel(const float* __restri
     __shared__ float red[4][64];
     const int b = blockIdx.y, k = blockIdx.x * 64 + (threadIdx.x & 63), ig = threadIdx.x >> 6;
     float acc = 0.f;
-    if (k < w_dim)
-        for (int i = ig; i < Cin; i += 4) acc += dstot[(size_t)b * Cin + i] * A[(size_t)i * w_dim + k];
+    if (k < w_dim) {
+        float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // 8 independent load chains in flight
+        int i = ig;
+        for (; i + 28 < Cin; i += 32) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                part[u] += dstot[(size_t)b * Cin + i + 4 * u] * A[(size_t)(i + 4 * u) * w_dim + k];
+        }
+        for (; i < Cin; i += 4) part[0] += dstot[(size_t)b * Cin + i] * A[(size_t)i * w_dim + k];
+        acc = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
+    }
     red[ig][threadIdx.x & 63] = acc;
     __syncthreads();
     if (ig == 0 && k < w_dim) {
