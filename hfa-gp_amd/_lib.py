@@ -79,7 +79,7 @@ class PointwiseBwdArgs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "dxs_conv", "s_conv", "dxs_rgb", "s_rgb", "g_rgb_small", "w_rgb_small", "s_small", "g_direct", "x",
         "dcoef_p", "bias_p", "noise_p", "g_out", "partial", "sums")] + \
-        [(n, C.c_int32) for n in ("B", "H", "W", "C", "Co", "nchunks", "has_producer", "act_p")] + \
+        [(n, C.c_int32) for n in ("B", "H", "W", "C", "Co", "nchunks", "has_producer", "act_p", "param_grads")] + \
         [(n, C.c_float) for n in ("noise_strength_p", "alpha", "gain", "clamp")]
 
 
@@ -87,6 +87,11 @@ class StyleBwdArgs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("ds", "dd", "styles", "dcoef", "wsq", "affine_w", "dstot", "dw")] + \
         [(n, C.c_int32) for n in ("B", "Cin", "Cout", "w_dim", "dw_stride", "accumulate")] + \
         [("style_gain", C.c_float)]
+
+
+class WgradArgs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("x", "styles", "g", "weight", "dd", "dcoef", "dweight", "workspace")] + \
+        [(n, C.c_int32) for n in ("B", "H", "W", "Cin", "Cout", "mode", "ksplit")]
 
 
 class RaymarchBwdArgs(C.Structure):
@@ -111,6 +116,10 @@ SYMBOLS = {
     "hfagp_planes_to_nhwc": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p]),
     "hfagp_style_bwd": (C.c_int, [C.POINTER(StyleBwdArgs), C.c_void_p]),
     "hfagp_raymarch_bwd": (C.c_int, [C.POINTER(RaymarchBwdArgs), C.c_void_p]),
+    "hfagp_wgrad_workspace_bytes": (C.c_size_t, [C.POINTER(WgradArgs)]),
+    "hfagp_conv_wgrad": (C.c_int, [C.POINTER(WgradArgs), C.c_void_p]),
+    "hfagp_affine_grad": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 4 + [C.c_void_p]),
+    "hfagp_channel_sum": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "hfagp_upfirdn2d_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int32] * 12 + [C.c_float, C.c_void_p]),
     "hfagp_bias_act_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64,
                                      C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p]),

@@ -12,7 +12,9 @@
 
 namespace hfagp {
 
-constexpr int kRed = 4;      // reductions per channel: ds_conv, ds_rgb, ds_small, dd_p
+// reductions per channel: 0 ds_conv, 1 ds_rgb, 2 ds_small, 3 dd_p, 4 dbias_p = sum g_pre, 5 sum g_pre*noise,
+// 6..9 sum_pix g_rgb_small[c] * x   (weight gradient rows of the small toRGB, before the style factor)
+constexpr int kRed = 10;
 
 __global__ void __launch_bounds__(256) pointwise_bwd_kernel(const HfagpPointwiseBwdArgs a, int rows_per_block) {
     // block = (chunk of pixel rows, sample b); thread = (pixel lane, 4-channel group)
@@ -69,6 +71,10 @@ __global__ void __launch_bounds__(256) pointwise_bwd_kernel(const HfagpPointwise
                     if (c < a.Co) {
                         const float g = a.g_rgb_small[((size_t)b * a.Co + c) * HW + p];
                         t[0] += g * wsm[c].x; t[1] += g * wsm[c].y; t[2] += g * wsm[c].z; t[3] += g * wsm[c].w;
+                        if (a.param_grads) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) acc[6 + c][k] += g * xv[k];
+                        }
                     }
                 const float sv[4] = {s_sm.x, s_sm.y, s_sm.z, s_sm.w};
 #pragma unroll
@@ -92,6 +98,7 @@ __global__ void __launch_bounds__(256) pointwise_bwd_kernel(const HfagpPointwise
                     pre = xv[k] / a.gain;
                     if (a.act_p == HFAGP_ACT_LRELU && xv[k] < 0.f) { g *= a.alpha; pre /= a.alpha; }
                     acc[3][k] += g * (pre - bv[k] - nz) / dv[k];
+                    if (a.param_grads) { acc[4][k] += g; acc[5][k] += g * nz; }
                     g *= dv[k];
                 }
                 go[k] = g;
@@ -267,6 +274,7 @@ int hfagp_pointwise_bwd(const HfagpPointwiseBwdArgs* a, void* stream) {
     HFAGP_REQUIRE(a && a->x && a->g_out && a->partial && a->sums, HFAGP_EBADARG, "pointwise_bwd: null pointer");
     HFAGP_REQUIRE(a->C % 4 == 0 && a->C / 4 <= 256 && a->B > 0 && a->H > 0 && a->W > 0, HFAGP_EUNSUPPORTED,
                   "pointwise_bwd: C=%d must be a multiple of 4 and <= 1024", a->C);
+    HFAGP_REQUIRE(a->noise_strength_p == a->noise_strength_p, HFAGP_EBADARG, "pointwise_bwd: NaN noise strength");
     HFAGP_REQUIRE(!a->g_rgb_small || (a->Co >= 1 && a->Co <= 4 && a->w_rgb_small && a->s_small), HFAGP_EBADARG,
                   "pointwise_bwd: small toRGB needs 1..4 channels, weights and styles");
     HFAGP_REQUIRE(a->nchunks >= 1, HFAGP_EBADARG, "pointwise_bwd: nchunks");

@@ -1,0 +1,266 @@
+// Weight gradient of the modulated convolutions (gfx950, v_mfma_f32_32x32x2_f32, exact fp32).
+//
+//   dW[t][ci][co] = sum_{b, m, n}  (x * s_b)[b][m + ady_t][n + adx_t][ci] * g[img_t][b][m + bdy_t][n + bdx_t][co]
+//
+// GEMM view per tap: M = ci, N = co, K = B*H*W positions.  A block owns a 64(ci) x 64(co) tile for ALL taps
+// (each wave a 32x32 tile x ntaps accumulators) and walks 4x16-position tiles: the x patch and the g patch
+// (both with a 1-pixel halo) are staged in LDS once per position tile and reused by the 9 taps.  Split-K over
+// (b, position tile) writes deterministic slabs; wgrad_reduce_kernel sums them, adds the demodulation term
+// and writes the gradient in the parameter's [Cout][Cin][kh][kw] layout.
+//   3x3 conv     : x shifts with the tap (ady, adx in -1..1), g does not.
+//   up-conv      : g = the four parity images of the y_t gradient (hfagp_upfir_bwd); tap (ti,tj) reads parity
+//                  (ti&1, tj&1) at shift (ti>>1, tj>>1); x does not shift.
+//   1x1 (toRGB)  : one tap, no shifts.
+#include "common.h"
+
+namespace hfagp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int TPH = 4, TPW = 16;                 // position tile
+constexpr int PPH = TPH + 2, PPW = TPW + 2;      // patch with halo
+constexpr int WT = 64;                           // ci / co tile
+constexpr int WS = WT + 4;                       // LDS row stride (floats)
+
+struct WTap { signed char ady, adx, bdy, bdx, widx; };
+
+struct WgradParams {
+    const float* x; const float* styles; const float* g;
+    float* slabs;                                // [nunits_split][ntaps][Cin][Cout]
+    int B, H, W, Cin, Cout;                      // x is [B][H][W][Cin]
+    int gH, gW;                                  // g images are [B][gH][gW][Cout]
+    int ntaps, tiles_h, tiles_w, ksplit;
+    WTap tap[9];
+};
+
+template <int NT>
+__global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* As = lds;                             // [PPH*PPW][WS]  x patch  (ci contiguous)
+    float* Bs = lds + PPH * PPW * WS;            // [PPH*PPW][WS]  g patch (co contiguous)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;     // wave tile: ci rows 32*wi.., co cols 32*wj..
+    const int h = lane >> 5, l31 = lane & 31;
+    const int ci0 = blockIdx.x * WT, co0 = blockIdx.y * WT, ks = blockIdx.z;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int units = p.B * p.tiles_h * p.tiles_w;
+    const int u_begin = (int)(((long long)units * ks) / p.ksplit), u_end = (int)(((long long)units * (ks + 1)) / p.ksplit);
+    for (int u = u_begin; u < u_end; ++u) {
+        const int tw = u % p.tiles_w, th = (u / p.tiles_w) % p.tiles_h, b = u / (p.tiles_w * p.tiles_h);
+        const int m0 = th * TPH, n0 = tw * TPW;
+        __syncthreads();
+        // ---- stage the x patch (x * s) and the g patch(es); 16 lanes x float4 per pixel row of 64 channels
+        for (int idx = tid; idx < PPH * PPW * 16; idx += 256) {
+            const int pix = idx >> 4, q = idx & 15;
+            const int iy = m0 - 1 + pix / PPW, ix = n0 - 1 + pix % PPW;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && ci0 + 4 * q < p.Cin) {
+                v = *reinterpret_cast<const float4*>(p.x + (((size_t)b * p.H + iy) * p.W + ix) * p.Cin + ci0 + 4 * q);
+                if (p.styles) {
+                    const float4 s = *reinterpret_cast<const float4*>(p.styles + (size_t)b * p.Cin + ci0 + 4 * q);
+                    v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w;
+                }
+            }
+            *reinterpret_cast<float4*>(As + pix * WS + 4 * q) = v;
+        }
+        for (int idx = tid; idx < PPH * PPW * 16; idx += 256) {
+            const int pix = idx >> 4, q = idx & 15;
+            const int iy = m0 - 1 + pix / PPW, ix = n0 - 1 + pix % PPW;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (iy >= 0 && iy < p.gH && ix >= 0 && ix < p.gW && co0 + 4 * q < p.Cout)
+                v = *reinterpret_cast<const float4*>(p.g + (((size_t)b * p.gH + iy) * p.gW + ix) * p.Cout + co0 + 4 * q);
+            *reinterpret_cast<float4*>(Bs + pix * WS + 4 * q) = v;
+        }
+        __syncthreads();
+        // ---- K loop over the 64 positions of the tile, two per MFMA (lane half h takes position 2k + h)
+#pragma unroll 2
+        for (int k = 0; k < TPH * TPW / 2; ++k) {
+            const int pos = 2 * k + h;
+            const int pr = pos / TPW + 1, pc = pos % TPW + 1;           // patch coordinates of (m, n)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const WTap tp = p.tap[t];
+                const float av = As[((pr + tp.ady) * PPW + pc + tp.adx) * WS + 32 * wi + l31];
+                const float bv = Bs[((pr + tp.bdy) * PPW + pc + tp.bdx) * WS + 32 * wj + l31];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+            }
+        }
+    }
+    // ---- store the slab: C/D layout row = (r&3) + 8*(r>>2) + 4*h (ci), col = lane&31 (co)
+    float* slab = p.slabs + (size_t)ks * p.ntaps * p.Cin * p.Cout;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = ci0 + 32 * wi + (r & 3) + 8 * (r >> 2) + 4 * h, co = co0 + 32 * wj + l31;
+            if (ci < p.Cin && co < p.Cout) slab[((size_t)t * p.Cin + ci) * p.Cout + co] = acc[t][r];
+        }
+}
+
+// dW[co][ci][tap] = sum_ks slab[ks][tap(widx)][ci][co]  -  W[co][ci][tap] * sum_b dd[b][co] d[b][co]^3 s[b][ci]^2
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ slabs, const float* __restrict__ weight,
+                                                           const float* __restrict__ dd, const float* __restrict__ dcoef,
+                                                           const float* __restrict__ styles, float* __restrict__ dW,
+                                                           int ksplit, int ntaps, int Cin, int Cout, int B, int wtaps, WTap t0,
+                                                           WTap t1, WTap t2, WTap t3, WTap t4, WTap t5, WTap t6,
+                                                           WTap t7, WTap t8) {
+    const WTap taps[9] = {t0, t1, t2, t3, t4, t5, t6, t7, t8};
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // over Cin * Cout, co fastest (coalesced slab reads)
+    if (idx >= Cin * Cout) return;
+    const int co = idx % Cout, ci = idx / Cout;
+    float dem = 0.f;
+    if (dd)
+        for (int b = 0; b < B; ++b) {
+            const float d = dcoef[(size_t)b * Cout + co], s = styles[(size_t)b * Cin + ci];
+            dem += dd[(size_t)b * Cout + co] * d * d * d * s * s;
+        }
+    for (int t = 0; t < ntaps; ++t) {
+        float acc = 0.f;
+        for (int k = 0; k < ksplit; ++k) acc += slabs[(((size_t)k * ntaps + t) * Cin + ci) * Cout + co];
+        const size_t wi = ((size_t)co * Cin + ci) * wtaps + taps[t].widx;
+        dW[wi] = acc - weight[wi] * dem;
+    }
+}
+
+// dA[i][k] = wgain * sum_b dstot[b][i] * w[b][k];  db[i] = sum_b dstot[b][i]   (accumulating)
+__global__ void __launch_bounds__(256) affine_grad_kernel(const float* __restrict__ dstot, const float* __restrict__ w,
+                                                          float* __restrict__ dA, float* __restrict__ db, int B, int Cin,
+                                                          int w_dim, int w_stride, float wgain) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Cin * w_dim) return;
+    const int i = idx / w_dim, k = idx % w_dim;
+    float acc = 0.f, sb = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float d = dstot[(size_t)b * Cin + i];
+        acc += d * w[(size_t)b * w_stride + k];
+        sb += d;
+    }
+    dA[idx] += acc * wgain;
+    if (k == 0) db[i] += sb;
+}
+
+// per-channel sums over all pixels of a channels-last tensor: out[c] += sum_{b,pix} g[b][pix][c] (deterministic 2-stage)
+__global__ void __launch_bounds__(256) channel_sum_kernel(const float* __restrict__ g, float* __restrict__ partial,
+                                                          long long npix, int C) {
+    // block handles a slice of pixels; thread = (pixel lane, channel)
+    __shared__ float red[256];
+    const int c = threadIdx.x % C, pl = threadIdx.x / C, npl = 256 / C;
+    float acc = 0.f;
+    if (pl < npl)
+        for (long long px = (long long)blockIdx.x * npl + pl; px < npix; px += (long long)gridDim.x * npl)
+            acc += g[px * C + c];
+    red[threadIdx.x] = pl < npl ? acc : 0.f;
+    __syncthreads();
+    if (threadIdx.x < C) {
+        float s = 0.f;
+        for (int q = 0; q < npl; ++q) s += red[q * C + threadIdx.x];
+        partial[(size_t)blockIdx.x * C + threadIdx.x] = s;
+    }
+}
+
+__global__ void __launch_bounds__(256) channel_sum_final_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                                int nblocks, int C, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int q = 0; q < nblocks; ++q) s += partial[(size_t)q * C + c];
+    out[c] = accumulate ? out[c] + s : s;
+}
+
+}  // namespace hfagp
+
+using namespace hfagp;
+
+template <int NT>
+static int run_wgrad(WgradParams& p, const HfagpWgradArgs* a, hipStream_t s) {
+    p.ntaps = NT;
+    const size_t lds = (size_t)2 * PPH * PPW * WS * sizeof(float);
+    dim3 grid((a->Cin + WT - 1) / WT, (a->Cout + WT - 1) / WT, a->ksplit);
+    wgrad_kernel<NT><<<grid, 256, lds, s>>>(p);
+    int rc = check_launch("conv_wgrad");
+    if (rc != HFAGP_OK) return rc;
+    const int n = a->Cin * a->Cout;
+    wgrad_reduce_kernel<<<(n + 255) / 256, 256, 0, s>>>(a->workspace, a->weight, a->dd, a->dcoef, a->styles, a->dweight,
+                                                       a->ksplit, NT, a->Cin, a->Cout, a->B, a->mode == HFAGP_CONV1X1 ? 1 : 9,
+                                                       p.tap[0], p.tap[1], p.tap[2], p.tap[3], p.tap[4], p.tap[5], p.tap[6],
+                                                       p.tap[7], p.tap[8]);
+    return check_launch("conv_wgrad/reduce");
+}
+
+extern "C" {
+
+size_t hfagp_wgrad_workspace_bytes(const HfagpWgradArgs* a) {
+    if (!a || a->ksplit <= 0) return 0;
+    const int ntaps = a->mode == HFAGP_CONV1X1 ? 1 : (a->mode == HFAGP_CONVT3X3_UP2 ? 4 : 9);
+    return (size_t)a->ksplit * ntaps * a->Cin * a->Cout * sizeof(float);
+}
+
+int hfagp_conv_wgrad(const HfagpWgradArgs* a, void* stream) {
+    HFAGP_REQUIRE(a && a->x && a->g && a->weight && a->dweight && a->workspace, HFAGP_EBADARG, "conv_wgrad: null pointer");
+    HFAGP_REQUIRE(a->Cin % 4 == 0 && a->Cout % 4 == 0 && a->B > 0 && a->H > 0 && a->W > 0 && a->ksplit >= 1,
+                  HFAGP_EUNSUPPORTED, "conv_wgrad: Cin=%d Cout=%d must be multiples of 4", a->Cin, a->Cout);
+    HFAGP_REQUIRE(!a->dd || (a->dcoef && a->styles), HFAGP_EBADARG, "conv_wgrad: dd needs dcoef and styles");
+    WgradParams p{};
+    p.x = a->x; p.styles = a->styles; p.g = a->g; p.slabs = a->workspace;
+    p.B = a->B; p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.Cout = a->Cout; p.ksplit = a->ksplit;
+    p.tiles_h = (a->H + TPH - 1) / TPH; p.tiles_w = (a->W + TPW - 1) / TPW;      // position grid = x positions
+    hipStream_t s = (hipStream_t)stream;
+    if (a->mode == HFAGP_CONV3X3) {
+        p.gH = a->H; p.gW = a->W;
+        for (int t = 0; t < 9; ++t) p.tap[t] = WTap{(signed char)(t / 3 - 1), (signed char)(t % 3 - 1), 0, 0, (signed char)t};
+        return run_wgrad<9>(p, a, s);
+    }
+    if (a->mode == HFAGP_CONV1X1) {
+        p.gH = a->H; p.gW = a->W;
+        p.tap[0] = WTap{0, 0, 0, 0, 0};
+        return run_wgrad<1>(p, a, s);
+    }
+    if (a->mode == HFAGP_CONVT3X3_UP2) {
+        // g = the four parity images [2][2][B][H+1][W+1][Cout] of the y_t gradient; tap (ti, tj) reads parity
+        // (ti&1, tj&1) at shift (ti>>1, tj>>1).  One launch per parity image.
+        p.gH = a->H + 1; p.gW = a->W + 1;
+        const long long img = (long long)a->B * p.gH * p.gW * a->Cout;
+        static const int taps_of[4][4] = {{0, 2, 6, 8}, {1, 7, -1, -1}, {3, 5, -1, -1}, {4, -1, -1, -1}};
+        static const int ntaps_of[4] = {4, 2, 2, 1};
+        for (int ph = 0; ph < 4; ++ph) {
+            p.g = a->g + ph * img;
+            for (int k = 0; k < ntaps_of[ph]; ++k) {
+                const int t = taps_of[ph][k], ti = t / 3, tj = t % 3;
+                p.tap[k] = WTap{0, 0, (signed char)(ti >> 1), (signed char)(tj >> 1), (signed char)t};
+            }
+            const int rc = ntaps_of[ph] == 4 ? run_wgrad<4>(p, a, s) : ntaps_of[ph] == 2 ? run_wgrad<2>(p, a, s)
+                                                                                       : run_wgrad<1>(p, a, s);
+            if (rc != HFAGP_OK) return rc;
+        }
+        return HFAGP_OK;
+    }
+    set_error("conv_wgrad: unsupported mode %d", a->mode);
+    return HFAGP_EBADARG;
+}
+
+int hfagp_affine_grad(const float* dstot, const float* w, float* dA, float* db, int32_t B, int32_t Cin, int32_t w_dim,
+                      int32_t w_stride, void* stream) {
+    HFAGP_REQUIRE(dstot && w && dA && db, HFAGP_EBADARG, "affine_grad: null pointer");
+    const int n = Cin * w_dim;
+    affine_grad_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(dstot, w, dA, db, B, Cin, w_dim, w_stride,
+                                                                         1.0f / sqrtf((float)w_dim));
+    return check_launch("affine_grad");
+}
+
+int hfagp_channel_sum(const float* g, float* partial, float* out, int64_t npix, int32_t C, int32_t nblocks,
+                      int32_t accumulate, void* stream) {
+    HFAGP_REQUIRE(g && partial && out, HFAGP_EBADARG, "channel_sum: null pointer");
+    HFAGP_REQUIRE(C >= 1 && C <= 256 && nblocks >= 1, HFAGP_EUNSUPPORTED, "channel_sum: C=%d (max 256)", C);
+    hipStream_t s = (hipStream_t)stream;
+    channel_sum_kernel<<<nblocks, 256, 0, s>>>(g, partial, npix, C);
+    channel_sum_final_kernel<<<(C + 255) / 256, 256, 0, s>>>(partial, out, nblocks, C, accumulate);
+    return check_launch("channel_sum");
+}
+
+}  // extern "C"

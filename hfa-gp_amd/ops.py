@@ -250,23 +250,25 @@ def nhwc_to_nchw(x: torch.Tensor) -> torch.Tensor:
 
 # ----------------------------------------------------------------------------- backward pass
 def pointwise_bwd(x: torch.Tensor, dxs_conv=None, s_conv=None, dxs_rgb=None, s_rgb=None, g_rgb_small=None,
-                  w_rgb_small=None, s_small=None, g_direct=None, producer: Optional[dict] = None):
+                  w_rgb_small=None, s_small=None, g_direct=None, producer: Optional[dict] = None,
+                  param_grads: bool = False):
     """Fused streaming pass over the saved activation x [B,H,W,C] (see include/hfagp.h).  `producer` =
     dict(dcoef, bias, noise, noise_strength, act, alpha, gain, clamp) of the layer that produced x, or None.
-    Returns (g_out [B,H,W,C], sums [B,4,C])."""
+    Returns (g_out [B,H,W,C], sums [B,10,C])."""
     _chk(x, "x")
     b, h, w, c = x.shape
     nchunks = max(1, min(256, (h * w) // 64))
     a = L.PointwiseBwdArgs()
     g_out = torch.empty_like(x)
-    partial = torch.empty(b, nchunks, 4, c, device=x.device, dtype=torch.float32)
-    sums = torch.empty(b, 4, c, device=x.device, dtype=torch.float32)
+    partial = torch.empty(b, nchunks, 10, c, device=x.device, dtype=torch.float32)
+    sums = torch.empty(b, 10, c, device=x.device, dtype=torch.float32)
     a.x, a.g_out, a.partial, a.sums = _ptr(x), _ptr(g_out), _ptr(partial), _ptr(sums)
     a.dxs_conv, a.s_conv, a.dxs_rgb, a.s_rgb = _ptr(dxs_conv), _ptr(s_conv), _ptr(dxs_rgb), _ptr(s_rgb)
     a.g_rgb_small, a.w_rgb_small, a.s_small, a.g_direct = _ptr(g_rgb_small), _ptr(w_rgb_small), _ptr(s_small), _ptr(g_direct)
     a.B, a.H, a.W, a.C, a.nchunks = b, h, w, c, nchunks
     a.Co = g_rgb_small.shape[1] if g_rgb_small is not None else 0
     a.clamp = -1.0
+    a.param_grads = int(param_grads)
     if producer is not None:
         a.has_producer = 1
         a.dcoef_p, a.bias_p, a.noise_p = _ptr(producer.get("dcoef")), _ptr(producer.get("bias")), _ptr(producer.get("noise"))
@@ -314,8 +316,9 @@ def planes_to_nhwc(pm: torch.Tensor) -> torch.Tensor:
 
 def style_bwd(ds: torch.Tensor, dd: Optional[torch.Tensor], styles: torch.Tensor, dcoef: Optional[torch.Tensor],
               wsq: Optional[torch.Tensor], affine_w: torch.Tensor, dw: torch.Tensor, style_gain: float = 1.0,
-              accumulate: bool = True) -> None:
-    """Accumulate d ws for one layer into the row view dw [B, w_dim] (strided view of d_ws)."""
+              accumulate: bool = True) -> torch.Tensor:
+    """Accumulate d ws for one layer into the row view dw [B, w_dim] (strided view of d_ws); returns
+    dstot [B, Cin] = gradient w.r.t. the raw affine output (input of affine_grad)."""
     b, cin = styles.shape
     a = L.StyleBwdArgs()
     dstot = torch.empty(b, cin, device=styles.device, dtype=torch.float32)
@@ -329,6 +332,46 @@ def style_bwd(ds: torch.Tensor, dd: Optional[torch.Tensor], styles: torch.Tensor
     a.w_dim, a.dw_stride, a.accumulate = affine_w.shape[1], dw.stride(0), int(accumulate)
     a.style_gain = style_gain
     L.check(L.lib().hfagp_style_bwd(C.byref(a), _stream()), "style_bwd")
+    return dstot
+
+
+def conv_wgrad(x: torch.Tensor, styles: Optional[torch.Tensor], g: torch.Tensor, weight: torch.Tensor, mode: int,
+               dd: Optional[torch.Tensor] = None, dcoef: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Weight gradient of a modulated conv (see include/hfagp.h): returns dweight like `weight`."""
+    _chk(x, "x")
+    _chk(g, "g")
+    b, h, w, cin = x.shape
+    cout = weight.shape[0]
+    a = L.WgradArgs()
+    dweight = torch.empty_like(weight)
+    units = b * ((h + 3) // 4) * ((w + 15) // 16)
+    tiles = ((cin + 63) // 64) * ((cout + 63) // 64)
+    ksplit = max(1, min(units, (768 + tiles - 1) // tiles, 256))
+    a.x, a.styles, a.g = _ptr(x), _ptr(styles), _ptr(g)
+    a.weight, a.dd, a.dcoef, a.dweight = _ptr(_chk(weight.detach(), "weight")), _ptr(dd), _ptr(dcoef), _ptr(dweight)
+    a.B, a.H, a.W, a.Cin, a.Cout, a.mode, a.ksplit = b, h, w, cin, cout, mode, ksplit
+    ws = torch.empty(L.lib().hfagp_wgrad_workspace_bytes(C.byref(a)) // 4, device=x.device, dtype=torch.float32)
+    a.workspace = _ptr(ws)
+    L.check(L.lib().hfagp_conv_wgrad(C.byref(a), _stream()), "conv_wgrad")
+    return dweight
+
+
+def affine_grad(dstot: torch.Tensor, w: torch.Tensor, dA: torch.Tensor, db: torch.Tensor) -> None:
+    """dA [Cin, w_dim] += dstot^T . w / sqrt(w_dim); db [Cin] += sum_b dstot.  w is a row view [B, w_dim] of ws."""
+    b, cin = dstot.shape
+    L.check(L.lib().hfagp_affine_grad(_ptr(dstot), w.data_ptr(), _ptr(dA), _ptr(db), b, cin, w.shape[1], w.stride(0),
+                                      _stream()), "affine_grad")
+
+
+def channel_sum(g: torch.Tensor, out: torch.Tensor, accumulate: bool = True) -> None:
+    """out[c] (+)= sum over all leading dims of the channels-last tensor g [..., C]."""
+    _chk(g, "g")
+    c = g.shape[-1]
+    npix = g.numel() // c
+    nblocks = int(max(1, min(512, npix // 256)))
+    partial = torch.empty(nblocks, c, device=g.device, dtype=torch.float32)
+    L.check(L.lib().hfagp_channel_sum(_ptr(g), _ptr(partial), _ptr(out), npix, c, nblocks, int(accumulate), _stream()),
+            "channel_sum")
 
 
 def raymarch_bwd(g_feat: torch.Tensor, planes: torch.Tensor, cam2world, intrinsics, u_strat, u_imp, dec_w0, dec_b0,

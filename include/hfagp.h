@@ -187,7 +187,11 @@ int hfagp_torgb_fwd(const HfagpTorgbArgs* a, void* stream);
  *   gX      = dxs_conv*s_conv + dxs_rgb*s_rgb + s_small * (w_rgb_small^T g_rgb_small) + g_direct
  *   g_out   = has_producer ? gX * gain * lrelu'(X) * [|X|<clamp] * dcoef_p : gX
  *   sums[b][0] = sum_pix dxs_conv*X   sums[b][1] = sum_pix dxs_rgb*X   sums[b][2] = sum_pix (w^T g)*X
- *   sums[b][3] = sum_pix g_pre * conv_p      (gradient of P's demodulation coefficients)              */
+ *   sums[b][3] = sum_pix g_pre * conv_p      (gradient of P's demodulation coefficients)
+ * and, when param_grads != 0 (generator being tuned):
+ *   sums[b][4] = sum_pix g_pre (bias of P)   sums[b][5] = sum_pix g_pre * noise_p*strength (per channel)
+ *   sums[b][6+c] = sum_pix g_rgb_small[c] * X   (small-toRGB weight gradient before the style factor)
+ * sums is [B][10][C].                                                                                    */
 typedef struct {
     const float* dxs_conv;    /* [B][H][W][C] or NULL */
     const float* s_conv;      /* [B][C] */
@@ -202,9 +206,9 @@ typedef struct {
     const float* bias_p;      /* [C] or NULL */
     const float* noise_p;     /* [H][W] or NULL */
     float*       g_out;       /* [B][H][W][C] */
-    float*       partial;     /* workspace [B][nchunks][4][C] */
-    float*       sums;        /* out [B][4][C] */
-    int32_t B, H, W, C, Co, nchunks, has_producer, act_p;
+    float*       partial;     /* workspace [B][nchunks][10][C] */
+    float*       sums;        /* out [B][10][C] */
+    int32_t B, H, W, C, Co, nchunks, has_producer, act_p, param_grads;
     float noise_strength_p, alpha, gain, clamp;
 } HfagpPointwiseBwdArgs;
 
@@ -248,6 +252,38 @@ typedef struct {
 } HfagpRaymarchBwdArgs;
 
 int hfagp_raymarch_bwd(const HfagpRaymarchBwdArgs* a, void* stream);
+
+/* ------------------------------------------------------------------ gradients w.r.t. the generator weights
+ * (needed once HFA-GP calls tune_generator(), trainer_rgb.py:69-71)                                       */
+
+/* dweight[Cout][Cin][k][k] = conv-weight-gradient( x * styles , g )  -  weight * sum_b dd d^3 styles^2
+ * (second term: through the demodulation coefficients; dd may be NULL).
+ *   mode HFAGP_CONV3X3      : g = gradient w.r.t. the raw conv output            [B][H][W][Cout]
+ *   mode HFAGP_CONVT3X3_UP2 : g = parity images from hfagp_upfir_bwd             [2][2][B][H+1][W+1][Cout]
+ *   mode HFAGP_CONV1X1      : g = gradient w.r.t. the toRGB output               [B][H][W][Cout]            */
+typedef struct {
+    const float* x;           /* [B][H][W][Cin] layer input */
+    const float* styles;      /* [B][Cin] or NULL */
+    const float* g;
+    const float* weight;      /* [Cout][Cin][k][k] */
+    const float* dd;          /* [B][Cout] or NULL */
+    const float* dcoef;       /* [B][Cout] */
+    float*       dweight;     /* out [Cout][Cin][k][k] (overwritten) */
+    float*       workspace;   /* >= hfagp_wgrad_workspace_bytes() */
+    int32_t B, H, W, Cin, Cout, mode;
+    int32_t ksplit;           /* number of split-K slabs over (b, position tiles); >= 1 */
+} HfagpWgradArgs;
+
+size_t hfagp_wgrad_workspace_bytes(const HfagpWgradArgs* a);
+int hfagp_conv_wgrad(const HfagpWgradArgs* a, void* stream);
+
+/* affine layer: dA[Cin][w_dim] += dstot^T . w / sqrt(w_dim);  db[Cin] += sum_b dstot   (dstot from hfagp_style_bwd) */
+int hfagp_affine_grad(const float* dstot, const float* w, float* dA, float* db, int32_t B, int32_t Cin, int32_t w_dim,
+                      int32_t w_stride, void* stream);
+
+/* out[c] (+)= sum over npix rows of a [npix][C] channels-last tensor (C <= 256); partial: [nblocks][C] workspace */
+int hfagp_channel_sum(const float* g, float* partial, float* out, int64_t npix, int32_t C, int32_t nblocks,
+                      int32_t accumulate, void* stream);
 
 /* ------------------------------------------------------------------ standalone ops (NCHW, test surface) */
 int hfagp_upfirdn2d_fwd(const float* x, const float* f, float* y,

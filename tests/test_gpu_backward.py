@@ -205,3 +205,30 @@ def test_rgb_trainer_and_render_harness_on_gpu(dev):
         ref = to_uint8(tr.gen.get_image(tr.gen.get_latent(tr.gen.get_weights(real)), lab))
     # same frame up to the renderer's fresh uniforms: compare statistics, not pixels
     assert abs(frames[0].float().mean().item() - ref.float().mean().item()) < 8.0
+
+
+@pytest.mark.parametrize("b,h,cin,cout,mode", [(1, 4, 8, 32, "3x3"), (2, 9, 24, 96, "3x3"), (2, 21, 64, 128, "3x3"),
+                                               (1, 4, 8, 32, "up"), (2, 11, 32, 64, "up"), (2, 13, 40, 96, "1x1")])
+def test_conv_weight_gradient(dev, b, h, cin, cout, mode):
+    """hfagp_conv_wgrad == autograd of the (modulated) convolution w.r.t. its weight (no demodulation term)."""
+    from hfa_gp_amd import ops
+    from oracle import eg3d_oracle as O
+    g = torch.Generator().manual_seed(7)
+    k = 1 if mode == "1x1" else 3
+    x = torch.randn(b, cin, h, h, generator=g)
+    s = torch.randn(b, cin, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g, requires_grad=True)
+    xs = x * s[:, :, None, None]
+    if mode == "up":
+        y = O._conv_up2(xs, w, O.fir_kernel())
+    else:
+        y = F.conv2d(xs, w, padding=k // 2)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    xh = ops.nchw_to_nhwc(x.to(dev))
+    gh = ops.nchw_to_nhwc(gy.to(dev))
+    if mode == "up":
+        dw = ops.conv_wgrad(xh, s.to(dev), ops.upfir_bwd(gh), w.detach().to(dev), ops.CONVT3X3_UP2)
+    else:
+        dw = ops.conv_wgrad(xh, s.to(dev), gh, w.detach().to(dev), ops.CONV3X3 if k == 3 else ops.CONV1X1)
+    close(dw, w.grad, atol=1e-4 * w.grad.abs().max().item(), rtol=1e-4)
