@@ -95,7 +95,8 @@ class WgradArgs(C.Structure):
 
 
 class RaymarchBwdArgs(C.Structure):
-    _fields_ = [("fwd", RaymarchArgs), ("g_feat", C.c_void_p), ("d_planes", C.c_void_p), ("rec", C.c_void_p)]
+    _fields_ = [("fwd", RaymarchArgs), ("g_feat", C.c_void_p), ("d_planes", C.c_void_p), ("rec", C.c_void_p),
+                ("d_dec_w0", C.c_void_p), ("d_dec_b0", C.c_void_p), ("d_dec_w1", C.c_void_p), ("d_dec_b1", C.c_void_p)]
 
 
 # every symbol include/hfagp.h declares: name -> (restype, argtypes)

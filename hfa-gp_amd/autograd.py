@@ -30,9 +30,20 @@ def _masked(g: torch.Tensor, y: Optional[torch.Tensor], clamp: Optional[float]) 
 
 
 class _Backward:
-    def __init__(self, gen, tape, d_ws: torch.Tensor):
-        self.gen, self.tape, self.d_ws = gen, tape, d_ws
-        self._wt_t = {}
+    def __init__(self, gen, tape, d_ws: torch.Tensor, ws: torch.Tensor, param_grads: bool):
+        self.gen, self.tape, self.d_ws, self.ws, self.pg = gen, tape, d_ws, ws, param_grads
+        self.grads = {}            # id(parameter) -> gradient (only when the generator is being tuned)
+
+    def _acc(self, param: torch.Tensor, g: torch.Tensor):
+        key = id(param)
+        self.grads[key] = g if key not in self.grads else self.grads[key] + g
+
+    def affine_grads(self, affine, dstot: torch.Tensor, row: int):
+        dA = torch.zeros_like(affine.weight)
+        db = torch.zeros_like(affine.bias)
+        ops.affine_grad(dstot, self.ws[:, row], dA, db)
+        self._acc(affine.weight, dA)
+        self._acc(affine.bias, db)
 
     # transposed-weight images for the bwd-data GEMMs (cached on the generator like the forward ones)
     def wt_t(self, weight: torch.Tensor) -> torch.Tensor:
@@ -74,47 +85,90 @@ class _Backward:
             dxs_rgb = ops.modconv(g_y, self.wt_t(tr.weight), cin, ops.CONV1X1)
             kw = dict(dxs_rgb=dxs_rgb, s_rgb=rgb["styles"])
         # ---- X = conv1 output: consumers = next conv0 (+) toRGB; producer = conv1
-        g_conv1, sums = ops.pointwise_bwd(x1, dxs_conv=dxs_next, s_conv=s_next, producer=c1["producer"], **kw)
+        g_conv1, sums = ops.pointwise_bwd(x1, dxs_conv=dxs_next, s_conv=s_next, producer=c1["producer"],
+                                          param_grads=self.pg, **kw)
         if next_layer_rec is not None:
             next_layer_rec["ds"] = sums[:, 0]
         ds_rgb = sums[:, 2] if rgb["small"] else sums[:, 1]
-        ops.style_bwd(ds_rgb, None, rgb["styles"], None, None, tr.affine.weight, self.d_ws[:, rgb["row"]],
-                      1.0 / math.sqrt(cin), accumulate=True)
+        dstot = ops.style_bwd(ds_rgb, None, rgb["styles"], None, None, tr.affine.weight, self.d_ws[:, rgb["row"]],
+                              1.0 / math.sqrt(cin), accumulate=True)
         c1["dd"] = sums[:, 3]
+        if self.pg:
+            self.affine_grads(tr.affine, dstot, rgb["row"])
+            if rgb["small"]:
+                co = tr.weight.shape[0]
+                dw = (sums[:, 6:6 + co] * rgb["styles"][:, None, :]).sum(0)          # [Co, C]: tiny host-side glue
+                self._acc(tr.weight, dw.reshape(tr.weight.shape))
+                db = torch.zeros_like(tr.bias)
+                ops.channel_sum(g_y.permute(0, 2, 3, 1).contiguous(), db)
+            else:
+                self._acc(tr.weight, ops.conv_wgrad(x1, rgb["styles"], g_y, tr.weight, ops.CONV1X1))
+                db = torch.zeros_like(tr.bias)
+                ops.channel_sum(g_y, db)
+            self._acc(tr.bias, db)
+            self.layer_param_grads(c1, sums, g_conv1)
         # ---- conv1 bwd-data
         c1_cin = c1["layer"].weight.shape[1]
         dxs1 = ops.modconv(g_conv1, self.wt_t(c1["layer"].weight), c1_cin, ops.CONV3X3_BWD)
         if c0 is None:
             # b4: the input is the learned constant (broadcast over the batch): only the style gradient is needed
             xc = c1["x"].expand(dxs1.shape[0], -1, -1, -1).contiguous()
-            _, s0 = ops.pointwise_bwd(xc, dxs_conv=dxs1, s_conv=c1["styles"])
+            gconst, s0 = ops.pointwise_bwd(xc, dxs_conv=dxs1, s_conv=c1["styles"])
             c1["ds"] = s0[:, 0]
             self.finish_layer(c1)
+            if self.pg:
+                self._acc(rec["const"], gconst.sum(0).permute(2, 0, 1).contiguous())
             return None, None, g_img_prev
         # ---- X = conv0 output: consumer = conv1; producer = conv0 (up-sampling layer)
-        g_conv0, s0 = ops.pointwise_bwd(c0["out"], dxs_conv=dxs1, s_conv=c1["styles"], producer=c0["producer"])
+        g_conv0, s0 = ops.pointwise_bwd(c0["out"], dxs_conv=dxs1, s_conv=c1["styles"], producer=c0["producer"],
+                                        param_grads=self.pg)
         c1["ds"] = s0[:, 0]
         c0["dd"] = s0[:, 3]
         self.finish_layer(c1)
         gph = ops.upfir_bwd(g_conv0)
+        if self.pg:
+            self.layer_param_grads(c0, s0, gph)
         c0_cin = c0["layer"].weight.shape[1]
         dxs0 = ops.modconv(gph, self.wt_t(c0["layer"].weight), c0_cin, ops.CONVS2_BWD)
         return dxs0, c0, g_img_prev
 
+    def layer_param_grads(self, rec: dict, sums_out: torch.Tensor, g: torch.Tensor):
+        """weight / bias / noise-strength gradients of one SynthesisLayer.  `sums_out` = reductions of the pass over
+        the layer's OUTPUT; `g` = gradient w.r.t. its raw conv output (parity images for the up-sampling layer)."""
+        layer = rec["layer"]
+        x = rec["x"]
+        if x.shape[0] != g.shape[-4]:                      # b4: the learned constant is shared by the batch
+            x = x.expand(g.shape[-4], -1, -1, -1).contiguous()
+        mode = ops.CONVT3X3_UP2 if rec["up"] == 2 else ops.CONV3X3
+        self._acc(layer.weight, ops.conv_wgrad(x, rec["styles"], g, layer.weight, mode, dd=rec["dd"].contiguous(),
+                                               dcoef=rec["dcoef"]))
+        self._acc(layer.bias, sums_out[:, 4].sum(0))
+        if rec["producer"]["noise"] is not None:
+            self._acc(layer.noise_strength, sums_out[:, 5].sum())
+
     def finish_layer(self, rec: dict):
         """ds (from the pass over the layer's input) and dd (from the pass over its output) are both known."""
-        ops.style_bwd(rec["ds"], rec["dd"], rec["styles"], rec["dcoef"], rec["wsq"], rec["layer"].affine.weight,
-                      self.d_ws[:, rec["row"]], 1.0, accumulate=True)
+        dstot = ops.style_bwd(rec["ds"], rec["dd"], rec["styles"], rec["dcoef"], rec["wsq"],
+                              rec["layer"].affine.weight, self.d_ws[:, rec["row"]], 1.0, accumulate=True)
+        if self.pg:
+            self.affine_grads(rec["layer"].affine, dstot, rec["row"])
 
 
 class SynthesisFn(torch.autograd.Function):
+    """inputs: ws, c, u_strat, u_imp, gen, *generator parameters (listed only so that autograd can hand their
+    gradients back when the generator is being tuned; the forward reads them from `gen`)."""
+
     @staticmethod
-    def forward(ctx, ws, c, u_strat, u_imp, gen):
+    def forward(ctx, ws, c, u_strat, u_imp, gen, *params):
         tape = {}
+        ws_c = ws.detach().float().contiguous()
         with torch.no_grad():
-            img, rgb_raw, depth, _, _ = gen._forward_impl(ws.detach().float().contiguous(),
-                                                         c.detach().float().contiguous(), u_strat, u_imp, tape)
-        ctx.gen, ctx.tape = gen, tape
+            img, rgb_raw, depth, planes, feat_img = gen._forward_impl(ws_c, c.detach().float().contiguous(), u_strat,
+                                                                      u_imp, tape)
+        gen._last_extras = (planes, feat_img)        # for synthesis(return_planes=True)
+        ctx.gen, ctx.tape, ctx.ws_c = gen, tape, ws_c
+        ctx.params = params
+        ctx.pg = any(p.requires_grad for p in params)
         ctx.ws_shape = ws.shape
         ctx.mark_non_differentiable(depth)
         return img, rgb_raw, depth
@@ -127,7 +181,7 @@ class SynthesisFn(torch.autograd.Function):
         b = tape["batch"]
         dev = tape["planes"].device
         d_ws = torch.zeros(ctx.ws_shape, device=dev, dtype=torch.float32)
-        bw = _Backward(gen, tape, d_ws)
+        bw = _Backward(gen, tape, d_ws, ctx.ws_c, ctx.pg)
         if g_img is None:
             g_img = torch.zeros(b, cfg.img_channels, cfg.img_resolution, cfg.img_resolution, device=dev)
         g_img = g_img.float().contiguous()
@@ -148,8 +202,15 @@ class SynthesisFn(torch.autograd.Function):
         bw.finish_layer(c0rec0)
         # ---- renderer
         res = cfg.neural_rendering_resolution
-        d_planes = ops.raymarch_bwd(g_feat.view(b, res * res, 32), tape["planes"], u_strat=tape["u_strat"],
-                                    u_imp=tape["u_imp"], **gen._render_args(tape["c"]))
+        rb = ops.raymarch_bwd(g_feat.view(b, res * res, 32), tape["planes"], u_strat=tape["u_strat"],
+                              u_imp=tape["u_imp"], decoder_grads=ctx.pg, **gen._render_args(tape["c"]))
+        if ctx.pg:
+            d_planes, dec = rb
+            net = gen.decoder.net
+            for prm, g in zip((net["0"].weight, net["0"].bias, net["2"].weight, net["2"].bias), dec):
+                bw._acc(prm, g)
+        else:
+            d_planes = rb
         # ---- backbone, last block first
         g_img_b = ops.planes_to_nhwc(d_planes)
         dxs, nxt = None, None
@@ -160,4 +221,5 @@ class SynthesisFn(torch.autograd.Function):
                 bw.finish_layer(nxt)
             dxs, nxt = dxs_new, c0
         ctx.tape = None
-        return d_ws, None, None, None, None
+        pgrads = tuple(bw.grads.get(id(p)) if p.requires_grad else None for p in ctx.params)
+        return (d_ws, None, None, None, None) + pgrads

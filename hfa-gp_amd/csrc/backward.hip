@@ -85,7 +85,8 @@ __global__ void __launch_bounds__(256) pointwise_bwd_kernel(const HfagpPointwise
                 gx[0] += g.x; gx[1] += g.y; gx[2] += g.z; gx[3] += g.w;
             }
             // producer layer P: through clamp / gain / leaky-ReLU, then the demodulation
-            const float nz = a.noise_p ? a.noise_p[p] * a.noise_strength_p : 0.f;
+            const float nraw = a.noise_p ? a.noise_p[p] : 0.f;
+            const float nz = nraw * a.noise_strength_p;
             const float dv[4] = {d_p.x, d_p.y, d_p.z, d_p.w}, bv[4] = {b_p.x, b_p.y, b_p.z, b_p.w};
             float go[4];
 #pragma unroll
@@ -98,7 +99,7 @@ __global__ void __launch_bounds__(256) pointwise_bwd_kernel(const HfagpPointwise
                     pre = xv[k] / a.gain;
                     if (a.act_p == HFAGP_ACT_LRELU && xv[k] < 0.f) { g *= a.alpha; pre /= a.alpha; }
                     acc[3][k] += g * (pre - bv[k] - nz) / dv[k];
-                    if (a.param_grads) { acc[4][k] += g; acc[5][k] += g * nz; }
+                    if (a.param_grads) { acc[4][k] += g; acc[5][k] += g * nraw; }
                     g *= dv[k];
                 }
                 go[k] = g;

@@ -20,9 +20,19 @@ struct TileLds {
     float wgt[16 * 12];       // bilinear weight / 3
 };
 
-template <int S>
-__global__ void __launch_bounds__(256, 2) raymarch_bwd_tiles_kernel(const RayParams p, float* __restrict__ d_planes) {
+// decoder-weight gradients (PG): per-tile operand images for the sample-contracting products
+//   dW1c[32x64] += dO[32x16] . SP^T[16x64]      dW0[64x32] += dHpre[64x16] . F[16x32]
+struct GradLds {
+    float sp[64 * 17], dp[64 * 17], dO[32 * 17], f[16 * 33];
+};
+
+struct DecGrads { float *w0, *b0, *w1, *b1; };   // [64][32], [64], [33][64], [33]; accumulated with atomics
+
+template <int S, bool PG>
+__global__ void __launch_bounds__(256, PG ? 1 : 2)
+raymarch_bwd_tiles_kernel(const RayParams p, float* __restrict__ d_planes, const DecGrads dg) {
     __shared__ TileLds lds_all[4];
+    __shared__ GradLds glds_all[PG ? 4 : 1];
     // A operands of the two backward products, lane-linear ([step][lane]: conflict-free ds_read_b32), shared by
     // the 4 waves:  w1t[mt][ot*4+r][lane] = W1[1 + 16ot + 4g + r][16mt + j] * g1
     //               w0t[ft][mt*4+r][lane] = W0[16mt + 4g + r][16ft + j] * g0
@@ -52,6 +62,24 @@ __global__ void __launch_bounds__(256, 2) raymarch_bwd_tiles_kernel(const RayPar
             w0t[i] = a.dec_w0[(16 * (st >> 2) + 4 * gg + (st & 3)) * 32 + 16 * ft + jj] * g0;
         }
         __syncthreads();
+    }
+
+    GradLds& gl = glds_all[PG ? wave : 0];
+    f32x4 aw1[2][4], aw0[4][2];                      // PG: dW1c tiles [ct][kt], dW0 tiles [kt][ft]
+    float s_dO[2][4], s_dp[4][4], s_sw[4][4], s_ds = 0.f;
+    if constexpr (PG) {
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 4; ++y) {
+                aw1[x][y] = f32x4{0.f, 0.f, 0.f, 0.f};
+                aw0[y][x] = f32x4{0.f, 0.f, 0.f, 0.f};
+                s_dO[x][y] = 0.f;
+            }
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int y = 0; y < 4; ++y) { s_dp[x][y] = 0.f; s_sw[x][y] = 0.f; }
     }
 
     const long long ntiles = (long long)p.total_rays * NT;
@@ -115,6 +143,54 @@ __global__ void __launch_bounds__(256, 2) raymarch_bwd_tiles_kernel(const RayPar
             *reinterpret_cast<float4*>(&lds.df[j * 32 + 16 * ft + 4 * g]) =
                 make_float4(dF[ft][0], dF[ft][1], dF[ft][2], dF[ft][3]);
         }
+        if constexpr (PG) {
+            // operand images for the weight-gradient products + running bias / sigma-row sums
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    gl.sp[(16 * mt + 4 * g + r) * 17 + j] = h[mt][r];
+                    gl.dp[(16 * mt + 4 * g + r) * 17 + j] = dH[mt][r];
+                    s_dp[mt][r] += dH[mt][r];
+                    s_sw[mt][r] += rec.z * h[mt][r];
+                }
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    gl.dO[(16 * ot + 4 * g + r) * 17 + j] = dO[ot][r];
+                    s_dO[ot][r] += dO[ot][r];
+                }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) gl.f[j * 33 + 8 * g + t] = f[t];
+            if (g == 0) s_ds += rec.z;
+            WAVE_SYNC();
+            // MFMA operands: A[i][k] -> lane (i = j, k = g); B[k][n] -> lane (k = g, n = j); 4 samples per step
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const int smp = 4 * st + g;
+                float a1[2], bsp[4], a0[4], bf[2];
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) a1[ct] = gl.dO[(16 * ct + j) * 17 + smp];
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) {
+                    bsp[kt] = gl.sp[(16 * kt + j) * 17 + smp];
+                    a0[kt] = gl.dp[(16 * kt + j) * 17 + smp];
+                }
+#pragma unroll
+                for (int ft = 0; ft < 2; ++ft) bf[ft] = gl.f[smp * 33 + 16 * ft + j];
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt)
+                        aw1[ct][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[ct], bsp[kt], aw1[ct][kt], 0, 0, 0);
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int ft = 0; ft < 2; ++ft)
+                        aw0[kt][ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[kt], bf[ft], aw0[kt][ft], 0, 0, 0);
+            }
+        }
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)                 // lane (j, g = pl) publishes plane pl's taps of sample j
             if (g == pl) {
@@ -147,6 +223,49 @@ __global__ void __launch_bounds__(256, 2) raymarch_bwd_tiles_kernel(const RayPar
         }
         WAVE_SYNC();
     }
+    if constexpr (PG) {
+        // effective weight = parameter * gain  ->  d parameter = d effective * gain
+        const float g0 = a.decoder_lr_mul * 0.17677669529663687f, g1 = a.decoder_lr_mul * 0.125f, gb = a.decoder_lr_mul;
+        // C layout: lane (col = j, rows 4g + r)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    unsafeAtomicAdd(dg.w1 + (1 + 16 * ct + 4 * g + r) * 64 + 16 * kt + j, aw1[ct][kt][r] * g1);
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    unsafeAtomicAdd(dg.w0 + (16 * kt + 4 * g + r) * 32 + 16 * ft + j, aw0[kt][ft][r] * g0);
+        // per-lane running sums: reduce over the 16 sample lanes (j), lane j == 0 commits
+        auto red16 = [](float v) {
+            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+            return v;
+        };
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float vb = red16(s_dp[mt][r]), vw = red16(s_sw[mt][r]);
+                if (j == 0) {
+                    unsafeAtomicAdd(dg.b0 + 16 * mt + 4 * g + r, vb * gb);
+                    unsafeAtomicAdd(dg.w1 + 16 * mt + 4 * g + r, vw * g1);          // sigma row of W1
+                }
+            }
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = red16(s_dO[ot][r]);
+                if (j == 0) unsafeAtomicAdd(dg.b1 + 1 + 16 * ot + 4 * g + r, v * gb);
+            }
+        const float vs = red16(s_ds);
+        if (lane == 0) unsafeAtomicAdd(dg.b1, vs * gb);
+    }
 }
 
 }  // namespace hfagp
@@ -168,8 +287,18 @@ extern "C" int hfagp_raymarch_bwd(const HfagpRaymarchBwdArgs* a, void* stream) {
     long long blocks = (ntiles + 3) / 4;
     const long long cap = (long long)kNumCU * 2 * 8;
     if (blocks > cap) blocks = cap;
-    if (S == 96) raymarch_bwd_tiles_kernel<96><<<(unsigned)blocks, 256, 0, s>>>(p, a->d_planes);
-    else if (S == 64) raymarch_bwd_tiles_kernel<64><<<(unsigned)blocks, 256, 0, s>>>(p, a->d_planes);
-    else raymarch_bwd_tiles_kernel<32><<<(unsigned)blocks, 256, 0, s>>>(p, a->d_planes);
+    DecGrads dg{a->d_dec_w0, a->d_dec_b0, a->d_dec_w1, a->d_dec_b1};
+    const bool pg = a->d_dec_w0 != nullptr;
+    HFAGP_REQUIRE(!pg || (a->d_dec_b0 && a->d_dec_w1 && a->d_dec_b1), HFAGP_EBADARG,
+                  "raymarch_bwd: decoder gradients need all four buffers");
+    if (pg) {
+        if (S == 96) raymarch_bwd_tiles_kernel<96, true><<<(unsigned)blocks, 256, 0, s>>>(p, a->d_planes, dg);
+        else if (S == 64) raymarch_bwd_tiles_kernel<64, true><<<(unsigned)blocks, 256, 0, s>>>(p, a->d_planes, dg);
+        else raymarch_bwd_tiles_kernel<32, true><<<(unsigned)blocks, 256, 0, s>>>(p, a->d_planes, dg);
+    } else {
+        if (S == 96) raymarch_bwd_tiles_kernel<96, false><<<(unsigned)blocks, 256, 0, s>>>(p, a->d_planes, dg);
+        else if (S == 64) raymarch_bwd_tiles_kernel<64, false><<<(unsigned)blocks, 256, 0, s>>>(p, a->d_planes, dg);
+        else raymarch_bwd_tiles_kernel<32, false><<<(unsigned)blocks, 256, 0, s>>>(p, a->d_planes, dg);
+    }
     return check_launch("raymarch_bwd/tiles");
 }

@@ -215,7 +215,7 @@ class TriPlaneGenerator(nn.Module):
 
     def _block(self, x, img, blk: _SynthesisBlock, ws, rows, batch, noise_mode, conv_clamp, small_rgb, last, tape):
         """rows = the ws row of (conv0,) conv1, torgb."""
-        rec = dict(conv0=None, first=blk.in_channels == 0, img_in=img)
+        rec = dict(conv0=None, first=blk.in_channels == 0, img_in=img, const=getattr(blk, "const", None))
         if blk.in_channels == 0:
             x, rec["conv1"] = self._layer(self._const(blk.const), blk.conv1, ws[:, rows[0]], rows[0], batch,
                                           noise_mode, conv_clamp, tape)
@@ -336,18 +336,19 @@ class TriPlaneGenerator(nn.Module):
     def synthesis(self, ws: torch.Tensor, c: torch.Tensor, noise_mode: str = "const",
                   u_strat: Optional[torch.Tensor] = None, u_imp: Optional[torch.Tensor] = None,
                   return_planes: bool = False, **_unused) -> Dict[str, torch.Tensor]:
-        """Drop-in for EG3D's TriPlaneGenerator.synthesis.  Differentiable w.r.t. `ws` (the latent-basis
-        fitting of HFA-GP); generator parameters must be frozen (backward w.r.t. weights: not built yet)."""
+        """Drop-in for EG3D's TriPlaneGenerator.synthesis.  Differentiable w.r.t. `ws` (the latent-basis fitting of
+        HFA-GP) and w.r.t. the generator parameters that require grad (after `tune_generator()`)."""
         self._check_inputs(ws, c, noise_mode)
-        need_grad = torch.is_grad_enabled() and ws.requires_grad
+        params = [p for n, p in self.named_parameters() if not n.startswith("backbone.mapping.")]
+        need_grad = torch.is_grad_enabled() and (ws.requires_grad or any(p.requires_grad for p in params))
         if need_grad:
-            if any(p.requires_grad for p in self.parameters()):
-                raise NotImplementedError(
-                    "gradients w.r.t. the generator weights (tune_generator, trainer_rgb.py:69-71) are not built "
-                    "yet on the MI355X path; keep the generator frozen (requires_grad_(False))")
             from .autograd import SynthesisFn
-            img, rgb_raw, depth = SynthesisFn.apply(ws, c.detach(), u_strat, u_imp, self)
-            return {"image": img, "image_raw": rgb_raw, "image_depth": depth}
+            img, rgb_raw, depth = SynthesisFn.apply(ws, c.detach(), u_strat, u_imp, self, *params)
+            out = {"image": img, "image_raw": rgb_raw, "image_depth": depth}
+            if return_planes:
+                out["planes"], out["feature_image"] = self._last_extras
+            self._last_extras = None
+            return out
         with torch.no_grad():
             img, rgb_raw, depth, planes, feat_img = self._forward_impl(
                 ws.detach().float().contiguous(), c.detach().float().contiguous(), u_strat, u_imp, None)

@@ -377,7 +377,7 @@ def channel_sum(g: torch.Tensor, out: torch.Tensor, accumulate: bool = True) -> 
 def raymarch_bwd(g_feat: torch.Tensor, planes: torch.Tensor, cam2world, intrinsics, u_strat, u_imp, dec_w0, dec_b0,
                  dec_w1, dec_b1, res: int, ray_start: float, ray_end: float, box_warp: float,
                  decoder_lr_mul: float = 1.0, plane_axes: int = 0, white_back: bool = False,
-                 return_rec: bool = False):
+                 return_rec: bool = False, decoder_grads: bool = False):
     """g_feat [B,R,32] → d planes [B,3,H,W,32] (fp32 atomics into a zero-initialised buffer)."""
     _chk(planes, "planes")
     _chk(g_feat, "g_feat")
@@ -395,5 +395,11 @@ def raymarch_bwd(g_feat: torch.Tensor, planes: torch.Tensor, cam2world, intrinsi
     f.plane_axes, f.white_back = plane_axes, int(white_back)
     f.ray_start, f.ray_end, f.box_warp, f.decoder_lr_mul = ray_start, ray_end, box_warp, decoder_lr_mul
     a.g_feat, a.d_planes, a.rec = _ptr(g_feat), _ptr(d_planes), _ptr(rec)
+    dec = None
+    if decoder_grads:
+        dec = tuple(torch.zeros_like(t) for t in (dec_w0, dec_b0, dec_w1, dec_b1))
+        a.d_dec_w0, a.d_dec_b0, a.d_dec_w1, a.d_dec_b1 = (_ptr(t) for t in dec)
     L.check(L.lib().hfagp_raymarch_bwd(C.byref(a), _stream()), "raymarch_bwd")
+    if decoder_grads:
+        return d_planes, dec
     return (d_planes, rec) if return_rec else d_planes

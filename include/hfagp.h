@@ -189,7 +189,7 @@ int hfagp_torgb_fwd(const HfagpTorgbArgs* a, void* stream);
  *   sums[b][0] = sum_pix dxs_conv*X   sums[b][1] = sum_pix dxs_rgb*X   sums[b][2] = sum_pix (w^T g)*X
  *   sums[b][3] = sum_pix g_pre * conv_p      (gradient of P's demodulation coefficients)
  * and, when param_grads != 0 (generator being tuned):
- *   sums[b][4] = sum_pix g_pre (bias of P)   sums[b][5] = sum_pix g_pre * noise_p*strength (per channel)
+ *   sums[b][4] = sum_pix g_pre (bias of P)   sums[b][5] = sum_pix g_pre * noise_p (per channel: d noise_strength)
  *   sums[b][6+c] = sum_pix g_rgb_small[c] * X   (small-toRGB weight gradient before the style factor)
  * sums is [B][10][C].                                                                                    */
 typedef struct {
@@ -249,6 +249,11 @@ typedef struct {
     const float* g_feat;      /* [B][R][32] gradient of the composited features */
     float*       d_planes;    /* [B][3][H][W][32], accumulated into */
     float*       rec;         /* workspace [B][R][Sc+Sf][4] floats (per-sample depth, omega, d sigma) */
+    /* optional (all four or none): gradients of the decoder parameters, zero-initialised, accumulated into */
+    float*       d_dec_w0;    /* [64][32] */
+    float*       d_dec_b0;    /* [64] */
+    float*       d_dec_w1;    /* [33][64] */
+    float*       d_dec_b1;    /* [33] */
 } HfagpRaymarchBwdArgs;
 
 int hfagp_raymarch_bwd(const HfagpRaymarchBwdArgs* a, void* stream);

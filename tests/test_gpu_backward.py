@@ -188,10 +188,12 @@ def test_rgb_trainer_and_render_harness_on_gpu(dev):
     for _ in range(5):
         l2b, _, _ = tr.gen_update(real, label.clone())
     assert float(l2b) < float(l2a)
-    # tuning the generator weights is not built yet: it must fail loudly, not silently skip gradients
+    # after tune_generator() the same optimiser moves the generator too (trainer_rgb.py:58-60,69-71)
     tr.tune_generator()
-    with pytest.raises(NotImplementedError, match="generator weights"):
-        tr.gen_update(real, label.clone())
+    tr.gen_update(real, label.clone())
+    moved = [k for k, v in tr.gen.generator.state_dict().items() if not torch.equal(v, g0[k])]
+    assert any(k.endswith("b8.conv0.weight") for k in moved) and any(k.startswith("decoder.net.") for k in moved)
+    assert any(k.endswith("torgb.affine.bias") for k in moved) and "backbone.synthesis.b4.const" in moved
     for p in tr.gen.generator.parameters():
         p.requires_grad_(False)
     # batched reenactment
@@ -232,3 +234,41 @@ def test_conv_weight_gradient(dev, b, h, cin, cout, mode):
     else:
         dw = ops.conv_wgrad(xh, s.to(dev), gh, w.detach().to(dev), ops.CONV3X3 if k == 3 else ops.CONV1X1)
     close(dw, w.grad, atol=1e-4 * w.grad.abs().max().item(), rtol=1e-4)
+
+
+@pytest.mark.parametrize("preset,batch", [("tiny64", 2), ("tiny14", 1), ("small128", 1)])
+def test_generator_parameter_gradients_vs_oracle_autograd(dev, preset, batch):
+    """tune_generator() mode: dL/d(every generator parameter) and dL/d ws against autograd through the oracle."""
+    from hfa_gp_amd.config import PRESETS
+    from hfa_gp_amd.generator import TriPlaneGenerator
+    from oracle import eg3d_oracle as O
+    cfg = PRESETS[preset]()
+    gen = perturb_state(TriPlaneGenerator(cfg, seed=0))
+    P = {k: v.detach().clone() for k, v in gen.state_dict().items()}
+    names = [n for n, _ in gen.named_parameters() if not n.startswith("backbone.mapping.")]
+    for n in names:
+        P[n].requires_grad_(True)
+    gen = gen.to(dev)
+    ws, c, us, ui = make_inputs(cfg, batch)
+    g = torch.Generator().manual_seed(8)
+    G = torch.randn(batch, 3, cfg.img_resolution, cfg.img_resolution, generator=g) / cfg.img_resolution
+    ws_ref = ws.clone().requires_grad_(True)
+    (O.synthesis(P, cfg, ws_ref, c, us, ui)["image"] * G).sum().backward()
+    ws_d = ws.to(dev).requires_grad_(True)
+    out = gen.synthesis(ws_d, c.to(dev), noise_mode="const", u_strat=us.to(dev), u_imp=ui.to(dev))
+    (out["image"] * G.to(dev)).sum().backward()
+    close(ws_d.grad, ws_ref.grad, atol=2e-4 * ws_ref.grad.abs().max().item(), rtol=2e-3)
+    params = dict(gen.named_parameters())
+    bad = []
+    for n in names:
+        ref = P[n].grad
+        got = params[n].grad
+        if ref is None:                       # unused by the path (SR noise_strength with noise_mode 'none')
+            assert got is None or float(got.abs().max()) == 0.0, n
+            continue
+        assert got is not None, n
+        scale = max(ref.abs().max().item(), 1e-12)
+        err = (got.cpu() - ref).abs().max().item()
+        if not err <= 5e-4 * scale + 1e-7:
+            bad.append((n, err, scale))
+    assert not bad, bad[:8]
