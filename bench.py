@@ -88,26 +88,34 @@ def train_leg(args, cfg_name, dev, rank, world, dist):
     params = torch.randn(B, fa.params_len, generator=g).to(dev)
     label = look_at_label(math.pi / 2 + 0.3 * torch.randn(B, generator=g),
                           math.pi / 2 + 0.155 * torch.randn(B, generator=g), flipped=False).to(dev)
-    for _ in range(2):
-        tr.gen_update(real, label.clone(), params)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.train_steps):
-        l2, _, _ = tr.gen_update(real, label.clone(), params)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    assert torch.isfinite(l2)
-    return dt / args.train_steps * 1e3, B
+    def timed(steps):
+        for _ in range(2):
+            tr.gen_update(real, label.clone(), params)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            l2, _, _ = tr.gen_update(real, label.clone(), params)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        assert torch.isfinite(l2)
+        return dt / steps * 1e3
+
+    frozen_ms = timed(args.train_steps)
+    # after tune_iter the reference also trains the generator (trainer_rgb.py:69-71): all 30.7 M parameters get
+    # gradients and are all-reduced with the basis / driver gradients
+    tr.tune_generator()
+    tune_ms = timed(max(2, args.train_steps // 2))
+    return frozen_ms, tune_ms, B
 
 
 def main():
@@ -171,11 +179,11 @@ def main():
         units = sum(u for _, _, u in evs)
         return ms, units, len(evs)
 
-    train_ms = train_B = None
+    train_ms = tune_ms = train_B = None
     if not args.no_train:
         del img
         torch.cuda.empty_cache()
-        train_ms, train_B = train_leg(args, args.preset, dev, rank, world, dist)
+        train_ms, tune_ms, train_B = train_leg(args, args.preset, dev, rank, world, dist)
 
     if rank == 0:
         frames = world * B * args.steps
@@ -204,6 +212,7 @@ def main():
         }
         if train_ms is not None:
             out["train_step_ms"] = train_ms
+            out["train_step_ms_generator_tuned"] = tune_ms
             out["train_config"] = {"workload": "3DMM-driven latent-basis fitting step (fwd + bwd + Adam), K=50, "
                                                "generator frozen, L2 at 256^2, synthetic frames",
                                    "frames_per_step_per_gpu": train_B,

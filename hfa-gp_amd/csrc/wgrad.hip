@@ -17,7 +17,7 @@ namespace hfagp {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int TPH = 4, TPW = 16;                 // position tile
+constexpr int TPH = 2, TPW = 16;                 // position tile (2 x 16: 78 KB of LDS double-buffered -> 2 blocks per CU)
 constexpr int PPH = TPH + 2, PPW = TPW + 2;      // patch with halo
 constexpr int WT = 64;                           // ci / co tile
 constexpr int WS = WT + 4;                       // LDS row stride (floats)
@@ -33,11 +33,17 @@ struct WgradParams {
     WTap tap[9];
 };
 
+// Double-buffered: the x / g patches of position tile u+1 are fetched into registers before the MFMAs of tile u
+// and written to the other LDS buffer after them, so there is ONE barrier per tile and the global latency hides
+// under 288 MFMAs.  117 KB of LDS -> one workgroup (one wave per SIMD) per CU, which is enough to keep the
+// matrix pipe busy because the 9 tap accumulators are independent.
+constexpr int STG = (PPH * PPW * 16 + 255) / 256;      // float4 per thread per patch
+
 template <int NT>
-__global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
+__global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* As = lds;                             // [PPH*PPW][WS]  x patch  (ci contiguous)
-    float* Bs = lds + PPH * PPW * WS;            // [PPH*PPW][WS]  g patch (co contiguous)
+    constexpr int PATCH = PPH * PPW * WS;
+    // buffer k: As = lds + k*2*PATCH, Bs = As + PATCH
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave >> 1, wj = wave & 1;     // wave tile: ci rows 32*wi.., co cols 32*wj..
     const int h = lane >> 5, l31 = lane & 31;
@@ -51,46 +57,85 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
 
     const int units = p.B * p.tiles_h * p.tiles_w;
     const int u_begin = (int)(((long long)units * ks) / p.ksplit), u_end = (int)(((long long)units * (ks + 1)) / p.ksplit);
-    for (int u = u_begin; u < u_end; ++u) {
+    float4 ra[STG], rb[STG];
+
+    auto fetch = [&](int u) {
         const int tw = u % p.tiles_w, th = (u / p.tiles_w) % p.tiles_h, b = u / (p.tiles_w * p.tiles_h);
         const int m0 = th * TPH, n0 = tw * TPW;
-        __syncthreads();
-        // ---- stage the x patch (x * s) and the g patch(es); 16 lanes x float4 per pixel row of 64 channels
-        for (int idx = tid; idx < PPH * PPW * 16; idx += 256) {
+#pragma unroll
+        for (int k = 0; k < STG; ++k) {
+            const int idx = tid + k * 256;
             const int pix = idx >> 4, q = idx & 15;
             const int iy = m0 - 1 + pix / PPW, ix = n0 - 1 + pix % PPW;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && ci0 + 4 * q < p.Cin) {
-                v = *reinterpret_cast<const float4*>(p.x + (((size_t)b * p.H + iy) * p.W + ix) * p.Cin + ci0 + 4 * q);
-                if (p.styles) {
-                    const float4 s = *reinterpret_cast<const float4*>(p.styles + (size_t)b * p.Cin + ci0 + 4 * q);
-                    v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w;
+            float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+            if (idx < PPH * PPW * 16) {
+                if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && ci0 + 4 * q < p.Cin) {
+                    va = *reinterpret_cast<const float4*>(p.x + (((size_t)b * p.H + iy) * p.W + ix) * p.Cin + ci0 + 4 * q);
+                    if (p.styles) {
+                        const float4 sv = *reinterpret_cast<const float4*>(p.styles + (size_t)b * p.Cin + ci0 + 4 * q);
+                        va.x *= sv.x; va.y *= sv.y; va.z *= sv.z; va.w *= sv.w;
+                    }
                 }
+                if (iy >= 0 && iy < p.gH && ix >= 0 && ix < p.gW && co0 + 4 * q < p.Cout)
+                    vb = *reinterpret_cast<const float4*>(p.g + (((size_t)b * p.gH + iy) * p.gW + ix) * p.Cout + co0 + 4 * q);
             }
-            *reinterpret_cast<float4*>(As + pix * WS + 4 * q) = v;
+            ra[k] = va; rb[k] = vb;
         }
-        for (int idx = tid; idx < PPH * PPW * 16; idx += 256) {
-            const int pix = idx >> 4, q = idx & 15;
-            const int iy = m0 - 1 + pix / PPW, ix = n0 - 1 + pix % PPW;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (iy >= 0 && iy < p.gH && ix >= 0 && ix < p.gW && co0 + 4 * q < p.Cout)
-                v = *reinterpret_cast<const float4*>(p.g + (((size_t)b * p.gH + iy) * p.gW + ix) * p.Cout + co0 + 4 * q);
-            *reinterpret_cast<float4*>(Bs + pix * WS + 4 * q) = v;
+    };
+    auto commit = [&](int buf) {
+        float* As = lds + buf * 2 * PATCH;
+        float* Bs = As + PATCH;
+#pragma unroll
+        for (int k = 0; k < STG; ++k) {
+            const int idx = tid + k * 256;
+            if (idx < PPH * PPW * 16) {
+                *reinterpret_cast<float4*>(As + (idx >> 4) * WS + 4 * (idx & 15)) = ra[k];
+                *reinterpret_cast<float4*>(Bs + (idx >> 4) * WS + 4 * (idx & 15)) = rb[k];
+            }
         }
-        __syncthreads();
-        // ---- K loop over the 64 positions of the tile, two per MFMA (lane half h takes position 2k + h)
-#pragma unroll 2
-        for (int k = 0; k < TPH * TPW / 2; ++k) {
-            const int pos = 2 * k + h;
-            const int pr = pos / TPW + 1, pc = pos % TPW + 1;           // patch coordinates of (m, n)
+    };
+
+    // per-lane LDS word offsets: everything except the tap shift and the buffer is a compile-time constant of k,
+    // so each operand fetch is one ds_read_b32 with an immediate offset
+    int ta[NT], tb[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        ta[t] = (p.tap[t].ady * PPW + p.tap[t].adx + h) * WS + 32 * wi + l31;
+        tb[t] = PATCH + (p.tap[t].bdy * PPW + p.tap[t].bdx + h) * WS + 32 * wj + l31;
+    }
+
+    int cur = 0;
+    if (u_begin < u_end) { fetch(u_begin); commit(0); }
+    __syncthreads();
+    for (int u = u_begin; u < u_end; ++u) {
+        if (u + 1 < u_end) fetch(u + 1);
+        const int boff = cur * 2 * PATCH;
+        // ---- K loop over the positions of the tile, two per MFMA (lane half h takes position 2k + h).
+        // Operands of step k+1 are fetched from LDS before the MFMAs of step k are issued (register double buffer;
+        // the sched_group_barriers pin that order), so the matrix pipe never waits for a ds_read.
+        constexpr int KS = TPH * TPW / 2;
+        float av[2][NT], bv[2][NT];
+        auto ldk = [&](int k, int slot) {
+            const int posoff = ((((2 * k) / TPW) + 1) * PPW + ((2 * k) % TPW) + 1) * WS;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const WTap tp = p.tap[t];
-                const float av = As[((pr + tp.ady) * PPW + pc + tp.adx) * WS + 32 * wi + l31];
-                const float bv = Bs[((pr + tp.bdy) * PPW + pc + tp.bdx) * WS + 32 * wj + l31];
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+                av[slot][t] = lds[boff + ta[t] + posoff];
+                bv[slot][t] = lds[boff + tb[t] + posoff];
             }
+        };
+        ldk(0, 0);
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            if (k + 1 < KS) ldk(k + 1, (k + 1) & 1);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[k & 1][t], bv[k & 1][t], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * NT, 0);     // DS reads of step k+1
+            __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);         // MFMAs of step k
         }
+        if (u + 1 < u_end) commit(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
     }
     // ---- store the slab: C/D layout row = (r&3) + 8*(r>>2) + 4*h (ci), col = lane&31 (co)
     float* slab = p.slabs + (size_t)ks * p.ntaps * p.Cin * p.Cout;
@@ -180,8 +225,13 @@ using namespace hfagp;
 template <int NT>
 static int run_wgrad(WgradParams& p, const HfagpWgradArgs* a, hipStream_t s) {
     p.ntaps = NT;
-    const size_t lds = (size_t)2 * PPH * PPW * WS * sizeof(float);
+    const size_t lds = (size_t)4 * PPH * PPW * WS * sizeof(float);        // two buffers x (x patch + g patch)
     dim3 grid((a->Cin + WT - 1) / WT, (a->Cout + WT - 1) / WT, a->ksplit);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
+    }
     wgrad_kernel<NT><<<grid, 256, lds, s>>>(p);
     int rc = check_launch("conv_wgrad");
     if (rc != HFAGP_OK) return rc;

@@ -344,9 +344,10 @@ def conv_wgrad(x: torch.Tensor, styles: Optional[torch.Tensor], g: torch.Tensor,
     cout = weight.shape[0]
     a = L.WgradArgs()
     dweight = torch.empty_like(weight)
-    units = b * ((h + 3) // 4) * ((w + 15) // 16)
+    units = b * ((h + 1) // 2) * ((w + 15) // 16)
     tiles = ((cin + 63) // 64) * ((cout + 63) // 64)
-    ksplit = max(1, min(units, (768 + tiles - 1) // tiles, 256))
+    # one resident block per CU (117 KB of LDS): aim at a whole number of rounds over the 256 CUs
+    ksplit = max(1, min(units, max(512 // tiles, 1), 256))
     a.x, a.styles, a.g = _ptr(x), _ptr(styles), _ptr(g)
     a.weight, a.dd, a.dcoef, a.dweight = _ptr(_chk(weight.detach(), "weight")), _ptr(dd), _ptr(dcoef), _ptr(dweight)
     a.B, a.H, a.W, a.Cin, a.Cout, a.mode, a.ksplit = b, h, w, cin, cout, mode, ksplit
