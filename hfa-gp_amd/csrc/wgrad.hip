@@ -39,7 +39,10 @@ struct WgradParams {
 // matrix pipe busy because the 9 tap accumulators are independent.
 constexpr int STG = (PPH * PPW * 16 + 255) / 256;      // float4 per thread per patch
 
-template <int NT>
+// SHARE = 1: all taps read the same g element (3x3 / 1x1: only x shifts) -> one B fetch per K step;
+// SHARE = 2: all taps read the same x element (up-conv parity launches: only g shifts) -> one A fetch per K step.
+// (halves the ds_read traffic per MFMA, which is what bounds this kernel: 2 dwords per lane per MFMA otherwise)
+template <int NT, int SHARE>
 __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int PATCH = PPH * PPW * WS;
@@ -119,8 +122,8 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p) {
             const int posoff = ((((2 * k) / TPW) + 1) * PPW + ((2 * k) % TPW) + 1) * WS;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                av[slot][t] = lds[boff + ta[t] + posoff];
-                bv[slot][t] = lds[boff + tb[t] + posoff];
+                if (SHARE != 2 || t == 0) av[slot][t] = lds[boff + ta[t] + posoff];
+                if (SHARE != 1 || t == 0) bv[slot][t] = lds[boff + tb[t] + posoff];
             }
         };
         ldk(0, 0);
@@ -129,9 +132,8 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p) {
             if (k + 1 < KS) ldk(k + 1, (k + 1) & 1);
 #pragma unroll
             for (int t = 0; t < NT; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[k & 1][t], bv[k & 1][t], acc[t], 0, 0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2 * NT, 0);     // DS reads of step k+1
-            __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);         // MFMAs of step k
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[k & 1][SHARE == 2 ? 0 : t], bv[k & 1][SHARE == 1 ? 0 : t],
+                                                              acc[t], 0, 0, 0);
         }
         if (u + 1 < u_end) commit(cur ^ 1);
         __syncthreads();
@@ -222,17 +224,17 @@ __global__ void __launch_bounds__(256) channel_sum_final_kernel(const float* __r
 
 using namespace hfagp;
 
-template <int NT>
+template <int NT, int SHARE>
 static int run_wgrad(WgradParams& p, const HfagpWgradArgs* a, hipStream_t s) {
     p.ntaps = NT;
     const size_t lds = (size_t)4 * PPH * PPW * WS * sizeof(float);        // two buffers x (x patch + g patch)
     dim3 grid((a->Cin + WT - 1) / WT, (a->Cout + WT - 1) / WT, a->ksplit);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<NT, SHARE>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
-    wgrad_kernel<NT><<<grid, 256, lds, s>>>(p);
+    wgrad_kernel<NT, SHARE><<<grid, 256, lds, s>>>(p);
     int rc = check_launch("conv_wgrad");
     if (rc != HFAGP_OK) return rc;
     const int n = a->Cin * a->Cout;
@@ -264,12 +266,12 @@ int hfagp_conv_wgrad(const HfagpWgradArgs* a, void* stream) {
     if (a->mode == HFAGP_CONV3X3) {
         p.gH = a->H; p.gW = a->W;
         for (int t = 0; t < 9; ++t) p.tap[t] = WTap{(signed char)(t / 3 - 1), (signed char)(t % 3 - 1), 0, 0, (signed char)t};
-        return run_wgrad<9>(p, a, s);
+        return run_wgrad<9, 1>(p, a, s);
     }
     if (a->mode == HFAGP_CONV1X1) {
         p.gH = a->H; p.gW = a->W;
         p.tap[0] = WTap{0, 0, 0, 0, 0};
-        return run_wgrad<1>(p, a, s);
+        return run_wgrad<1, 1>(p, a, s);
     }
     if (a->mode == HFAGP_CONVT3X3_UP2) {
         // g = the four parity images [2][2][B][H+1][W+1][Cout] of the y_t gradient; tap (ti, tj) reads parity
@@ -284,8 +286,8 @@ int hfagp_conv_wgrad(const HfagpWgradArgs* a, void* stream) {
                 const int t = taps_of[ph][k], ti = t / 3, tj = t % 3;
                 p.tap[k] = WTap{0, 0, (signed char)(ti >> 1), (signed char)(tj >> 1), (signed char)t};
             }
-            const int rc = ntaps_of[ph] == 4 ? run_wgrad<4>(p, a, s) : ntaps_of[ph] == 2 ? run_wgrad<2>(p, a, s)
-                                                                                       : run_wgrad<1>(p, a, s);
+            const int rc = ntaps_of[ph] == 4 ? run_wgrad<4, 2>(p, a, s) : ntaps_of[ph] == 2 ? run_wgrad<2, 2>(p, a, s)
+                                                                                          : run_wgrad<1, 2>(p, a, s);
             if (rc != HFAGP_OK) return rc;
         }
         return HFAGP_OK;
