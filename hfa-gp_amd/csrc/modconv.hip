@@ -20,6 +20,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int CK = 8;            // input channels per K-chunk
 constexpr int AS = 12;           // LDS pixel stride of the A patch in floats (8 + pad, 16-B aligned)
 constexpr int PW = 16;           // patch width in output positions
+constexpr int LPW = 32;          // LDS row pitch of the patch in pixels: with AS = 12 (3 x 16-B slots, odd) every
+                                 // 16-lane group of a ds_read_b128 then hits 16 distinct slots (no bank conflicts)
 constexpr int MAXTAPS = 9;
 
 struct Phase {
@@ -51,7 +53,7 @@ __global__ void __launch_bounds__(256) modconv_kernel(const ConvParams p) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, PH = BM / PW;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* As = lds;                                   // [ph*pw][AS]
-    float* Bs = lds + ((PH + 2) * (PW + 2)) * AS;      // [ntaps][2][BN][4]
+    float* Bs = lds + ((PH + 2) * LPW) * AS;           // [ntaps][2][BN][4]
 
     const Phase& ph = p.phase[blockIdx.y];
     // ---- decode the block id: N tile fastest (neighbours share the input patch in L2)
@@ -83,12 +85,15 @@ __global__ void __launch_bounds__(256) modconv_kernel(const ConvParams p) {
 
     // chunk-independent source offsets (-1 = zero fill)
     long long aoff[A_PER_T], boff[B_PER_T];
+    int lds_a[A_PER_T];          // LDS word offset of each staged float4 of the patch
 #pragma unroll
     for (int k = 0; k < A_PER_T; ++k) {
         const int idx = tid + k * 256;
         aoff[k] = -1;
+        lds_a[k] = 0;
         if (idx < npatch * 2) {
             const int pix = idx >> 1, q = idx & 1;
+            lds_a[k] = ((pix / p.pw) * LPW + pix % p.pw) * AS + 4 * q;
             const int iy = m0 + p.dymin + pix / p.pw, ix = n0 + p.dxmin + pix % p.pw;
             if (iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w) aoff[k] = ((long long)iy * p.in_w + ix) * p.Cin + 4 * q;
         }
@@ -128,7 +133,7 @@ __global__ void __launch_bounds__(256) modconv_kernel(const ConvParams p) {
 #pragma unroll
         for (int k = 0; k < A_PER_T; ++k) {
             const int idx = tid + k * 256;
-            if (idx < npatch * 2) *reinterpret_cast<float4*>(As + (idx >> 1) * AS + 4 * (idx & 1)) = ra[k];
+            if (idx < npatch * 2) *reinterpret_cast<float4*>(As + lds_a[k]) = ra[k];
         }
 #pragma unroll
         for (int k = 0; k < B_PER_T; ++k) {
@@ -142,7 +147,7 @@ __global__ void __launch_bounds__(256) modconv_kernel(const ConvParams p) {
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
         const int pidx = (wm * TM + tm) * 32 + l31;
-        apix[tm] = ((pidx >> 4) * p.pw + (pidx & 15)) * AS + 4 * h;
+        apix[tm] = ((pidx >> 4) * LPW + (pidx & 15)) * AS + 4 * h;
     }
     int bcol[TN];
 #pragma unroll
@@ -162,7 +167,7 @@ __global__ void __launch_bounds__(256) modconv_kernel(const ConvParams p) {
         __syncthreads();
         if (c + 1 < c_end) load_regs(c + 1);
         for (int t = 0; t < ph.ntaps; ++t) {
-            const int toff = ((ph.dy[t] - p.dymin) * p.pw + (ph.dx[t] - p.dxmin)) * AS;
+            const int toff = ((ph.dy[t] - p.dymin) * LPW + (ph.dx[t] - p.dxmin)) * AS;
             float4 a4[TM], b4[TN];
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) a4[tm] = *reinterpret_cast<const float4*>(As + apix[tm] + toff);
@@ -358,7 +363,7 @@ static int make_plan(const HfagpModconvArgs* a, Plan& pl) {
     if (ks * p.nslab > 1) p.fused = 0;
     pl.ws_bytes = ks * p.nslab > 1 ? (size_t)ks * p.nslab * p.slab * sizeof(float) : 0;
     pl.grid = dim3((unsigned)(p.tiles_h * p.tiles_w * a->B * p.tiles_n * ks), (unsigned)p.nphase, 1);
-    pl.lds_bytes = ((size_t)(PH + 2) * (PW + 2) * AS + (size_t)MAXTAPS * 2 * pl.bn * 4) * sizeof(float);
+    pl.lds_bytes = ((size_t)(PH + 2) * LPW * AS + (size_t)MAXTAPS * 2 * pl.bn * 4) * sizeof(float);
     return HFAGP_OK;
 }
 
