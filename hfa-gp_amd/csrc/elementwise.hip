@@ -49,6 +49,20 @@ __global__ void __launch_bounds__(256) demod_kernel(const float* __restrict__ st
     if (lane == 0) dcoef[wave] = rsqrtf(acc + eps);
 }
 
+// ---------------------------------------------------------------- fully connected (mapping network)
+// y[b][o] = act( (x[b] . W[o]) * wgain + bias[o] * bgain ) * act_gain ;  one wave per output element
+__global__ void __launch_bounds__(256) fc_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                 const float* __restrict__ bias, float* __restrict__ y, int B, int In,
+                                                 int Out, float wgain, float bgain, int act, float alpha, float gain) {
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= B * Out) return;
+    const int b = wave / Out, o = wave % Out;
+    float acc = 0.f;
+    for (int k = lane; k < In; k += 64) acc += x[(size_t)b * In + k] * W[(size_t)o * In + k];
+    for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m);
+    if (lane == 0) y[wave] = lrelu_gain_clamp(acc * wgain + (bias ? bias[o] * bgain : 0.f), act, alpha, gain, -1.f);
+}
+
 // ---------------------------------------------------------------- weight prep
 __global__ void __launch_bounds__(256) weight_prep_kernel(const float* __restrict__ w, float* __restrict__ wt,
                                                           float* __restrict__ wsq, int Cout, int Cin, int taps) {
@@ -313,6 +327,17 @@ int hfagp_style_fwd(const HfagpStyleArgs* a, void* stream) {
         demod_kernel<<<(waves + 3) / 4, 256, 0, s>>>(a->styles, a->wsq, a->dcoef, a->B, a->Cin, a->Cout, a->eps);
     }
     return check_launch("style_fwd");
+}
+
+int hfagp_fc_fwd(const float* x, const float* weight, const float* bias, float* y, int32_t B, int32_t In, int32_t Out,
+                 float lr_mul, int32_t act, float alpha, float gain, void* stream) {
+    HFAGP_REQUIRE(x && weight && y, HFAGP_EBADARG, "fc_fwd: null pointer");
+    HFAGP_REQUIRE(B > 0 && In > 0 && Out > 0, HFAGP_EBADARG, "fc_fwd: bad dims");
+    HFAGP_REQUIRE(act == HFAGP_ACT_LINEAR || act == HFAGP_ACT_LRELU, HFAGP_EUNSUPPORTED, "fc_fwd: act %d", act);
+    const int waves = B * Out;
+    fc_kernel<<<(waves + 3) / 4, 256, 0, (hipStream_t)stream>>>(x, weight, bias, y, B, In, Out,
+                                                                lr_mul / sqrtf((float)In), lr_mul, act, alpha, gain);
+    return check_launch("fc_fwd");
 }
 
 int hfagp_weight_prep(const float* weight, float* wt, float* wsq, int32_t Cout, int32_t Cin, int32_t taps,

@@ -358,6 +358,26 @@ class TriPlaneGenerator(nn.Module):
             out["feature_image"] = feat_img
         return out
 
+    @torch.no_grad()
+    def mapping(self, z: torch.Tensor, c: torch.Tensor, truncation_psi: float = 1.0) -> torch.Tensor:
+        """EG3D MappingNetwork.forward (z, c) -> ws [B, num_ws, 512].  HFA-GP never calls it (its ws come from the
+        latent basis, headnerf.py:81-102); provided for unconditional sampling.  Inference only."""
+        cfg = self.cfg
+        mp = self.backbone.mapping
+
+        def norm2(x):       # normalize_2nd_moment: tiny host-side glue
+            return x * (x.square().mean(1, keepdim=True) + 1e-8).rsqrt()
+        x = norm2(z.float().contiguous())
+        y = norm2(ops.fully_connected(c.float().contiguous(), mp.embed.weight, mp.embed.bias))
+        x = torch.cat([x, y], 1).contiguous()
+        for i in range(cfg.mapping_layers):
+            fc = getattr(mp, f"fc{i}")
+            x = ops.fully_connected(x, fc.weight, fc.bias, cfg.mapping_lr_mul, act="lrelu", alpha=0.2)
+        ws = x[:, None].repeat(1, cfg.num_ws, 1)
+        if truncation_psi != 1.0:
+            ws = mp.w_avg.lerp(ws, truncation_psi)
+        return ws
+
     def forward(self, *args, **kwargs):
         raise NotImplementedError("HFA-GP only calls generator.synthesis (headnerf.py:112); mapping is in mapping()")
 

@@ -74,6 +74,20 @@ def styles_demod(w: torch.Tensor, affine_w: torch.Tensor, affine_b: torch.Tensor
     return styles, dcoef
 
 
+def fully_connected(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], lr_mul: float = 1.0,
+                    act: str = "linear", alpha: float = 0.2, gain: Optional[float] = None) -> torch.Tensor:
+    """EG3D FullyConnectedLayer: act((x @ (W*lr_mul/sqrt(in)).T + b*lr_mul)) * gain."""
+    _chk(x, "x")
+    b, fin = x.shape
+    fout = weight.shape[0]
+    if gain is None:
+        gain = math.sqrt(2.0) if act == "lrelu" else 1.0
+    y = torch.empty(b, fout, device=x.device, dtype=torch.float32)
+    L.check(L.lib().hfagp_fc_fwd(_ptr(x), _ptr(_chk(weight, "weight")), _ptr(bias), _ptr(y), b, fin, fout, lr_mul,
+                                 _ACT[act], alpha, gain, _stream()), "fc_fwd")
+    return y
+
+
 # ----------------------------------------------------------------------------- modulated conv
 def modconv(x: torch.Tensor, wt: torch.Tensor, cout: int, mode: int, styles: Optional[torch.Tensor] = None,
             dcoef: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None,

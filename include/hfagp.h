@@ -92,6 +92,10 @@ typedef struct {
 
 int hfagp_style_fwd(const HfagpStyleArgs* a, void* stream);
 
+/* FullyConnectedLayer (mapping network): y = act((x . W^T) * lr_mul/sqrt(In) + bias*lr_mul) * gain   [B][Out] */
+int hfagp_fc_fwd(const float* x, const float* weight, const float* bias, float* y, int32_t B, int32_t In, int32_t Out,
+                 float lr_mul, int32_t act, float alpha, float gain, void* stream);
+
 /* weight preparation (cached by the host while the generator is frozen)
  *   wt  [taps][Cin/4][Cout][4]  <- weight [Cout][Cin][kh][kw]      (MFMA B-operand image)
  *   wsq [Cout][Cin]             <- sum over taps of weight^2                           */

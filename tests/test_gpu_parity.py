@@ -315,3 +315,20 @@ def test_state_dict_round_trip_and_headnerf_boundary(dev, tmp_path):
     ws = m.get_latent(m.get_weights(params))
     ref = O.synthesis(state_cpu(g1), cfg, ws.cpu(), flipped.cpu(), us.cpu()[..., None], ui.cpu())["image"]
     close(img, ref)
+
+
+def test_mapping_network(dev):
+    """(z, c) -> ws: never used by HFA-GP, listed in north_star; two lrelu FC layers on the HIP fc kernel."""
+    from hfa_gp_amd.config import tiny64
+    from hfa_gp_amd.generator import TriPlaneGenerator
+    from oracle import eg3d_oracle as O
+    cfg = tiny64()
+    gen = TriPlaneGenerator(cfg, seed=5)
+    P = state_cpu(gen)
+    P["backbone.mapping.w_avg"] = torch.randn(512, generator=torch.Generator().manual_seed(1))
+    gen.backbone.mapping.w_avg.copy_(P["backbone.mapping.w_avg"])
+    gen = gen.to(dev)
+    g = torch.Generator().manual_seed(2)
+    z, c = torch.randn(3, 512, generator=g), torch.randn(3, 25, generator=g)
+    for psi in (1.0, 0.7):
+        close(gen.mapping(z.to(dev), c.to(dev), truncation_psi=psi), O.mapping(P, cfg, z, c, truncation_psi=psi), atol=1e-5)
