@@ -199,3 +199,32 @@ def test_flat_allreduce_numerics():
         for rank in range(world):
             n, ga, gb = out[rank]
             assert n == 17 and torch.equal(ga, torch.full((3, 4), 1.5)) and torch.equal(gb, torch.zeros(5))
+
+
+def test_lpips_alex_module_and_objective():
+    """LPIPS(alex) stand-in: lpips-package key names, zero for identical images, used as the reference's second loss
+    term (trainer_rgb.py:86-91: g_loss = l2 + mean(lpips))."""
+    from hfa_gp_amd.lpips_alex import LPIPSAlex
+    torch.manual_seed(0)
+    lp = LPIPSAlex()
+    keys = list(lp.state_dict())
+    for k in ("scaling_layer.shift", "net.slice1.0.weight", "net.slice2.3.bias", "net.slice5.10.weight", "lin0.model.1.weight",
+              "lin4.model.1.weight"):
+        assert k in keys, k
+    assert all(not p.requires_grad for p in lp.parameters())
+    a = torch.rand(2, 3, 64, 64) * 2 - 1
+    b = torch.rand(2, 3, 64, 64) * 2 - 1
+    assert lp(a, a).abs().max().item() == 0.0
+    d = lp(a, b)
+    assert d.shape == (2, 1, 1, 1) and bool((d > 0).all())
+    assert torch.allclose(d, lp(b, a), atol=1e-6)
+    lp2 = LPIPSAlex(state_dict=lp.state_dict())
+    assert torch.equal(lp2(a, b), d)
+    # as the second term of the step
+    torch.manual_seed(4)
+    gen = headnerf.HeadNeRF_3DMM(Args(), Args.size, "cpu", 512, Args.latent_dim_shape)
+    OracleGenerator.adopt(gen.generator)
+    tr = Trainer(Args(), "cpu", mode="3dmm", gen=gen, lpips=lp)
+    real, label, params = frame(9)
+    l2, lpv, _ = tr.gen_update(real, label, params)
+    assert float(lpv) > 0 and torch.isfinite(l2) and tr.gen.bases.grad.abs().sum() > 0
