@@ -185,6 +185,19 @@ def main():
         torch.cuda.empty_cache()
         train_ms, tune_ms, train_B = train_leg(args, args.preset, dev, rank, world, dist)
 
+    def profiled_traffic(prefix):
+        """HBM bytes per launch from the committed PMC passes (profiles/traffic.json), only if the batch matches."""
+        try:
+            t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            if t.get("batch") != B:
+                return None
+            for k, v in t.items():
+                if k.startswith(prefix):
+                    return v["hbm_bytes"]
+        except Exception:
+            pass
+        return None
+
     if rank == 0:
         frames = world * B * args.steps
         rm_ms, rm_bytes, rm_n = agg("raymarch")
@@ -202,12 +215,13 @@ def main():
             # dominant kernel by time: the fp32 MFMA modulated-conv implicit GEMM (all 17 conv launches per frame)
             "roofline": {"bound": "mfma", "kernel": "modconv_kernel (v_mfma_f32_32x32x2_f32)",
                          "achieved": mc_tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": mc_tf / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                         "frac": mc_tf / MFMA_F32_PEAK_TFLOPS, "traffic": profiled_traffic("modconv_kernel<2, 2, 2, 2>"),
                          "avg_launch_ms": mc_ms / max(mc_n, 1), "launches": mc_n},
             # the kernel north_star sets the HBM target on
             "roofline_raymarch": {"bound": "hbm", "kernel": "raymarch_kernel<3,3>", "achieved": rm_gbs,
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rm_gbs / HBM_PEAK_GBS,
-                                  "traffic": None, "avg_launch_ms": rm_ms / max(rm_n, 1), "launches": rm_n,
+                                  "traffic": profiled_traffic("raymarch_kernel"),
+                                  "avg_launch_ms": rm_ms / max(rm_n, 1), "launches": rm_n,
                                   "algorithmic_bytes_per_launch": rm_bytes / max(rm_n, 1)},
         }
         if train_ms is not None:

@@ -37,6 +37,7 @@ def main():
         for r in csv.DictReader(open(stats)):
             print(f"| {short(r['Name'])} | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.3f} | "
                   f"{float(r['AverageNs'])/1e3:.1f} | {float(r['Percentage']):.2f} |")
+    traffic = {}
     for kind, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
         f = find(os.path.join(out, kind), "*counter_collection.csv")
         if not f:
@@ -52,6 +53,17 @@ def main():
         print("| kernel | launches | avg per launch (MB, raw) |\n|---|---|---|")
         for k, (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
             print(f"| {k} | {n} | {v / n * 1024 / 1e6:.2f} |")
+            traffic.setdefault(k, {})[counter] = v / n * 1024          # bytes per launch, as reported (KiB units)
+    # HBM/fabric bytes per launch for bench.py's `traffic` field: FETCH_SIZE doubled (gfx950 reports half of a wide
+    # coalesced read, MI355X_MICROARCH.md section HBM) + WRITE_SIZE
+    out_t = {"tag": tag, "batch": 4, "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of bench.py "
+             "--no-train; bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (KiB -> bytes); averages over all launches of "
+             "the kernel in one synthesis"}
+    for k, v in traffic.items():
+        if k.startswith("modconv_kernel<2, 2, 2, 2>") or k.startswith("raymarch_kernel"):
+            out_t[k] = {"fetch_raw": v.get("FETCH_SIZE"), "write": v.get("WRITE_SIZE"),
+                        "hbm_bytes": 2 * v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)}
+    json.dump(out_t, open(os.path.join(out, "traffic.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":
