@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(256) modconv_kernel(const ConvParams p) {
     const int npatch = p.ph * p.pw;
     constexpr int A_PER_T = ((PH + 2) * (PW + 2) * 2 + 255) / 256;   // float4 per thread, A
     constexpr int B_PER_T = (MAXTAPS * 2 * BN + 255) / 256;          // float4 per thread, B
-    float4 ra[A_PER_T], rb[B_PER_T];
+    float4 ra[A_PER_T], rs[A_PER_T], rb[B_PER_T];
     const float* xb = p.x + ph.in_off + (long long)b * p.x_batch_stride;
     const float* sb = p.styles ? p.styles + (size_t)b * p.Cin : nullptr;
     const int nB = ph.ntaps * 2 * BN;
@@ -112,15 +112,14 @@ __global__ void __launch_bounds__(256) modconv_kernel(const ConvParams p) {
         const int c0 = chunk * CK;
 #pragma unroll
         for (int k = 0; k < A_PER_T; ++k) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            // no use of the loaded values here: the style multiply happens in store_lds, so the loads of the
+            // chunk stay in flight under the MFMAs (a use right after a load costs an exposed L2 round trip)
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f), sv = make_float4(1.f, 1.f, 1.f, 1.f);
             if (aoff[k] >= 0) {
                 v = *reinterpret_cast<const float4*>(xb + aoff[k] + c0);
-                if (sb) {
-                    const float4 s = *reinterpret_cast<const float4*>(sb + c0 + 4 * ((tid + k * 256) & 1));
-                    v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w;
-                }
+                if (sb) sv = *reinterpret_cast<const float4*>(sb + c0 + 4 * ((tid + k * 256) & 1));
             }
-            ra[k] = v;
+            ra[k] = v; rs[k] = sv;
         }
 #pragma unroll
         for (int k = 0; k < B_PER_T; ++k) {
@@ -133,7 +132,9 @@ __global__ void __launch_bounds__(256) modconv_kernel(const ConvParams p) {
 #pragma unroll
         for (int k = 0; k < A_PER_T; ++k) {
             const int idx = tid + k * 256;
-            if (idx < npatch * 2) *reinterpret_cast<float4*>(As + lds_a[k]) = ra[k];
+            if (idx < npatch * 2)
+                *reinterpret_cast<float4*>(As + lds_a[k]) =
+                    make_float4(ra[k].x * rs[k].x, ra[k].y * rs[k].y, ra[k].z * rs[k].z, ra[k].w * rs[k].w);
         }
 #pragma unroll
         for (int k = 0; k < B_PER_T; ++k) {
@@ -153,6 +154,14 @@ __global__ void __launch_bounds__(256) modconv_kernel(const ConvParams p) {
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) bcol[tn] = (h * BN + (wn * TN + tn) * 32 + l31) * 4;
 
+    // tap table -> registers once (reading it from the kernel argument inside the K loop costs a memory round
+    // trip per tap per chunk)
+    int toffs[MAXTAPS];
+#pragma unroll
+    for (int t = 0; t < MAXTAPS; ++t)
+        toffs[t] = t < ph.ntaps ? ((ph.dy[t] - p.dymin) * LPW + (ph.dx[t] - p.dxmin)) * AS : 0;
+    const int ntaps = ph.ntaps;
+
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
@@ -166,8 +175,10 @@ __global__ void __launch_bounds__(256) modconv_kernel(const ConvParams p) {
         store_lds();
         __syncthreads();
         if (c + 1 < c_end) load_regs(c + 1);
-        for (int t = 0; t < ph.ntaps; ++t) {
-            const int toff = ((ph.dy[t] - p.dymin) * LPW + (ph.dx[t] - p.dxmin)) * AS;
+#pragma unroll
+        for (int t = 0; t < MAXTAPS; ++t) {
+            if (t >= ntaps) break;
+            const int toff = toffs[t];
             float4 a4[TM], b4[TN];
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) a4[tm] = *reinterpret_cast<const float4*>(As + apix[tm] + toff);
@@ -198,7 +209,14 @@ __global__ void __launch_bounds__(256) modconv_kernel(const ConvParams p) {
             if (p.bias) bs = p.bias[co];
         }
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
+        for (int tm = 0; tm < TM; ++tm) {
+            float nz[16];                          // noise of the 16 rows first: independent loads, one wait
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pidx = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int m = min(m0 + (pidx >> 4), ph.mh - 1), n = min(n0 + (pidx & 15), ph.mw - 1);
+                nz[r] = (p.fused && p.noise) ? p.noise[(size_t)(ph.sy * m + ph.oy0) * p.Wo + ph.sx * n + ph.ox0] : 0.f;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int pidx = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -207,12 +225,12 @@ __global__ void __launch_bounds__(256) modconv_kernel(const ConvParams p) {
                 const int oy = ph.sy * m + ph.oy0, ox = ph.sx * n + ph.ox0;
                 float v = acc[tm][tn][r];
                 if (p.fused) {
-                    v = v * d + bs;
-                    if (p.noise) v += p.noise[(size_t)oy * p.Wo + ox] * p.noise_strength;
+                    v = v * d + bs + nz[r] * p.noise_strength;
                     v = lrelu_gain_clamp(v, p.act, p.alpha, p.gain, p.clamp);
                 }
                 out[(((size_t)b * p.Ho + oy) * p.Wo + ox) * p.Cout + co] = v;
             }
+        }
     }
 }
 
