@@ -26,13 +26,15 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32 dense peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_bf16 dense peak
+SPLIT_MFMAS = {"bf16x3": 3, "bf16x6": 6}   # bf16 MFMAs per algorithmic (fp32) product on the split path
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=4, help="frames per step per GPU")
     ap.add_argument("--preset", default="ffhq512_128")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -40,6 +42,9 @@ def parse():
     ap.add_argument("--train-batch", type=int, default=2, help="frames per fitting step per GPU")
     ap.add_argument("--train-steps", type=int, default=6)
     ap.add_argument("--cpu-runs", type=int, default=2)
+    ap.add_argument("--precision", default=None, choices=["fp32", "bf16x3", "bf16x6"],
+                    help="conv GEMM arithmetic of the headline leg (default: the preset's conv_precision)")
+    ap.add_argument("--no-fp32-leg", action="store_true", help="skip the second render leg on the exact fp32 kernel")
     return ap.parse_args()
 
 
@@ -151,37 +156,46 @@ def main():
     def step():
         return gen.synthesis(ws, c, noise_mode="const", u_strat=us, u_imp=ui)["image"]
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    gen.timing = {}
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        img = step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    timing, gen.timing = gen.timing, None
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    assert torch.isfinite(img).all()
+    def render_leg(precision):
+        """W warm-up + K timed steps with the conv GEMMs in ``precision``; (seconds max over ranks, event table)."""
+        gen.conv_precision = precision
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        gen.timing = {}
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            img = step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        timing, gen.timing = gen.timing, None
+        if dist is not None:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        assert torch.isfinite(img).all()
+        return dt, timing
 
-    def agg(key):
-        evs = timing.get(key, [])
+    prec = args.precision or cfg.conv_precision
+    dt32 = timing32 = None
+    if prec != "fp32" and not args.no_fp32_leg:
+        dt32, timing32 = render_leg("fp32")
+    dt, timing = render_leg(prec)
+
+    def agg(key, table=None):
+        evs = (timing if table is None else table).get(key, [])
         ms = sum(e0.elapsed_time(e1) for e0, e1, _ in evs)
         units = sum(u for _, _, u in evs)
         return ms, units, len(evs)
 
     train_ms = tune_ms = train_B = None
     if not args.no_train:
-        del img
         torch.cuda.empty_cache()
         train_ms, tune_ms, train_B = train_leg(args, args.preset, dev, rank, world, dist)
 
@@ -201,22 +215,43 @@ def main():
     if rank == 0:
         frames = world * B * args.steps
         rm_ms, rm_bytes, rm_n = agg("raymarch")
-        mc_ms, mc_flops, mc_n = agg("modconv")
         rm_gbs = rm_bytes / (rm_ms * 1e-3) / 1e9
-        mc_tf = mc_flops / (mc_ms * 1e-3) / 1e12
+
+        def f32_roofline(table):
+            ms, flops, n = agg("modconv", table)
+            tf = flops / (ms * 1e-3) / 1e12
+            return {"bound": "mfma", "kernel": "modconv_kernel (v_mfma_f32_32x32x2_f32, exact fp32)",
+                    "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
+                    "traffic": profiled_traffic("modconv_kernel<2, 2, 2, 2>"), "avg_launch_ms": ms / max(n, 1),
+                    "launches": n}
+
+        if prec == "fp32":
+            roof = f32_roofline(timing)
+        else:
+            # split-bf16 path: ALGORITHMIC flops (2*M*N*K of the fp32 conv) against the bf16 dense MFMA peak divided
+            # by the bf16 MFMAs each algorithmic product costs (3 or 6)
+            ms, flops, n = agg("modconv_split")
+            tf = flops / (ms * 1e-3) / 1e12
+            peak = MFMA_BF16_PEAK_TFLOPS / SPLIT_MFMAS[prec]
+            roof = {"bound": "mfma", "kernel": f"modconv_bf16_kernel ({SPLIT_MFMAS[prec]} x v_mfma_f32_32x32x16_bf16 "
+                                               f"per fp32 product)",
+                    "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
+                    "traffic": profiled_traffic("modconv_bf16_kernel"), "avg_launch_ms": ms / max(n, 1), "launches": n,
+                    "bf16_mfma_tflops": tf * SPLIT_MFMAS[prec]}
         out = {
             "metric": "rendered 512^2 frames/sec (96 depth samples), whole job",
             "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": "f32" if prec == "fp32" else f"f32 tensors and accumulation; conv GEMM products as {prec} "
+                                                  f"(operands split into bf16 parts, {SPLIT_MFMAS[prec]} bf16 MFMAs "
+                                                  f"per product)",
+            "data": "synthetic",
             "config": {"workload": f"{cfg.name}: synthesis(ws[B,14,512], c[B,25]) forward, 512x512 out, 128^2 rays x "
                                    f"(48+48) samples, random-init weights, random latents+cameras",
                        "frames_per_step_per_gpu": B, "parallelism": f"frame-parallel x{world}"},
-            # dominant kernel by time: the fp32 MFMA modulated-conv implicit GEMM (all 17 conv launches per frame)
-            "roofline": {"bound": "mfma", "kernel": "modconv_kernel (v_mfma_f32_32x32x2_f32)",
-                         "achieved": mc_tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": mc_tf / MFMA_F32_PEAK_TFLOPS, "traffic": profiled_traffic("modconv_kernel<2, 2, 2, 2>"),
-                         "avg_launch_ms": mc_ms / max(mc_n, 1), "launches": mc_n},
+            # dominant kernel by time: the modulated-conv implicit GEMM
+            "roofline": roof,
             # the kernel north_star sets the HBM target on
             "roofline_raymarch": {"bound": "hbm", "kernel": "raymarch_kernel<3,3>", "achieved": rm_gbs,
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rm_gbs / HBM_PEAK_GBS,
@@ -224,6 +259,10 @@ def main():
                                   "avg_launch_ms": rm_ms / max(rm_n, 1), "launches": rm_n,
                                   "algorithmic_bytes_per_launch": rm_bytes / max(rm_n, 1)},
         }
+        out["config"]["conv_precision"] = prec
+        if dt32 is not None:
+            out["value_fp32_exact"] = frames / dt32
+            out["roofline_fp32_exact"] = f32_roofline(timing32)
         if train_ms is not None:
             out["train_step_ms"] = train_ms
             out["train_step_ms_generator_tuned"] = tune_ms

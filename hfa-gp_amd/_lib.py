@@ -13,7 +13,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhfagp_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_float_p = C.c_void_p  # device pointers travel as integers
 
@@ -48,6 +48,7 @@ class ModconvArgs(C.Structure):
         ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32),
         ("mode", C.c_int32), ("act", C.c_int32), ("ksplit", C.c_int32),
         ("noise_strength", C.c_float), ("alpha", C.c_float), ("gain", C.c_float), ("clamp", C.c_float),
+        ("precision", C.c_int32),
     ]
 
 
@@ -107,6 +108,7 @@ SYMBOLS = {
     "hfagp_style_fwd": (C.c_int, [C.POINTER(StyleArgs), C.c_void_p]),
     "hfagp_fc_fwd": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 3 + [C.c_float, C.c_int32, C.c_float, C.c_float, C.c_void_p]),
     "hfagp_weight_prep": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "hfagp_weight_prep_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "hfagp_modconv_workspace_bytes": (C.c_size_t, [C.POINTER(ModconvArgs)]),
     "hfagp_modconv_fwd": (C.c_int, [C.POINTER(ModconvArgs), C.c_void_p]),
     "hfagp_upfir_epilogue_fwd": (C.c_int, [C.POINTER(UpfirEpilogueArgs), C.c_void_p]),

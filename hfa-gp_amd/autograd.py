@@ -47,13 +47,7 @@ class _Backward:
 
     # transposed-weight images for the bwd-data GEMMs (cached on the generator like the forward ones)
     def wt_t(self, weight: torch.Tensor) -> torch.Tensor:
-        key = ("T", id(weight))
-        hit = self.gen._prep.get(key)
-        if hit is not None and hit[0] == weight._version and hit[1] == weight.data_ptr():
-            return hit[2]
-        wt, _ = ops.weight_prep(weight.detach().transpose(0, 1).contiguous())
-        self.gen._prep[key] = (weight._version, weight.data_ptr(), wt, None)
-        return wt
+        return self.gen._gemm_image(weight, transposed=True)
 
     def style_grad(self, rec_layer: dict, ds: torch.Tensor, dd: Optional[torch.Tensor], style_gain: float = 1.0,
                    affine=None, wsq=None, dcoef=None):

@@ -46,6 +46,11 @@ class GeneratorConfig:
     resample_filter: Tuple[int, ...] = (1, 3, 3, 1)
     lrelu_alpha: float = 0.2
     demod_eps: float = 1e-8
+    # arithmetic of the conv GEMMs (include/hfagp.h HFAGP_PREC_*): "fp32" = exact v_mfma_f32_32x32x2_f32;
+    # "bf16x3" = operands split into hi+lo bf16, 3 bf16 MFMAs per product, fp32 accumulation (relative error of a
+    # layer ~5e-6, i.e. ~200x below the fp16 the reference's CUDA path runs the super-resolution blocks in, U4);
+    # "bf16x6" = 3 parts / 6 MFMAs (fp32-class).  Layers the split kernel cannot take run on the exact kernel.
+    conv_precision: str = "bf16x3"
     # ---- mapping network (never called by HFA-GP) ---------------
     z_dim: int = 512
     mapping_layers: int = 2

@@ -1,0 +1,167 @@
+// Planning shared by the modulated-conv kernels (fp32-exact modconv.hip, split-bf16 modconv_bf16.hip): the
+// phase/tap tables of the five conv modes, tiling, split-K choice.  gfx950 only.
+#pragma once
+#include "common.h"
+
+namespace hfagp {
+
+constexpr int PW = 16;           // patch width in output positions
+constexpr int MAXTAPS = 9;
+
+struct Phase {
+    int ntaps;
+    int mh, mw;                  // extent of the (m, n) position grid of this phase
+    int sy, sx, oy0, ox0;        // output pixel = (sy*m + oy0, sx*n + ox0)
+    int slab;                    // output slab of this phase (phases that ACCUMULATE into the same pixels)
+    long long in_off;            // element offset of this phase's input image inside x
+    signed char dy[MAXTAPS], dx[MAXTAPS], widx[MAXTAPS];
+};
+
+struct ConvParams {
+    const float* x; const void* wt; const float* styles; const float* dcoef;
+    const float* noise; const float* bias;
+    float* out;                  // y, or the split-K workspace
+    long long x_batch_stride;
+    long long slab;              // elements per split-K slab (B*Ho*Wo*Cout)
+    int B, H, W, Cin, Cout, Ho, Wo;
+    int in_h, in_w;              // extent of the input image(s) (differs from H, W for the parity images)
+    int nphase, nslab, tiles_h, tiles_w, tiles_n, ksplit, nchunks;
+    int wtaps;                   // taps of the weight image (9, or 1 for the 1x1 conv)
+    int dymin, dxmin, ph, pw;    // patch origin offset and patch extent (pixels)
+    int fused;                   // 1: apply the epilogue here, 0: store raw accumulators
+    int act; float noise_strength, alpha, gain, clamp;
+    Phase phase[4];
+};
+
+// ------------------------------------------------------------------ host side
+struct Plan {
+    ConvParams p;
+    int bn;           // N tile: 128, 96, 64 or 32
+    int bm;           // M tile: pixels per block
+    dim3 grid;
+    size_t ws_bytes;
+};
+
+static inline void set_phase(Phase& ph, int ntaps, int mh, int mw, int sy, int sx, int oy0, int ox0,
+                      const int (*taps)[3], int slab = 0, long long in_off = 0) {
+    ph.ntaps = ntaps; ph.mh = mh; ph.mw = mw; ph.sy = sy; ph.sx = sx; ph.oy0 = oy0; ph.ox0 = ox0;
+    ph.slab = slab; ph.in_off = in_off;
+    for (int t = 0; t < ntaps; ++t) {
+        ph.dy[t] = (signed char)taps[t][0]; ph.dx[t] = (signed char)taps[t][1]; ph.widx[t] = (signed char)taps[t][2];
+    }
+}
+
+static inline int make_plan(const HfagpModconvArgs* a, Plan& pl, int ck) {
+    ConvParams& p = pl.p;
+    p = ConvParams{};
+    p.x = a->x; p.wt = a->wt; p.styles = a->styles; p.dcoef = a->dcoef; p.noise = a->noise; p.bias = a->bias;
+    p.x_batch_stride = a->x_batch_stride;
+    p.B = a->B; p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.Cout = a->Cout;
+    p.act = a->act; p.noise_strength = a->noise_strength; p.alpha = a->alpha; p.gain = a->gain; p.clamp = a->clamp;
+    p.nchunks = a->Cin / ck;
+    p.nslab = 1;
+    int in_h = a->H, in_w = a->W;      // extent of the image(s) the patches are read from
+
+    // N tile / wave arrangement
+    if (a->Cout % 128 == 0) pl.bn = 128;
+    else if (a->Cout % 96 == 0) pl.bn = 96;
+    else if (a->Cout % 64 == 0) pl.bn = 64;
+    else pl.bn = 32;
+    pl.bm = 128;
+    const int PH = pl.bm / PW;
+    p.tiles_n = (a->Cout + pl.bn - 1) / pl.bn;
+
+    int gh, gw;   // extent of the position grid that the tiles cover
+    if (a->mode == HFAGP_CONV3X3) {
+        static const int t9[9][3] = {{-1, -1, 0}, {-1, 0, 1}, {-1, 1, 2}, {0, -1, 3}, {0, 0, 4},
+                                     {0, 1, 5},   {1, -1, 6}, {1, 0, 7},  {1, 1, 8}};
+        p.nphase = 1; p.Ho = a->H; p.Wo = a->W;
+        set_phase(p.phase[0], 9, a->H, a->W, 1, 1, 0, 0, t9);
+        p.dymin = -1; p.dxmin = -1; p.ph = PH + 2; p.pw = PW + 2;
+        gh = a->H; gw = a->W; p.fused = 1;
+    } else if (a->mode == HFAGP_CONV1X1) {
+        static const int t1[1][3] = {{0, 0, 0}};
+        p.nphase = 1; p.Ho = a->H; p.Wo = a->W;
+        set_phase(p.phase[0], 1, a->H, a->W, 1, 1, 0, 0, t1);
+        p.dymin = 0; p.dxmin = 0; p.ph = PH; p.pw = PW;
+        gh = a->H; gw = a->W; p.fused = 1;
+    } else if (a->mode == HFAGP_CONVT3X3_UP2) {
+        // y_t[2i+ti][2j+tj] += x[i][j] * w[ti][tj]; output phase (a,b) collects ti = a (mod 2), tj = b (mod 2)
+        static const int t00[4][3] = {{0, 0, 0}, {-1, 0, 6}, {0, -1, 2}, {-1, -1, 8}};
+        static const int t01[2][3] = {{0, 0, 1}, {-1, 0, 7}};
+        static const int t10[2][3] = {{0, 0, 3}, {0, -1, 5}};
+        static const int t11[1][3] = {{0, 0, 4}};
+        p.nphase = 4; p.Ho = 2 * a->H + 1; p.Wo = 2 * a->W + 1;
+        set_phase(p.phase[0], 4, a->H + 1, a->W + 1, 2, 2, 0, 0, t00);
+        set_phase(p.phase[1], 2, a->H + 1, a->W, 2, 2, 0, 1, t01);
+        set_phase(p.phase[2], 2, a->H, a->W + 1, 2, 2, 1, 0, t10);
+        set_phase(p.phase[3], 1, a->H, a->W, 2, 2, 1, 1, t11);
+        p.dymin = -1; p.dxmin = -1; p.ph = PH + 1; p.pw = PW + 1;
+        gh = a->H + 1; gw = a->W + 1; p.fused = 0;
+    } else if (a->mode == HFAGP_CONV3X3_BWD) {
+        // adjoint of mode 0 w.r.t. its input: dx[p][q] = sum_t g[p - dy_t][q - dx_t] . W_t^T  (taps mirrored)
+        static const int t9[9][3] = {{1, 1, 0}, {1, 0, 1}, {1, -1, 2}, {0, 1, 3}, {0, 0, 4},
+                                     {0, -1, 5}, {-1, 1, 6}, {-1, 0, 7}, {-1, -1, 8}};
+        p.nphase = 1; p.Ho = a->H; p.Wo = a->W;
+        set_phase(p.phase[0], 9, a->H, a->W, 1, 1, 0, 0, t9);
+        p.dymin = -1; p.dxmin = -1; p.ph = PH + 2; p.pw = PW + 2;
+        gh = a->H; gw = a->W; p.fused = 1;
+    } else if (a->mode == HFAGP_CONVS2_BWD) {
+        // adjoint of mode 1 w.r.t. its input: dx[i][j] = sum_{ti,tj} g_yt[2i+ti][2j+tj] . W_{ti,tj}^T.
+        // x holds the four parity images of g_yt: x[a][b] [B][H+1][W+1][Cin], (a,b) = (ti&1, tj&1);
+        // each parity is one phase accumulating into its own slab (summed by the split-K reducer).
+        static const int t00[4][3] = {{0, 0, 0}, {1, 0, 6}, {0, 1, 2}, {1, 1, 8}};
+        static const int t01[2][3] = {{0, 0, 1}, {1, 0, 7}};
+        static const int t10[2][3] = {{0, 0, 3}, {0, 1, 5}};
+        static const int t11[1][3] = {{0, 0, 4}};
+        const long long img = (long long)a->B * (a->H + 1) * (a->W + 1) * a->Cin;
+        p.nphase = 4; p.nslab = 4; p.Ho = a->H; p.Wo = a->W;
+        set_phase(p.phase[0], 4, a->H, a->W, 1, 1, 0, 0, t00, 0, 0);
+        set_phase(p.phase[1], 2, a->H, a->W, 1, 1, 0, 0, t01, 1, img);
+        set_phase(p.phase[2], 2, a->H, a->W, 1, 1, 0, 0, t10, 2, 2 * img);
+        set_phase(p.phase[3], 1, a->H, a->W, 1, 1, 0, 0, t11, 3, 3 * img);
+        p.dymin = 0; p.dxmin = 0; p.ph = PH + 1; p.pw = PW + 1;
+        in_h = a->H + 1; in_w = a->W + 1;
+        gh = a->H; gw = a->W; p.fused = 0;
+    } else {
+        set_error("modconv: unknown mode %d", a->mode);
+        return HFAGP_EBADARG;
+    }
+    p.in_h = in_h; p.in_w = in_w;
+    p.wtaps = a->mode == HFAGP_CONV1X1 ? 1 : 9;
+    p.tiles_h = (gh + PH - 1) / PH;
+    p.tiles_w = (gw + PW - 1) / PW;
+    p.slab = (long long)a->B * p.Ho * p.Wo * a->Cout;
+
+    const long long base_blocks = (long long)p.tiles_h * p.tiles_w * a->B * p.tiles_n * p.nphase;
+    int ks = a->ksplit;
+    if (ks <= 0) {
+        ks = 1;
+        const long long target = 2 * kNumCU;
+        if (base_blocks < target) ks = (int)((target + base_blocks - 1) / base_blocks);
+        const int max_ks = p.nchunks / 2 > 0 ? p.nchunks / 2 : 1;   // at least 2 chunks per split
+        if (ks > max_ks) ks = max_ks;
+        if (ks > 64) ks = 64;
+    }
+    if (ks > p.nchunks) ks = p.nchunks;
+    p.ksplit = ks;
+    if (ks * p.nslab > 1) p.fused = 0;
+    pl.ws_bytes = ks * p.nslab > 1 ? (size_t)ks * p.nslab * p.slab * sizeof(float) : 0;
+    pl.grid = dim3((unsigned)(p.tiles_h * p.tiles_w * a->B * p.tiles_n * ks), (unsigned)p.nphase, 1);
+    return HFAGP_OK;
+}
+
+static inline int validate(const HfagpModconvArgs* a, int ck) {
+    HFAGP_REQUIRE(a && a->x && a->wt && a->y, HFAGP_EBADARG, "modconv: null pointer");
+    HFAGP_REQUIRE(a->B > 0 && a->H > 0 && a->W > 0 && a->Cin > 0 && a->Cout > 0, HFAGP_EBADARG, "modconv: bad dims");
+    HFAGP_REQUIRE(a->Cin % ck == 0, HFAGP_EUNSUPPORTED, "modconv: Cin=%d must be a multiple of %d", a->Cin, ck);
+    HFAGP_REQUIRE(a->Cout % 4 == 0, HFAGP_EUNSUPPORTED, "modconv: Cout=%d must be a multiple of 4", a->Cout);
+    HFAGP_REQUIRE(a->act == HFAGP_ACT_LINEAR || a->act == HFAGP_ACT_LRELU, HFAGP_EUNSUPPORTED, "modconv: act %d", a->act);
+    return HFAGP_OK;
+}
+
+
+// modconv_bf16.hip
+int launch_modconv_bf16(const HfagpModconvArgs* a, Plan& pl, hipStream_t s);
+
+}  // namespace hfagp

@@ -141,7 +141,9 @@ class TriPlaneGenerator(nn.Module):
             "2": _FC(cfg.decoder_hidden, 1 + cfg.plane_channels, gen, cfg.decoder_lr_mul),
         })
         self.decoder = dec
-        self._prep: Dict[int, tuple] = {}        # id(param) -> (version, data_ptr, wt, wsq)
+        self._prep: Dict[object, tuple] = {}     # (kind, ..., id(param)) -> (version, data_ptr, image, wsq)
+        self._conv_precision = "fp32"
+        self.conv_precision = cfg.conv_precision
         self._scalars: Dict[int, tuple] = {}     # id(param) -> (version, data_ptr, python float)
         self._const_nhwc: Optional[tuple] = None
         self.timing: Optional[Dict[str, list]] = None   # bench.py: {'raymarch': [(ev0, ev1, units)], 'modconv': [...]}
@@ -158,14 +160,47 @@ class TriPlaneGenerator(nn.Module):
         return out
 
     # ----------------------------------------------------------------- caches
-    def _prepared(self, weight: torch.Tensor):
-        key = id(weight)
+    @property
+    def conv_precision(self) -> str:
+        """Arithmetic of the conv GEMMs: 'fp32' (exact MFMA), 'bf16x3' or 'bf16x6' (split-bf16 MFMA, fp32
+        accumulation; include/hfagp.h HFAGP_PREC_*).  Layers whose shape the split kernel does not take
+        (Cin % 16, Cout % 128) always run on the exact fp32 kernel."""
+        return self._conv_precision
+
+    @conv_precision.setter
+    def conv_precision(self, value: str):
+        if value not in ops.PRECISIONS:
+            raise ValueError(f"conv_precision must be one of {sorted(ops.PRECISIONS)}, got {value!r}")
+        self._conv_precision = value
+
+    def _gemm_image(self, weight: torch.Tensor, transposed: bool = False) -> torch.Tensor:
+        """MFMA B-operand image of a conv weight (of its Cin/Cout transpose for the bwd-data GEMMs), in the layout
+        of the configured precision; cached until the parameter changes."""
+        co, ci = weight.shape[:2]
+        if transposed:
+            co, ci = ci, co
+        nparts = {"fp32": 0, "bf16x3": 2, "bf16x6": 3}[self._conv_precision]
+        if not ops.split_supported(ci, co):
+            nparts = 0
+        key = ("G", nparts, transposed, id(weight))
         hit = self._prep.get(key)
         if hit is not None and hit[0] == weight._version and hit[1] == weight.data_ptr():
-            return hit[2], hit[3]
-        wt, wsq = ops.weight_prep(weight.detach().contiguous())
-        self._prep[key] = (weight._version, weight.data_ptr(), wt, wsq)
-        return wt, wsq
+            return hit[2]
+        w = weight.detach()
+        w = (w.transpose(0, 1) if transposed else w).contiguous()
+        img = ops.weight_prep_split(w, nparts) if nparts else ops.weight_prep(w)[0]
+        self._prep[key] = (weight._version, weight.data_ptr(), img, None)
+        return img
+
+    def _prepared(self, weight: torch.Tensor):
+        """(GEMM image, wsq [Cout, Cin] = sum over taps of weight^2 for the demodulation)."""
+        key = ("Q", id(weight))
+        hit = self._prep.get(key)
+        if hit is None or hit[0] != weight._version or hit[1] != weight.data_ptr():
+            _, wsq = ops.weight_prep(weight.detach().contiguous())
+            hit = (weight._version, weight.data_ptr(), None, wsq)
+            self._prep[key] = hit
+        return self._gemm_image(weight), hit[3]
 
     def _scalar(self, t: torch.Tensor) -> float:
         """Host copy of a 0-d parameter (noise_strength), cached so steady state has no device sync."""
@@ -199,11 +234,12 @@ class TriPlaneGenerator(nn.Module):
         # algorithmic FLOPs: 2 * B * H_in * W_in * Cin * Cout * 9 (the up-conv is counted in its
         # polyphase / transposed form at INPUT resolution)
         flops = 2.0 * batch * x.shape[1] * x.shape[2] * x.shape[3] * cout * 9
+        key = "modconv" if wt.dtype == torch.float32 else "modconv_split"      # which kernel bench.py times
         if layer.up == 2:
-            yt = self._timed("modconv", flops, ops.modconv, x, wt, cout, ops.CONVT3X3_UP2, styles=styles, batch=batch)
+            yt = self._timed(key, flops, ops.modconv, x, wt, cout, ops.CONVT3X3_UP2, styles=styles, batch=batch)
             out = ops.upfir_epilogue(yt, dcoef, noise, ns, layer.bias, "lrelu", cfg.lrelu_alpha, gain, conv_clamp)
         else:
-            out = self._timed("modconv", flops, ops.modconv, x, wt, cout, ops.CONV3X3, styles=styles, dcoef=dcoef,
+            out = self._timed(key, flops, ops.modconv, x, wt, cout, ops.CONV3X3, styles=styles, dcoef=dcoef,
                               noise=noise, noise_strength=ns, bias=layer.bias, act="lrelu", alpha=cfg.lrelu_alpha,
                               gain=gain, clamp=conv_clamp, batch=batch)
         rec = None

@@ -53,6 +53,26 @@ def weight_prep(weight: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     return wt, wsq
 
 
+PREC_F32, PREC_BF16X3, PREC_BF16X6 = 0, 1, 2
+PRECISIONS = {"fp32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16x6": PREC_BF16X6}
+
+
+def split_supported(cin: int, cout: int) -> bool:
+    """Shapes the split-bf16 conv path takes (hfagp.h: Cin % 16 == 0, Cout % 128 == 0)."""
+    return cin % 16 == 0 and cout % 128 == 0
+
+
+def weight_prep_split(weight: torch.Tensor, nparts: int) -> torch.Tensor:
+    """weight [Cout, Cin, k, k] fp32 → split-bf16 B-operand image [nparts, k*k, Cin/8, Cout, 8] (bfloat16):
+    weight = sum of the parts, each the round-to-nearest bf16 of the residual (nparts 2: BF16X3, 3: BF16X6)."""
+    _chk(weight, "weight")
+    co, ci, kh, kw = weight.shape
+    wb = torch.empty(nparts, kh * kw, ci // 8, co, 8, device=weight.device, dtype=torch.bfloat16)
+    L.check(L.lib().hfagp_weight_prep_split(_ptr(weight), wb.data_ptr(), co, ci, kh * kw, nparts, _stream()),
+            "weight_prep_split")
+    return wb
+
+
 def styles_demod(w: torch.Tensor, affine_w: torch.Tensor, affine_b: torch.Tensor,
                  wsq: Optional[torch.Tensor], style_gain: float = 1.0, eps: float = 1e-8):
     """w [B, w_dim] (may be a strided row view of ws) → styles [B, Cin], dcoef [B, Cout] | None."""
@@ -95,7 +115,9 @@ def modconv(x: torch.Tensor, wt: torch.Tensor, cout: int, mode: int, styles: Opt
             alpha: float = 0.2, gain: float = 1.0, clamp: Optional[float] = None, batch: Optional[int] = None,
             ksplit: int = 0) -> torch.Tensor:
     """x [B|1, H, W, Cin] channels-last.  mode CONV3X3 / CONV1X1: fused epilogue, returns [B,H,W,Cout];
-    mode CONVT3X3_UP2: returns the RAW transposed-conv result [B, 2H+1, 2W+1, Cout]."""
+    mode CONVT3X3_UP2: returns the RAW transposed-conv result [B, 2H+1, 2W+1, Cout].
+    ``wt`` from :func:`weight_prep` (fp32, exact MFMA) or :func:`weight_prep_split` (bfloat16 parts: the
+    split-bf16 MFMA path, BF16X3 for 2 parts, BF16X6 for 3)."""
     _chk(x, "x")
     if mode == CONVS2_BWD:                      # x = four parity images [2,2,B,H+1,W+1,Cin]
         _, _, xb, h, w, cin = x.shape
@@ -104,7 +126,14 @@ def modconv(x: torch.Tensor, wt: torch.Tensor, cout: int, mode: int, styles: Opt
         xb, h, w, cin = x.shape
     b = batch if batch is not None else xb
     a = L.ModconvArgs()
-    a.x, a.wt = _ptr(x), _ptr(_chk(wt, "wt"))
+    if wt.dtype == torch.bfloat16:
+        if not (wt.is_cuda and wt.is_contiguous() and wt.dim() == 5 and wt.shape[0] in (2, 3)):
+            raise RuntimeError("modconv: split weights must come from weight_prep_split")
+        a.x, a.wt = _ptr(x), wt.data_ptr()
+        a.precision = PREC_BF16X3 if wt.shape[0] == 2 else PREC_BF16X6
+    else:
+        a.x, a.wt = _ptr(x), _ptr(_chk(wt, "wt"))
+        a.precision = PREC_F32
     a.styles, a.dcoef, a.noise, a.bias = _ptr(styles), _ptr(dcoef), _ptr(noise), _ptr(bias)
     a.x_batch_stride = 0 if (xb == 1 and b > 1) else x.shape[-3] * x.shape[-2] * cin
     a.B, a.H, a.W, a.Cin, a.Cout = b, h, w, cin, cout

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define HFAGP_ABI_VERSION 1
+#define HFAGP_ABI_VERSION 2
 
 enum { HFAGP_OK = 0, HFAGP_EBADARG = -1, HFAGP_EUNSUPPORTED = -2, HFAGP_ELAUNCH = -3 };
 
@@ -102,6 +102,12 @@ int hfagp_fc_fwd(const float* x, const float* weight, const float* bias, float* 
 int hfagp_weight_prep(const float* weight, float* wt, float* wsq,
                       int32_t Cout, int32_t Cin, int32_t taps, void* stream);
 
+/* split-bf16 weight image for the HFAGP_PREC_BF16X3 / _BF16X6 conv path:
+ *   wb [nparts][taps][Cin/8][Cout][8] bf16  <- weight [Cout][Cin][kh][kw],  w = part0 + part1 (+ part2),
+ *   each part the round-to-nearest bf16 of the residual left by the parts before it (nparts = 2 or 3).   */
+int hfagp_weight_prep_split(const float* weight, void* wb, int32_t Cout, int32_t Cin, int32_t taps,
+                            int32_t nparts, void* stream);
+
 /* ------------------------------------------------------------------ modulated conv
  * Implicit-GEMM on v_mfma_f32_32x32x2_f32 (exact fp32).  Input is scaled by
  * styles on the way into LDS; demodulation, noise, bias, leaky-ReLU, gain and
@@ -117,10 +123,17 @@ enum {
                             /* [2][2][B][H+1][W+1][Cin] (hfagp_upfir_bwd), H, W = resolution of dx          */
 };
 enum { HFAGP_ACT_LINEAR = 0, HFAGP_ACT_LRELU = 1 };
+/* arithmetic of the GEMM (accumulation is always fp32):
+ *   F32     v_mfma_f32_32x32x2_f32, exact fp32 products
+ *   BF16X3  operands split into 2 bf16 parts (hi+lo), 3 v_mfma_f32_32x32x16_bf16 per product
+ *           (hi.hi + lo.hi + hi.lo): relative product error ~2^-16
+ *   BF16X6  3 parts, 6 MFMAs per product: relative product error ~2^-23 (fp32 class)
+ * The split paths need Cin % 16 == 0 and Cout % 128 == 0 (HFAGP_EUNSUPPORTED otherwise).             */
+enum { HFAGP_PREC_F32 = 0, HFAGP_PREC_BF16X3 = 1, HFAGP_PREC_BF16X6 = 2 };
 
 typedef struct {
     const float* x;           /* [B][H][W][Cin]; x_batch_stride (elements) may be 0 (const)   */
-    const float* wt;          /* from hfagp_weight_prep                                       */
+    const void*  wt;          /* hfagp_weight_prep (F32) or hfagp_weight_prep_split (BF16X3: 2, BF16X6: 3 parts) */
     const float* styles;      /* [B][Cin] or NULL                                             */
     const float* dcoef;       /* [B][Cout] or NULL                                            */
     const float* noise;       /* [Ho][Wo] or NULL                                             */
@@ -132,6 +145,7 @@ typedef struct {
     int32_t mode, act;
     int32_t ksplit;           /* 0 = let the library choose                                   */
     float noise_strength, alpha, gain, clamp;   /* clamp < 0: none                            */
+    int32_t precision;        /* HFAGP_PREC_*                                                 */
 } HfagpModconvArgs;
 
 size_t hfagp_modconv_workspace_bytes(const HfagpModconvArgs* a);
