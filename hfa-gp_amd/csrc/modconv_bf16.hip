@@ -12,6 +12,7 @@
 //   fragment order: a lane's 8 K values are one 16-B load / one ds_read_b128.
 //   A K chunk is consumed in steps of up to 3 taps; the B image of the next step and the A patch of the next chunk
 //   are prefetched into registers under the MFMAs and written to the other LDS buffer before the step's barrier.
+#include <type_traits>
 #include "modconv_plan.h"
 
 namespace hfagp {
@@ -20,6 +21,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int CKB = 16;          // channels per K chunk
 constexpr int TS = 3;            // taps per pipeline step
@@ -74,89 +76,72 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
 
     const int c_begin = (int)(((long long)p.nchunks * ks) / p.ksplit);
     const int c_end = (int)(((long long)p.nchunks * (ks + 1)) / p.ksplit);
-    const int ntaps = ph.ntaps;
-    const int nsteps = (ntaps + TS - 1) / TS;
 
-    // ---- A staging: float4 (4 channels of one position) per slot, 4 slots per position
+    // ---- A staging: float4 (4 channels of one position) per slot, 4 slots per position.  Loads are branch-free:
+    // a slot outside the image (zero padding) or past the patch reads element 0 and is multiplied by 0.
     const int npatch = p.ph * p.pw;
     constexpr int A_PER_T = ((PH + 2) * (PW + 2) * 4 + 255) / 256;
     float4 ra[A_PER_T], rs[A_PER_T];
     const float* xb = p.x + ph.in_off + (long long)b * p.x_batch_stride;
     const float* sb = p.styles ? p.styles + (size_t)b * p.Cin : nullptr;
-    long long aoff[A_PER_T];
-    int lds_a[A_PER_T];
+    int aoff[A_PER_T], lds_a[A_PER_T];
+    float amask[A_PER_T];
 #pragma unroll
     for (int k = 0; k < A_PER_T; ++k) {
         const int idx = tid + k * 256;
-        aoff[k] = -1;
+        aoff[k] = 0;
+        amask[k] = 0.f;
         lds_a[k] = -1;
         if (idx < npatch * 4) {
             const int pix = idx >> 2, q = idx & 3;
             const int pos = (pix / p.pw) * LPWB + pix % p.pw;
             lds_a[k] = pos * 32 + ((((q >> 1) ^ (pos >> 3)) & 1) << 4) + ((q & 1) << 3);
             const int iy = m0 + p.dymin + pix / p.pw, ix = n0 + p.dxmin + pix % p.pw;
-            if (iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w) aoff[k] = ((long long)iy * p.in_w + ix) * p.Cin + 4 * q;
+            if (iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w) {
+                aoff[k] = (iy * p.in_w + ix) * p.Cin + 4 * q;      // < 2^31: one image of the batch
+                amask[k] = 1.f;
+            }
         }
     }
-    auto load_a = [&](int chunk) {
+    auto load_a = [&](int chunk) __attribute__((always_inline)) {
         const int c0 = chunk * CKB;
 #pragma unroll
         for (int k = 0; k < A_PER_T; ++k) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f), sv = make_float4(1.f, 1.f, 1.f, 1.f);
-            if (aoff[k] >= 0) {
-                v = *reinterpret_cast<const float4*>(xb + aoff[k] + c0);
-                if (sb) sv = *reinterpret_cast<const float4*>(sb + c0 + 4 * ((tid + k * 256) & 3));
-            }
-            ra[k] = v; rs[k] = sv;
+            ra[k] = *reinterpret_cast<const float4*>(xb + aoff[k] + c0);
+            float4 sv = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (sb) sv = *reinterpret_cast<const float4*>(sb + c0 + 4 * ((tid + k * 256) & 3));
+            rs[k] = sv;
         }
     };
-    auto store_a = [&](int buf) {
+    auto store_a = [&](int buf) __attribute__((always_inline)) {
         char* dst = As + buf * A_BUF;
 #pragma unroll
         for (int k = 0; k < A_PER_T; ++k) {
             if (lds_a[k] < 0) continue;
+            const float m = amask[k];
             uint2 parts[NP];
-            split4<NP>(make_float4(ra[k].x * rs[k].x, ra[k].y * rs[k].y, ra[k].z * rs[k].z, ra[k].w * rs[k].w), parts);
+            split4<NP>(make_float4(ra[k].x * (rs[k].x * m), ra[k].y * (rs[k].y * m), ra[k].z * (rs[k].z * m),
+                                   ra[k].w * (rs[k].w * m)), parts);
 #pragma unroll
             for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2*>(dst + q * A_PART + lds_a[k]) = parts[q];
         }
     };
 
-    // ---- B staging: one step = TS taps x NP parts x [2 k-groups][128 co] 16-B slots; thread = (kg, co)
-    constexpr int B_PER_T = TS * NP;
-    uint4 rb[B_PER_T];
-    const uint4* wb = reinterpret_cast<const uint4*>(p.wt);
+    // ---- B staging: one step = up to TS taps x NP parts x [2 k-groups][128 co] 16-B slots; thread = (kg, co)
+    u32x4 rb[TS * NP];
+    const u32x4* wb = reinterpret_cast<const u32x4*>(p.wt);
     const int cq8 = p.Cin >> 3;
-    const long long part_stride = (long long)p.wtaps * cq8 * p.Cout;          // uint4 per part
-    const long long bthread = (long long)(tid >> 7) * p.Cout + co0 + (tid & 127);
-    auto load_b = [&](int chunk, int step) {
+    const int part_stride = p.wtaps * cq8 * p.Cout;                           // uint4 per part
+    const int bthread = (tid >> 7) * p.Cout + co0 + (tid & 127);
+    int wtap[MAXTAPS];                                                        // tap table -> registers, once
 #pragma unroll
-        for (int j = 0; j < TS; ++j) {
-            const int t = step * TS + j;
-#pragma unroll
-            for (int q = 0; q < NP; ++q) {
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (t < ntaps)
-                    v = wb[q * part_stride + ((long long)ph.widx[t] * cq8 + chunk * 2) * p.Cout + bthread];
-                rb[j * NP + q] = v;
-            }
-        }
-    };
-    auto store_b = [&](int buf, int step) {
-        char* dst = Bs + buf * B_BUF + tid * 16;
-#pragma unroll
-        for (int j = 0; j < TS; ++j) {
-            if (step * TS + j >= ntaps) break;
-#pragma unroll
-            for (int q = 0; q < NP; ++q) *reinterpret_cast<uint4*>(dst + (j * NP + q) * 4096) = rb[j * NP + q];
-        }
-    };
+    for (int t = 0; t < MAXTAPS; ++t) wtap[t] = t < ph.ntaps ? ph.widx[t] * cq8 * p.Cout : 0;
 
     // ---- per-lane fragment addresses (bytes inside one part image), one per (tap, M tile)
     int aaddr[MAXTAPS][TM];
 #pragma unroll
     for (int t = 0; t < MAXTAPS; ++t) {
-        const int tpos = t < ntaps ? (ph.dy[t] - p.dymin) * LPWB + (ph.dx[t] - p.dxmin) : 0;
+        const int tpos = t < ph.ntaps ? (ph.dy[t] - p.dymin) * LPWB + (ph.dx[t] - p.dxmin) : 0;
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
             const int pidx = (wm * TM + tm) * 32 + l31;
@@ -181,25 +166,45 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
     constexpr int PA[6] = {0, 1, 0, 1, 2, 0};
     constexpr int PB[6] = {0, 0, 1, 1, 0, 2};
 
-    int bbuf = 0;
-    if (c_begin < c_end) { load_a(c_begin); load_b(c_begin, 0); }
-    for (int c = c_begin; c < c_end; ++c) {
-        const int abuf = (c - c_begin) & 1;
-        store_a(abuf);
-        const char* Ac = As + abuf * A_BUF;
+    // the K loop for a compile-time tap count NT (9: 3x3, 4/2/1: the phases of the stride-2 transposed conv and
+    // the 1x1 conv): straight-line steps of up to TS taps, so the LDS reads of a tap are scheduled under the MFMAs
+    // of the tap before
+    auto run = [&](auto nt_tag) __attribute__((always_inline)) {
+        constexpr int NT = decltype(nt_tag)::value;
+        constexpr int NSTEPS = (NT + TS - 1) / TS;
+        auto load_b = [&](int chunk, auto step_tag) __attribute__((always_inline)) {
+            constexpr int S = decltype(step_tag)::value;
+            constexpr int NJ = NT - S * TS < TS ? NT - S * TS : TS;
 #pragma unroll
-        for (int s = 0; s < (MAXTAPS + TS - 1) / TS; ++s) {
-            if (s >= nsteps) break;
-            store_b(bbuf, s);
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int q = 0; q < NP; ++q)
+                    rb[j * NP + q] = wb[q * part_stride + wtap[S * TS + j] + chunk * 2 * p.Cout + bthread];
+        };
+        auto store_b = [&](int buf, auto step_tag) __attribute__((always_inline)) {
+            constexpr int S = decltype(step_tag)::value;
+            char* dst = Bs + buf * B_BUF + tid * 16;
+            constexpr int NJ = NT - S * TS < TS ? NT - S * TS : TS;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int q = 0; q < NP; ++q) *reinterpret_cast<u32x4*>(dst + (j * NP + q) * 4096) = rb[j * NP + q];
+        };
+        auto step = [&](int c, int abuf, int& bbuf, auto step_tag) __attribute__((always_inline)) {
+            constexpr int S = decltype(step_tag)::value;
+            store_b(bbuf, step_tag);
             __syncthreads();
-            if (s + 1 < nsteps) load_b(c, s + 1);
-            else if (c + 1 < c_end) load_b(c + 1, 0);
-            if (s == 0 && c + 1 < c_end) load_a(c + 1);
+#ifndef HFAGP_DIAG_NOLOAD
+            if constexpr (S + 1 < NSTEPS) load_b(c, std::integral_constant<int, S + 1>{});
+            else if (c + 1 < c_end) load_b(c + 1, std::integral_constant<int, 0>{});
+            if (S == 0 && c + 1 < c_end) load_a(c + 1);
+#endif
+            const char* Ac = As + abuf * A_BUF;
             const char* Bc = Bs + bbuf * B_BUF;
+            constexpr int NJ = NT - S * TS < TS ? NT - S * TS : TS;
 #pragma unroll
-            for (int j = 0; j < TS; ++j) {
-                const int t = s * TS + j;
-                if (t >= ntaps) break;
+            for (int j = 0; j < NJ; ++j) {
+                const int t = S * TS + j;
                 bf16x8 af[TM][NP], bfr[TN][NP];
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm)
@@ -211,6 +216,18 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
 #pragma unroll
                     for (int q = 0; q < NP; ++q)
                         bfr[tn][q] = *reinterpret_cast<const bf16x8*>(Bc + (j * NP + q) * 4096 + bcol[tn]);
+#ifdef HFAGP_DIAG_NOMFMA
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                        for (int q = 0; q < NP; ++q) {
+                            acc[tm][tn][q] += __builtin_bit_cast(float, __builtin_bit_cast(u32x4, af[tm][q])[0]);
+                            acc[tm][tn][q + 4] += __builtin_bit_cast(float, __builtin_bit_cast(u32x4, bfr[tn][q])[1]);
+                        }
+                continue;
+#endif
 #pragma unroll
                 for (int pr = 0; pr < NPROD; ++pr)
 #pragma unroll
@@ -221,7 +238,22 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
                                                                                   acc[tm][tn], 0, 0, 0);
             }
             bbuf ^= 1;
+        };
+        int bbuf = 0;
+        if (c_begin < c_end) { load_a(c_begin); load_b(c_begin, std::integral_constant<int, 0>{}); }
+        for (int c = c_begin; c < c_end; ++c) {
+            const int abuf = (c - c_begin) & 1;
+            store_a(abuf);
+            step(c, abuf, bbuf, std::integral_constant<int, 0>{});
+            if constexpr (NSTEPS > 1) step(c, abuf, bbuf, std::integral_constant<int, 1>{});
+            if constexpr (NSTEPS > 2) step(c, abuf, bbuf, std::integral_constant<int, 2>{});
         }
+    };
+    switch (ph.ntaps) {
+        case 9: run(std::integral_constant<int, 9>{}); break;
+        case 4: run(std::integral_constant<int, 4>{}); break;
+        case 2: run(std::integral_constant<int, 2>{}); break;
+        default: run(std::integral_constant<int, 1>{}); break;
     }
 
     // ---- epilogue.  C/D layout of 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
