@@ -24,8 +24,11 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int CKB = 16;          // channels per K chunk
-constexpr int TS = 3;            // taps per pipeline step
-constexpr int LPWB = PW + 2;     // LDS row pitch of the patch in positions
+constexpr int APITCH = 48;       // LDS bytes per patch position and part: 16 bf16 + 16 B pad (3 x 16-B slots, odd)
+// LDS row pitch of the patch in positions.  32 (a multiple of 16) makes every 16-lane group of a ds_read_b128
+// cover 16 consecutive columns -> 16 distinct 16-B slots, no bank conflicts (the groups are {0-3,12-15,20-27},...);
+// the 3-part image would not fit twice per CU at that pitch and keeps the dense one (1 extra LDS cycle per group).
+template <int NP> struct RowPitch { static constexpr int value = NP == 2 ? 32 : PW + 2; };
 constexpr int BNB = 128;         // output channels per block
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
@@ -50,17 +53,17 @@ __device__ __forceinline__ void split4(float4 v, uint2 (&out)[NP]) {
     }
 }
 
-template <int NP, int TM>
-__global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p) {
+template <int NP, int TM, int NTAPS>
+__global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p, const int phase0) {
     constexpr int TN = 2, WN = 2, BM = 2 * TM * 32, PH = BM / PW;
+    constexpr int LPWB = RowPitch<NP>::value;
     constexpr int APOS = (PH + 2) * LPWB;                 // positions of the staged patch
-    constexpr int A_PART = APOS * 32, A_BUF = NP * A_PART;
-    constexpr int B_TAP = NP * 2 * BNB * 16, B_BUF = TS * B_TAP;
+    constexpr int A_PART = APOS * APITCH, A_BUF = NP * A_PART;
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-    char* As = lds_raw;                                   // [2][NP][APOS][32 B]
-    char* Bs = lds_raw + 2 * A_BUF;                       // [2][TS][NP][2][128][16 B]
+    char* As = lds_raw;                                   // [2][NP][APOS][48 B]
+    float* Ss = reinterpret_cast<float*>(lds_raw + 2 * A_BUF);   // [Cin] styles of this sample (or ones)
 
-    const Phase& ph = p.phase[blockIdx.y];
+    const Phase& ph = p.phase[phase0 + blockIdx.y];   // every phase of one launch has NTAPS taps
     unsigned id = blockIdx.x;
     const int tn_blk = id % p.tiles_n; id /= p.tiles_n;
     const int tw = id % p.tiles_w;     id /= p.tiles_w;
@@ -77,81 +80,76 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
     const int c_begin = (int)(((long long)p.nchunks * ks) / p.ksplit);
     const int c_end = (int)(((long long)p.nchunks * (ks + 1)) / p.ksplit);
 
-    // ---- A staging: float4 (4 channels of one position) per slot, 4 slots per position.  Loads are branch-free:
-    // a slot outside the image (zero padding) or past the patch reads element 0 and is multiplied by 0.
+    // ---- A staging: float4 (4 channels of one position) per slot, 4 slots per position.  Everything is
+    // branch-free: a slot outside the image (zero padding) reads element 0 and is multiplied by 0, a thread past
+    // the end of the patch repeats the last slot (same value to the same LDS address), and addresses are a
+    // uniform base + a 32-bit per-lane byte offset (global_load with an SGPR base: no 64-bit VALU address math).
     const int npatch = p.ph * p.pw;
     constexpr int A_PER_T = ((PH + 2) * (PW + 2) * 4 + 255) / 256;
-    float4 ra[A_PER_T], rs[A_PER_T];
-    const float* xb = p.x + ph.in_off + (long long)b * p.x_batch_stride;
-    const float* sb = p.styles ? p.styles + (size_t)b * p.Cin : nullptr;
-    int aoff[A_PER_T], lds_a[A_PER_T];
+    float4 ra[A_PER_T];
+    const char* xb = reinterpret_cast<const char*>(p.x + ph.in_off + (long long)b * p.x_batch_stride);
+    for (int i = tid; i < p.Cin; i += 256) Ss[i] = p.styles ? p.styles[(size_t)b * p.Cin + i] : 1.f;
+    unsigned aoff[A_PER_T];
+    int lds_a[A_PER_T], soff[A_PER_T];
     float amask[A_PER_T];
 #pragma unroll
     for (int k = 0; k < A_PER_T; ++k) {
-        const int idx = tid + k * 256;
-        aoff[k] = 0;
-        amask[k] = 0.f;
-        lds_a[k] = -1;
-        if (idx < npatch * 4) {
-            const int pix = idx >> 2, q = idx & 3;
-            const int pos = (pix / p.pw) * LPWB + pix % p.pw;
-            lds_a[k] = pos * 32 + ((((q >> 1) ^ (pos >> 3)) & 1) << 4) + ((q & 1) << 3);
-            const int iy = m0 + p.dymin + pix / p.pw, ix = n0 + p.dxmin + pix % p.pw;
-            if (iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w) {
-                aoff[k] = (iy * p.in_w + ix) * p.Cin + 4 * q;      // < 2^31: one image of the batch
-                amask[k] = 1.f;
-            }
-        }
+        const int idx = min(tid + k * 256, npatch * 4 - 1);
+        const int pix = idx >> 2, q = idx & 3;
+        lds_a[k] = ((pix / p.pw) * LPWB + pix % p.pw) * APITCH + 8 * q;
+        const int iy = m0 + p.dymin + pix / p.pw, ix = n0 + p.dxmin + pix % p.pw;
+        const bool inside = iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
+        aoff[k] = inside ? (unsigned)((iy * p.in_w + ix) * p.Cin + 4 * q) * 4u : 0u;     // bytes, < 2^32 per image
+        amask[k] = inside ? 1.f : 0.f;
+        soff[k] = 4 * q;
     }
     auto load_a = [&](int chunk) __attribute__((always_inline)) {
-        const int c0 = chunk * CKB;
+        const char* xc = xb + (long long)chunk * (CKB * 4);
 #pragma unroll
-        for (int k = 0; k < A_PER_T; ++k) {
-            ra[k] = *reinterpret_cast<const float4*>(xb + aoff[k] + c0);
-            float4 sv = make_float4(1.f, 1.f, 1.f, 1.f);
-            if (sb) sv = *reinterpret_cast<const float4*>(sb + c0 + 4 * ((tid + k * 256) & 3));
-            rs[k] = sv;
-        }
+        for (int k = 0; k < A_PER_T; ++k) ra[k] = *reinterpret_cast<const float4*>(xc + aoff[k]);
     };
-    auto store_a = [&](int buf) __attribute__((always_inline)) {
-        char* dst = As + buf * A_BUF;
+    auto store_a = [&](int chunk, auto buf_tag) __attribute__((always_inline)) {
+        constexpr int BUF = decltype(buf_tag)::value;
 #pragma unroll
         for (int k = 0; k < A_PER_T; ++k) {
-            if (lds_a[k] < 0) continue;
             const float m = amask[k];
+            const float4 sv = *reinterpret_cast<const float4*>(Ss + chunk * CKB + soff[k]);
             uint2 parts[NP];
-            split4<NP>(make_float4(ra[k].x * (rs[k].x * m), ra[k].y * (rs[k].y * m), ra[k].z * (rs[k].z * m),
-                                   ra[k].w * (rs[k].w * m)), parts);
+            split4<NP>(make_float4(ra[k].x * (sv.x * m), ra[k].y * (sv.y * m), ra[k].z * (sv.z * m),
+                                   ra[k].w * (sv.w * m)), parts);
 #pragma unroll
-            for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2*>(dst + q * A_PART + lds_a[k]) = parts[q];
+            for (int q = 0; q < NP; ++q)
+                *reinterpret_cast<uint2*>(As + BUF * A_BUF + q * A_PART + lds_a[k]) = parts[q];
         }
     };
 
-    // ---- B staging: one step = up to TS taps x NP parts x [2 k-groups][128 co] 16-B slots; thread = (kg, co)
-    u32x4 rb[TS * NP];
-    const u32x4* wb = reinterpret_cast<const u32x4*>(p.wt);
+    // ---- B operand: straight from global/L2 into the fragment registers (no LDS, no barrier): a lane's fragment
+    // is 16 contiguous bytes of the split image and lanes 0-31 / 32-63 of a fragment read two contiguous 512-B
+    // runs, so the loads are full 128-B lines.  A ring of RB (2..4) fragment sets keeps the loads RB items ahead of the
+    // MFMAs that consume them (item = one tap of one K chunk).
+    const char* wb = reinterpret_cast<const char*>(p.wt);
     const int cq8 = p.Cin >> 3;
     const int part_stride = p.wtaps * cq8 * p.Cout;                           // uint4 per part
-    const int bthread = (tid >> 7) * p.Cout + co0 + (tid & 127);
+    unsigned bth[TN];                                                         // per-lane byte offset of a fragment
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) bth[tn] = (unsigned)(h * p.Cout + co0 + (wn * TN + tn) * 32 + l31) * 16u;
     int wtap[MAXTAPS];                                                        // tap table -> registers, once
 #pragma unroll
     for (int t = 0; t < MAXTAPS; ++t) wtap[t] = t < ph.ntaps ? ph.widx[t] * cq8 * p.Cout : 0;
 
-    // ---- per-lane fragment addresses (bytes inside one part image), one per (tap, M tile)
-    int aaddr[MAXTAPS][TM];
+    // ---- per-lane fragment address of each M tile (bytes inside one part image, tap (0,0)); a tap adds the
+    // uniform offset toff[t] (for the 3x3 modes the taps are sorted by (dy, dx), see make_plan, so that the offset
+    // is a compile-time immediate of the ds_read)
+    int apos[TM];
 #pragma unroll
-    for (int t = 0; t < MAXTAPS; ++t) {
-        const int tpos = t < ph.ntaps ? (ph.dy[t] - p.dymin) * LPWB + (ph.dx[t] - p.dxmin) : 0;
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-            const int pidx = (wm * TM + tm) * 32 + l31;
-            const int pos = (pidx >> 4) * LPWB + (pidx & 15) + tpos;
-            aaddr[t][tm] = pos * 32 + (((h ^ (pos >> 3)) & 1) << 4);
-        }
+    for (int tm = 0; tm < TM; ++tm) {
+        const int pidx = (wm * TM + tm) * 32 + l31;
+        apos[tm] = ((pidx >> 4) * LPWB + (pidx & 15)) * APITCH + 16 * h;
     }
-    int bcol[TN];
+    int toff[4];
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn) bcol[tn] = (h * BNB + (wn * TN + tn) * 32 + l31) * 16;
+    for (int t = 0; t < 4; ++t)
+        toff[t] = t < ph.ntaps ? ((ph.dy[t] - p.dymin) * LPWB + (ph.dx[t] - p.dxmin)) * APITCH : 0;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -167,94 +165,100 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
     constexpr int PB[6] = {0, 0, 1, 1, 0, 2};
 
     // the K loop for a compile-time tap count NT (9: 3x3, 4/2/1: the phases of the stride-2 transposed conv and
-    // the 1x1 conv): straight-line steps of up to TS taps, so the LDS reads of a tap are scheduled under the MFMAs
-    // of the tap before
+    // the 1x1 conv).  U chunks are unrolled so that U*NT is a multiple of the ring size: every item then has a
+    // compile-time ring slot and the whole group is straight-line code.
     auto run = [&](auto nt_tag) __attribute__((always_inline)) {
         constexpr int NT = decltype(nt_tag)::value;
-        constexpr int NSTEPS = (NT + TS - 1) / TS;
-        auto load_b = [&](int chunk, auto step_tag) __attribute__((always_inline)) {
-            constexpr int S = decltype(step_tag)::value;
-            constexpr int NJ = NT - S * TS < TS ? NT - S * TS : TS;
+        constexpr int RB = NT == 9 ? 3 : NT == 4 ? 4 : 2;      // ring size: divides U*NT
+        constexpr int U = 2;                                   // chunk pairs: chunk parity = A buffer = compile time
+        u32x4 bq[RB][TN][NP];
+        // loads of item (chunk c, tap t) into ring slot `slot`; c is clamped so that the look-ahead past the last
+        // chunk re-reads valid memory instead of branching
+        auto issue_b = [&](int c, auto t_tag, auto slot_tag) __attribute__((always_inline)) {
+            constexpr int T = decltype(t_tag)::value, SL = decltype(slot_tag)::value;
+            const int cc = min(c, c_end - 1);
 #pragma unroll
-            for (int j = 0; j < NJ; ++j)
+            for (int q = 0; q < NP; ++q) {
+                const char* base = wb + (long long)(q * part_stride + wtap[T] + cc * 2 * p.Cout) * 16;   // uniform
 #pragma unroll
-                for (int q = 0; q < NP; ++q)
-                    rb[j * NP + q] = wb[q * part_stride + wtap[S * TS + j] + chunk * 2 * p.Cout + bthread];
+                for (int tn = 0; tn < TN; ++tn) bq[SL][tn][q] = *reinterpret_cast<const u32x4*>(base + bth[tn]);
+            }
         };
-        auto store_b = [&](int buf, auto step_tag) __attribute__((always_inline)) {
-            constexpr int S = decltype(step_tag)::value;
-            char* dst = Bs + buf * B_BUF + tid * 16;
-            constexpr int NJ = NT - S * TS < TS ? NT - S * TS : TS;
+        bf16x8 af[2][TM][NP];                               // A fragments of the current and the next tap
+        auto read_a = [&](auto u_tag, auto t_tag) __attribute__((always_inline)) {
+            constexpr int UU = decltype(u_tag)::value, T = decltype(t_tag)::value;
+            const char* Ac = As + UU * A_BUF;               // chunk parity = LDS buffer: immediate offsets
 #pragma unroll
-            for (int j = 0; j < NJ; ++j)
+            for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                for (int q = 0; q < NP; ++q) *reinterpret_cast<u32x4*>(dst + (j * NP + q) * 4096) = rb[j * NP + q];
+                for (int q = 0; q < NP; ++q) {
+                    if constexpr (NT == 9)
+                        af[T & 1][tm][q] = *reinterpret_cast<const bf16x8*>(
+                            Ac + q * A_PART + ((T / 3) * LPWB + T % 3) * APITCH + apos[tm]);
+                    else
+                        af[T & 1][tm][q] = *reinterpret_cast<const bf16x8*>(Ac + q * A_PART + toff[T & 3] + apos[tm]);
+                }
         };
-        auto step = [&](int c, int abuf, int& bbuf, auto step_tag) __attribute__((always_inline)) {
-            constexpr int S = decltype(step_tag)::value;
-            store_b(bbuf, step_tag);
-            __syncthreads();
-#ifndef HFAGP_DIAG_NOLOAD
-            if constexpr (S + 1 < NSTEPS) load_b(c, std::integral_constant<int, S + 1>{});
-            else if (c + 1 < c_end) load_b(c + 1, std::integral_constant<int, 0>{});
-            if (S == 0 && c + 1 < c_end) load_a(c + 1);
-#endif
-            const char* Ac = As + abuf * A_BUF;
-            const char* Bc = Bs + bbuf * B_BUF;
-            constexpr int NJ = NT - S * TS < TS ? NT - S * TS : TS;
+        auto item = [&](int c, auto u_tag, auto t_tag) __attribute__((always_inline)) {
+            constexpr int UU = decltype(u_tag)::value, T = decltype(t_tag)::value;
+            constexpr int SL = (UU * NT + T) % RB;
+            // LDS reads of the next tap go out before this tap's MFMAs (the last tap of a chunk has no successor in
+            // this buffer: the next chunk's patch is published by the barrier in between)
+            // (sched_barrier: without it the scheduler sinks every load to just before its first use to save
+            // registers, i.e. it undoes the look-ahead)
+            if constexpr (T + 1 < NT) read_a(u_tag, std::integral_constant<int, T + 1>{});
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int t = S * TS + j;
-                bf16x8 af[TM][NP], bfr[TN][NP];
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                    for (int q = 0; q < NP; ++q)
-                        af[tm][q] = *reinterpret_cast<const bf16x8*>(Ac + q * A_PART + aaddr[t][tm]);
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                    for (int q = 0; q < NP; ++q)
-                        bfr[tn][q] = *reinterpret_cast<const bf16x8*>(Bc + (j * NP + q) * 4096 + bcol[tn]);
-#ifdef HFAGP_DIAG_NOMFMA
+            for (int pr = 0; pr < NPROD; ++pr)
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                        for (int q = 0; q < NP; ++q) {
-                            acc[tm][tn][q] += __builtin_bit_cast(float, __builtin_bit_cast(u32x4, af[tm][q])[0]);
-                            acc[tm][tn][q + 4] += __builtin_bit_cast(float, __builtin_bit_cast(u32x4, bfr[tn][q])[1]);
-                        }
-                continue;
-#endif
-#pragma unroll
-                for (int pr = 0; pr < NPROD; ++pr)
-#pragma unroll
-                    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                        for (int tn = 0; tn < TN; ++tn)
-                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][PA[pr]], bfr[tn][PB[pr]],
-                                                                                  acc[tm][tn], 0, 0, 0);
-            }
-            bbuf ^= 1;
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            af[T & 1][tm][PA[pr]], __builtin_bit_cast(bf16x8, bq[SL][tn][PB[pr]]), acc[tm][tn], 0, 0, 0);
+            // refill the slot with the item RB ahead
+            constexpr int T2 = (T + RB) % NT, DC = (T + RB) / NT;
+            issue_b(c + DC, std::integral_constant<int, T2>{}, std::integral_constant<int, SL>{});
+            __builtin_amdgcn_sched_barrier(0);
         };
-        int bbuf = 0;
-        if (c_begin < c_end) { load_a(c_begin); load_b(c_begin, std::integral_constant<int, 0>{}); }
-        for (int c = c_begin; c < c_end; ++c) {
-            const int abuf = (c - c_begin) & 1;
-            store_a(abuf);
-            step(c, abuf, bbuf, std::integral_constant<int, 0>{});
-            if constexpr (NSTEPS > 1) step(c, abuf, bbuf, std::integral_constant<int, 1>{});
-            if constexpr (NSTEPS > 2) step(c, abuf, bbuf, std::integral_constant<int, 2>{});
+        auto chunk = [&](int c, auto u_tag) __attribute__((always_inline)) {
+            store_a(c, u_tag);
+            __syncthreads();
+            read_a(u_tag, std::integral_constant<int, 0>{});
+            load_a(min(c + 1, c_end - 1));
+            __builtin_amdgcn_sched_barrier(0);
+            item(c, u_tag, std::integral_constant<int, 0>{});
+            if constexpr (NT > 1) item(c, u_tag, std::integral_constant<int, 1>{});
+            if constexpr (NT > 2) {
+                item(c, u_tag, std::integral_constant<int, 2>{});
+                item(c, u_tag, std::integral_constant<int, 3>{});
+            }
+            if constexpr (NT > 4) {
+                item(c, u_tag, std::integral_constant<int, 4>{});
+                item(c, u_tag, std::integral_constant<int, 5>{});
+                item(c, u_tag, std::integral_constant<int, 6>{});
+                item(c, u_tag, std::integral_constant<int, 7>{});
+                item(c, u_tag, std::integral_constant<int, 8>{});
+            }
+        };
+        if (c_begin >= c_end) return;
+        __syncthreads();                                    // styles are in LDS
+        load_a(c_begin);
+        // prologue: the first RB items
+        issue_b(c_begin + 0 / NT, std::integral_constant<int, 0 % NT>{}, std::integral_constant<int, 0>{});
+        issue_b(c_begin + 1 / NT, std::integral_constant<int, 1 % NT>{}, std::integral_constant<int, 1>{});
+        if constexpr (RB > 2)
+            issue_b(c_begin + 2 / NT, std::integral_constant<int, 2 % NT>{}, std::integral_constant<int, 2>{});
+        if constexpr (RB > 3)
+            issue_b(c_begin + 3 / NT, std::integral_constant<int, 3 % NT>{}, std::integral_constant<int, 3>{});
+        static_assert((U * NT) % RB == 0, "ring slots must repeat every iteration");
+        for (int cg = c_begin; cg < c_end; cg += U) {
+            chunk(cg, std::integral_constant<int, 0>{});
+            if (cg + 1 >= c_end) break;
+            chunk(cg + 1, std::integral_constant<int, 1>{});
         }
     };
-    switch (ph.ntaps) {
-        case 9: run(std::integral_constant<int, 9>{}); break;
-        case 4: run(std::integral_constant<int, 4>{}); break;
-        case 2: run(std::integral_constant<int, 2>{}); break;
-        default: run(std::integral_constant<int, 1>{}); break;
-    }
+    run(std::integral_constant<int, NTAPS>{});
 
     // ---- epilogue.  C/D layout of 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     float* out = p.out + (size_t)(ks * p.nslab + ph.slab) * p.slab;
@@ -294,30 +298,40 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
 }
 
 template <int NP, int TM>
-static size_t bf16_lds_bytes() {
+static size_t bf16_lds_bytes(int cin) {
     constexpr int PH = 2 * TM * 32 / PW;
-    return (size_t)2 * NP * (PH + 2) * LPWB * 32 + (size_t)2 * TS * NP * 2 * BNB * 16;
+    return (size_t)2 * NP * (PH + 2) * RowPitch<NP>::value * APITCH + (size_t)cin * sizeof(float);
+}
+
+template <int NP>
+static void launch_group(const Plan& pl, int phase0, int nphase, int ntaps, size_t lds, hipStream_t s) {
+    const dim3 grid(pl.grid.x, (unsigned)nphase, 1);
+    switch (ntaps) {
+        case 9: modconv_bf16_kernel<NP, 2, 9><<<grid, 256, lds, s>>>(pl.p, phase0); break;
+        case 4: modconv_bf16_kernel<NP, 2, 4><<<grid, 256, lds, s>>>(pl.p, phase0); break;
+        case 2: modconv_bf16_kernel<NP, 2, 2><<<grid, 256, lds, s>>>(pl.p, phase0); break;
+        default: modconv_bf16_kernel<NP, 2, 1><<<grid, 256, lds, s>>>(pl.p, phase0); break;
+    }
 }
 
 int launch_modconv_bf16(const HfagpModconvArgs* a, Plan& pl, hipStream_t s) {
     HFAGP_REQUIRE(a->Cin % CKB == 0 && a->Cout % BNB == 0, HFAGP_EUNSUPPORTED,
                   "modconv (split bf16): Cin=%d must be a multiple of %d and Cout=%d of %d", a->Cin, CKB, a->Cout, BNB);
     HFAGP_REQUIRE(pl.bn == BNB && pl.bm == 128, HFAGP_EUNSUPPORTED, "modconv (split bf16): unexpected plan");
-    static bool attr = false;           // both images exceed the 64 KB default dynamic-LDS limit
-    if (!attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(modconv_bf16_kernel<2, 2>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bf16_lds_bytes<2, 2>());
-        hipFuncSetAttribute(reinterpret_cast<const void*>(modconv_bf16_kernel<3, 2>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bf16_lds_bytes<3, 2>());
-        attr = true;
-    }
-    if (a->precision == HFAGP_PREC_BF16X3) {
-        modconv_bf16_kernel<2, 2><<<pl.grid, 256, bf16_lds_bytes<2, 2>(), s>>>(pl.p);
-    } else if (a->precision == HFAGP_PREC_BF16X6) {
-        modconv_bf16_kernel<3, 2><<<pl.grid, 256, bf16_lds_bytes<3, 2>(), s>>>(pl.p);
-    } else {
-        set_error("modconv: unknown precision %d", a->precision);
-        return HFAGP_EBADARG;
+    HFAGP_REQUIRE(a->Cin <= 512, HFAGP_EUNSUPPORTED, "modconv (split bf16): Cin=%d > 512 (style image in LDS)", a->Cin);
+    HFAGP_REQUIRE(a->precision == HFAGP_PREC_BF16X3 || a->precision == HFAGP_PREC_BF16X6, HFAGP_EBADARG,
+                  "modconv: unknown precision %d", a->precision);
+    // the kernel is specialised on the tap count: one launch per run of phases with the same number of taps
+    // (3x3: one; stride-2 transposed conv and its adjoint: 4 | 2, 2 | 1)
+    const ConvParams& p = pl.p;
+    for (int p0 = 0; p0 < p.nphase;) {
+        int n = 1;
+        while (p0 + n < p.nphase && p.phase[p0 + n].ntaps == p.phase[p0].ntaps) ++n;
+        const int nt = p.phase[p0].ntaps;
+        HFAGP_REQUIRE(nt == 9 || nt == 4 || nt == 2 || nt == 1, HFAGP_EUNSUPPORTED, "modconv (split bf16): %d taps", nt);
+        if (a->precision == HFAGP_PREC_BF16X3) launch_group<2>(pl, p0, n, nt, bf16_lds_bytes<2, 2>(a->Cin), s);
+        else launch_group<3>(pl, p0, n, nt, bf16_lds_bytes<3, 2>(a->Cin), s);
+        p0 += n;
     }
     return check_launch("modconv_fwd (split bf16)");
 }

@@ -100,8 +100,9 @@ static inline int make_plan(const HfagpModconvArgs* a, Plan& pl, int ck) {
         gh = a->H + 1; gw = a->W + 1; p.fused = 0;
     } else if (a->mode == HFAGP_CONV3X3_BWD) {
         // adjoint of mode 0 w.r.t. its input: dx[p][q] = sum_t g[p - dy_t][q - dx_t] . W_t^T  (taps mirrored)
-        static const int t9[9][3] = {{1, 1, 0}, {1, 0, 1}, {1, -1, 2}, {0, 1, 3}, {0, 0, 4},
-                                     {0, -1, 5}, {-1, 1, 6}, {-1, 0, 7}, {-1, -1, 8}};
+        // (listed in ascending (dy, dx) like mode 0: modconv_bf16.hip relies on that order for its 9-tap loop)
+        static const int t9[9][3] = {{-1, -1, 8}, {-1, 0, 7}, {-1, 1, 6}, {0, -1, 5}, {0, 0, 4},
+                                     {0, 1, 3},   {1, -1, 2}, {1, 0, 1},  {1, 1, 0}};
         p.nphase = 1; p.Ho = a->H; p.Wo = a->W;
         set_phase(p.phase[0], 9, a->H, a->W, 1, 1, 0, 0, t9);
         p.dymin = -1; p.dxmin = -1; p.ph = PH + 2; p.pw = PW + 2;
