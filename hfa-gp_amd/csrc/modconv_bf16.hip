@@ -86,6 +86,7 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
     // uniform base + a 32-bit per-lane byte offset (global_load with an SGPR base: no 64-bit VALU address math).
     const int npatch = p.ph * p.pw;
     constexpr int A_PER_T = ((PH + 2) * (PW + 2) * 4 + 255) / 256;
+    static_assert(A_PER_T == 3, "the staging schedule below is written for three slots per thread");
     float4 ra[A_PER_T];
     const char* xb = reinterpret_cast<const char*>(p.x + ph.in_off + (long long)b * p.x_batch_stride);
     for (int i = tid; i < p.Cin; i += 256) Ss[i] = p.styles ? p.styles[(size_t)b * p.Cin + i] : 1.f;
@@ -108,10 +109,10 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
 #pragma unroll
         for (int k = 0; k < A_PER_T; ++k) ra[k] = *reinterpret_cast<const float4*>(xc + aoff[k]);
     };
-    auto store_a = [&](int chunk, auto buf_tag) __attribute__((always_inline)) {
-        constexpr int BUF = decltype(buf_tag)::value;
-#pragma unroll
-        for (int k = 0; k < A_PER_T; ++k) {
+    // slot K of the staged patch of `chunk`: scale by the style, split, write the parts to LDS buffer BUF
+    auto store_a = [&](int chunk, auto buf_tag, auto k_tag) __attribute__((always_inline)) {
+        constexpr int BUF = decltype(buf_tag)::value, k = decltype(k_tag)::value;
+        {
             const float m = amask[k];
             const float4 sv = *reinterpret_cast<const float4*>(Ss + chunk * CKB + soff[k]);
             uint2 parts[NP];
@@ -199,6 +200,9 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
                         af[T & 1][tm][q] = *reinterpret_cast<const bf16x8*>(Ac + q * A_PART + toff[T & 3] + apos[tm]);
                 }
         };
+        // The patch of chunk c+1 is converted and written to the OTHER LDS buffer inside the last A_PER_T taps of
+        // chunk c, one slot per tap and in the same scheduling region as that tap's MFMAs, so that the VALU work
+        // of the conversion is issued between MFMAs instead of in front of the barrier.
         auto item = [&](int c, auto u_tag, auto t_tag) __attribute__((always_inline)) {
             constexpr int UU = decltype(u_tag)::value, T = decltype(t_tag)::value;
             constexpr int SL = (UU * NT + T) % RB;
@@ -216,16 +220,24 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
                     for (int tn = 0; tn < TN; ++tn)
                         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                             af[T & 1][tm][PA[pr]], __builtin_bit_cast(bf16x8, bq[SL][tn][PB[pr]]), acc[tm][tn], 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < A_PER_T; ++k) {
+                const int tk = NT - A_PER_T + k < 0 ? 0 : NT - A_PER_T + k;      // tap that carries slot k
+                if (tk == T) {
+                    if (k == 0) store_a(min(c + 1, c_end - 1), std::integral_constant<int, 1 - UU>{}, std::integral_constant<int, 0>{});
+                    if (k == 1) store_a(min(c + 1, c_end - 1), std::integral_constant<int, 1 - UU>{}, std::integral_constant<int, 1>{});
+                    if (k == 2) store_a(min(c + 1, c_end - 1), std::integral_constant<int, 1 - UU>{}, std::integral_constant<int, 2>{});
+                }
+            }
             // refill the slot with the item RB ahead
             constexpr int T2 = (T + RB) % NT, DC = (T + RB) / NT;
             issue_b(c + DC, std::integral_constant<int, T2>{}, std::integral_constant<int, SL>{});
+            if constexpr (T == NT - 1) load_a(min(c + 2, c_end - 1));
             __builtin_amdgcn_sched_barrier(0);
         };
         auto chunk = [&](int c, auto u_tag) __attribute__((always_inline)) {
-            store_a(c, u_tag);
-            __syncthreads();
+            __syncthreads();                                // publishes the patch of chunk c
             read_a(u_tag, std::integral_constant<int, 0>{});
-            load_a(min(c + 1, c_end - 1));
             __builtin_amdgcn_sched_barrier(0);
             item(c, u_tag, std::integral_constant<int, 0>{});
             if constexpr (NT > 1) item(c, u_tag, std::integral_constant<int, 1>{});
@@ -244,6 +256,10 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
         if (c_begin >= c_end) return;
         __syncthreads();                                    // styles are in LDS
         load_a(c_begin);
+        store_a(c_begin, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        store_a(c_begin, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+        store_a(c_begin, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+        load_a(min(c_begin + 1, c_end - 1));
         // prologue: the first RB items
         issue_b(c_begin + 0 / NT, std::integral_constant<int, 0 % NT>{}, std::integral_constant<int, 0>{});
         issue_b(c_begin + 1 / NT, std::integral_constant<int, 1 % NT>{}, std::integral_constant<int, 1>{});
@@ -297,6 +313,197 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The stride-2 transposed 3x3 convolution (mode CONVT3X3_UP2) with its four output phases MERGED in one block:
+// the input patch of a K chunk is staged once and its 4+2+2+1 = 9 taps feed four accumulator sets (one per output
+// parity), instead of four passes that each re-stage the patch for 4, 2, 2 and 1 taps.  M = 8x16 input positions,
+// N = 64 output channels per block (4 phases x 2 x 1 MFMA tiles per wave = 128 accumulator registers).
+// The taps are grouped by their LDS shift (dy, dx) so that each shifted A fragment is read once per chunk:
+//   shift ( 0, 0): phase 0 w[0], phase 1 w[1], phase 2 w[3], phase 3 w[4]
+//   shift (-1, 0): phase 0 w[6], phase 1 w[7]        shift (0,-1): phase 0 w[2], phase 2 w[5]
+//   shift (-1,-1): phase 0 w[8]                       (w[k] = tap k of the 3x3 kernel, y_t[2i+ti][2j+tj] += x[i][j] w[ti][tj])
+template <int NP>
+__global__ void __launch_bounds__(256, 1) upconv_bf16_kernel(const ConvParams p) {
+    constexpr int TM = 2, TN = 1, WN = 2, BM = 128, BNU = WN * TN * 32, PH = BM / PW, NITEM = 9, RB = 3;
+    constexpr int LPWB = RowPitch<NP>::value;
+    constexpr int APOS = (PH + 2) * LPWB;
+    constexpr int A_PART = APOS * APITCH, A_BUF = NP * A_PART;
+    constexpr int I_GRP[NITEM] = {0, 0, 0, 0, 1, 1, 2, 2, 3};
+    constexpr int I_PHASE[NITEM] = {0, 1, 2, 3, 0, 1, 0, 2, 0};
+    constexpr int I_W[NITEM] = {0, 1, 3, 4, 6, 7, 2, 5, 8};
+    constexpr int G_FIRST[4] = {0, 4, 6, 8};               // first item of each shift group
+    constexpr int G_OFF[4] = {(1 * LPWB + 1) * APITCH, (0 * LPWB + 1) * APITCH, (1 * LPWB + 0) * APITCH, 0};
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    char* As = lds_raw;
+    float* Ss = reinterpret_cast<float*>(lds_raw + 2 * A_BUF);
+
+    unsigned id = blockIdx.x;
+    const int tiles_nu = p.Cout / BNU;
+    const int tn_blk = id % tiles_nu;  id /= tiles_nu;
+    const int tw = id % p.tiles_w;     id /= p.tiles_w;
+    const int th = id % p.tiles_h;     id /= p.tiles_h;
+    const int b = id % p.B;            id /= p.B;
+    const int ks = id;
+    const int m0 = th * PH, n0 = tw * PW, co0 = tn_blk * BNU;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int c_begin = (int)(((long long)p.nchunks * ks) / p.ksplit);
+    const int c_end = (int)(((long long)p.nchunks * (ks + 1)) / p.ksplit);
+
+    // ---- A staging (as in modconv_bf16_kernel): patch rows m0-1 .. m0+PH-1, columns n0-1 .. n0+PW-1
+    const int npatch = p.ph * p.pw;
+    constexpr int A_PER_T = ((PH + 2) * (PW + 2) * 4 + 255) / 256;
+    float4 ra[A_PER_T];
+    const char* xb = reinterpret_cast<const char*>(p.x + (long long)b * p.x_batch_stride);
+    for (int i = tid; i < p.Cin; i += 256) Ss[i] = p.styles ? p.styles[(size_t)b * p.Cin + i] : 1.f;
+    unsigned aoff[A_PER_T];
+    int lds_a[A_PER_T], soff[A_PER_T];
+    float amask[A_PER_T];
+#pragma unroll
+    for (int k = 0; k < A_PER_T; ++k) {
+        const int idx = min(tid + k * 256, npatch * 4 - 1);
+        const int pix = idx >> 2, q = idx & 3;
+        lds_a[k] = ((pix / p.pw) * LPWB + pix % p.pw) * APITCH + 8 * q;
+        const int iy = m0 - 1 + pix / p.pw, ix = n0 - 1 + pix % p.pw;
+        const bool inside = iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
+        aoff[k] = inside ? (unsigned)((iy * p.in_w + ix) * p.Cin + 4 * q) * 4u : 0u;
+        amask[k] = inside ? 1.f : 0.f;
+        soff[k] = 4 * q;
+    }
+    auto load_a = [&](int chunk) __attribute__((always_inline)) {
+        const char* xc = xb + (long long)chunk * (CKB * 4);
+#pragma unroll
+        for (int k = 0; k < A_PER_T; ++k) ra[k] = *reinterpret_cast<const float4*>(xc + aoff[k]);
+    };
+    auto store_a = [&](int chunk, auto buf_tag) __attribute__((always_inline)) {
+        constexpr int BUF = decltype(buf_tag)::value;
+#pragma unroll
+        for (int k = 0; k < A_PER_T; ++k) {
+            const float m = amask[k];
+            const float4 sv = *reinterpret_cast<const float4*>(Ss + chunk * CKB + soff[k]);
+            uint2 parts[NP];
+            split4<NP>(make_float4(ra[k].x * (sv.x * m), ra[k].y * (sv.y * m), ra[k].z * (sv.z * m),
+                                   ra[k].w * (sv.w * m)), parts);
+#pragma unroll
+            for (int q = 0; q < NP; ++q)
+                *reinterpret_cast<uint2*>(As + BUF * A_BUF + q * A_PART + lds_a[k]) = parts[q];
+        }
+    };
+
+    // ---- B fragments: one 32-column tile per wave, ring of RB items
+    const char* wb = reinterpret_cast<const char*>(p.wt);
+    const int cq8 = p.Cin >> 3;
+    const int part_stride = 9 * cq8 * p.Cout;
+    unsigned bth[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) bth[tn] = (unsigned)(h * p.Cout + co0 + (wn * TN + tn) * 32 + l31) * 16u;
+    int apos[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        const int pidx = (wm * TM + tm) * 32 + l31;
+        apos[tm] = ((pidx >> 4) * LPWB + (pidx & 15)) * APITCH + 16 * h;
+    }
+
+    f32x16 acc[4][TM][TN];
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[f][tm][tn][r] = 0.f;
+
+    constexpr int NPROD = NP == 2 ? 3 : 6;
+    constexpr int PA[6] = {0, 1, 0, 1, 2, 0};
+    constexpr int PB[6] = {0, 0, 1, 1, 0, 2};
+    u32x4 bq[RB][TN][NP];
+    bf16x8 af[2][TM][NP];                 // A fragments of the current and the next shift group
+    auto issue_b = [&](int c, auto i_tag) __attribute__((always_inline)) {
+        constexpr int I = decltype(i_tag)::value;
+        const int cc = min(c, c_end - 1);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const char* base = wb + (long long)(q * part_stride + (I_W[I] * cq8 + cc * 2) * p.Cout) * 16;
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) bq[I % RB][tn][q] = *reinterpret_cast<const u32x4*>(base + bth[tn]);
+        }
+    };
+    auto read_a = [&](auto u_tag, auto g_tag) __attribute__((always_inline)) {
+        constexpr int UU = decltype(u_tag)::value, G = decltype(g_tag)::value;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int q = 0; q < NP; ++q)
+                af[G & 1][tm][q] = *reinterpret_cast<const bf16x8*>(As + UU * A_BUF + q * A_PART + G_OFF[G] + apos[tm]);
+    };
+    auto item = [&](int c, auto u_tag, auto i_tag) __attribute__((always_inline)) {
+        constexpr int I = decltype(i_tag)::value, G = I_GRP[I], F = I_PHASE[I];
+        if constexpr (I == G_FIRST[G] && G < 3) read_a(u_tag, std::integral_constant<int, G + 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int pr = 0; pr < NPROD; ++pr)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[F][tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        af[G & 1][tm][PA[pr]], __builtin_bit_cast(bf16x8, bq[I % RB][tn][PB[pr]]), acc[F][tm][tn], 0, 0, 0);
+        issue_b(c + (I + RB) / NITEM, std::integral_constant<int, (I + RB) % NITEM>{});
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto chunk = [&](int c, auto u_tag) __attribute__((always_inline)) {
+        store_a(c, u_tag);
+        __syncthreads();
+        read_a(u_tag, std::integral_constant<int, 0>{});
+        load_a(min(c + 1, c_end - 1));
+        __builtin_amdgcn_sched_barrier(0);
+        item(c, u_tag, std::integral_constant<int, 0>{});
+        item(c, u_tag, std::integral_constant<int, 1>{});
+        item(c, u_tag, std::integral_constant<int, 2>{});
+        item(c, u_tag, std::integral_constant<int, 3>{});
+        item(c, u_tag, std::integral_constant<int, 4>{});
+        item(c, u_tag, std::integral_constant<int, 5>{});
+        item(c, u_tag, std::integral_constant<int, 6>{});
+        item(c, u_tag, std::integral_constant<int, 7>{});
+        item(c, u_tag, std::integral_constant<int, 8>{});
+    };
+    if (c_begin < c_end) {
+        __syncthreads();                                    // styles are in LDS
+        load_a(c_begin);
+        issue_b(c_begin, std::integral_constant<int, 0>{});
+        issue_b(c_begin, std::integral_constant<int, 1>{});
+        issue_b(c_begin, std::integral_constant<int, 2>{});
+        for (int cg = c_begin; cg < c_end; cg += 2) {
+            chunk(cg, std::integral_constant<int, 0>{});
+            if (cg + 1 >= c_end) break;
+            chunk(cg + 1, std::integral_constant<int, 1>{});
+        }
+    }
+
+    // ---- raw stores of the four phases: y_t[2m + (f>>1)][2n + (f&1)], extents (H+1-(f>>1)) x (W+1-(f&1))
+    float* out = p.out + (size_t)ks * p.slab;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const int mh = p.H + 1 - (f >> 1), mw = p.W + 1 - (f & 1);
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int co = co0 + (wn * TN + tn) * 32 + l31;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int pidx = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int m = m0 + (pidx >> 4), n = n0 + (pidx & 15);
+                    if (m >= mh || n >= mw) continue;
+                    out[(((size_t)b * p.Ho + 2 * m + (f >> 1)) * p.Wo + 2 * n + (f & 1)) * p.Cout + co] = acc[f][tm][tn][r];
+                }
+        }
+    }
+}
+
 template <int NP, int TM>
 static size_t bf16_lds_bytes(int cin) {
     constexpr int PH = 2 * TM * 32 / PW;
@@ -324,6 +531,13 @@ int launch_modconv_bf16(const HfagpModconvArgs* a, Plan& pl, hipStream_t s) {
     // the kernel is specialised on the tap count: one launch per run of phases with the same number of taps
     // (3x3: one; stride-2 transposed conv and its adjoint: 4 | 2, 2 | 1)
     const ConvParams& p = pl.p;
+    if (pl.merged_up) {                 // one block for the four phases (grid.y = 1)
+        if (a->precision == HFAGP_PREC_BF16X3)
+            upconv_bf16_kernel<2><<<pl.grid, 256, bf16_lds_bytes<2, 2>(a->Cin), s>>>(p);
+        else
+            upconv_bf16_kernel<3><<<pl.grid, 256, bf16_lds_bytes<3, 2>(a->Cin), s>>>(p);
+        return check_launch("modconv_fwd (split bf16, merged up-conv)");
+    }
     for (int p0 = 0; p0 < p.nphase;) {
         int n = 1;
         while (p0 + n < p.nphase && p.phase[p0 + n].ntaps == p.phase[p0].ntaps) ++n;

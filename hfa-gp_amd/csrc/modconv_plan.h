@@ -39,6 +39,7 @@ struct Plan {
     int bn;           // N tile: 128, 96, 64 or 32
     int bm;           // M tile: pixels per block
     dim3 grid;
+    bool merged_up;   // split-bf16 CONVT3X3_UP2: one block computes all four output phases (upconv_bf16_kernel)
     size_t ws_bytes;
 };
 
@@ -134,7 +135,10 @@ static inline int make_plan(const HfagpModconvArgs* a, Plan& pl, int ck) {
     p.tiles_w = (gw + PW - 1) / PW;
     p.slab = (long long)a->B * p.Ho * p.Wo * a->Cout;
 
-    const long long base_blocks = (long long)p.tiles_h * p.tiles_w * a->B * p.tiles_n * p.nphase;
+    pl.merged_up = a->precision != HFAGP_PREC_F32 && a->mode == HFAGP_CONVT3X3_UP2;
+    const int grid_tiles_n = pl.merged_up ? a->Cout / 64 : p.tiles_n;
+    const int grid_phases = pl.merged_up ? 1 : p.nphase;
+    const long long base_blocks = (long long)p.tiles_h * p.tiles_w * a->B * grid_tiles_n * grid_phases;
     int ks = a->ksplit;
     if (ks <= 0) {
         ks = 1;
@@ -148,7 +152,7 @@ static inline int make_plan(const HfagpModconvArgs* a, Plan& pl, int ck) {
     p.ksplit = ks;
     if (ks * p.nslab > 1) p.fused = 0;
     pl.ws_bytes = ks * p.nslab > 1 ? (size_t)ks * p.nslab * p.slab * sizeof(float) : 0;
-    pl.grid = dim3((unsigned)(p.tiles_h * p.tiles_w * a->B * p.tiles_n * ks), (unsigned)p.nphase, 1);
+    pl.grid = dim3((unsigned)(p.tiles_h * p.tiles_w * a->B * grid_tiles_n * ks), (unsigned)grid_phases, 1);
     return HFAGP_OK;
 }
 
