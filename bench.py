@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=4, help="frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=8, help="frames per step per GPU")
     ap.add_argument("--preset", default="ffhq512_128")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the fitting-step leg (train_step_ms)")

@@ -377,10 +377,9 @@ __global__ void __launch_bounds__(256, 1) upconv_bf16_kernel(const ConvParams p)
 #pragma unroll
         for (int k = 0; k < A_PER_T; ++k) ra[k] = *reinterpret_cast<const float4*>(xc + aoff[k]);
     };
-    auto store_a = [&](int chunk, auto buf_tag) __attribute__((always_inline)) {
-        constexpr int BUF = decltype(buf_tag)::value;
-#pragma unroll
-        for (int k = 0; k < A_PER_T; ++k) {
+    auto store_a = [&](int chunk, auto buf_tag, auto k_tag) __attribute__((always_inline)) {
+        constexpr int BUF = decltype(buf_tag)::value, k = decltype(k_tag)::value;
+        {
             const float m = amask[k];
             const float4 sv = *reinterpret_cast<const float4*>(Ss + chunk * CKB + soff[k]);
             uint2 parts[NP];
@@ -421,14 +420,14 @@ __global__ void __launch_bounds__(256, 1) upconv_bf16_kernel(const ConvParams p)
     constexpr int PB[6] = {0, 0, 1, 1, 0, 2};
     u32x4 bq[RB][TN][NP];
     bf16x8 af[2][TM][NP];                 // A fragments of the current and the next shift group
-    auto issue_b = [&](int c, auto i_tag) __attribute__((always_inline)) {
-        constexpr int I = decltype(i_tag)::value;
+    auto issue_b = [&](int c, auto i_tag, auto slot_tag) __attribute__((always_inline)) {
+        constexpr int I = decltype(i_tag)::value, SL = decltype(slot_tag)::value;
         const int cc = min(c, c_end - 1);
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
             const char* base = wb + (long long)(q * part_stride + (I_W[I] * cq8 + cc * 2) * p.Cout) * 16;
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn) bq[I % RB][tn][q] = *reinterpret_cast<const u32x4*>(base + bth[tn]);
+            for (int tn = 0; tn < TN; ++tn) bq[SL][tn][q] = *reinterpret_cast<const u32x4*>(base + bth[tn]);
         }
     };
     auto read_a = [&](auto u_tag, auto g_tag) __attribute__((always_inline)) {
@@ -441,6 +440,7 @@ __global__ void __launch_bounds__(256, 1) upconv_bf16_kernel(const ConvParams p)
     };
     auto item = [&](int c, auto u_tag, auto i_tag) __attribute__((always_inline)) {
         constexpr int I = decltype(i_tag)::value, G = I_GRP[I], F = I_PHASE[I];
+        constexpr int SL = (decltype(u_tag)::value * NITEM + I) % RB;     // ring slot: repeats every chunk pair
         if constexpr (I == G_FIRST[G] && G < 3) read_a(u_tag, std::integral_constant<int, G + 1>{});
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -450,15 +450,18 @@ __global__ void __launch_bounds__(256, 1) upconv_bf16_kernel(const ConvParams p)
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn)
                     acc[F][tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                        af[G & 1][tm][PA[pr]], __builtin_bit_cast(bf16x8, bq[I % RB][tn][PB[pr]]), acc[F][tm][tn], 0, 0, 0);
-        issue_b(c + (I + RB) / NITEM, std::integral_constant<int, (I + RB) % NITEM>{});
+                        af[G & 1][tm][PA[pr]], __builtin_bit_cast(bf16x8, bq[SL][tn][PB[pr]]), acc[F][tm][tn], 0, 0, 0);
+        // the patch of the next chunk is converted into the other LDS buffer under the last three items
+        if constexpr (I >= NITEM - 3)
+            store_a(min(c + 1, c_end - 1), std::integral_constant<int, 1 - decltype(u_tag)::value>{},
+                    std::integral_constant<int, I - (NITEM - 3)>{});
+        issue_b(c + (I + RB) / NITEM, std::integral_constant<int, (I + RB) % NITEM>{}, std::integral_constant<int, SL>{});
+        if constexpr (I == NITEM - 1) load_a(min(c + 2, c_end - 1));
         __builtin_amdgcn_sched_barrier(0);
     };
     auto chunk = [&](int c, auto u_tag) __attribute__((always_inline)) {
-        store_a(c, u_tag);
-        __syncthreads();
+        __syncthreads();                                    // publishes the patch of chunk c
         read_a(u_tag, std::integral_constant<int, 0>{});
-        load_a(min(c + 1, c_end - 1));
         __builtin_amdgcn_sched_barrier(0);
         item(c, u_tag, std::integral_constant<int, 0>{});
         item(c, u_tag, std::integral_constant<int, 1>{});
@@ -470,12 +473,22 @@ __global__ void __launch_bounds__(256, 1) upconv_bf16_kernel(const ConvParams p)
         item(c, u_tag, std::integral_constant<int, 7>{});
         item(c, u_tag, std::integral_constant<int, 8>{});
     };
+    static_assert((2 * NITEM) % RB == 0 && RB <= NITEM, "ring slots must repeat every chunk pair");
     if (c_begin < c_end) {
         __syncthreads();                                    // styles are in LDS
         load_a(c_begin);
-        issue_b(c_begin, std::integral_constant<int, 0>{});
-        issue_b(c_begin, std::integral_constant<int, 1>{});
-        issue_b(c_begin, std::integral_constant<int, 2>{});
+        issue_b(c_begin, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        issue_b(c_begin, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+        issue_b(c_begin, std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
+        if constexpr (RB > 3) {
+            issue_b(c_begin, std::integral_constant<int, 3>{}, std::integral_constant<int, 3>{});
+            issue_b(c_begin, std::integral_constant<int, 4>{}, std::integral_constant<int, 4>{});
+            issue_b(c_begin, std::integral_constant<int, 5>{}, std::integral_constant<int, 5>{});
+        }
+        store_a(c_begin, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        store_a(c_begin, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+        store_a(c_begin, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+        load_a(min(c_begin + 1, c_end - 1));
         for (int cg = c_begin; cg < c_end; cg += 2) {
             chunk(cg, std::integral_constant<int, 0>{});
             if (cg + 1 >= c_end) break;
