@@ -236,7 +236,7 @@ def main():
             roof = {"bound": "mfma", "kernel": f"modconv_bf16_kernel ({SPLIT_MFMAS[prec]} x v_mfma_f32_32x32x16_bf16 "
                                                f"per fp32 product)",
                     "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
-                    "traffic": profiled_traffic("modconv_bf16_kernel"), "avg_launch_ms": ms / max(n, 1), "launches": n,
+                    "traffic": profiled_traffic("modconv_bf16_kernel<2, 2, 9>"), "avg_launch_ms": ms / max(n, 1), "launches": n,
                     "bf16_mfma_tflops": tf * SPLIT_MFMAS[prec]}
         out = {
             "metric": "rendered 512^2 frames/sec (96 depth samples), whole job",

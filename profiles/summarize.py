@@ -25,9 +25,13 @@ def main():
         for line in open(js):
             if line.startswith("{"):
                 d = json.loads(line)
+                r32 = d.get("roofline_fp32_exact")
+                extra = (f"; exact-fp32 leg {d['value_fp32_exact']:.1f} frames/s, modconv_kernel {r32['achieved']:.1f} "
+                         f"TFLOP/s ({r32['frac']:.3f} of 157.3)") if r32 else ""
                 print(f"bench (un-profiled): {d['value']:.1f} {d['unit']}, {d['ms_per_step']:.2f} ms/step, "
-                      f"B={d['config']['frames_per_step_per_gpu']}; modconv {d['roofline']['achieved']:.1f} TFLOP/s "
-                      f"({d['roofline']['frac']:.3f} of fp32 MFMA peak); raymarch "
+                      f"B={d['config']['frames_per_step_per_gpu']}, conv precision {d['config'].get('conv_precision')}; "
+                      f"{d['roofline']['kernel']} {d['roofline']['achieved']:.1f} TFLOP/s "
+                      f"({d['roofline']['frac']:.3f} of {d['roofline']['peak']:.0f}){extra}; raymarch "
                       f"{d['roofline_raymarch']['achieved']:.0f} GB/s algorithmic ({d['roofline_raymarch']['frac']:.3f} of 8 TB/s), "
                       f"{d['roofline_raymarch']['avg_launch_ms']:.3f} ms/launch\n")
     stats = find(os.path.join(out, "trace"), "*kernel_stats.csv")
@@ -56,11 +60,17 @@ def main():
             traffic.setdefault(k, {})[counter] = v / n * 1024          # bytes per launch, as reported (KiB units)
     # HBM/fabric bytes per launch for bench.py's `traffic` field: FETCH_SIZE doubled (gfx950 reports half of a wide
     # coalesced read, MI355X_MICROARCH.md section HBM) + WRITE_SIZE
-    out_t = {"tag": tag, "batch": 4, "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of bench.py "
+    batch = 8
+    try:
+        batch = json.loads([l for l in open(js) if l.startswith("{")][0])["config"]["frames_per_step_per_gpu"]
+    except Exception:
+        pass
+    out_t = {"tag": tag, "batch": batch, "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of bench.py "
              "--no-train; bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (KiB -> bytes); averages over all launches of "
              "the kernel in one synthesis"}
     for k, v in traffic.items():
-        if k.startswith("modconv_kernel<2, 2, 2, 2>") or k.startswith("raymarch_kernel"):
+        if k.startswith(("modconv_kernel<2, 2, 2, 2>", "modconv_bf16_kernel<2, 2, 9>", "upconv_bf16_kernel",
+                         "raymarch_kernel")):
             out_t[k] = {"fetch_raw": v.get("FETCH_SIZE"), "write": v.get("WRITE_SIZE"),
                         "hbm_bytes": 2 * v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)}
     json.dump(out_t, open(os.path.join(out, "traffic.json"), "w"), indent=1)
