@@ -170,7 +170,10 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
     // compile-time ring slot and the whole group is straight-line code.
     auto run = [&](auto nt_tag) __attribute__((always_inline)) {
         constexpr int NT = decltype(nt_tag)::value;
-        constexpr int RB = NT == 9 ? 3 : NT == 4 ? 4 : 2;      // ring size: divides U*NT
+#ifndef HFAGP_RB9
+#define HFAGP_RB9 3
+#endif
+        constexpr int RB = NT == 9 ? HFAGP_RB9 : NT == 4 ? 4 : 2;      // ring size: divides U*NT
         constexpr int U = 2;                                   // chunk pairs: chunk parity = A buffer = compile time
         u32x4 bq[RB][TN][NP];
         // loads of item (chunk c, tap t) into ring slot `slot`; c is clamped so that the look-ahead past the last
@@ -267,6 +270,10 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
             issue_b(c_begin + 2 / NT, std::integral_constant<int, 2 % NT>{}, std::integral_constant<int, 2>{});
         if constexpr (RB > 3)
             issue_b(c_begin + 3 / NT, std::integral_constant<int, 3 % NT>{}, std::integral_constant<int, 3>{});
+        if constexpr (RB > 4) {
+            issue_b(c_begin + 4 / NT, std::integral_constant<int, 4 % NT>{}, std::integral_constant<int, 4>{});
+            issue_b(c_begin + 5 / NT, std::integral_constant<int, 5 % NT>{}, std::integral_constant<int, 5>{});
+        }
         static_assert((U * NT) % RB == 0, "ring slots must repeat every iteration");
         for (int cg = c_begin; cg < c_end; cg += U) {
             chunk(cg, std::integral_constant<int, 0>{});
