@@ -84,62 +84,92 @@ __global__ void __launch_bounds__(256) weight_prep_kernel(const float* __restric
 // f = [1,3,3,1]/4 per axis (= outer([1,3,3,1])/64 * gain 4).  Each thread owns 4 channels
 // of one output column and walks a vertical strip with a sliding window of
 // horizontally filtered rows, so every input row is read once per column.
+// Each thread owns 4 channels of TWO adjacent output columns and walks a vertical strip: 5 input columns per
+// row feed both columns (2.5 loads per output row instead of 4), every input row of the strip is read once, and
+// the image borders are handled by clamped addresses with zeroed tap weights (no branches in the loop).
 constexpr int kStrip = 8;
 
 __global__ void __launch_bounds__(256) upfir_epilogue_kernel(HfagpUpfirEpilogueArgs a) {
     const int C4 = a.C >> 2;
     const int Wo = 2 * a.W, Ho = 2 * a.H, Wi = 2 * a.W + 1, Hi = 2 * a.H + 1;
+    const int Wp = a.W;                                      // column pairs
     const int strips = (Ho + kStrip - 1) / kStrip;
-    const long long total = (long long)a.B * strips * Wo * C4;
+    const long long total = (long long)a.B * strips * Wp * C4;
     const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= total) return;
     const int c4 = (int)(tid % C4);
-    const int X = (int)((tid / C4) % Wo);
-    const int st = (int)((tid / ((long long)C4 * Wo)) % strips);
-    const int b = (int)(tid / ((long long)C4 * Wo * strips));
+    const int X = 2 * (int)((tid / C4) % Wp);
+    const int st = (int)((tid / ((long long)C4 * Wp)) % strips);
+    const int b = (int)(tid / ((long long)C4 * Wp * strips));
     const int Y0 = st * kStrip;
     const float4* src = reinterpret_cast<const float4*>(a.yt) + (size_t)b * Hi * Wi * C4 + c4;
     const float f0 = 0.25f, f1 = 0.75f;
 
-    auto hrow = [&](int yin) -> float4 {
-        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (yin < 0 || yin >= Hi) return r;
-        const float4* row = src + (size_t)yin * Wi * C4;
-        const float fw[4] = {f0, f1, f1, f0};
+    // input columns X-1 .. X+3: clamped offset + validity
+    int xo[5]; float xm[5];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int xin = X + q - 1;
-            if (xin >= 0 && xin < Wi) {
-                const float4 v = row[(size_t)xin * C4];
-                r.x += fw[q] * v.x; r.y += fw[q] * v.y; r.z += fw[q] * v.z; r.w += fw[q] * v.w;
-            }
-        }
-        return r;
+    for (int q = 0; q < 5; ++q) {
+        const int xin = X + q - 1;
+        xm[q] = (xin >= 0 && xin < Wi) ? 1.f : 0.f;
+        xo[q] = min(max(xin, 0), Wi - 1) * C4;
+    }
+    const float wa[4] = {f0 * xm[0], f1 * xm[1], f1 * xm[2], f0 * xm[3]};     // output column X
+    const float wb[4] = {f0 * xm[1], f1 * xm[2], f1 * xm[3], f0 * xm[4]};     // output column X+1
+
+    auto hrow = [&](int yin, float4& ha, float4& hb) {
+        const float m = (yin >= 0 && yin < Hi) ? 1.f : 0.f;
+        const float4* row = src + (size_t)min(max(yin, 0), Hi - 1) * Wi * C4;
+        float4 v[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) v[q] = row[xo[q]];
+        ha.x = m * (wa[0] * v[0].x + wa[1] * v[1].x + wa[2] * v[2].x + wa[3] * v[3].x);
+        ha.y = m * (wa[0] * v[0].y + wa[1] * v[1].y + wa[2] * v[2].y + wa[3] * v[3].y);
+        ha.z = m * (wa[0] * v[0].z + wa[1] * v[1].z + wa[2] * v[2].z + wa[3] * v[3].z);
+        ha.w = m * (wa[0] * v[0].w + wa[1] * v[1].w + wa[2] * v[2].w + wa[3] * v[3].w);
+        hb.x = m * (wb[0] * v[1].x + wb[1] * v[2].x + wb[2] * v[3].x + wb[3] * v[4].x);
+        hb.y = m * (wb[0] * v[1].y + wb[1] * v[2].y + wb[2] * v[3].y + wb[3] * v[4].y);
+        hb.z = m * (wb[0] * v[1].z + wb[1] * v[2].z + wb[2] * v[3].z + wb[3] * v[4].z);
+        hb.w = m * (wb[0] * v[1].w + wb[1] * v[2].w + wb[2] * v[3].w + wb[3] * v[4].w);
     };
 
     float4 d = make_float4(1.f, 1.f, 1.f, 1.f), bs = make_float4(0.f, 0.f, 0.f, 0.f);
     if (a.dcoef) d = reinterpret_cast<const float4*>(a.dcoef + (size_t)b * a.C)[c4];
     if (a.bias) bs = reinterpret_cast<const float4*>(a.bias)[c4];
 
-    float4 h0 = hrow(Y0 - 1), h1 = hrow(Y0), h2 = hrow(Y0 + 1);
+    float4 a0, a1, a2, b0, b1, b2;
+    hrow(Y0 - 1, a0, b0); hrow(Y0, a1, b1); hrow(Y0 + 1, a2, b2);
     float4* dst = reinterpret_cast<float4*>(a.y) + (size_t)b * Ho * Wo * C4 + c4;
-#pragma unroll
-    for (int k = 0; k < kStrip; ++k) {
-        const int Y = Y0 + k;
-        if (Y >= Ho) break;
-        const float4 h3 = hrow(Y + 2);
-        float4 o;
-        o.x = f0 * h0.x + f1 * h1.x + f1 * h2.x + f0 * h3.x;
-        o.y = f0 * h0.y + f1 * h1.y + f1 * h2.y + f0 * h3.y;
-        o.z = f0 * h0.z + f1 * h1.z + f1 * h2.z + f0 * h3.z;
-        o.w = f0 * h0.w + f1 * h1.w + f1 * h2.w + f0 * h3.w;
-        const float nz = a.noise ? a.noise[(size_t)Y * Wo + X] * a.noise_strength : 0.f;
+    auto finish = [&](float4 o, float nz) -> float4 {
         o.x = lrelu_gain_clamp(o.x * d.x + nz + bs.x, a.act, a.alpha, a.gain, a.clamp);
         o.y = lrelu_gain_clamp(o.y * d.y + nz + bs.y, a.act, a.alpha, a.gain, a.clamp);
         o.z = lrelu_gain_clamp(o.z * d.z + nz + bs.z, a.act, a.alpha, a.gain, a.clamp);
         o.w = lrelu_gain_clamp(o.w * d.w + nz + bs.w, a.act, a.alpha, a.gain, a.clamp);
-        dst[((size_t)Y * Wo + X) * C4] = o;
-        h0 = h1; h1 = h2; h2 = h3;
+        return o;
+    };
+#pragma unroll
+    for (int k = 0; k < kStrip; ++k) {
+        const int Y = Y0 + k;
+        if (Y >= Ho) break;
+        float4 a3, b3;
+        hrow(Y + 2, a3, b3);
+        float4 oa, ob;
+        oa.x = f0 * a0.x + f1 * a1.x + f1 * a2.x + f0 * a3.x;
+        oa.y = f0 * a0.y + f1 * a1.y + f1 * a2.y + f0 * a3.y;
+        oa.z = f0 * a0.z + f1 * a1.z + f1 * a2.z + f0 * a3.z;
+        oa.w = f0 * a0.w + f1 * a1.w + f1 * a2.w + f0 * a3.w;
+        ob.x = f0 * b0.x + f1 * b1.x + f1 * b2.x + f0 * b3.x;
+        ob.y = f0 * b0.y + f1 * b1.y + f1 * b2.y + f0 * b3.y;
+        ob.z = f0 * b0.z + f1 * b1.z + f1 * b2.z + f0 * b3.z;
+        ob.w = f0 * b0.w + f1 * b1.w + f1 * b2.w + f0 * b3.w;
+        float nza = 0.f, nzb = 0.f;
+        if (a.noise) {
+            nza = a.noise[(size_t)Y * Wo + X] * a.noise_strength;
+            nzb = a.noise[(size_t)Y * Wo + X + 1] * a.noise_strength;
+        }
+        dst[((size_t)Y * Wo + X) * C4] = finish(oa, nza);
+        dst[((size_t)Y * Wo + X + 1) * C4] = finish(ob, nzb);
+        a0 = a1; a1 = a2; a2 = a3;
+        b0 = b1; b1 = b2; b2 = b3;
     }
 }
 
@@ -195,6 +225,85 @@ __global__ void __launch_bounds__(256) skip_kernel(HfagpSkipArgs a) {
 // reads 8 full 128-byte-aligned runs per load instruction.
 constexpr int kTorgbMaxOut = 4;
 
+// epilogue of one (pixel, output channel c): bias, (pre-clamp copy), clamp, + upsample2d(rgb_in), store.
+// The 8 lanes of a pixel all hold the reduced sums; lane c finishes channel c, so the 4-tap skip gathers of the
+// channels run side by side instead of one lane walking all of them.
+__device__ __forceinline__ void torgb_finish(const HfagpTorgbArgs& a, int b, int pix, int c, float acc) {
+    const int HW = a.H * a.W;
+    const int Y = pix / a.W, X = pix % a.W;
+    float v = acc + a.bias[c];
+    if (a.y_pre) a.y_pre[((size_t)b * a.Cout + c) * HW + pix] = v;      // before the clamp: backward mask
+    if (a.clamp >= 0.f) v = fminf(fmaxf(v, -a.clamp), a.clamp);
+    if (a.rgb_in) {
+        const int Hi = a.H >> 1, Wi = a.W >> 1;
+        int y0, y1, x0, x1; float wy0, wy1, wx0, wx1;
+        up2_taps(Y, y0, y1, wy0, wy1);
+        up2_taps(X, x0, x1, wx0, wx1);
+        const float* src = a.rgb_in + ((size_t)b * a.Cout + c) * Hi * Wi;
+        // clamped addresses + zeroed weights: four unconditional loads
+        const float my0 = y0 >= 0 ? wy0 : 0.f, my1 = y1 < Hi ? wy1 : 0.f;
+        const float mx0 = x0 >= 0 ? wx0 : 0.f, mx1 = x1 < Wi ? wx1 : 0.f;
+        const int cy0 = max(y0, 0), cy1 = min(y1, Hi - 1), cx0 = max(x0, 0), cx1 = min(x1, Wi - 1);
+        v += my0 * (mx0 * src[cy0 * Wi + cx0] + mx1 * src[cy0 * Wi + cx1]) +
+             my1 * (mx0 * src[cy1 * Wi + cx0] + mx1 * src[cy1 * Wi + cx1]);
+    }
+    a.rgb_out[((size_t)b * a.Cout + c) * HW + pix] = v;
+}
+
+// Cin = 32*KQ: lane `sub` of a pixel owns the channel quads sub, sub+8, ...; its slice of the modulated weight
+// stays in registers and the block walks kTorgbPix pixels, so the KQ loads of a pixel are all in flight together
+// and the weight set-up is paid once per 32*kTorgbIter pixels.
+constexpr int kTorgbIter = 8;
+
+template <int KQ>
+__global__ void __launch_bounds__(256) torgb_reg_kernel(HfagpTorgbArgs a) {
+    const int b = blockIdx.y;
+    const int sub = threadIdx.x & 7;
+    const int HW = a.H * a.W;
+    float4 w[kTorgbMaxOut][KQ];
+#pragma unroll
+    for (int c = 0; c < kTorgbMaxOut; ++c)
+#pragma unroll
+        for (int i = 0; i < KQ; ++i) {
+            w[c][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < a.Cout) {
+                const float4 wv = reinterpret_cast<const float4*>(a.weight + (size_t)c * a.Cin)[sub + 8 * i];
+                const float4 sv = reinterpret_cast<const float4*>(a.styles + (size_t)b * a.Cin)[sub + 8 * i];
+                w[c][i] = make_float4(wv.x * sv.x, wv.y * sv.y, wv.z * sv.z, wv.w * sv.w);
+            }
+        }
+    const int pix0 = blockIdx.x * (32 * kTorgbIter) + (threadIdx.x >> 3);
+    const float4* xb = reinterpret_cast<const float4*>(a.x + (size_t)b * HW * a.Cin) + sub;
+    const int cq = a.Cin >> 2;
+    float4 v[KQ], vn[KQ];
+#pragma unroll
+    for (int i = 0; i < KQ; ++i) v[i] = xb[(size_t)min(pix0, HW - 1) * cq + 8 * i];
+    for (int it = 0; it < kTorgbIter; ++it) {
+        const int pix = pix0 + it * 32;
+        if (pix >= HW) return;
+        // next pixel's loads go out before this pixel's reduction and epilogue
+        const int pn = min(pix + 32, HW - 1);
+#pragma unroll
+        for (int i = 0; i < KQ; ++i) vn[i] = xb[(size_t)pn * cq + 8 * i];
+        float acc[kTorgbMaxOut] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < KQ; ++i)
+#pragma unroll
+            for (int c = 0; c < kTorgbMaxOut; ++c)
+                acc[c] += v[i].x * w[c][i].x + v[i].y * w[c][i].y + v[i].z * w[c][i].z + v[i].w * w[c][i].w;
+#pragma unroll
+        for (int c = 0; c < kTorgbMaxOut; ++c) {
+            acc[c] += __shfl_xor(acc[c], 1);
+            acc[c] += __shfl_xor(acc[c], 2);
+            acc[c] += __shfl_xor(acc[c], 4);
+        }
+        if (sub < a.Cout) torgb_finish(a, b, pix, sub, sub == 0 ? acc[0] : sub == 1 ? acc[1] : sub == 2 ? acc[2] : acc[3]);
+#pragma unroll
+        for (int i = 0; i < KQ; ++i) v[i] = vn[i];
+    }
+}
+
+// any Cin % 4 == 0: modulated weight in LDS
 __global__ void __launch_bounds__(256) torgb_kernel(HfagpTorgbArgs a) {
     extern __shared__ __attribute__((aligned(16))) float wmod[];   // [Cout][Cin]
     const int b = blockIdx.y;
@@ -222,27 +331,7 @@ __global__ void __launch_bounds__(256) torgb_kernel(HfagpTorgbArgs a) {
         acc[c] += __shfl_xor(acc[c], 2);
         acc[c] += __shfl_xor(acc[c], 4);
     }
-    if (sub != 0) return;
-    const int Y = pix / a.W, X = pix % a.W;
-    for (int c = 0; c < a.Cout; ++c) {
-        float v = acc[c] + a.bias[c];
-        if (a.y_pre) a.y_pre[((size_t)b * a.Cout + c) * HW + pix] = v;      // before the clamp: backward mask
-        if (a.clamp >= 0.f) v = fminf(fmaxf(v, -a.clamp), a.clamp);
-        if (a.rgb_in) {
-            const int Hi = a.H >> 1, Wi = a.W >> 1;
-            int y0, y1, x0, x1; float wy0, wy1, wx0, wx1;
-            up2_taps(Y, y0, y1, wy0, wy1);
-            up2_taps(X, x0, x1, wx0, wx1);
-            const float* src = a.rgb_in + ((size_t)b * a.Cout + c) * Hi * Wi;
-            float u = 0.f;
-            if (y0 >= 0 && x0 >= 0) u += wy0 * wx0 * src[y0 * Wi + x0];
-            if (y0 >= 0 && x1 < Wi) u += wy0 * wx1 * src[y0 * Wi + x1];
-            if (y1 < Hi && x0 >= 0) u += wy1 * wx0 * src[y1 * Wi + x0];
-            if (y1 < Hi && x1 < Wi) u += wy1 * wx1 * src[y1 * Wi + x1];
-            v += u;
-        }
-        a.rgb_out[((size_t)b * a.Cout + c) * HW + pix] = v;
-    }
+    if (sub < a.Cout) torgb_finish(a, b, pix, sub, sub == 0 ? acc[0] : sub == 1 ? acc[1] : sub == 2 ? acc[2] : acc[3]);
 }
 
 // ---------------------------------------------------------------- generic upfirdn2d (NCHW, test surface)
@@ -355,7 +444,7 @@ int hfagp_upfir_epilogue_fwd(const HfagpUpfirEpilogueArgs* a, void* stream) {
     HFAGP_REQUIRE(a->C % 4 == 0 && a->B > 0 && a->H > 0 && a->W > 0, HFAGP_EUNSUPPORTED,
                   "upfir_epilogue: C=%d must be a multiple of 4", a->C);
     const int strips = (2 * a->H + kStrip - 1) / kStrip;
-    const long long total = (long long)a->B * strips * 2 * a->W * (a->C / 4);
+    const long long total = (long long)a->B * strips * a->W * (a->C / 4);
     upfir_epilogue_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(*a);
     return check_launch("upfir_epilogue");
 }
@@ -375,9 +464,18 @@ int hfagp_torgb_fwd(const HfagpTorgbArgs* a, void* stream) {
     HFAGP_REQUIRE(a->Cout >= 1 && a->Cout <= kTorgbMaxOut && a->Cin % 4 == 0 && a->H % 2 == 0 && a->W % 2 == 0,
                   HFAGP_EUNSUPPORTED, "torgb: Cout=%d (max %d), Cin=%d", a->Cout, kTorgbMaxOut, a->Cin);
     const int HW = a->H * a->W;
-    dim3 grid((HW + 31) / 32, a->B);
-    const size_t lds = (size_t)a->Cout * a->Cin * sizeof(float);
-    torgb_kernel<<<grid, 256, lds, (hipStream_t)stream>>>(*a);
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 rgrid((HW + 32 * kTorgbIter - 1) / (32 * kTorgbIter), a->B);
+    switch (a->Cin) {
+        case 64:  torgb_reg_kernel<2><<<rgrid, 256, 0, s>>>(*a); break;
+        case 128: torgb_reg_kernel<4><<<rgrid, 256, 0, s>>>(*a); break;
+        case 256: torgb_reg_kernel<8><<<rgrid, 256, 0, s>>>(*a); break;
+        default: {
+            dim3 grid((HW + 31) / 32, a->B);
+            const size_t lds = (size_t)a->Cout * a->Cin * sizeof(float);
+            torgb_kernel<<<grid, 256, lds, s>>>(*a);
+        }
+    }
     return check_launch("torgb");
 }
 
