@@ -91,9 +91,17 @@ raymarch_bwd_tiles_kernel(const RayParams p, float* __restrict__ d_planes, const
         const int s = 16 * tt + j;
         const float4 rec = *reinterpret_cast<const float4*>(p.rec + ((size_t)ray * S + s) * 4);   // depth, omega, dsigma
         PlaneTaps taps[3];
-        sample_taps(p, o3, d3, rec.x, taps);
+        sample_taps(p, o3, d3, rec.x, taps);          // taps of sample j: the scatter below publishes them
         float f[8];
-        gather8(a, b, g, taps, f);
+        {
+            // gather in the quad layout of raymarch_kernel (4 adjacent lanes per texel line), then to the MFMA layout
+            PlaneTaps tq[3];
+            sample_taps(p, o3, d3, p.rec[((size_t)ray * S + 16 * tt + (lane >> 2)) * 4], tq);
+            gather8(a, b, lane & 3, tq, f);
+            const int src = 4 * j + g;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) f[c] = __shfl(f[c], src);
+        }
         f32x4 hp[4], h[4], o[2];
         float sigma;
         decoder_fwd_lds<true>(wfwd, lane, f, hp, h, sigma, o);
