@@ -190,3 +190,35 @@ def test_layout_grid_quantisation_formula():
     from hfa_gp_amd.render import layout_grid
     out = layout_grid(T("grid_in"), grid_w=2, grid_h=1)
     assert out.dtype == np.uint8 and np.array_equal(out, G["grid_out"])
+
+
+def test_converter_key_selection_round_trip(tmp_path):
+    """tools/convert_eg3d_pickle.py: an EG3D-style state dict (extra keys, same names) and an HFA-GP checkpoint
+    (`generator.` prefix) both map onto the generator's state dict; shape mismatches are refused."""
+    import importlib.util
+    import pytest
+    import torch
+    from safetensors.torch import load_file, save_file
+    from hfa_gp_amd.config import tiny64
+    from hfa_gp_amd.generator import TriPlaneGenerator
+    spec = importlib.util.spec_from_file_location("convert_eg3d_pickle", os.path.join(ROOT, "tools", "convert_eg3d_pickle.py"))
+    conv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(conv)
+    src_gen = TriPlaneGenerator(tiny64(), seed=11)
+    sd = {k: v.clone() for k, v in src_gen.state_dict().items()}
+    sd["rendering_kwargs_placeholder"] = torch.zeros(1)                       # keys EG3D has and we do not
+    picked = conv.select_for(TriPlaneGenerator(tiny64(), seed=0), sd)
+    assert set(picked) == set(src_gen.state_dict())
+    path = str(tmp_path / "g.safetensors")
+    save_file(picked, path)
+    dst = TriPlaneGenerator(tiny64(), seed=0)
+    dst.load_state_dict(load_file(path), strict=True)
+    for k, v in src_gen.state_dict().items():
+        assert torch.equal(dst.state_dict()[k], v), k
+    ck = str(tmp_path / "000100.pt")
+    torch.save({"gen": {"generator." + k: v for k, v in sd.items()} | {"bases": torch.zeros(2, 2)}}, ck)
+    assert set(conv.hfagp_state_dict(ck)) == set(sd)
+    bad = dict(sd)
+    bad["decoder.net.0.weight"] = torch.zeros(3, 3)
+    with pytest.raises(SystemExit, match="shape mismatch"):
+        conv.select_for(dst, bad)
