@@ -183,9 +183,11 @@ def main():
         return dt, timing
 
     prec = args.precision or cfg.conv_precision
-    dt32 = timing32 = None
+    dt32 = timing32 = dt6 = None
     if prec != "fp32" and not args.no_fp32_leg:
         dt32, timing32 = render_leg("fp32")
+        if prec != "bf16x6":
+            dt6, _ = render_leg("bf16x6")
     dt, timing = render_leg(prec)
 
     def agg(key, table=None):
@@ -260,6 +262,8 @@ def main():
                                   "algorithmic_bytes_per_launch": rm_bytes / max(rm_n, 1)},
         }
         out["config"]["conv_precision"] = prec
+        if dt6 is not None:
+            out["value_bf16x6"] = frames / dt6       # 6 bf16 MFMAs per product: image error = the exact kernel's
         if dt32 is not None:
             out["value_fp32_exact"] = frames / dt32
             out["roofline_fp32_exact"] = f32_roofline(timing32)
