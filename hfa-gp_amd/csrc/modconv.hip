@@ -31,12 +31,13 @@ __global__ void __launch_bounds__(256) modconv_kernel(const ConvParams p) {
 
     const Phase& ph = p.phase[blockIdx.y];
     // ---- decode the block id: N tile fastest (neighbours share the input patch in L2)
+    // (readfirstlane: run-time divisions are vector ops; keep what derives from the block coordinates in SGPRs)
     unsigned id = blockIdx.x;
-    const int tn_blk = id % p.tiles_n; id /= p.tiles_n;
-    const int tw = id % p.tiles_w;     id /= p.tiles_w;
-    const int th = id % p.tiles_h;     id /= p.tiles_h;
-    const int b = id % p.B;            id /= p.B;
-    const int ks = id;
+    const int tn_blk = __builtin_amdgcn_readfirstlane(id % p.tiles_n); id /= p.tiles_n;
+    const int tw = __builtin_amdgcn_readfirstlane(id % p.tiles_w);     id /= p.tiles_w;
+    const int th = __builtin_amdgcn_readfirstlane(id % p.tiles_h);     id /= p.tiles_h;
+    const int b = __builtin_amdgcn_readfirstlane(id % p.B);            id /= p.B;
+    const int ks = __builtin_amdgcn_readfirstlane(id);
     const int m0 = th * PH, n0 = tw * PW, co0 = tn_blk * BN;
     if (m0 >= ph.mh || n0 >= ph.mw) return;
 
@@ -44,8 +45,8 @@ __global__ void __launch_bounds__(256) modconv_kernel(const ConvParams p) {
     const int wm = wave / WN, wn = wave % WN;
     const int h = lane >> 5, l31 = lane & 31;
 
-    const int c_begin = (int)(((long long)p.nchunks * ks) / p.ksplit);
-    const int c_end = (int)(((long long)p.nchunks * (ks + 1)) / p.ksplit);
+    const int c_begin = __builtin_amdgcn_readfirstlane((int)(((long long)p.nchunks * ks) / p.ksplit));
+    const int c_end = __builtin_amdgcn_readfirstlane((int)(((long long)p.nchunks * (ks + 1)) / p.ksplit));
 
     // ---- staging assignment (register prefetch: global -> regs -> LDS)
     const int npatch = p.ph * p.pw;

@@ -64,12 +64,15 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
     float* Ss = reinterpret_cast<float*>(lds_raw + 2 * A_BUF);   // [Cin] styles of this sample (or ones)
 
     const Phase& ph = p.phase[phase0 + blockIdx.y];   // every phase of one launch has NTAPS taps
+    // (readfirstlane: the divisions by run-time values are done on the vector ALU; without it every index derived
+    // from the block coordinates stays in VGPRs and the uniform address arithmetic of the K loop — chunk x Cout
+    // products, clamps — is issued as quarter-rate vector multiplies between the MFMAs)
     unsigned id = blockIdx.x;
-    const int tn_blk = id % p.tiles_n; id /= p.tiles_n;
-    const int tw = id % p.tiles_w;     id /= p.tiles_w;
-    const int th = id % p.tiles_h;     id /= p.tiles_h;
-    const int b = id % p.B;            id /= p.B;
-    const int ks = id;
+    const int tn_blk = __builtin_amdgcn_readfirstlane(id % p.tiles_n); id /= p.tiles_n;
+    const int tw = __builtin_amdgcn_readfirstlane(id % p.tiles_w);     id /= p.tiles_w;
+    const int th = __builtin_amdgcn_readfirstlane(id % p.tiles_h);     id /= p.tiles_h;
+    const int b = __builtin_amdgcn_readfirstlane(id % p.B);            id /= p.B;
+    const int ks = __builtin_amdgcn_readfirstlane(id);
     const int m0 = th * PH, n0 = tw * PW, co0 = tn_blk * BNB;
     if (m0 >= ph.mh || n0 >= ph.mw) return;
 
@@ -77,8 +80,8 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
     const int wm = wave / WN, wn = wave % WN;
     const int h = lane >> 5, l31 = lane & 31;
 
-    const int c_begin = (int)(((long long)p.nchunks * ks) / p.ksplit);
-    const int c_end = (int)(((long long)p.nchunks * (ks + 1)) / p.ksplit);
+    const int c_begin = __builtin_amdgcn_readfirstlane((int)(((long long)p.nchunks * ks) / p.ksplit));
+    const int c_end = __builtin_amdgcn_readfirstlane((int)(((long long)p.nchunks * (ks + 1)) / p.ksplit));
 
     // ---- A staging: float4 (4 channels of one position) per slot, 4 slots per position.  Everything is
     // branch-free: a slot outside the image (zero padding) reads element 0 and is multiplied by 0, a thread past
@@ -283,8 +286,11 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
     };
     run(std::integral_constant<int, NTAPS>{});
 
-    // ---- epilogue.  C/D layout of 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // ---- epilogue.  C/D layout of 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5): the 16 registers of
+    // a tile are 2 patch rows (r>>3) x columns 8*((r>>2)&1) + 4h + (r&3).  One 64-bit row pointer per (tile, patch
+    // row); everything else is a 32-bit offset (the per-element 64-bit index products were ~8k VALU cycles per wave).
     float* out = p.out + (size_t)(ks * p.nslab + ph.slab) * p.slab;
+    const int cstep = ph.sx * p.Cout;                                     // elements between neighbouring columns
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
         const int co = co0 + (wn * TN + tn) * 32 + l31;
@@ -295,28 +301,29 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
             if (p.bias) bs = p.bias[co];
         }
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-            float nz[16];
+        for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int pidx = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int m = min(m0 + (pidx >> 4), ph.mh - 1), n = min(n0 + (pidx & 15), ph.mw - 1);
-                nz[r] = (p.fused && p.noise) ? p.noise[(size_t)(ph.sy * m + ph.oy0) * p.Wo + ph.sx * n + ph.ox0] : 0.f;
-            }
+            for (int rw = 0; rw < 2; ++rw) {
+                const int m = m0 + 2 * (wm * TM + tm) + rw;
+                if (m >= ph.mh) continue;
+                const int oy = ph.sy * m + ph.oy0;
+                float* rowp = out + (((size_t)b * p.Ho + oy) * p.Wo + ph.ox0) * p.Cout + co;
+                const float* nrow = (p.fused && p.noise) ? p.noise + (size_t)oy * p.Wo + ph.ox0 : nullptr;
+                float nz[8];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int pidx = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int m = m0 + (pidx >> 4), n = n0 + (pidx & 15);
-                if (m >= ph.mh || n >= ph.mw) continue;
-                const int oy = ph.sy * m + ph.oy0, ox = ph.sx * n + ph.ox0;
-                float v = acc[tm][tn][r];
-                if (p.fused) {
-                    v = v * d + bs + nz[r] * p.noise_strength;
-                    v = lrelu_gain_clamp(v, p.act, p.alpha, p.gain, p.clamp);
+                for (int q = 0; q < 8; ++q) {
+                    const int n = min(n0 + 8 * (q >> 2) + 4 * h + (q & 3), ph.mw - 1);
+                    nz[q] = nrow ? nrow[ph.sx * n] * p.noise_strength : 0.f;
                 }
-                out[(((size_t)b * p.Ho + oy) * p.Wo + ox) * p.Cout + co] = v;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int n = n0 + 8 * (q >> 2) + 4 * h + (q & 3);
+                    if (n >= ph.mw) continue;
+                    float v = acc[tm][tn][8 * rw + q];
+                    if (p.fused) v = lrelu_gain_clamp(v * d + bs + nz[q], p.act, p.alpha, p.gain, p.clamp);
+                    rowp[n * cstep] = v;
+                }
             }
-        }
     }
 }
 
@@ -346,18 +353,18 @@ __global__ void __launch_bounds__(256, 1) upconv_bf16_kernel(const ConvParams p)
 
     unsigned id = blockIdx.x;
     const int tiles_nu = p.Cout / BNU;
-    const int tn_blk = id % tiles_nu;  id /= tiles_nu;
-    const int tw = id % p.tiles_w;     id /= p.tiles_w;
-    const int th = id % p.tiles_h;     id /= p.tiles_h;
-    const int b = id % p.B;            id /= p.B;
-    const int ks = id;
+    const int tn_blk = __builtin_amdgcn_readfirstlane(id % tiles_nu);  id /= tiles_nu;
+    const int tw = __builtin_amdgcn_readfirstlane(id % p.tiles_w);     id /= p.tiles_w;
+    const int th = __builtin_amdgcn_readfirstlane(id % p.tiles_h);     id /= p.tiles_h;
+    const int b = __builtin_amdgcn_readfirstlane(id % p.B);            id /= p.B;
+    const int ks = __builtin_amdgcn_readfirstlane(id);
     const int m0 = th * PH, n0 = tw * PW, co0 = tn_blk * BNU;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int h = lane >> 5, l31 = lane & 31;
-    const int c_begin = (int)(((long long)p.nchunks * ks) / p.ksplit);
-    const int c_end = (int)(((long long)p.nchunks * (ks + 1)) / p.ksplit);
+    const int c_begin = __builtin_amdgcn_readfirstlane((int)(((long long)p.nchunks * ks) / p.ksplit));
+    const int c_end = __builtin_amdgcn_readfirstlane((int)(((long long)p.nchunks * (ks + 1)) / p.ksplit));
 
     // ---- A staging (as in modconv_bf16_kernel): patch rows m0-1 .. m0+PH-1, columns n0-1 .. n0+PW-1
     const int npatch = p.ph * p.pw;
@@ -503,7 +510,8 @@ __global__ void __launch_bounds__(256, 1) upconv_bf16_kernel(const ConvParams p)
         }
     }
 
-    // ---- raw stores of the four phases: y_t[2m + (f>>1)][2n + (f&1)], extents (H+1-(f>>1)) x (W+1-(f&1))
+    // ---- raw stores of the four phases: y_t[2m + (f>>1)][2n + (f&1)], extents (H+1-(f>>1)) x (W+1-(f&1));
+    // one 64-bit row pointer per (phase, tile, patch row), 32-bit column offsets
     float* out = p.out + (size_t)ks * p.slab;
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
@@ -514,11 +522,16 @@ __global__ void __launch_bounds__(256, 1) upconv_bf16_kernel(const ConvParams p)
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int pidx = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    const int m = m0 + (pidx >> 4), n = n0 + (pidx & 15);
-                    if (m >= mh || n >= mw) continue;
-                    out[(((size_t)b * p.Ho + 2 * m + (f >> 1)) * p.Wo + 2 * n + (f & 1)) * p.Cout + co] = acc[f][tm][tn][r];
+                for (int rw = 0; rw < 2; ++rw) {
+                    const int m = m0 + 2 * (wm * TM + tm) + rw;
+                    if (m >= mh) continue;
+                    float* rowp = out + (((size_t)b * p.Ho + 2 * m + (f >> 1)) * p.Wo + (f & 1)) * p.Cout + co;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int n = n0 + 8 * (q >> 2) + 4 * h + (q & 3);
+                        if (n >= mw) continue;
+                        rowp[2 * n * p.Cout] = acc[f][tm][tn][8 * rw + q];
+                    }
                 }
         }
     }
