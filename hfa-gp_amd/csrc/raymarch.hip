@@ -56,8 +56,8 @@ __global__ void __launch_bounds__(256, 2) raymarch_kernel(const RayParams p) {
     DecoderRegs dec;
     load_decoder(a, j, g, dec);
 
-    for (int ray = blockIdx.x * 4 + wave; ray < p.total_rays; ray += gridDim.x * 4) {
-        const int b = ray / R, rr = ray % R;
+    for (int ray = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave); ray < p.total_rays; ray += gridDim.x * 4) {
+        const int b = ray / R, rr = ray % R;                 // wave-uniform -> scalar registers
         const int pi = rr / a.res, pj = rr % a.res;
         float o3[3], d3[3];
         ray_setup(a, b, pi, pj, o3, d3);

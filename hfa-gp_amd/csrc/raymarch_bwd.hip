@@ -84,7 +84,8 @@ raymarch_bwd_tiles_kernel(const RayParams p, float* __restrict__ d_planes, const
 
     const long long ntiles = (long long)p.total_rays * NT;
     for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long long)gridDim.x * 4) {
-        const int ray = (int)(tile / NT), tt = (int)(tile % NT);
+        const int ray = __builtin_amdgcn_readfirstlane((int)(tile / NT));        // wave-uniform -> scalar registers
+        const int tt = __builtin_amdgcn_readfirstlane((int)(tile % NT));
         const int b = ray / R, rr = ray % R;
         float o3[3], d3[3];
         ray_setup(a, b, rr / a.res, rr % a.res, o3, d3);

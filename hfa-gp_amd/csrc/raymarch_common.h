@@ -152,13 +152,14 @@ __device__ __forceinline__ void gather8(const HfagpRaymarchArgs& a, int b, int g
     for (int c = 0; c < 8; ++c) f[c] = 0.f;
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) {
-        const float* base = a.planes + ((size_t)(b * 3 + pl) * a.H * a.W) * 32 + 8 * g;
+        // uniform plane base (b is wave-uniform: callers pass it through readfirstlane) + 32-bit lane offset
+        const char* base = reinterpret_cast<const char*>(a.planes + ((size_t)(b * 3 + pl) * a.H * a.W) * 32);
         float4 v0[4], v1[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float4* ptr = reinterpret_cast<const float4*>(base + (size_t)taps[pl].idx[k] * 32);
-            v0[k] = ptr[0];
-            v1[k] = ptr[1];
+            const unsigned off = ((unsigned)taps[pl].idx[k] * 32u + 8u * g) * 4u;      // < 2^32: one plane
+            v0[k] = *reinterpret_cast<const float4*>(base + off);
+            v1[k] = *reinterpret_cast<const float4*>(base + off + 16);
         }
         const float v[4][8] = {{v0[0].x, v0[0].y, v0[0].z, v0[0].w, v1[0].x, v1[0].y, v1[0].z, v1[0].w},
                                {v0[1].x, v0[1].y, v0[1].z, v0[1].w, v1[1].x, v1[1].y, v1[1].z, v1[1].w},
