@@ -210,24 +210,41 @@ raymarch_bwd_tiles_kernel(const RayParams p, float* __restrict__ d_planes, const
                 }
             }
         WAVE_SYNC();
-        // ---- scatter: half-wave hf handles samples hf, hf+2, ...; lane = channel
+        // ---- scatter: lane = channel, half-wave hf walks tap (2kp + hf) of one plane through the 16 depth-sorted
+        // samples and MERGES RUNS: consecutive samples whose tap lands on the same texel (the plane the ray is steep
+        // to moves < 1 texel per sample; the importance samples cluster) are summed in a register and leave as one
+        // 128-byte atomic: 96 -> ~67 atomics per tile on the bench workload (plane (x,y): 3.0 taps per run, the two
+        // depth planes: 1.1).  Measured 9.3 -> 8.8 ms per 4 frames; without any atomics the call takes 2.7 ms, i.e.
+        // the cost follows the number of DISTINCT lines touched more than the number of atomic instructions.
         {
             const int c = lane & 31, hf = lane >> 5;
             float* base = d_planes + (size_t)b * 3 * a.H * a.W * 32 + c;
-            for (int sm = hf; sm < 16; sm += 2) {
-                const float v = lds.df[sm * 32 + c];
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const float wgt = lds.wgt[sm * 12 + pl * 4 + k];
+#pragma unroll 1
+            for (int pk = 0; pk < 6; ++pk) {
+                const int pl = pk >> 1, k = 2 * (pk & 1) + hf;
+                float* pbase = base + (size_t)pl * a.H * a.W * 32;
+                int cur = -1;
+                float run = 0.f;
+#pragma unroll 4
+                for (int sm = 0; sm < 16; ++sm) {
+                    const float wgt = lds.wgt[sm * 12 + pl * 4 + k];
+                    const int t = lds.idx[sm * 12 + pl * 4 + k];
+                    const float v = lds.df[sm * 32 + c] * wgt;
+                    if (wgt != 0.f) {
+                        if (t == cur) {
+                            run += v;
+                        } else {
 #ifndef HFAGP_NO_ATOMICS
-                        if (wgt != 0.f)
-#else
-                        if (wgt == 12345.f)
+                            if (cur >= 0) unsafeAtomicAdd(pbase + (size_t)cur * 32, run);
 #endif
-                            unsafeAtomicAdd(base + ((size_t)pl * a.H * a.W + lds.idx[sm * 12 + pl * 4 + k]) * 32, v * wgt);
+                            cur = t;
+                            run = v;
+                        }
                     }
+                }
+#ifndef HFAGP_NO_ATOMICS
+                if (cur >= 0) unsafeAtomicAdd(pbase + (size_t)cur * 32, run);
+#endif
             }
         }
         WAVE_SYNC();
