@@ -148,6 +148,10 @@ def lib() -> C.CDLL:
                 f"hfa_gp_amd: HIP library not found at {LIB_PATH}. There is no CPU fallback; build it with "
                 f"`bash {os.path.join(_HERE, 'csrc', 'build.sh')}` (hipcc --offload-arch=gfx950).")
         try:
+            # PyTorch-ROCm ships its own libamdhip64: it must be in the process BEFORE this library is loaded, or the
+            # dlopen pulls a second HIP runtime from /opt/rocm and launches on torch's streams fail with
+            # "no ROCm-capable device is detected"
+            import torch  # noqa: F401
             handle = C.CDLL(LIB_PATH)
         except OSError as e:  # missing libamdhip64 etc.
             raise RuntimeError(f"hfa_gp_amd: cannot load {LIB_PATH}: {e}") from e
