@@ -55,7 +55,12 @@ __device__ __forceinline__ void split4(float4 v, uint2 (&out)[NP]) {
 
 template <int NP, int TM, int NTAPS>
 __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p, const int phase0) {
-    constexpr int TN = 2, WN = 2, BM = 2 * TM * 32, PH = BM / PW;
+#ifndef HFAGP_WAVES_N
+#define HFAGP_WAVES_N 2
+#endif
+    // wave grid WM x WN over the 128 x 128 block tile; TM here is the M tiles per wave for WN = 2
+    constexpr int WN = HFAGP_WAVES_N, WM = 4 / WN, TN = 4 / WN, TMW = 4 / WM, BM = 128, PH = BM / PW;
+    static_assert(TM == 2, "block tile is 128 positions");
     constexpr int LPWB = RowPitch<NP>::value;
     constexpr int APOS = (PH + 2) * LPWB;                 // positions of the staged patch
     constexpr int A_PART = APOS * APITCH, A_BUF = NP * A_PART;
@@ -144,10 +149,10 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
     // ---- per-lane fragment address of each M tile (bytes inside one part image, tap (0,0)); a tap adds the
     // uniform offset toff[t] (for the 3x3 modes the taps are sorted by (dy, dx), see make_plan, so that the offset
     // is a compile-time immediate of the ds_read)
-    int apos[TM];
+    int apos[TMW];
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-        const int pidx = (wm * TM + tm) * 32 + l31;
+    for (int tm = 0; tm < TMW; ++tm) {
+        const int pidx = (wm * TMW + tm) * 32 + l31;
         apos[tm] = ((pidx >> 4) * LPWB + (pidx & 15)) * APITCH + 16 * h;
     }
     int toff[4];
@@ -155,9 +160,9 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
     for (int t = 0; t < 4; ++t)
         toff[t] = t < ph.ntaps ? ((ph.dy[t] - p.dymin) * LPWB + (ph.dx[t] - p.dxmin)) * APITCH : 0;
 
-    f32x16 acc[TM][TN];
+    f32x16 acc[TMW][TN];
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
+    for (int tm = 0; tm < TMW; ++tm)
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
@@ -191,12 +196,12 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
                 for (int tn = 0; tn < TN; ++tn) bq[SL][tn][q] = *reinterpret_cast<const u32x4*>(base + bth[tn]);
             }
         };
-        bf16x8 af[2][TM][NP];                               // A fragments of the current and the next tap
+        bf16x8 af[2][TMW][NP];                               // A fragments of the current and the next tap
         auto read_a = [&](auto u_tag, auto t_tag) __attribute__((always_inline)) {
             constexpr int UU = decltype(u_tag)::value, T = decltype(t_tag)::value;
             const char* Ac = As + UU * A_BUF;               // chunk parity = LDS buffer: immediate offsets
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
+            for (int tm = 0; tm < TMW; ++tm)
 #pragma unroll
                 for (int q = 0; q < NP; ++q) {
                     if constexpr (NT == 9)
@@ -221,7 +226,7 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
 #pragma unroll
             for (int pr = 0; pr < NPROD; ++pr)
 #pragma unroll
-                for (int tm = 0; tm < TM; ++tm)
+                for (int tm = 0; tm < TMW; ++tm)
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn)
                         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
@@ -301,10 +306,10 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
             if (p.bias) bs = p.bias[co];
         }
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
+        for (int tm = 0; tm < TMW; ++tm)
 #pragma unroll
             for (int rw = 0; rw < 2; ++rw) {
-                const int m = m0 + 2 * (wm * TM + tm) + rw;
+                const int m = m0 + 2 * (wm * TMW + tm) + rw;
                 if (m >= ph.mh) continue;
                 const int oy = ph.sy * m + ph.oy0;
                 float* rowp = out + (((size_t)b * p.Ho + oy) * p.Wo + ph.ox0) * p.Cout + co;
