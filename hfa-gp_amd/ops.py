@@ -22,7 +22,15 @@ ACT_LINEAR, ACT_LRELU = 0, 1
 _ACT = {"linear": ACT_LINEAR, "lrelu": ACT_LRELU}
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream() -> int:
+    """hipStream_t of torch's current stream on the current device.  The raw accessor is ~20x cheaper than
+    ``torch.cuda.current_stream()`` (which builds a Stream object): it is called once per launch, ~350 times per
+    fitting step."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
