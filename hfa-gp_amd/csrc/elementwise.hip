@@ -49,6 +49,45 @@ __global__ void __launch_bounds__(256) demod_kernel(const float* __restrict__ st
     if (lane == 0) dcoef[wave] = rsqrtf(acc + eps);
 }
 
+// The same two kernels for up to kStyleBatch layers in ONE launch each (blockIdx.y = layer): a synthesis pass needs
+// the styles of 26 layers and the demodulation coefficients of 17; they only depend on ws, so they are computed up
+// front in 2 + 2 launches (backbone, super-resolution) instead of 43.
+constexpr int kStyleBatch = 32;
+struct StyleBatch { HfagpStyleArgs it[kStyleBatch]; };
+
+__global__ void __launch_bounds__(256) style_batch_kernel(const StyleBatch t) {
+    const HfagpStyleArgs& a = t.it[blockIdx.y];
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (wave >= a.B * a.Cin) return;
+    const int b = wave / a.Cin, i = wave % a.Cin;
+    const float* wr = a.w + (size_t)b * a.w_stride;
+    const float* ar = a.affine_w + (size_t)i * a.w_dim;
+    float acc = 0.f;
+    for (int k = lane * 4; k < a.w_dim; k += 256) {
+        const float4 x = *reinterpret_cast<const float4*>(wr + k);
+        const float4 y = *reinterpret_cast<const float4*>(ar + k);
+        acc += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) a.styles[wave] = (acc * rsqrtf((float)a.w_dim) + a.affine_b[i]) * a.style_gain;
+}
+
+__global__ void __launch_bounds__(256) demod_batch_kernel(const StyleBatch t) {
+    const HfagpStyleArgs& a = t.it[blockIdx.y];
+    if (!a.dcoef) return;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (wave >= a.B * a.Cout) return;
+    const int b = wave / a.Cout, o = wave % a.Cout;
+    const float* s = a.styles + (size_t)b * a.Cin;
+    const float* q = a.wsq + (size_t)o * a.Cin;
+    float acc = 0.f;
+    for (int k = lane; k < a.Cin; k += 64) acc += s[k] * s[k] * q[k];
+    for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m);
+    if (lane == 0) a.dcoef[wave] = rsqrtf(acc + a.eps);
+}
+
 // ---------------------------------------------------------------- fully connected (mapping network)
 // y[b][o] = act( (x[b] . W[o]) * wgain + bias[o] * bgain ) * act_gain ;  one wave per output element
 __global__ void __launch_bounds__(256) fc_kernel(const float* __restrict__ x, const float* __restrict__ W,
@@ -416,6 +455,26 @@ int hfagp_style_fwd(const HfagpStyleArgs* a, void* stream) {
         demod_kernel<<<(waves + 3) / 4, 256, 0, s>>>(a->styles, a->wsq, a->dcoef, a->B, a->Cin, a->Cout, a->eps);
     }
     return check_launch("style_fwd");
+}
+
+int hfagp_style_batch_fwd(const HfagpStyleArgs* items, int32_t n, void* stream) {
+    HFAGP_REQUIRE(items && n >= 1 && n <= kStyleBatch, HFAGP_EBADARG, "style_batch_fwd: 1..%d items, got %d", kStyleBatch, n);
+    StyleBatch t;
+    int max_s = 0, max_d = 0;
+    for (int i = 0; i < n; ++i) {
+        const HfagpStyleArgs& a = items[i];
+        HFAGP_REQUIRE(a.w && a.affine_w && a.affine_b && a.styles, HFAGP_EBADARG, "style_batch_fwd: null pointer in item %d", i);
+        HFAGP_REQUIRE(a.B > 0 && a.Cin > 0 && a.w_dim > 0 && a.w_dim % 4 == 0 && a.w_stride % 4 == 0, HFAGP_EBADARG,
+                      "style_batch_fwd: bad dims in item %d: B=%d Cin=%d w_dim=%d", i, a.B, a.Cin, a.w_dim);
+        HFAGP_REQUIRE(!a.dcoef || (a.wsq && a.Cout > 0), HFAGP_EBADARG, "style_batch_fwd: item %d: dcoef without wsq", i);
+        t.it[i] = a;
+        max_s = a.B * a.Cin > max_s ? a.B * a.Cin : max_s;
+        if (a.dcoef) max_d = a.B * a.Cout > max_d ? a.B * a.Cout : max_d;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    style_batch_kernel<<<dim3((max_s + 3) / 4, n), 256, 0, s>>>(t);
+    if (max_d) demod_batch_kernel<<<dim3((max_d + 3) / 4, n), 256, 0, s>>>(t);
+    return check_launch("style_batch_fwd");
 }
 
 int hfagp_fc_fwd(const float* x, const float* weight, const float* bias, float* y, int32_t B, int32_t In, int32_t Out,

@@ -144,6 +144,7 @@ class TriPlaneGenerator(nn.Module):
         self._prep: Dict[object, tuple] = {}     # (kind, ..., id(param)) -> (version, data_ptr, image, wsq)
         self._conv_precision = "fp32"
         self.conv_precision = cfg.conv_precision
+        self._styles: Dict[int, tuple] = {}      # id(layer) -> (styles, dcoef) of the pass in flight
         self._scalars: Dict[int, tuple] = {}     # id(param) -> (version, data_ptr, python float)
         self._const_nhwc: Optional[tuple] = None
         self.timing: Optional[Dict[str, list]] = None   # bench.py: {'raymarch': [(ev0, ev1, units)], 'modconv': [...]}
@@ -223,7 +224,9 @@ class TriPlaneGenerator(nn.Module):
     def _layer(self, x, layer: _SynthesisLayer, w, row, batch, noise_mode, conv_clamp, tape):
         cfg = self.cfg
         wt, wsq = self._prepared(layer.weight)
-        styles, dcoef = ops.styles_demod(w, layer.affine.weight, layer.affine.bias, wsq, 1.0, cfg.demod_eps)
+        pre = self._styles.pop(id(layer), None) if self._styles else None      # computed up front (_precompute_styles)
+        styles, dcoef = pre if pre is not None else ops.styles_demod(w, layer.affine.weight, layer.affine.bias, wsq,
+                                                                     1.0, cfg.demod_eps)
         noise, ns = None, 0.0
         if noise_mode == "const":
             noise, ns = layer.noise_const, self._scalar(layer.noise_strength)
@@ -261,7 +264,9 @@ class TriPlaneGenerator(nn.Module):
         tr = blk.torgb
         cin = tr.weight.shape[1]
         row = rows[-1]
-        styles, _ = ops.styles_demod(ws[:, row], tr.affine.weight, tr.affine.bias, None, 1.0 / math.sqrt(cin))
+        pre = self._styles.pop(id(tr), None) if self._styles else None
+        styles = pre[0] if pre is not None else ops.styles_demod(ws[:, row], tr.affine.weight, tr.affine.bias, None,
+                                                                 1.0 / math.sqrt(cin))[0]
         y = y_pre = None
         if small_rgb:
             if tape is not None and conv_clamp is not None:
@@ -279,6 +284,26 @@ class TriPlaneGenerator(nn.Module):
             tape.append(rec)
         return x, img
 
+    def _precompute_styles(self, ws: torch.Tensor, blocks_rows) -> None:
+        """Styles (and demodulation coefficients) of every layer of ``blocks_rows`` = [(block, rows)] in two
+        launches; `_layer` / `_block` pick them up by layer identity."""
+        cfg = self.cfg
+        items, keys = [], []
+        for blk, rows in blocks_rows:
+            convs = [blk.conv1] if blk.in_channels == 0 else [blk.conv0, blk.conv1]
+            for layer, row in zip(convs, rows):
+                items.append((ws[:, row], layer.affine.weight, layer.affine.bias, self._prepared(layer.weight)[1], 1.0,
+                              cfg.demod_eps))
+                keys.append(id(layer))
+            tr = blk.torgb
+            items.append((ws[:, rows[-1]], tr.affine.weight, tr.affine.bias, None, 1.0 / math.sqrt(tr.weight.shape[1]),
+                          cfg.demod_eps))
+            keys.append(id(tr))
+        self._styles = {}
+        for i in range(0, len(items), 32):
+            for k, v in zip(keys[i:i + 32], ops.styles_demod_batch(items[i:i + 32])):
+                self._styles[k] = v
+
     # ----------------------------------------------------------------- public API
     def backbone_planes(self, ws: torch.Tensor, tape=None) -> torch.Tensor:
         """ws [B, num_ws, 512] → tri-plane volume [B, 3, R, R, 32] (plane-major, channels-last)."""
@@ -286,6 +311,13 @@ class TriPlaneGenerator(nn.Module):
         syn = self.backbone.synthesis
         b = ws.shape[0]
         x = img = None
+        idx = 0
+        plan = []
+        for res in cfg.block_resolutions:
+            n_conv = 1 if res == 4 else 2
+            plan.append((getattr(syn, f"b{res}"), list(range(idx, idx + n_conv + 1))))
+            idx += n_conv
+        self._precompute_styles(ws, plan)
         idx = 0
         for res in cfg.block_resolutions:
             blk = getattr(syn, f"b{res}")
@@ -331,6 +363,7 @@ class TriPlaneGenerator(nn.Module):
         b = ws.shape[0]
         last = cfg.num_ws - 1
         sr = self.superresolution
+        self._precompute_styles(ws, [(sr.block0, [last] * 3), (sr.block1, [last] * 3)])
         x, rgb = self._block(feat_img, rgb_raw, sr.block0, ws, [last] * 3, b, cfg.sr_noise_mode, cfg.sr_conv_clamp,
                              True, False, tape)
         x, rgb = self._block(x, rgb, sr.block1, ws, [last] * 3, b, cfg.sr_noise_mode, cfg.sr_conv_clamp, True, False,

@@ -102,6 +102,32 @@ def styles_demod(w: torch.Tensor, affine_w: torch.Tensor, affine_b: torch.Tensor
     return styles, dcoef
 
 
+def styles_demod_batch(items):
+    """``items``: sequence of (w [B, w_dim] row view, affine_w, affine_b, wsq | None, style_gain, eps), at most 32.
+    One launch for all the styles, one for all the demodulation coefficients.  Returns [(styles, dcoef | None)]."""
+    n = len(items)
+    arr = (L.StyleArgs * n)()
+    out = []
+    for i, (w, affine_w, affine_b, wsq, style_gain, eps) in enumerate(items):
+        if w.dtype != torch.float32 or not w.is_cuda or w.stride(-1) != 1:
+            raise RuntimeError("styles_demod_batch: w must be a CUDA fp32 tensor with unit inner stride")
+        b, wd = w.shape
+        cin = affine_w.shape[0]
+        styles = torch.empty(b, cin, device=w.device, dtype=torch.float32)
+        dcoef = None
+        a = arr[i]
+        a.w, a.affine_w, a.affine_b = _ptr(w), _ptr(_chk(affine_w, "affine_w")), _ptr(_chk(affine_b, "affine_b"))
+        a.styles = _ptr(styles)
+        a.B, a.w_dim, a.w_stride, a.Cin = b, wd, w.stride(0), cin
+        a.style_gain, a.eps = style_gain, eps
+        if wsq is not None:
+            dcoef = torch.empty(b, wsq.shape[0], device=w.device, dtype=torch.float32)
+            a.wsq, a.dcoef, a.Cout = _ptr(_chk(wsq, "wsq")), _ptr(dcoef), wsq.shape[0]
+        out.append((styles, dcoef))
+    L.check(L.lib().hfagp_style_batch_fwd(arr, n, _stream()), "style_batch_fwd")
+    return out
+
+
 def fully_connected(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], lr_mul: float = 1.0,
                     act: str = "linear", alpha: float = 0.2, gain: Optional[float] = None) -> torch.Tensor:
     """EG3D FullyConnectedLayer: act((x @ (W*lr_mul/sqrt(in)).T + b*lr_mul)) * gain."""

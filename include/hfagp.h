@@ -91,6 +91,9 @@ typedef struct {
 } HfagpStyleArgs;
 
 int hfagp_style_fwd(const HfagpStyleArgs* a, void* stream);
+/* the same for n <= 32 layers in one launch per kernel (styles, then demodulation): the styles of a whole
+ * synthesis pass depend only on ws, so the host computes them up front                                    */
+int hfagp_style_batch_fwd(const HfagpStyleArgs* items, int32_t n, void* stream);
 
 /* FullyConnectedLayer (mapping network): y = act((x . W^T) * lr_mul/sqrt(In) + bias*lr_mul) * gain   [B][Out] */
 int hfagp_fc_fwd(const float* x, const float* weight, const float* bias, float* y, int32_t B, int32_t In, int32_t Out,
