@@ -139,39 +139,86 @@ __global__ void __launch_bounds__(256) reduce_partials_kernel(const float* __res
 // ---------------------------------------------------------------- adjoint of (FIR pad 1 gain 4) + parity split
 // g_y [B][2H][2W][C] -> gph [2][2][B][H+1][W+1][C],  gph[a][b][m][n] = g_yt[2m+a][2n+b],
 // g_yt[Y][X] = sum_{p,q} f[p] f[q] g_y[Y-p+1][X-q+1],  f = [1,3,3,1]/4.
+// Separable sliding window like upfir_epilogue_kernel: a thread owns 4 channels of two adjacent g_yt columns and
+// walks a strip of rows; 5 input columns per input row feed both columns and every input row of the strip is
+// read once (3.4 loads per output instead of 16); borders by clamped addresses and zeroed tap weights.
+constexpr int kBwdStrip = 8;
+
 __global__ void __launch_bounds__(256) upfir_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gph,
                                                         int B, int H, int W, int C) {
     const int C4 = C >> 2;
-    const long long per = (long long)B * (H + 1) * (W + 1) * C4;
+    const int Ho = 2 * H, Wo = 2 * W, Hi = 2 * H + 1;          // g_y is Ho x Wo, g_yt is Hi x (Wo + 1)
+    const int Wp = W + 1;                                       // column pairs (X, X+1), X = 2n
+    const int strips = (Hi + 1 + kBwdStrip - 1) / kBwdStrip;    // rows 0 .. Hi (row Hi = the zero padding of a = 1)
+    const long long total = (long long)B * strips * Wp * C4;
     const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid >= 4 * per) return;
-    const int phase = (int)(tid / per);
-    long long r = tid % per;
-    const int c4 = (int)(r % C4); r /= C4;
-    const int n = (int)(r % (W + 1)); r /= (W + 1);
-    const int m = (int)(r % (H + 1));
-    const int b = (int)(r / (H + 1));
-    const int Y = 2 * m + (phase >> 1), X = 2 * n + (phase & 1);
-    const int Ho = 2 * H, Wo = 2 * W;
-    const float f[4] = {0.25f, 0.75f, 0.75f, 0.25f};
-    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (Y <= Ho && X <= Wo) {
-        const float4* src = reinterpret_cast<const float4*>(gy) + (size_t)b * Ho * Wo * C4 + c4;
+    if (tid >= total) return;
+    const int c4 = (int)(tid % C4);
+    const int n = (int)((tid / C4) % Wp);
+    const int st = (int)((tid / ((long long)C4 * Wp)) % strips);
+    const int b = (int)(tid / ((long long)C4 * Wp * strips));
+    const int X = 2 * n, Y0 = st * kBwdStrip;
+    const float4* src = reinterpret_cast<const float4*>(gy) + (size_t)b * Ho * Wo * C4 + c4;
+    const float f0 = 0.25f, f1 = 0.75f;
+
+    // input columns X-2 .. X+2
+    int xo[5]; float xm[5];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int y = Y - p + 1;
-            if (y < 0 || y >= Ho) continue;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int x = X - q + 1;
-                if (x < 0 || x >= Wo) continue;
-                const float4 v = src[((size_t)y * Wo + x) * C4];
-                const float wgt = f[p] * f[q];
-                o.x += wgt * v.x; o.y += wgt * v.y; o.z += wgt * v.z; o.w += wgt * v.w;
-            }
-        }
+    for (int q = 0; q < 5; ++q) {
+        const int x = X + q - 2;
+        xm[q] = (x >= 0 && x < Wo) ? 1.f : 0.f;
+        xo[q] = min(max(x, 0), Wo - 1) * C4;
     }
-    reinterpret_cast<float4*>(gph)[tid] = o;
+    // column X: inputs X-2, X-1, X, X+1 with f3, f2, f1, f0;  column X+1: inputs X-1 .. X+2
+    const float wa[4] = {f0 * xm[0], f1 * xm[1], f1 * xm[2], f0 * xm[3]};
+    const float wb[4] = {f0 * xm[1], f1 * xm[2], f1 * xm[3], f0 * xm[4]};
+    const bool colb = X + 1 <= Wo;                              // column X+1 exists in g_yt (else: zero padding)
+
+    auto hrow = [&](int y, float4& ha, float4& hb) {
+        const float m = (y >= 0 && y < Ho) ? 1.f : 0.f;
+        const float4* row = src + (size_t)min(max(y, 0), Ho - 1) * Wo * C4;
+        float4 v[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) v[q] = row[xo[q]];
+        ha.x = m * (wa[0] * v[0].x + wa[1] * v[1].x + wa[2] * v[2].x + wa[3] * v[3].x);
+        ha.y = m * (wa[0] * v[0].y + wa[1] * v[1].y + wa[2] * v[2].y + wa[3] * v[3].y);
+        ha.z = m * (wa[0] * v[0].z + wa[1] * v[1].z + wa[2] * v[2].z + wa[3] * v[3].z);
+        ha.w = m * (wa[0] * v[0].w + wa[1] * v[1].w + wa[2] * v[2].w + wa[3] * v[3].w);
+        hb.x = m * (wb[0] * v[1].x + wb[1] * v[2].x + wb[2] * v[3].x + wb[3] * v[4].x);
+        hb.y = m * (wb[0] * v[1].y + wb[1] * v[2].y + wb[2] * v[3].y + wb[3] * v[4].y);
+        hb.z = m * (wb[0] * v[1].z + wb[1] * v[2].z + wb[2] * v[3].z + wb[3] * v[4].z);
+        hb.w = m * (wb[0] * v[1].w + wb[1] * v[2].w + wb[2] * v[3].w + wb[3] * v[4].w);
+    };
+
+    // g_yt[Y] = f0 h[Y+1] + f1 h[Y] + f1 h[Y-1] + f0 h[Y-2]
+    float4 a0, a1, a2, b0, b1, b2;
+    hrow(Y0 - 2, a0, b0); hrow(Y0 - 1, a1, b1); hrow(Y0, a2, b2);
+    const long long img = (long long)B * (H + 1) * (W + 1) * C4;         // float4 per parity image
+    float4* dst = reinterpret_cast<float4*>(gph) + ((size_t)b * (H + 1) * (W + 1) + n) * C4 + c4;
+#pragma unroll
+    for (int k = 0; k < kBwdStrip; ++k) {
+        const int Y = Y0 + k;
+        if (Y > Hi) break;                                      // rows 0 .. Hi inclusive are stored
+        float4 a3, b3;
+        hrow(Y + 1, a3, b3);
+        float4 oa, ob;
+        oa.x = f0 * a3.x + f1 * a2.x + f1 * a1.x + f0 * a0.x;
+        oa.y = f0 * a3.y + f1 * a2.y + f1 * a1.y + f0 * a0.y;
+        oa.z = f0 * a3.z + f1 * a2.z + f1 * a1.z + f0 * a0.z;
+        oa.w = f0 * a3.w + f1 * a2.w + f1 * a1.w + f0 * a0.w;
+        ob.x = f0 * b3.x + f1 * b2.x + f1 * b1.x + f0 * b0.x;
+        ob.y = f0 * b3.y + f1 * b2.y + f1 * b1.y + f0 * b0.y;
+        ob.z = f0 * b3.z + f1 * b2.z + f1 * b1.z + f0 * b0.z;
+        ob.w = f0 * b3.w + f1 * b2.w + f1 * b1.w + f0 * b0.w;
+        if (Y > Ho) oa = make_float4(0.f, 0.f, 0.f, 0.f);       // row Hi of the a = 1 images: zero padding
+        if (Y > Ho || !colb) ob = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int pa = Y & 1, m = Y >> 1;                       // parity image (pa, 0 / 1), row m
+        float4* row = dst + (size_t)(2 * pa) * img + (size_t)m * (W + 1) * C4;
+        row[0] = oa;                                            // image (pa, 0), column n
+        row[img] = ob;                                          // image (pa, 1), column n
+        a0 = a1; a1 = a2; a2 = a3;
+        b0 = b1; b1 = b2; b2 = b3;
+    }
 }
 
 // ---------------------------------------------------------------- adjoint of upsample2d (skip images)
@@ -294,7 +341,8 @@ int hfagp_pointwise_bwd(const HfagpPointwiseBwdArgs* a, void* stream) {
 int hfagp_upfir_bwd(const float* gy, float* gph, int32_t B, int32_t H, int32_t W, int32_t C, void* stream) {
     HFAGP_REQUIRE(gy && gph, HFAGP_EBADARG, "upfir_bwd: null pointer");
     HFAGP_REQUIRE(C % 4 == 0 && B > 0 && H > 0 && W > 0, HFAGP_EUNSUPPORTED, "upfir_bwd: C=%d", C);
-    const long long total = 4ll * B * (H + 1) * (W + 1) * (C / 4);
+    const int strips = (2 * H + 2 + kBwdStrip - 1) / kBwdStrip;
+    const long long total = (long long)B * strips * (W + 1) * (C / 4);
     upfir_bwd_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(gy, gph, B, H, W, C);
     return check_launch("upfir_bwd");
 }
