@@ -334,7 +334,10 @@ def pointwise_bwd(x: torch.Tensor, dxs_conv=None, s_conv=None, dxs_rgb=None, s_r
     Returns (g_out [B,H,W,C], sums [B,10,C])."""
     _chk(x, "x")
     b, h, w, c = x.shape
-    nchunks = max(1, min(256, (h * w) // 64))
+    # blocks per sample: at most 4 pixels per thread (the low-resolution layers are latency-bound otherwise: one block
+    # walking 64 pixels of 512 channels took 45 us), at most 256 (the partial sums are reduced by a second kernel)
+    npl = max(1, 256 // (c // 4))
+    nchunks = max(1, min(256, -(-(h * w) // (npl * 4))))
     a = L.PointwiseBwdArgs()
     g_out = torch.empty_like(x)
     partial = torch.empty(b, nchunks, 10, c, device=x.device, dtype=torch.float32)
