@@ -1,0 +1,81 @@
+// Householder QR of the tall-skinny latent basis, A = (bases + 1e-8)^T  [7168 x K<=64], without touching A's
+// 7168 rows in the serial part (gfx950).  SURVEY.md section 8f-4; replaces the ~250 rocSOLVER launches of
+// torch.linalg.qr in HeadNeRF_*.get_latent (/root/reference/code/networks/headnerf.py:85-91).
+//
+// LAPACK's geqrf applies K reflections H_j = I - tau_j v_j v_j^T.  Everything step j needs is
+//   * the pivot            p      = A_j[j][j]                          (A_j = H_{j-1} ... H_1 A)
+//   * the column norm      |x|^2  = G_j[j][j],   G_j = Gram matrix of rows >= j of A_j
+//   * w = A_j[j:, :]^T v_j        = G_j[:, j] - beta A_j[j, :]^T,      beta = -sign(p) |x|   (= R[j][j])
+// and then only the top K x K block T of A_j and G_j have to be updated:
+//   T[i, :] -= tau v_j[i] w^T  (i >= j),      G_{j+1} = G_j - r r^T,  r = row j of the updated T (= R[j, :]),
+// because the Gram matrix of rows >= j is invariant under H_j.  So the host forms G = A^T A (one GEMM), this
+// kernel runs the K steps on two K x K matrices in LDS and returns R (LAPACK's signs) and R^-1, and the host
+// forms Q = A R^-1 (one GEMM).  Cost ~0.1 ms instead of ~1.4 ms; in fp32 the result is closer to the fp64
+// factorisation than rocSOLVER's (the basis is well conditioned; accuracy degrades like cond(A)^2 * eps).
+#include "common.h"
+
+namespace hfagp {
+
+constexpr int kQrMax = 64;
+
+__global__ void __launch_bounds__(256) qr_gram_kernel(const float* __restrict__ G_in, const float* __restrict__ T_in,
+                                                      float* __restrict__ R_out, float* __restrict__ Rinv_out, int n) {
+    __shared__ float G[kQrMax][kQrMax + 1], T[kQrMax][kQrMax + 1], Ri[kQrMax][kQrMax + 1];
+    __shared__ float w[kQrMax], v[kQrMax];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < n * n; i += 256) {
+        G[i / n][i % n] = G_in[i];
+        T[i / n][i % n] = T_in[i];
+    }
+    __syncthreads();
+    for (int j = 0; j < n; ++j) {
+        // scalars of the step (every thread reads the same LDS words)
+        const float p = T[j][j], norm2 = G[j][j];
+        const float xnorm2 = norm2 - p * p;                     // |x[1:]|^2
+        const bool reflect = xnorm2 > 0.f && norm2 > 0.f;       // LAPACK larfg: xnorm == 0 -> H = I
+        const float beta = reflect ? (p >= 0.f ? -sqrtf(norm2) : sqrtf(norm2)) : p;
+        const float tau = reflect ? 1.f / (norm2 - beta * p) : 0.f;       // 2 / (v^T v), v = x - beta e_j
+        if (tid < n) {
+            w[tid] = G[tid][j] - beta * T[j][tid];
+            v[tid] = tid == j ? p - beta : (tid > j ? T[tid][j] : 0.f);
+        }
+        __syncthreads();
+        for (int e = tid; e < (n - j) * n; e += 256) {
+            const int i = j + e / n, c = e % n;
+            T[i][c] -= tau * v[i] * w[c];
+        }
+        __syncthreads();
+        if (tid == 0) T[j][j] = beta;                            // exact value of the diagonal (the update rounds)
+        for (int e = tid; e < n * n; e += 256) {
+            const int a = e / n, c = e % n;
+            if (a >= j && c >= j) G[a][c] -= T[j][a] * T[j][c];
+        }
+        __syncthreads();
+    }
+    // R = triu(T);  R^-1 by back substitution, one column per thread
+    for (int e = tid; e < n * n; e += 256) {
+        const int i = e / n, c = e % n;
+        R_out[e] = c >= i ? T[i][c] : 0.f;
+    }
+    if (tid < n) {
+        const int c = tid;
+        for (int i = n - 1; i >= 0; --i) {
+            float acc = i == c ? 1.f : 0.f;
+            for (int k = i + 1; k <= c; ++k) acc -= T[i][k] * Ri[k][c];
+            Ri[i][c] = i <= c ? acc / T[i][i] : 0.f;
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < n * n; e += 256) Rinv_out[e] = Ri[e / n][e % n];
+}
+
+}  // namespace hfagp
+
+using namespace hfagp;
+
+extern "C" int hfagp_qr_gram_fwd(const float* gram, const float* top, float* R, float* Rinv, int32_t n, void* stream) {
+    HFAGP_REQUIRE(gram && top && R && Rinv, HFAGP_EBADARG, "qr_gram_fwd: null pointer");
+    HFAGP_REQUIRE(n >= 1 && n <= kQrMax, HFAGP_EUNSUPPORTED, "qr_gram_fwd: n=%d must be in 1..%d", n, kQrMax);
+    qr_gram_kernel<<<1, 256, 0, (hipStream_t)stream>>>(gram, top, R, Rinv, n);
+    return check_launch("qr_gram_fwd");
+}

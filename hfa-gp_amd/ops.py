@@ -128,6 +128,38 @@ def styles_demod_batch(items):
     return out
 
 
+def qr_gram(gram: torch.Tensor, top: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """gram = A^T A [n, n], top = A[:n, :n] → (R with LAPACK's signs, R^-1); Q = A @ R^-1 (n <= 64)."""
+    n = gram.shape[0]
+    r = torch.empty(n, n, device=gram.device, dtype=torch.float32)
+    rinv = torch.empty(n, n, device=gram.device, dtype=torch.float32)
+    L.check(L.lib().hfagp_qr_gram_fwd(_ptr(_chk(gram, "gram")), _ptr(_chk(top, "top")), _ptr(r), _ptr(rinv), n, _stream()),
+            "qr_gram_fwd")
+    return r, rinv
+
+
+class TallSkinnyQR(torch.autograd.Function):
+    """Q of the reduced QR of a tall-skinny fp32 CUDA matrix A [m, n <= 64] with torch.linalg.qr's (LAPACK's) sign
+    convention; backward = the standard QR adjoint for dR = 0:
+        dA = (dQ + Q S) R^-T,   X = triu(-Q^T dQ),   S = X + X^T - diag(X)."""
+
+    @staticmethod
+    def forward(ctx, a: torch.Tensor) -> torch.Tensor:
+        n = a.shape[1]
+        gram = (a.T @ a).contiguous()
+        _, rinv = qr_gram(gram, a[:n, :n].contiguous())
+        q = a @ rinv
+        ctx.save_for_backward(q, rinv)
+        return q
+
+    @staticmethod
+    def backward(ctx, gq: torch.Tensor):
+        q, rinv = ctx.saved_tensors
+        x = torch.triu(-(q.T @ gq))
+        s = x + x.T - torch.diag(torch.diagonal(x))
+        return (gq + q @ s) @ rinv.T
+
+
 def fully_connected(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], lr_mul: float = 1.0,
                     act: str = "linear", alpha: float = 0.2, gain: Optional[float] = None) -> torch.Tensor:
     """EG3D FullyConnectedLayer: act((x @ (W*lr_mul/sqrt(in)).T + b*lr_mul)) * gain."""

@@ -95,6 +95,12 @@ int hfagp_style_fwd(const HfagpStyleArgs* a, void* stream);
  * synthesis pass depend only on ws, so the host computes them up front                                    */
 int hfagp_style_batch_fwd(const HfagpStyleArgs* items, int32_t n, void* stream);
 
+/* Householder QR of the latent basis A = (bases + 1e-8)^T [m x n], n <= 64 (headnerf.py:85-91), split as
+ *   gram = A^T A [n][n] and top = A[0:n, 0:n] [n][n] (row-major, formed by the caller with one GEMM / one copy)
+ *   -> R [n][n] upper triangular with LAPACK geqrf's sign convention, Rinv = R^-1;  the caller forms Q = A . Rinv.
+ * One small kernel instead of the ~250 launches of a library geqrf + orgqr on a 7168 x 50 panel.            */
+int hfagp_qr_gram_fwd(const float* gram, const float* top, float* R, float* Rinv, int32_t n, void* stream);
+
 /* FullyConnectedLayer (mapping network): y = act((x . W^T) * lr_mul/sqrt(In) + bias*lr_mul) * gain   [B][Out] */
 int hfagp_fc_fwd(const float* x, const float* weight, const float* bias, float* y, int32_t B, int32_t In, int32_t Out,
                  float lr_mul, int32_t act, float alpha, float gain, void* stream);

@@ -290,3 +290,51 @@ def test_generator_parameter_gradients_vs_oracle_autograd(dev, preset, batch, pr
         if not err <= tol * scale + 1e-7:
             bad.append((n, err, scale))
     assert not bad, bad[:8]
+
+
+@pytest.mark.parametrize("m,n", [(7168, 50), (7168, 8), (7168, 64), (512, 64)])
+def test_tall_skinny_qr_matches_torch(dev, m, n):
+    """ops.TallSkinnyQR (Gram-matrix Householder kernel) against torch.linalg.qr on the CPU: same Q
+    including LAPACK's column signs, and the same gradient for a random upstream dQ (headnerf.py:85-98).  (The
+    method squares the condition number: it is for tall, well-conditioned panels like the latent basis; HeadNeRF
+    falls back to torch.linalg.qr for m < 8 n.)"""
+    from hfa_gp_amd import ops
+    g = torch.Generator().manual_seed(m + n)
+    bases = torch.randn(n, m, generator=g)
+    a_ref = (bases.double() + 1e-8).T.clone().requires_grad_(True)
+    q_ref = torch.linalg.qr(a_ref, mode="reduced")[0]
+    gq = torch.randn(m, n, generator=g)
+    (q_ref * gq.double()).sum().backward()
+    b_d = bases.to(dev).requires_grad_(True)
+    q = ops.TallSkinnyQR.apply((b_d + 1e-8).T)
+    (q * gq.to(dev)).sum().backward()
+    close(q, q_ref.float(), atol=2e-6)
+    eye = torch.eye(n)
+    close((q.T @ q).cpu(), eye, atol=5e-6)
+    scale = a_ref.grad.abs().max().item()
+    close(b_d.grad.T, a_ref.grad.float(), atol=2e-5 * scale)
+
+
+def test_get_latent_fast_qr_matches_torch_qr(dev):
+    """The latent-basis map ws = alpha @ Q^T + delta with Q from TallSkinnyQR against the same map with
+    torch.linalg.qr on the CPU: ws and the gradients w.r.t. bases, delta and alpha."""
+    from hfa_gp_amd import ops
+    g = torch.Generator().manual_seed(3)
+    k, dim = 50, 512
+    bases = torch.randn(k, 14 * dim, generator=g)
+    delta = bases.mean(0)
+    alpha = torch.randn(3, k, generator=g)
+    gws = torch.randn(3, 14, dim, generator=g)
+
+    def latent(b, d, al, qr):
+        q = qr((b + 1e-8).T)
+        return (al @ q.T).view(al.shape[0], -1, dim) + d.view(-1, dim)
+    ref_in = [t.double().clone().requires_grad_(True) for t in (bases, delta, alpha)]
+    ws_ref = latent(*ref_in, lambda a: torch.linalg.qr(a, mode="reduced")[0])
+    (ws_ref * gws.double()).sum().backward()
+    got_in = [t.to(dev).requires_grad_(True) for t in (bases, delta, alpha)]
+    ws = latent(*got_in, ops.TallSkinnyQR.apply)
+    (ws * gws.to(dev)).sum().backward()
+    close(ws, ws_ref.float(), atol=2e-5)
+    for got, ref in zip(got_in, ref_in):
+        close(got.grad, ref.grad.float(), atol=2e-5 * ref.grad.abs().max().item() + 1e-7)
