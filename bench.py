@@ -28,6 +28,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32 dense peak
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_bf16 dense peak
 SPLIT_MFMAS = {"bf16x3": 3, "bf16x6": 6}   # bf16 MFMAs per algorithmic (fp32) product on the split path
+MFMA_F16_PEAK_TFLOPS = 2500.0   # v_mfma_f32_32x32x16_f16 dense peak (same rate as bf16)
 
 
 def parse():
@@ -45,6 +46,8 @@ def parse():
     ap.add_argument("--precision", default=None, choices=["fp32", "bf16x3", "bf16x6"],
                     help="conv GEMM arithmetic of the headline leg (default: the preset's conv_precision)")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the second render leg on the exact fp32 kernel")
+    ap.add_argument("--no-f16-leg", action="store_true",
+                    help="skip the legs with the super-resolution / all convs on the single-pass fp16 MFMA path")
     return ap.parse_args()
 
 
@@ -156,9 +159,11 @@ def main():
     def step():
         return gen.synthesis(ws, c, noise_mode="const", u_strat=us, u_imp=ui)["image"]
 
-    def render_leg(precision):
-        """W warm-up + K timed steps with the conv GEMMs in ``precision``; (seconds max over ranks, event table)."""
+    def render_leg(precision, sr_precision=None):
+        """W warm-up + K timed steps with the conv GEMMs in ``precision`` (super-resolution blocks: ``sr_precision``
+        when given); (seconds max over ranks, event table)."""
         gen.conv_precision = precision
+        gen.sr_conv_precision = sr_precision
         for _ in range(args.warmup):
             step()
         torch.cuda.synchronize()
@@ -188,6 +193,11 @@ def main():
         dt32, timing32 = render_leg("fp32")
         if prec != "bf16x6":
             dt6, _ = render_leg("bf16x6")
+    dt16sr = dt16 = timing16 = None
+    if not args.no_f16_leg:
+        # the reference's CUDA defaults: fp32-class backbone, fp16 super-resolution; then every conv in fp16
+        dt16sr, timing16 = render_leg(prec, "f16")
+        dt16, _ = render_leg("f16")
     dt, timing = render_leg(prec)
 
     def agg(key, table=None):
@@ -262,6 +272,18 @@ def main():
                                   "algorithmic_bytes_per_launch": rm_bytes / max(rm_n, 1)},
         }
         out["config"]["conv_precision"] = prec
+        if dt16sr is not None:
+            # not the headline: products of the super-resolution convs (value_f16_sr: the reference's own CUDA
+            # precision split) or of all convs (value_f16) rounded to fp16, one fp16 MFMA per product
+            out["value_f16_sr"] = frames / dt16sr
+            out["value_f16"] = frames / dt16
+            ms, flops, n = agg("modconv_f16", timing16)
+            tf = flops / (ms * 1e-3) / 1e12
+            out["roofline_f16_sr"] = {"bound": "mfma", "kernel": "modconv_bf16_kernel<1> / upconv_bf16_kernel<1> "
+                                                                 "(1 x v_mfma_f32_32x32x16_f16 per product)",
+                                      "achieved": tf, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                      "frac": tf / MFMA_F16_PEAK_TFLOPS, "traffic": None,
+                                      "avg_launch_ms": ms / max(n, 1), "launches": n}
         if dt6 is not None:
             out["value_bf16x6"] = frames / dt6       # 6 bf16 MFMAs per product: image error = the exact kernel's
         if dt32 is not None:

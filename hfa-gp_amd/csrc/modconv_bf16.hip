@@ -22,13 +22,15 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int CKB = 16;          // channels per K chunk
 constexpr int APITCH = 48;       // LDS bytes per patch position and part: 16 bf16 + 16 B pad (3 x 16-B slots, odd)
 // LDS row pitch of the patch in positions.  32 (a multiple of 16) makes every 16-lane group of a ds_read_b128
 // cover 16 consecutive columns -> 16 distinct 16-B slots, no bank conflicts (the groups are {0-3,12-15,20-27},...);
 // the 3-part image would not fit twice per CU at that pitch and keeps the dense one (1 extra LDS cycle per group).
-template <int NP> struct RowPitch { static constexpr int value = NP == 2 ? 32 : PW + 2; };
+template <int NP> struct RowPitch { static constexpr int value = NP <= 2 ? 32 : PW + 2; };
 constexpr int BNB = 128;         // output channels per block
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
@@ -36,9 +38,27 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
 
-// v (4 floats) -> NP x 4 bf16 (two dwords per part)
+__device__ __forceinline__ unsigned pack_f16(float a, float b) {
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+}
+
+// one MFMA of the path: NP = 1 is the single-pass fp16 mode (HFAGP_PREC_F16), NP >= 2 the bf16 part products
+template <int NP>
+__device__ __forceinline__ f32x16 mfma16(u32x4 a, u32x4 b, f32x16 c) {
+    if constexpr (NP == 1)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// v (4 floats) -> NP x 4 bf16 (two dwords per part); NP = 1: 4 fp16 (round to nearest even)
 template <int NP>
 __device__ __forceinline__ void split4(float4 v, uint2 (&out)[NP]) {
+    if constexpr (NP == 1) {
+        out[0] = make_uint2(pack_f16(v.x, v.y), pack_f16(v.z, v.w));
+        return;
+    }
     float r[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
@@ -169,7 +189,7 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
     // part products in the order they are issued: (A part, B part)
-    constexpr int NPROD = NP == 2 ? 3 : 6;
+    constexpr int NPROD = NP == 1 ? 1 : NP == 2 ? 3 : 6;
     constexpr int PA[6] = {0, 1, 0, 1, 2, 0};
     constexpr int PB[6] = {0, 0, 1, 1, 0, 2};
 
@@ -181,7 +201,8 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
 #ifndef HFAGP_RB9
 #define HFAGP_RB9 3
 #endif
-        constexpr int RB = NT == 9 ? HFAGP_RB9 : NT == 4 ? 4 : 2;      // ring size: divides U*NT
+        // ring size: divides U*NT (the single-pass fp16 mode has a third of the MFMA time per item: deeper ring)
+        constexpr int RB = NT == 9 ? (NP == 1 ? 6 : HFAGP_RB9) : NT == 4 ? 4 : 2;
         constexpr int U = 2;                                   // chunk pairs: chunk parity = A buffer = compile time
         u32x4 bq[RB][TN][NP];
         // loads of item (chunk c, tap t) into ring slot `slot`; c is clamped so that the look-ahead past the last
@@ -196,7 +217,7 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
                 for (int tn = 0; tn < TN; ++tn) bq[SL][tn][q] = *reinterpret_cast<const u32x4*>(base + bth[tn]);
             }
         };
-        bf16x8 af[2][TMW][NP];                               // A fragments of the current and the next tap
+        u32x4 af[2][TMW][NP];                                // A fragments of the current and the next tap
         auto read_a = [&](auto u_tag, auto t_tag) __attribute__((always_inline)) {
             constexpr int UU = decltype(u_tag)::value, T = decltype(t_tag)::value;
             const char* Ac = As + UU * A_BUF;               // chunk parity = LDS buffer: immediate offsets
@@ -205,10 +226,10 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
 #pragma unroll
                 for (int q = 0; q < NP; ++q) {
                     if constexpr (NT == 9)
-                        af[T & 1][tm][q] = *reinterpret_cast<const bf16x8*>(
+                        af[T & 1][tm][q] = *reinterpret_cast<const u32x4*>(
                             Ac + q * A_PART + ((T / 3) * LPWB + T % 3) * APITCH + apos[tm]);
                     else
-                        af[T & 1][tm][q] = *reinterpret_cast<const bf16x8*>(Ac + q * A_PART + toff[T & 3] + apos[tm]);
+                        af[T & 1][tm][q] = *reinterpret_cast<const u32x4*>(Ac + q * A_PART + toff[T & 3] + apos[tm]);
                 }
         };
         // The patch of chunk c+1 is converted and written to the OTHER LDS buffer inside the last A_PER_T taps of
@@ -229,8 +250,7 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
                 for (int tm = 0; tm < TMW; ++tm)
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn)
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                            af[T & 1][tm][PA[pr]], __builtin_bit_cast(bf16x8, bq[SL][tn][PB[pr]]), acc[tm][tn], 0, 0, 0);
+                        acc[tm][tn] = mfma16<NP>(af[T & 1][tm][PA[pr]], bq[SL][tn][PB[pr]], acc[tm][tn]);
 #pragma unroll
             for (int k = 0; k < A_PER_T; ++k) {
                 const int tk = NT - A_PER_T + k < 0 ? 0 : NT - A_PER_T + k;      // tap that carries slot k
@@ -343,7 +363,7 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
 //   shift (-1,-1): phase 0 w[8]                       (w[k] = tap k of the 3x3 kernel, y_t[2i+ti][2j+tj] += x[i][j] w[ti][tj])
 template <int NP>
 __global__ void __launch_bounds__(256, 1) upconv_bf16_kernel(const ConvParams p) {
-    constexpr int TM = 2, TN = 1, WN = 2, BM = 128, BNU = WN * TN * 32, PH = BM / PW, NITEM = 9, RB = 3;
+    constexpr int TM = 2, TN = 1, WN = 2, BM = 128, BNU = WN * TN * 32, PH = BM / PW, NITEM = 9, RB = NP == 1 ? 6 : 3;
     constexpr int LPWB = RowPitch<NP>::value;
     constexpr int APOS = (PH + 2) * LPWB;
     constexpr int A_PART = APOS * APITCH, A_BUF = NP * A_PART;
@@ -434,11 +454,11 @@ __global__ void __launch_bounds__(256, 1) upconv_bf16_kernel(const ConvParams p)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[f][tm][tn][r] = 0.f;
 
-    constexpr int NPROD = NP == 2 ? 3 : 6;
+    constexpr int NPROD = NP == 1 ? 1 : NP == 2 ? 3 : 6;
     constexpr int PA[6] = {0, 1, 0, 1, 2, 0};
     constexpr int PB[6] = {0, 0, 1, 1, 0, 2};
     u32x4 bq[RB][TN][NP];
-    bf16x8 af[2][TM][NP];                 // A fragments of the current and the next shift group
+    u32x4 af[2][TM][NP];                  // A fragments of the current and the next shift group
     auto issue_b = [&](int c, auto i_tag, auto slot_tag) __attribute__((always_inline)) {
         constexpr int I = decltype(i_tag)::value, SL = decltype(slot_tag)::value;
         const int cc = min(c, c_end - 1);
@@ -455,7 +475,7 @@ __global__ void __launch_bounds__(256, 1) upconv_bf16_kernel(const ConvParams p)
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
             for (int q = 0; q < NP; ++q)
-                af[G & 1][tm][q] = *reinterpret_cast<const bf16x8*>(As + UU * A_BUF + q * A_PART + G_OFF[G] + apos[tm]);
+                af[G & 1][tm][q] = *reinterpret_cast<const u32x4*>(As + UU * A_BUF + q * A_PART + G_OFF[G] + apos[tm]);
     };
     auto item = [&](int c, auto u_tag, auto i_tag) __attribute__((always_inline)) {
         constexpr int I = decltype(i_tag)::value, G = I_GRP[I], F = I_PHASE[I];
@@ -468,8 +488,7 @@ __global__ void __launch_bounds__(256, 1) upconv_bf16_kernel(const ConvParams p)
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn)
-                    acc[F][tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                        af[G & 1][tm][PA[pr]], __builtin_bit_cast(bf16x8, bq[SL][tn][PB[pr]]), acc[F][tm][tn], 0, 0, 0);
+                    acc[F][tm][tn] = mfma16<NP>(af[G & 1][tm][PA[pr]], bq[SL][tn][PB[pr]], acc[F][tm][tn]);
         // the patch of the next chunk is converted into the other LDS buffer under the last three items
         if constexpr (I >= NITEM - 3)
             store_a(min(c + 1, c_end - 1), std::integral_constant<int, 1 - decltype(u_tag)::value>{},
@@ -564,13 +583,15 @@ int launch_modconv_bf16(const HfagpModconvArgs* a, Plan& pl, hipStream_t s) {
                   "modconv (split bf16): Cin=%d must be a multiple of %d and Cout=%d of %d", a->Cin, CKB, a->Cout, BNB);
     HFAGP_REQUIRE(pl.bn == BNB && pl.bm == 128, HFAGP_EUNSUPPORTED, "modconv (split bf16): unexpected plan");
     HFAGP_REQUIRE(a->Cin <= 512, HFAGP_EUNSUPPORTED, "modconv (split bf16): Cin=%d > 512 (style image in LDS)", a->Cin);
-    HFAGP_REQUIRE(a->precision == HFAGP_PREC_BF16X3 || a->precision == HFAGP_PREC_BF16X6, HFAGP_EBADARG,
-                  "modconv: unknown precision %d", a->precision);
+    HFAGP_REQUIRE(a->precision == HFAGP_PREC_BF16X3 || a->precision == HFAGP_PREC_BF16X6 || a->precision == HFAGP_PREC_F16,
+                  HFAGP_EBADARG, "modconv: unknown precision %d", a->precision);
     // the kernel is specialised on the tap count: one launch per run of phases with the same number of taps
     // (3x3: one; stride-2 transposed conv and its adjoint: 4 | 2, 2 | 1)
     const ConvParams& p = pl.p;
     if (pl.merged_up) {                 // one block for the four phases (grid.y = 1)
-        if (a->precision == HFAGP_PREC_BF16X3)
+        if (a->precision == HFAGP_PREC_F16)
+            upconv_bf16_kernel<1><<<pl.grid, 256, bf16_lds_bytes<1, 2>(a->Cin), s>>>(p);
+        else if (a->precision == HFAGP_PREC_BF16X3)
             upconv_bf16_kernel<2><<<pl.grid, 256, bf16_lds_bytes<2, 2>(a->Cin), s>>>(p);
         else
             upconv_bf16_kernel<3><<<pl.grid, 256, bf16_lds_bytes<3, 2>(a->Cin), s>>>(p);
@@ -581,14 +602,15 @@ int launch_modconv_bf16(const HfagpModconvArgs* a, Plan& pl, hipStream_t s) {
         while (p0 + n < p.nphase && p.phase[p0 + n].ntaps == p.phase[p0].ntaps) ++n;
         const int nt = p.phase[p0].ntaps;
         HFAGP_REQUIRE(nt == 9 || nt == 4 || nt == 2 || nt == 1, HFAGP_EUNSUPPORTED, "modconv (split bf16): %d taps", nt);
-        if (a->precision == HFAGP_PREC_BF16X3) launch_group<2>(pl, p0, n, nt, bf16_lds_bytes<2, 2>(a->Cin), s);
+        if (a->precision == HFAGP_PREC_F16) launch_group<1>(pl, p0, n, nt, bf16_lds_bytes<1, 2>(a->Cin), s);
+        else if (a->precision == HFAGP_PREC_BF16X3) launch_group<2>(pl, p0, n, nt, bf16_lds_bytes<2, 2>(a->Cin), s);
         else launch_group<3>(pl, p0, n, nt, bf16_lds_bytes<3, 2>(a->Cin), s);
         p0 += n;
     }
     return check_launch("modconv_fwd (split bf16)");
 }
 
-// weight [Cout][Cin][taps] -> wb [nparts][taps][Cin/8][Cout][8] bf16; thread = (tap, ci group, co)
+// weight [Cout][Cin][taps] -> wb [nparts][taps][Cin/8][Cout][8] bf16 (nparts = 1: fp16); thread = (tap, ci group, co)
 __global__ void __launch_bounds__(256) weight_prep_split_kernel(const float* __restrict__ w, uint4* __restrict__ wb,
                                                                 int Cout, int Cin, int taps, int nparts) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -601,6 +623,10 @@ __global__ void __launch_bounds__(256) weight_prep_split_kernel(const float* __r
     float r[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) r[e] = w[((size_t)co * Cin + 8 * g + e) * taps + t];
+    if (nparts == 1) {
+        wb[idx] = make_uint4(pack_f16(r[0], r[1]), pack_f16(r[2], r[3]), pack_f16(r[4], r[5]), pack_f16(r[6], r[7]));
+        return;
+    }
     for (int q = 0; q < nparts; ++q) {
         unsigned u[4];
 #pragma unroll
@@ -620,8 +646,8 @@ using namespace hfagp;
 extern "C" int hfagp_weight_prep_split(const float* weight, void* wb, int32_t Cout, int32_t Cin, int32_t taps,
                                        int32_t nparts, void* stream) {
     HFAGP_REQUIRE(weight && wb, HFAGP_EBADARG, "weight_prep_split: null pointer");
-    HFAGP_REQUIRE(Cin % 8 == 0 && Cout > 0 && (taps == 1 || taps == 9) && (nparts == 2 || nparts == 3),
-                  HFAGP_EUNSUPPORTED, "weight_prep_split: Cin=%d must be a multiple of 8, taps=%d in {1,9}, nparts=%d in {2,3}",
+    HFAGP_REQUIRE(Cin % 8 == 0 && Cout > 0 && (taps == 1 || taps == 9) && nparts >= 1 && nparts <= 3,
+                  HFAGP_EUNSUPPORTED, "weight_prep_split: Cin=%d must be a multiple of 8, taps=%d in {1,9}, nparts=%d in {1,2,3}",
                   Cin, taps, nparts);
     const long long n = (long long)taps * (Cin / 8) * Cout;
     weight_prep_split_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(

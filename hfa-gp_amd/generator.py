@@ -143,7 +143,10 @@ class TriPlaneGenerator(nn.Module):
         self.decoder = dec
         self._prep: Dict[object, tuple] = {}     # (kind, ..., id(param)) -> (version, data_ptr, image, wsq)
         self._conv_precision = "fp32"
+        self._sr_conv_precision: Optional[str] = None
         self.conv_precision = cfg.conv_precision
+        self.sr_conv_precision = cfg.sr_conv_precision
+        self._sr_weight_ids = {id(l.weight) for blk in (sr.block0, sr.block1) for l in (blk.conv0, blk.conv1)}
         self._styles: Dict[int, tuple] = {}      # id(layer) -> (styles, dcoef) of the pass in flight
         self._scalars: Dict[int, tuple] = {}     # id(param) -> (version, data_ptr, python float)
         self._const_nhwc: Optional[tuple] = None
@@ -164,9 +167,22 @@ class TriPlaneGenerator(nn.Module):
     @property
     def conv_precision(self) -> str:
         """Arithmetic of the conv GEMMs: 'fp32' (exact MFMA), 'bf16x3' or 'bf16x6' (split-bf16 MFMA, fp32
-        accumulation; include/hfagp.h HFAGP_PREC_*).  Layers whose shape the split kernel does not take
-        (Cin % 16, Cout % 128) always run on the exact fp32 kernel."""
+        accumulation; include/hfagp.h HFAGP_PREC_*), 'f16' (single-pass fp16 MFMA, fp32 accumulation: the
+        arithmetic of EG3D's fp16 blocks).  Layers whose shape the 16-bit kernels do not take (Cin % 16,
+        Cout % 128) always run on the exact fp32 kernel; gradient GEMMs of an 'f16' layer run in bf16x3 (a raw
+        gradient has no place in fp16's exponent range without loss scaling)."""
         return self._conv_precision
+
+    @property
+    def sr_conv_precision(self) -> Optional[str]:
+        """Precision of the super-resolution blocks' 3x3 convs; None = conv_precision."""
+        return self._sr_conv_precision
+
+    @sr_conv_precision.setter
+    def sr_conv_precision(self, value: Optional[str]):
+        if value is not None and value not in ops.PRECISIONS:
+            raise ValueError(f"sr_conv_precision must be None or one of {sorted(ops.PRECISIONS)}, got {value!r}")
+        self._sr_conv_precision = value
 
     @conv_precision.setter
     def conv_precision(self, value: str):
@@ -180,7 +196,12 @@ class TriPlaneGenerator(nn.Module):
         co, ci = weight.shape[:2]
         if transposed:
             co, ci = ci, co
-        nparts = {"fp32": 0, "bf16x3": 2, "bf16x6": 3}[self._conv_precision]
+        prec = self._conv_precision
+        if self._sr_conv_precision is not None and id(weight) in self._sr_weight_ids:
+            prec = self._sr_conv_precision
+        if transposed and prec == "f16":
+            prec = "bf16x3"
+        nparts = ops.NPARTS[prec]
         if not ops.split_supported(ci, co):
             nparts = 0
         key = ("G", nparts, transposed, id(weight))
@@ -234,15 +255,22 @@ class TriPlaneGenerator(nn.Module):
             raise NotImplementedError("noise_mode must be 'const' or 'none' (HFA-GP passes 'const', headnerf.py:112)")
         cout = layer.weight.shape[0]
         gain = math.sqrt(2.0)
+        k_styles, k_dcoef = styles, dcoef
+        if wt.dtype == torch.float16:
+            # EG3D's fp16 guard (modulated_conv2d: styles / max|styles| before the product, undone by the
+            # demodulation): keeps x * style inside fp16's range; the tape keeps the un-normalised pair
+            m = styles.abs().amax(1, keepdim=True)
+            k_styles, k_dcoef = styles / m, dcoef * m
         # algorithmic FLOPs: 2 * B * H_in * W_in * Cin * Cout * 9 (the up-conv is counted in its
         # polyphase / transposed form at INPUT resolution)
         flops = 2.0 * batch * x.shape[1] * x.shape[2] * x.shape[3] * cout * 9
-        key = "modconv" if wt.dtype == torch.float32 else "modconv_split"      # which kernel bench.py times
+        # which kernel bench.py times
+        key = {torch.float32: "modconv", torch.bfloat16: "modconv_split", torch.float16: "modconv_f16"}[wt.dtype]
         if layer.up == 2:
-            yt = self._timed(key, flops, ops.modconv, x, wt, cout, ops.CONVT3X3_UP2, styles=styles, batch=batch)
-            out = ops.upfir_epilogue(yt, dcoef, noise, ns, layer.bias, "lrelu", cfg.lrelu_alpha, gain, conv_clamp)
+            yt = self._timed(key, flops, ops.modconv, x, wt, cout, ops.CONVT3X3_UP2, styles=k_styles, batch=batch)
+            out = ops.upfir_epilogue(yt, k_dcoef, noise, ns, layer.bias, "lrelu", cfg.lrelu_alpha, gain, conv_clamp)
         else:
-            out = self._timed(key, flops, ops.modconv, x, wt, cout, ops.CONV3X3, styles=styles, dcoef=dcoef,
+            out = self._timed(key, flops, ops.modconv, x, wt, cout, ops.CONV3X3, styles=k_styles, dcoef=k_dcoef,
                               noise=noise, noise_strength=ns, bias=layer.bias, act="lrelu", alpha=cfg.lrelu_alpha,
                               gain=gain, clamp=conv_clamp, batch=batch)
         rec = None

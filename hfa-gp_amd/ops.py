@@ -61,8 +61,9 @@ def weight_prep(weight: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     return wt, wsq
 
 
-PREC_F32, PREC_BF16X3, PREC_BF16X6 = 0, 1, 2
-PRECISIONS = {"fp32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16x6": PREC_BF16X6}
+PREC_F32, PREC_BF16X3, PREC_BF16X6, PREC_F16 = 0, 1, 2, 3
+PRECISIONS = {"fp32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16x6": PREC_BF16X6, "f16": PREC_F16}
+NPARTS = {"fp32": 0, "f16": 1, "bf16x3": 2, "bf16x6": 3}      # parts of the 16-bit weight image (0: fp32 image)
 
 
 def split_supported(cin: int, cout: int) -> bool:
@@ -72,10 +73,12 @@ def split_supported(cin: int, cout: int) -> bool:
 
 def weight_prep_split(weight: torch.Tensor, nparts: int) -> torch.Tensor:
     """weight [Cout, Cin, k, k] fp32 → split-bf16 B-operand image [nparts, k*k, Cin/8, Cout, 8] (bfloat16):
-    weight = sum of the parts, each the round-to-nearest bf16 of the residual (nparts 2: BF16X3, 3: BF16X6)."""
+    weight = sum of the parts, each the round-to-nearest bf16 of the residual (nparts 2: BF16X3, 3: BF16X6).
+    nparts 1: the single-pass fp16 image (float16, HFAGP_PREC_F16)."""
     _chk(weight, "weight")
     co, ci, kh, kw = weight.shape
-    wb = torch.empty(nparts, kh * kw, ci // 8, co, 8, device=weight.device, dtype=torch.bfloat16)
+    wb = torch.empty(nparts, kh * kw, ci // 8, co, 8, device=weight.device,
+                     dtype=torch.float16 if nparts == 1 else torch.bfloat16)
     L.check(L.lib().hfagp_weight_prep_split(_ptr(weight), wb.data_ptr(), co, ci, kh * kw, nparts, _stream()),
             "weight_prep_split")
     return wb
@@ -183,7 +186,7 @@ def modconv(x: torch.Tensor, wt: torch.Tensor, cout: int, mode: int, styles: Opt
     """x [B|1, H, W, Cin] channels-last.  mode CONV3X3 / CONV1X1: fused epilogue, returns [B,H,W,Cout];
     mode CONVT3X3_UP2: returns the RAW transposed-conv result [B, 2H+1, 2W+1, Cout].
     ``wt`` from :func:`weight_prep` (fp32, exact MFMA) or :func:`weight_prep_split` (bfloat16 parts: the
-    split-bf16 MFMA path, BF16X3 for 2 parts, BF16X6 for 3)."""
+    split-bf16 MFMA path, BF16X3 for 2 parts, BF16X6 for 3; float16, 1 part: the single-pass fp16 path)."""
     _chk(x, "x")
     if mode == CONVS2_BWD:                      # x = four parity images [2,2,B,H+1,W+1,Cin]
         _, _, xb, h, w, cin = x.shape
@@ -192,11 +195,12 @@ def modconv(x: torch.Tensor, wt: torch.Tensor, cout: int, mode: int, styles: Opt
         xb, h, w, cin = x.shape
     b = batch if batch is not None else xb
     a = L.ModconvArgs()
-    if wt.dtype == torch.bfloat16:
-        if not (wt.is_cuda and wt.is_contiguous() and wt.dim() == 5 and wt.shape[0] in (2, 3)):
-            raise RuntimeError("modconv: split weights must come from weight_prep_split")
+    if wt.dtype in (torch.bfloat16, torch.float16):
+        nparts = (2, 3) if wt.dtype == torch.bfloat16 else (1,)
+        if not (wt.is_cuda and wt.is_contiguous() and wt.dim() == 5 and wt.shape[0] in nparts):
+            raise RuntimeError("modconv: 16-bit weight images must come from weight_prep_split")
         a.x, a.wt = _ptr(x), wt.data_ptr()
-        a.precision = PREC_BF16X3 if wt.shape[0] == 2 else PREC_BF16X6
+        a.precision = {1: PREC_F16, 2: PREC_BF16X3, 3: PREC_BF16X6}[wt.shape[0]]
     else:
         a.x, a.wt = _ptr(x), _ptr(_chk(wt, "wt"))
         a.precision = PREC_F32

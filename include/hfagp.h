@@ -113,7 +113,8 @@ int hfagp_weight_prep(const float* weight, float* wt, float* wsq,
 
 /* split-bf16 weight image for the HFAGP_PREC_BF16X3 / _BF16X6 conv path:
  *   wb [nparts][taps][Cin/8][Cout][8] bf16  <- weight [Cout][Cin][kh][kw],  w = part0 + part1 (+ part2),
- *   each part the round-to-nearest bf16 of the residual left by the parts before it (nparts = 2 or 3).   */
+ *   each part the round-to-nearest bf16 of the residual left by the parts before it (nparts = 2 or 3).
+ *   nparts = 1: the HFAGP_PREC_F16 image, same layout, elements rounded to IEEE fp16.                     */
 int hfagp_weight_prep_split(const float* weight, void* wb, int32_t Cout, int32_t Cin, int32_t taps,
                             int32_t nparts, void* stream);
 
@@ -137,12 +138,16 @@ enum { HFAGP_ACT_LINEAR = 0, HFAGP_ACT_LRELU = 1 };
  *   BF16X3  operands split into 2 bf16 parts (hi+lo), 3 v_mfma_f32_32x32x16_bf16 per product
  *           (hi.hi + lo.hi + hi.lo): relative product error ~2^-16
  *   BF16X6  3 parts, 6 MFMAs per product: relative product error ~2^-23 (fp32 class)
- * The split paths need Cin % 16 == 0 and Cout % 128 == 0 (HFAGP_EUNSUPPORTED otherwise).             */
-enum { HFAGP_PREC_F32 = 0, HFAGP_PREC_BF16X3 = 1, HFAGP_PREC_BF16X6 = 2 };
+ *   F16     operands rounded to fp16, ONE v_mfma_f32_32x32x16_f16 per product: relative product error ~2^-11.
+ *           The arithmetic EG3D's CUDA path uses in its fp16 blocks (super-resolution, sr_num_fp16_res = 4:
+ *           SURVEY.md U4) except that tensors stay fp32 in HBM and accumulation is fp32.  The caller keeps
+ *           |x * style| below 65504 (EG3D's pre-normalisation of the styles by their max, compensated in dcoef).
+ * The 16-bit paths need Cin % 16 == 0 and Cout % 128 == 0 (HFAGP_EUNSUPPORTED otherwise).            */
+enum { HFAGP_PREC_F32 = 0, HFAGP_PREC_BF16X3 = 1, HFAGP_PREC_BF16X6 = 2, HFAGP_PREC_F16 = 3 };
 
 typedef struct {
     const float* x;           /* [B][H][W][Cin]; x_batch_stride (elements) may be 0 (const)   */
-    const void*  wt;          /* hfagp_weight_prep (F32) or hfagp_weight_prep_split (BF16X3: 2, BF16X6: 3 parts) */
+    const void*  wt;          /* hfagp_weight_prep (F32) or hfagp_weight_prep_split (F16: 1, BF16X3: 2, BF16X6: 3 parts) */
     const float* styles;      /* [B][Cin] or NULL                                             */
     const float* dcoef;       /* [B][Cout] or NULL                                            */
     const float* noise;       /* [Ho][Wo] or NULL                                             */

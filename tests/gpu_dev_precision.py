@@ -20,11 +20,12 @@ def main():
     gen = gen.to(dev).requires_grad_(False)
     ws, c, us, ui = make_inputs(cfg, 1)
     ref = O.synthesis(P, cfg, ws, c, us, ui)["image"]
-    for prec in ("fp32", "bf16x6", "bf16x3"):
-        gen.conv_precision = prec
+    for prec, sr in (("fp32", None), ("bf16x6", None), ("bf16x3", None), ("bf16x3", "f16"), ("f16", None)):
+        gen.conv_precision, gen.sr_conv_precision = prec, sr
+        prec = prec if sr is None else f"{prec}+{sr} SR"
         out = gen.synthesis(ws.to(dev), c.to(dev), u_strat=us.to(dev), u_imp=ui.to(dev))["image"].cpu()
         err = (out - ref).abs()
-        print(f"{prec:7s}: max abs {err.max().item():.2e}, rms {err.pow(2).mean().sqrt().item():.2e}, "
+        print(f"{prec:14s}: max abs {err.max().item():.2e}, rms {err.pow(2).mean().sqrt().item():.2e}, "
               f"mse {err.pow(2).mean().item():.2e} (image range [{ref.min().item():.2f}, {ref.max().item():.2f}])")
 
 

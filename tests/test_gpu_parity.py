@@ -151,6 +151,49 @@ def test_synthesis_layer_split_bf16(dev, prec, b, h, cin, cout, up, ksplit, clam
     close(ops.nhwc_to_nchw(y), want, atol=SPLIT_TOL[prec] * float(want.abs().max()) + 1e-6)
 
 
+F16_TOL = 6e-3      # relative to max|ref| (which a conv_clamp caps): operands rounded to fp16 (2^-11 per product)
+
+
+@pytest.mark.parametrize("b,h,cin,cout,up,ksplit,clamp,xscale", [
+    (2, 17, 32, 128, 1, 0, None, 1.0), (1, 33, 16, 256, 1, 1, 0.8, 1.0), (1, 8, 64, 128, 1, 3, None, 1.0),
+    (2, 9, 48, 128, 2, 0, None, 1.0), (1, 16, 64, 256, 2, 3, 0.9, 1.0), (1, 1, 16, 128, 1, 0, None, 1.0),
+    (1, 12, 32, 128, 1, 0, None, 200.0)])
+def test_synthesis_layer_f16(dev, b, h, cin, cout, up, ksplit, clamp, xscale):
+    """The single-pass fp16 MFMA path (HFAGP_PREC_F16: the arithmetic of EG3D's fp16 blocks) of the same layer,
+    with EG3D's style pre-normalisation; xscale 200 = activations at the conv_clamp level, styles x 40: the
+    un-normalised product would leave fp16's range."""
+    from hfa_gp_amd import ops
+    from oracle import eg3d_oracle as O
+    res = h * up
+    P = _layer_state(cin, cout, res, seed=b * 100 + h)
+    if xscale != 1.0:
+        P["L.affine.bias"] = P["L.affine.bias"] * 40.0
+        P["L.affine.weight"] = P["L.affine.weight"] * 40.0
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(b, cin, h, h, generator=g) * xscale
+    w = torch.randn(b, 64, generator=g)
+    want = O.synthesis_layer(x, w, P, "L", up, O.fir_kernel(), "const", clamp, 0.2, True, 1e-8)
+    D = {k: v.to(dev) for k, v in P.items()}
+    _, wsq = ops.weight_prep(D["L.weight"])
+    wb = ops.weight_prep_split(D["L.weight"], 1)
+    assert wb.dtype == torch.float16 and wb.shape == (1, 9, cin // 8, cout, 8)
+    back = wb.float()[0].permute(2, 1, 3, 0).reshape(cout, cin, 3, 3)
+    assert torch.equal(back, D["L.weight"].half().float())            # round-to-nearest-even, like torch
+    styles, dcoef = ops.styles_demod(w.to(dev), D["L.affine.weight"], D["L.affine.bias"], wsq)
+    m = styles.abs().amax(1, keepdim=True)
+    styles, dcoef = styles / m, dcoef * m
+    xh = ops.nchw_to_nhwc(x.to(dev))
+    if up == 2:
+        yt = ops.modconv(xh, wb, cout, ops.CONVT3X3_UP2, styles=styles, ksplit=ksplit)
+        y = ops.upfir_epilogue(yt, dcoef, D["L.noise_const"], 0.37, D["L.bias"], clamp=clamp)
+    else:
+        y = ops.modconv(xh, wb, cout, ops.CONV3X3, styles=styles, dcoef=dcoef, noise=D["L.noise_const"],
+                        noise_strength=0.37, bias=D["L.bias"], act="lrelu", gain=math.sqrt(2), clamp=clamp,
+                        ksplit=ksplit)
+    assert torch.isfinite(y).all()
+    close(ops.nhwc_to_nchw(y), want, atol=F16_TOL * float(want.abs().max()) + 1e-6)
+
+
 def test_split_bf16_rejects_unsupported_shapes(dev):
     """Cin % 16 / Cout % 128 are the split kernel's shape contract: anything else is an error, not a fallback."""
     from hfa_gp_amd import ops
@@ -301,6 +344,38 @@ def test_synthesis_vs_oracle(dev, preset, batch, prec):
         # the oracle's "scale activations" (training-mode) form of modulated conv must agree as well
         ref2 = O.synthesis(P, cfg, ws, c, us, ui, fused=False)
         close(out["image"], ref2["image"], atol=atol)
+
+
+@pytest.mark.parametrize("sr_only", [True, False])
+def test_synthesis_f16_blocks_vs_oracle(dev, sr_only):
+    """BASELINE config 2 / 5 'fp16 variant': super-resolution convs (sr_only: the reference's CUDA defaults, fp32
+    backbone + fp16 super-resolution) or every conv on the single-pass fp16 MFMA path, against the fp32
+    oracle.  north_star's bar is 1e-3 MSE on [-1, 1] images; fp16 products land 3+ orders below it."""
+    from hfa_gp_amd.config import PRESETS
+    from hfa_gp_amd.generator import TriPlaneGenerator
+    from oracle import eg3d_oracle as O
+    cfg = PRESETS["ffhq512_128"]()
+    cfg = dataclasses.replace(cfg, sr_conv_precision="f16") if sr_only else dataclasses.replace(cfg, conv_precision="f16")
+    gen = perturb_state(TriPlaneGenerator(cfg, seed=0))
+    P = state_cpu(gen)
+    gen = gen.to(dev)
+    ws, c, us, ui = make_inputs(cfg, 1)
+    ref = O.synthesis(P, cfg, ws, c, us, ui, return_planes=True)
+    gen.timing = {}
+    out = gen.synthesis(ws.to(dev), c.to(dev), noise_mode="const", u_strat=us.to(dev), u_imp=ui.to(dev),
+                        return_planes=True)
+    ran = {k: len(v) for k, v in gen.timing.items()}
+    gen.timing = None
+    # the fp16 kernel really ran where asked (4 SR convs; + the backbone convs with Cin % 16 == 0, Cout % 128 == 0)
+    assert ran.get("modconv_f16", 0) == (4 if sr_only else 4 + 13), ran
+    r = cfg.plane_resolution
+    planes = out["planes"].permute(0, 1, 4, 2, 3).reshape(1, 96, r, r)
+    if sr_only:     # the backbone is untouched: the default precision's tolerance
+        close(planes, ref["planes"], atol=E2E_ATOL["bf16x3"] * max(1.0, float(ref["planes"].abs().max())))
+        close(out["image_raw"], ref["image_raw"], atol=E2E_ATOL["bf16x3"])
+    err = (out["image"].cpu() - ref["image"])
+    assert err.pow(2).mean().item() <= 1e-5, err.pow(2).mean().item()
+    assert err.abs().max().item() <= 3e-2, err.abs().max().item()
 
 
 def test_full_size_properties(dev):
