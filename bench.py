@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--no-train", action="store_true", help="skip the fitting-step leg (train_step_ms)")
     ap.add_argument("--train-batch", type=int, default=2, help="frames per fitting step per GPU")
     ap.add_argument("--train-steps", type=int, default=6)
+    ap.add_argument("--no-sweep", action="store_true",
+                    help="skip the batch-size sweeps (render B = 1, 4; fitting step B = 1, 4; SURVEY.md section 8d)")
     ap.add_argument("--cpu-runs", type=int, default=2)
     ap.add_argument("--precision", default=None, choices=["fp32", "bf16x3", "bf16x6"],
                     help="conv GEMM arithmetic of the headline leg (default: the preset's conv_precision)")
@@ -65,6 +67,16 @@ def cpu_baseline(cfg, state, runs: int):
     return {"value": 1.0 / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{runs} x synthesis(B=1) of the {cfg.name} workload with the fp32 PyTorch-CPU oracle, "
                       f"{dt:.2f} s/frame"}
+
+
+def _pct(ms_list):
+    """median / p10 / p90 of a list of per-step milliseconds (HIP event pairs)."""
+    v = sorted(ms_list)
+    n = len(v)
+    if n == 0:
+        return None
+    q = lambda f: v[min(n - 1, max(0, int(round(f * (n - 1)))))]
+    return {"median": q(0.5), "p10": q(0.1), "p90": q(0.9), "n": n}
 
 
 class _FitArgs:
@@ -91,18 +103,24 @@ def train_leg(args, cfg_name, dev, rank, world, dist):
     torch.manual_seed(0)
     tr = Trainer(fa, dev, rank=rank, world_size=world, mode="3dmm")
     g = torch.Generator().manual_seed(40 + rank)
-    B = args.train_batch
-    real = (0.5 * torch.randn(B, 3, fa.size, fa.size, generator=g)).clamp(-1, 1).to(dev)
-    params = torch.randn(B, fa.params_len, generator=g).to(dev)
-    label = look_at_label(math.pi / 2 + 0.3 * torch.randn(B, generator=g),
-                          math.pi / 2 + 0.155 * torch.randn(B, generator=g), flipped=False).to(dev)
-    def timed(steps):
+
+    def inputs(B):
+        real = (0.5 * torch.randn(B, 3, fa.size, fa.size, generator=g)).clamp(-1, 1).to(dev)
+        params = torch.randn(B, fa.params_len, generator=g).to(dev)
+        label = look_at_label(math.pi / 2 + 0.3 * torch.randn(B, generator=g),
+                              math.pi / 2 + 0.155 * torch.randn(B, generator=g), flipped=False).to(dev)
+        return real, params, label
+
+    def timed(steps, B):
+        """(max-over-ranks ms per step, {phase: mean ms} from HIP events on the launch stream)."""
+        real, params, label = inputs(B)
         for _ in range(2):
             tr.gen_update(real, label.clone(), params)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+        tr.timing = {}
         t0 = time.perf_counter()
         for _ in range(steps):
             l2, _, _ = tr.gen_update(real, label.clone(), params)
@@ -111,19 +129,27 @@ def train_leg(args, cfg_name, dev, rank, world, dist):
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        spans, tr.timing = tr.timing, None
         if dist is not None:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         assert torch.isfinite(l2)
-        return dt / steps * 1e3
+        phases = {k: sum(a.elapsed_time(b) for a, b in v) / max(len(v), 1) for k, v in spans.items()}
+        return dt / steps * 1e3, phases
 
-    frozen_ms = timed(args.train_steps)
+    B = args.train_batch
+    out = {"frozen": {}, "tuned": {}}
+    batches = [B] if args.no_sweep else sorted({1, B, 4})
+    for b in batches:
+        ms, phases = timed(args.train_steps, b)
+        out["frozen"][b] = {"step_ms": ms, "phases_ms": phases}
     # after tune_iter the reference also trains the generator (trainer_rgb.py:69-71): all 30.7 M parameters get
     # gradients and are all-reduced with the basis / driver gradients
     tr.tune_generator()
-    tune_ms = timed(max(2, args.train_steps // 2))
-    return frozen_ms, tune_ms, B
+    ms, phases = timed(max(2, args.train_steps // 2), B)
+    out["tuned"][B] = {"step_ms": ms, "phases_ms": phases}
+    return out, B
 
 
 def main():
@@ -171,21 +197,41 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         gen.timing = {}
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        marks[0].record()
+        for i in range(args.steps):
             img = step()
+            marks[i + 1].record()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         timing, gen.timing = gen.timing, None
+        timing["step"] = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
         if dist is not None:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         assert torch.isfinite(img).all()
         return dt, timing
+
+    def sweep_leg(b, precision, steps=20, warmup=3):
+        """batch sizes 1 and 4 beside the headline's; per-step HIP event pairs."""
+        gen.conv_precision, gen.sr_conv_precision = precision, None
+        w_, c_, us_, ui_ = [t.to(dev) for t in make_inputs(cfg, b, seed=10 + rank)]
+        for _ in range(warmup):
+            gen.synthesis(w_, c_, noise_mode="const", u_strat=us_, u_imp=ui_)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        ev[0].record()
+        for i in range(steps):
+            gen.synthesis(w_, c_, noise_mode="const", u_strat=us_, u_imp=ui_)
+            ev[i + 1].record()
+        torch.cuda.synchronize()
+        p = _pct([ev[i].elapsed_time(ev[i + 1]) for i in range(steps)])
+        p["frames_per_s_per_gpu"] = b / (p["median"] * 1e-3)
+        return p
 
     prec = args.precision or cfg.conv_precision
     dt32 = timing32 = dt6 = None
@@ -198,6 +244,9 @@ def main():
         # the reference's CUDA defaults: fp32-class backbone, fp16 super-resolution; then every conv in fp16
         dt16sr, timing16 = render_leg(prec, "f16")
         dt16, _ = render_leg("f16")
+    sweep = None
+    if not args.no_sweep:
+        sweep = {str(b): sweep_leg(b, prec) for b in (1, 4) if b != B}
     dt, timing = render_leg(prec)
 
     def agg(key, table=None):
@@ -206,10 +255,10 @@ def main():
         units = sum(u for _, _, u in evs)
         return ms, units, len(evs)
 
-    train_ms = tune_ms = train_B = None
+    train = train_B = None
     if not args.no_train:
         torch.cuda.empty_cache()
-        train_ms, tune_ms, train_B = train_leg(args, args.preset, dev, rank, world, dist)
+        train, train_B = train_leg(args, args.preset, dev, rank, world, dist)
 
     def profiled_traffic(prefix):
         """HBM bytes per launch from the committed PMC passes (profiles/traffic.json), only if the batch matches."""
@@ -289,9 +338,16 @@ def main():
         if dt32 is not None:
             out["value_fp32_exact"] = frames / dt32
             out["roofline_fp32_exact"] = f32_roofline(timing32)
-        if train_ms is not None:
-            out["train_step_ms"] = train_ms
-            out["train_step_ms_generator_tuned"] = tune_ms
+        out["step_ms"] = _pct(timing["step"])       # per-step HIP event pairs of the timed region (this rank)
+        if sweep is not None:
+            out["batch_sweep"] = sweep
+        if train is not None:
+            out["train_step_ms"] = train["frozen"][train_B]["step_ms"]
+            out["train_step_ms_generator_tuned"] = train["tuned"][train_B]["step_ms"]
+            # fwd / bwd / all-reduce / Adam from HIP events on the launch stream (mean ms per step, this rank)
+            out["train_phases_ms"] = train["frozen"][train_B]["phases_ms"]
+            out["train_phases_ms_generator_tuned"] = train["tuned"][train_B]["phases_ms"]
+            out["train_step_ms_by_batch"] = {str(b): v["step_ms"] for b, v in train["frozen"].items()}
             out["train_config"] = {"workload": "3DMM-driven latent-basis fitting step (fwd + bwd + Adam), K=50, "
                                                "generator frozen, L2 at 256^2, synthetic frames",
                                    "frames_per_step_per_gpu": train_B,

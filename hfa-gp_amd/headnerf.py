@@ -196,6 +196,13 @@ class AudioAttNet(nn.Module):
         y = self.attentionNet(y.view(1, self.seq_len)).view(self.seq_len, 1)
         return torch.sum(y * x, dim=0)
 
+    def forward_windows(self, x):
+        """Batched form for the reenactment harness: x [N, seq_len, D] (one smoothing window per frame) → [N, D];
+        row n equals ``forward(x[n])``."""
+        y = self.attentionConvNet(x[..., :self.dim_aud].permute(0, 2, 1))          # [N, 1, seq_len]
+        y = self.attentionNet(y.view(-1, self.seq_len))                             # softmax over the window
+        return torch.sum(y.unsqueeze(-1) * x, dim=1)
+
 
 class AudioNet(nn.Module):
     """DeepSpeech window [N,16,29] → per-frame audio feature [N, dim_aud] (:319-349)."""

@@ -22,7 +22,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .cam_utils import create_cam2world_matrix, make_label, sample_camera_positions
-from .headnerf import HeadNeRF_3DMM, HeadNeRF_final
+from .headnerf import AudioAttNet, AudioNet, HeadNeRF_3DMM, HeadNeRF_Audio, HeadNeRF_final
 
 
 def requires_grad(net: nn.Module, flag: bool = True) -> None:
@@ -72,6 +72,7 @@ class Trainer(nn.Module):
         requires_grad(self.gen.generator, False)
         self.lpips_loss = lpips
         self.face_pool = nn.AdaptiveAvgPool2d((args.size, args.size))
+        self.timing: Optional[dict] = None   # bench.py: {'fwd': [(ev0, ev1)], 'bwd': ..., 'allreduce': ..., 'optim': ...}
         if world_size > 1:
             self.broadcast_parameters()
 
@@ -91,9 +92,22 @@ class Trainer(nn.Module):
     def tune_generator(self):
         requires_grad(self.gen.generator, True)
 
+    def _mark(self):
+        """HIP event on the current stream when bench.py asked for the phase breakdown of the step."""
+        if self.timing is None:
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    def _span(self, key, e0, e1):
+        if self.timing is not None:
+            self.timing.setdefault(key, []).append((e0, e1))
+
     def gen_update(self, real_image, label, params=None, person_2=False):
         self.gen.train()
         self.g_optim.zero_grad()
+        t0 = self._mark()
         if self.mode == "rgb":
             weights = self.gen.get_weights(real_image)
             latent = self.gen.get_latent(weights, person_2)
@@ -106,10 +120,15 @@ class Trainer(nn.Module):
             lp = torch.squeeze(self.lpips_loss(real_image, generated)).mean()
         else:
             lp = torch.zeros((), device=l2.device)
+        t1 = self._mark()
         (l2 + lp).backward()
+        t2 = self._mark()
         if self.world_size > 1:
             allreduce_shared_grads(self.shared_parameters(), self.world_size)
+        t3 = self._mark()
         self.g_optim.step()
+        t4 = self._mark()
+        self._span("fwd", t0, t1), self._span("bwd", t1, t2), self._span("allreduce", t2, t3), self._span("optim", t3, t4)
         return l2.detach(), lp.detach(), generated.detach()
 
     def sample(self, real_image, label, params=None, person_2=False):
@@ -149,4 +168,157 @@ class Trainer(nn.Module):
     def save(self, idx: int, checkpoint_path: str) -> str:
         path = f"{checkpoint_path}/{str(idx).zfill(6)}.pt"
         torch.save({"gen": self.gen.state_dict(), "g_optim": self.g_optim.state_dict(), "args": self.args}, path)
+        return path
+
+
+def audio_window(auds: torch.Tensor, img_i: int, smo_size: int, limit: int) -> torch.Tensor:
+    """The smoothing window of frame ``img_i``: auds[img_i - h : img_i + h] (h = smo_size // 2) clipped to
+    [0, limit) and zero-padded back to smo_size rows — trainer_audio.py:66-83 (limit = i_train) / :127-144
+    (limit = len(auds))."""
+    half = int(smo_size / 2)
+    left, right = img_i - half, img_i + half
+    pad_left = pad_right = 0
+    if left < 0:
+        pad_left, left = -left, 0
+    if right > limit:
+        pad_right, right = right - limit, limit
+    win = auds[left:right]
+    if pad_left > 0:
+        win = torch.cat((torch.zeros_like(win)[:pad_left], win), dim=0)
+    if pad_right > 0:
+        win = torch.cat((win, torch.zeros_like(win)[:pad_right]), dim=0)
+    return win
+
+
+def audio_windows(auds: torch.Tensor, idx: torch.Tensor, smo_size: int, limit: int) -> torch.Tensor:
+    """Batched `audio_window`: idx [N] → [N, smo_size, ...]; one gather instead of N slices.  Reproduces the
+    reference's padding exactly, including its quirk that a pad longer than the clipped window is truncated
+    (``zeros_like(win)[:pad]``) — callers keep ``half <= limit``."""
+    half = int(smo_size / 2)
+    off = torch.arange(-half, half, device=idx.device)
+    pos = idx[:, None] + off[None, :]                                  # [N, smo_size]
+    valid = (pos >= 0) & (pos < limit)
+    win = auds[pos.clamp(0, limit - 1)]
+    return win * valid.view(*valid.shape, *([1] * (win.dim() - 2))).to(win.dtype)
+
+
+class AudioTrainer(nn.Module):
+    """Counterpart of /root/reference/code/trainer_audio.py:20-217: HeadNeRF_Audio driven by AudioNet (+ AudioAttNet
+    over a `smo_size` window once `global_step >= nosmo_iters`), three Adam optimisers, the reference's checkpoint
+    keys.  Multi-GPU as in `Trainer`: one flattened all-reduce of the shared gradients (latent basis, 3DMM net is
+    unused here, AudioNet, AudioAttNet; generator once tuned) per step instead of the reference's three DDP wrappers."""
+
+    def __init__(self, auds, i_train: int, args, device, rank: int = 0, world_size: int = 1,
+                 lpips: Optional[Callable] = None, gen: Optional[nn.Module] = None):
+        super().__init__()
+        self.args, self.device, self.rank, self.world_size = args, device, rank, world_size
+        self.batch_size = args.batch_size
+        if gen is None:
+            gen = HeadNeRF_Audio(args, args.size, device, args.latent_dim_style, args.latent_dim_shape,
+                                 getattr(args, "run_id", "nerface2"), getattr(args, "emb_dir", "./PTI/embeddings/"))
+        self.gen = gen.to(device)
+        self.AudNet = AudioNet(args.dim_aud, args.win_size).to(device)
+        self.AudAttNet = AudioAttNet().to(device)       # default dim_aud = 32 while features are 64-d: reference quirk 7
+        self.optimizer_Aud = torch.optim.Adam(params=list(self.AudNet.parameters()), lr=args.lr, betas=(0.9, 0.999))
+        self.optimizer_AudAtt = torch.optim.Adam(params=list(self.AudAttNet.parameters()), lr=args.lr,
+                                                 betas=(0.9, 0.999))
+        self.w_optim = torch.optim.Adam(self.gen.parameters(), lr=args.lr)
+        requires_grad(self.gen.generator, False)
+        self.lpips_loss = lpips
+        self.auds = torch.as_tensor(auds).to(device).float()
+        self.i_train = i_train
+        self.face_pool = nn.AdaptiveAvgPool2d((args.size, args.size))
+        if world_size > 1:
+            import torch.distributed as dist
+            for m in (self.gen, self.AudNet, self.AudAttNet):
+                for t in list(m.parameters()) + list(m.buffers()):
+                    dist.broadcast(t.data, src=0)
+
+    def shared_parameters(self):
+        return [p for m in (self.gen, self.AudNet, self.AudAttNet) for p in m.parameters() if p.requires_grad]
+
+    def l2_loss(self, real_images, generated_images):
+        return F.mse_loss(real_images, generated_images, reduction="mean")
+
+    def tune_generator(self):
+        requires_grad(self.gen.generator, True)
+
+    def _drive(self, global_step: int, img_i: int, limit: int) -> torch.Tensor:
+        """Audio feature of frame img_i → driver input of HeadNeRF_Audio [1, dim_aud] (trainer_audio.py:65-94)."""
+        # img_i: the data loader's 1-element index tensor in the reference; a plain int is accepted as well
+        if global_step >= self.args.nosmo_iters:
+            feats = self.AudNet(audio_window(self.auds, int(img_i), self.args.smo_size, limit))
+            aud = self.AudAttNet(feats)
+        else:
+            aud = self.AudNet(self.auds[img_i].reshape(-1, *self.auds.shape[1:]).squeeze(1))
+        return aud.unsqueeze(0) if aud.dim() == 1 else aud
+
+    def gen_update(self, real_image, label, params, global_step: int, img_i: int, person_2: bool = False):
+        self.gen.train(), self.AudNet.train(), self.AudAttNet.train()
+        self.w_optim.zero_grad(), self.optimizer_Aud.zero_grad(), self.optimizer_AudAtt.zero_grad()
+        generated = self.face_pool(self.gen(self._drive(global_step, img_i, self.i_train), label, person_2))
+        l2_3dmm = torch.zeros(1, device=self.device)
+        l2 = self.l2_loss(real_image, generated)
+        lp = (torch.squeeze(self.lpips_loss(real_image, generated)).mean() if self.lpips_loss is not None
+              else torch.zeros((), device=l2.device))
+        (l2_3dmm + l2 + lp).backward()
+        if self.world_size > 1:
+            allreduce_shared_grads(self.shared_parameters(), self.world_size)
+        self.w_optim.step()
+        self.optimizer_Aud.step()
+        if global_step >= self.args.nosmo_iters:
+            self.optimizer_AudAtt.step()
+        return l2_3dmm, l2.detach(), lp.detach(), generated.detach()
+
+    def sample(self, real_image, label, params, global_step: int, img_i: int, person_2: bool = False):
+        with torch.no_grad():
+            self.gen.eval(), self.AudNet.eval(), self.AudAttNet.eval()
+            return self.gen(self._drive(global_step, img_i, self.auds.shape[0]), label, person_2)
+
+    @torch.no_grad()
+    def sample_frames(self, idx: torch.Tensor, label: torch.Tensor, person_2: bool = False) -> torch.Tensor:
+        """Batched `sample` for the reenactment harness (BASELINE config 5): frames idx [N] with the smoothing
+        window, ONE AudioNet pass over the N*smo_size windows, one batched attention, one synthesis of N frames."""
+        self.gen.eval(), self.AudNet.eval(), self.AudAttNet.eval()
+        return self.gen(self.drive_frames(idx), label, person_2)
+
+    def drive_frames(self, idx: torch.Tensor) -> torch.Tensor:
+        """Smoothed audio features of frames idx [N] → [N, dim_aud]; row n equals `_drive` of frame idx[n]."""
+        n, smo = idx.shape[0], self.args.smo_size
+        win = audio_windows(self.auds, idx, smo, self.auds.shape[0])              # [N, smo, 16, 29]
+        feats = self.AudNet(win.reshape(n * smo, *win.shape[2:])).reshape(n, smo, -1)
+        return self.AudAttNet.forward_windows(feats)
+
+    def sample_bases(self, person_2: bool = False):
+        """trainer_audio.py:154-176: alpha = 5 e_i, frontal camera, ONE label tensor re-used (alternating flip)."""
+        imgs = []
+        with torch.no_grad():
+            pts, _, _ = sample_camera_positions(device=self.device, n=1, r=2.7, horizontal_mean=0.5 * math.pi,
+                                                vertical_mean=0.5 * math.pi, mode=None)
+            label = make_label(create_cam2world_matrix(-pts, pts, device=self.device))
+            self.gen.eval()
+            k = self.args.latent_dim_shape
+            for i in range(k):
+                w = torch.zeros(1, k, device=self.device)
+                w[0, i] = 5
+                imgs.append(self.gen.get_image(self.gen.get_latent(w, person_2), label))
+        return imgs
+
+    def resume(self, resume_ckpt: str) -> int:
+        ckpt = torch.load(resume_ckpt, map_location=self.device, weights_only=False)
+        start_iter = int(os.path.splitext(os.path.basename(resume_ckpt))[0])
+        self.gen.load_state_dict(ckpt["gen"])
+        self.AudNet.load_state_dict(ckpt["AudNet"])
+        self.AudAttNet.load_state_dict(ckpt["AudAttNet"])
+        self.w_optim.load_state_dict(ckpt["w_optim"])
+        self.optimizer_Aud.load_state_dict(ckpt["optimizer_Aud"])
+        self.optimizer_AudAtt.load_state_dict(ckpt["optimizer_AudAtt"])
+        return start_iter
+
+    def save(self, idx: int, checkpoint_path: str) -> str:
+        path = f"{checkpoint_path}/{str(idx).zfill(6)}.pt"
+        torch.save({"gen": self.gen.state_dict(), "AudAttNet": self.AudAttNet.state_dict(),
+                    "AudNet": self.AudNet.state_dict(), "w_optim": self.w_optim.state_dict(),
+                    "optimizer_Aud": self.optimizer_Aud.state_dict(),
+                    "optimizer_AudAtt": self.optimizer_AudAtt.state_dict(), "args": self.args}, path)
         return path

@@ -221,6 +221,50 @@ def test_rgb_trainer_and_render_harness_on_gpu(dev):
     assert abs(frames[0].float().mean().item() - ref.float().mean().item()) < 8.0
 
 
+def test_audio_trainer_and_batched_reenactment_on_gpu(dev):
+    """Audio-driven variant (trainer_audio.py; BASELINE config 5 mechanics): AudioNet (+ AudioAttNet over the
+    smoothing window) -> basis -> HIP generator.  One step per branch moves the right optimisers' parameters; the
+    batched reenactment path renders N frames in one synthesis and equals the per-frame loop given the same
+    renderer uniforms."""
+    from hfa_gp_amd.trainer import AudioTrainer
+    from tests.test_trainer_cpu import AudioArgs
+
+    class A(AudioArgs):
+        size = 64
+
+    torch.manual_seed(0)
+    auds = torch.randn(24, 16, 29, generator=torch.Generator().manual_seed(50)).numpy()
+    tr = AudioTrainer(auds, 20, A(), dev)
+    g = torch.Generator().manual_seed(1)
+    real = (0.5 * torch.randn(1, 3, 64, 64, generator=g)).clamp(-1, 1).to(dev)
+    label = look_at_label(torch.tensor([1.5]), torch.tensor([1.6]), flipped=False).to(dev)
+    b0 = tr.gen.bases.detach().clone()
+    a0 = next(tr.AudNet.parameters()).detach().clone()
+    t0 = next(tr.AudAttNet.parameters()).detach().clone()
+    _, l2, _, img = tr.gen_update(real, label.clone(), None, 0, torch.tensor([3], device=dev))
+    assert torch.isfinite(l2) and img.shape == (1, 3, 64, 64)
+    assert not torch.equal(tr.gen.bases.detach(), b0) and not torch.equal(next(tr.AudNet.parameters()).detach(), a0)
+    assert torch.equal(next(tr.AudAttNet.parameters()).detach(), t0)
+    tr.gen_update(real, label.clone(), None, A.nosmo_iters, 1)
+    assert not torch.equal(next(tr.AudAttNet.parameters()).detach(), t0)
+    # batched reenactment == per-frame loop when the renderer sees the same uniforms
+    cfg = tr.gen.generator.cfg
+    r = cfg.neural_rendering_resolution ** 2
+    n = 5
+    us = torch.rand(n, r, cfg.depth_resolution, device=dev)
+    ui = torch.rand(n * r, cfg.depth_resolution_importance, device=dev)
+    inner = tr.gen.generator.synthesis
+    idx = torch.tensor([0, 2, 11, 22, 23], device=dev)
+    tr.gen.generator.synthesis = lambda ws, c=None, noise_mode="const": inner(ws, c, noise_mode, u_strat=us, u_imp=ui)
+    batched = tr.sample_frames(idx, label.repeat(n, 1))
+    assert batched.shape == (n, 3, 64, 64)
+    for k, i in enumerate(idx.tolist()):
+        tr.gen.generator.synthesis = lambda ws, c=None, noise_mode="const", k=k: inner(
+            ws, c, noise_mode, u_strat=us[k:k + 1], u_imp=ui[k * r:(k + 1) * r])
+        one = tr.sample(None, label.clone(), None, A.nosmo_iters, i)
+        close(batched[k:k + 1], one, atol=2e-4)
+
+
 @pytest.mark.parametrize("b,h,cin,cout,mode", [(1, 4, 8, 32, "3x3"), (2, 9, 24, 96, "3x3"), (2, 21, 64, 128, "3x3"),
                                                (1, 4, 8, 32, "up"), (2, 11, 32, 64, "up"), (2, 13, 40, 96, "1x1")])
 def test_conv_weight_gradient(dev, b, h, cin, cout, mode):

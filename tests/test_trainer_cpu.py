@@ -228,3 +228,108 @@ def test_lpips_alex_module_and_objective():
     real, label, params = frame(9)
     l2, lpv, _ = tr.gen_update(real, label, params)
     assert float(lpv) > 0 and torch.isfinite(l2) and tr.gen.bases.grad.abs().sum() > 0
+
+
+# ----------------------------------------------------------------------------- audio-driven trainer
+class AudioArgs(Args):
+    params_len = 64          # train_audio.py:186
+    dim_aud = 64             # :206
+    win_size = 16            # :208
+    nosmo_iters = 5          # :210 (300000 in the reference; small so both branches run)
+    smo_size = 8             # :212
+
+
+def make_audio_trainer(seed=0, n=12, i_train=10, world_size=1, rank=0):
+    from hfa_gp_amd.trainer import AudioTrainer
+    torch.manual_seed(seed)
+    gen = headnerf.HeadNeRF_Audio(AudioArgs(), AudioArgs.size, "cpu", 512, AudioArgs.latent_dim_shape)
+    OracleGenerator.adopt(gen.generator)
+    auds = torch.randn(n, 16, 29, generator=torch.Generator().manual_seed(50)).numpy()      # BASELINE config 5 shape
+    return AudioTrainer(auds, i_train, AudioArgs(), "cpu", rank=rank, world_size=world_size, gen=gen)
+
+
+def test_audio_window_padding_matches_reference_semantics():
+    """trainer_audio.py:66-83: window [i-4, i+4) clipped to [0, limit), zero rows put back on the clipped side."""
+    from hfa_gp_amd.trainer import audio_window, audio_windows
+    auds = torch.arange(12.0)[:, None, None].expand(12, 16, 29) + 1.0          # frame i holds the value i+1
+    w = audio_window(auds, 1, 8, 10)
+    assert [int(v) for v in w[:, 0, 0]] == [0, 0, 0, 1, 2, 3, 4, 5]
+    w = audio_window(auds, 8, 8, 10)
+    assert [int(v) for v in w[:, 0, 0]] == [5, 6, 7, 8, 9, 10, 0, 0]          # limit = i_train = 10 hides frames 10, 11
+    w = audio_window(auds, 8, 8, 12)
+    assert [int(v) for v in w[:, 0, 0]] == [5, 6, 7, 8, 9, 10, 11, 12]
+    idx = torch.tensor([0, 1, 5, 8, 11])
+    batched = audio_windows(auds, idx, 8, 12)
+    for n, i in enumerate(idx.tolist()):
+        assert torch.equal(batched[n], audio_window(auds, i, 8, 12))
+    # the centre row of the window is the frame itself
+    assert torch.equal(batched[:, 4, 0, 0], idx.float() + 1.0)
+
+
+def test_audio_attention_batched_equals_per_window():
+    torch.manual_seed(0)
+    att = headnerf.AudioAttNet()
+    x = torch.randn(5, 8, 64)
+    want = torch.stack([att(x[i]) for i in range(5)])
+    assert torch.allclose(att.forward_windows(x), want, atol=1e-6)
+
+
+def test_audio_trainer_step_both_branches_and_checkpoint(tmp_path):
+    tr = make_audio_trainer()
+    real, label, _ = frame(4)
+    att0 = [p.detach().clone() for p in tr.AudAttNet.parameters()]
+    aud0 = [p.detach().clone() for p in tr.AudNet.parameters()]
+    # before nosmo_iters: AudioNet on the single frame, the attention net is neither used nor stepped
+    out = tr.gen_update(real, label.clone(), None, global_step=0, img_i=3)
+    assert len(out) == 4 and float(out[0]) == 0.0 and torch.isfinite(out[1]) and out[3].shape == (1, 3, 32, 32)
+    assert all(torch.equal(a, b.detach()) for a, b in zip(att0, tr.AudAttNet.parameters()))
+    assert any(not torch.equal(a, b.detach()) for a, b in zip(aud0, tr.AudNet.parameters()))
+    assert tr.gen.bases.grad.abs().sum() > 0
+    # after: smoothing window + attention, all three optimisers step
+    tr.gen_update(real, label.clone(), None, global_step=5, img_i=0)             # window clipped on the left
+    assert any(not torch.equal(a, b.detach()) for a, b in zip(att0, tr.AudAttNet.parameters()))
+    path = tr.save(7, str(tmp_path))
+    sd = torch.load(path, weights_only=False)
+    assert set(sd) == {"gen", "AudAttNet", "AudNet", "w_optim", "optimizer_Aud", "optimizer_AudAtt", "args"}
+    tr2 = make_audio_trainer(seed=9)
+    assert tr2.resume(path) == 7
+    a = tr.sample(None, label.clone(), None, 5, 11)                              # clipped on the right (limit = len(auds))
+    b = tr2.sample(None, label.clone(), None, 5, 11)
+    assert torch.allclose(a, b, atol=1e-6)
+    # the batched reenactment path renders the same frames as the per-frame loop
+    idx = torch.tensor([0, 6, 11])
+    lab = label.repeat(3, 1)
+    with torch.no_grad():
+        drv = tr.drive_frames(idx)
+        for n, i in enumerate(idx.tolist()):
+            assert torch.allclose(drv[n:n + 1], tr._drive(5, i, tr.auds.shape[0]), atol=1e-6)
+    batched = tr.sample_frames(idx, lab.clone())
+    assert batched.shape == (3, 3, 64, 64) and torch.isfinite(batched).all()
+    # (the test-only oracle generator draws its sampling uniforms per call, so images are compared loosely)
+    one = tr.sample(None, label.clone(), None, 5, 6)
+    assert (batched[1:2] - one).abs().max() < 5e-2
+
+
+def _audio_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    try:
+        tr = make_audio_trainer(seed=30 + rank, world_size=world, rank=rank)
+        real, label, _ = frame(40 + rank)
+        tr.gen_update(real, label, None, global_step=5, img_i=2 + 5 * rank)       # contiguous shards: own frame each
+        out[rank] = {"bases": tr.gen.bases.detach().clone(),
+                     "aud": next(tr.AudNet.parameters()).detach().clone(),
+                     "att_grad": next(tr.AudAttNet.parameters()).grad.detach().clone()}
+    finally:
+        dist.destroy_process_group()
+
+
+def test_audio_trainer_two_ranks():
+    world, port = 2, _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_audio_worker, args=(world, port, out), nprocs=world, join=True)
+        for k in ("bases", "aud", "att_grad"):
+            assert torch.equal(out[0][k], out[1][k]), k
