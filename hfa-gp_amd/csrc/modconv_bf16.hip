@@ -361,9 +361,14 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
 //   shift ( 0, 0): phase 0 w[0], phase 1 w[1], phase 2 w[3], phase 3 w[4]
 //   shift (-1, 0): phase 0 w[6], phase 1 w[7]        shift (0,-1): phase 0 w[2], phase 2 w[5]
 //   shift (-1,-1): phase 0 w[8]                       (w[k] = tap k of the 3x3 kernel, y_t[2i+ti][2j+tj] += x[i][j] w[ti][tj])
-template <int NP>
-__global__ void __launch_bounds__(256, 1) upconv_bf16_kernel(const ConvParams p) {
-    constexpr int TM = 2, TN = 1, WN = 2, BM = 128, BNU = WN * TN * 32, PH = BM / PW, NITEM = 9, RB = NP == 1 ? 6 : 3;
+// NW = 4 waves: N = 64 channels per block, one wave per SIMD.  NW = 8 waves (2 x 4 wave grid, 512 threads): N = 128
+// channels per block and two waves per SIMD (256 registers each) — the patch is staged once for twice the MFMA
+// work and the second wave of a SIMD covers the barrier / staging bubbles of the first; used when the layer
+// still fills the chip with the larger tile (make_plan).
+template <int NP, int NW>
+__global__ void __launch_bounds__(NW * 64, 1) upconv_bf16_kernel(const ConvParams p) {
+    constexpr int NTH = NW * 64;
+    constexpr int TM = 2, TN = 1, WN = NW / 2, BM = 128, BNU = WN * TN * 32, PH = BM / PW, NITEM = 9, RB = NP == 1 ? 6 : 3;
     constexpr int LPWB = RowPitch<NP>::value;
     constexpr int APOS = (PH + 2) * LPWB;
     constexpr int A_PART = APOS * APITCH, A_BUF = NP * A_PART;
@@ -393,16 +398,17 @@ __global__ void __launch_bounds__(256, 1) upconv_bf16_kernel(const ConvParams p)
 
     // ---- A staging (as in modconv_bf16_kernel): patch rows m0-1 .. m0+PH-1, columns n0-1 .. n0+PW-1
     const int npatch = p.ph * p.pw;
-    constexpr int A_PER_T = ((PH + 2) * (PW + 2) * 4 + 255) / 256;
+    constexpr int A_PER_T = ((PH + 2) * (PW + 2) * 4 + NTH - 1) / NTH;
+    static_assert(A_PER_T == 2 || A_PER_T == 3, "staging schedule: two or three slots per thread");
     float4 ra[A_PER_T];
     const char* xb = reinterpret_cast<const char*>(p.x + (long long)b * p.x_batch_stride);
-    for (int i = tid; i < p.Cin; i += 256) Ss[i] = p.styles ? p.styles[(size_t)b * p.Cin + i] : 1.f;
+    for (int i = tid; i < p.Cin; i += NTH) Ss[i] = p.styles ? p.styles[(size_t)b * p.Cin + i] : 1.f;
     unsigned aoff[A_PER_T];
     int lds_a[A_PER_T], soff[A_PER_T];
     float amask[A_PER_T];
 #pragma unroll
     for (int k = 0; k < A_PER_T; ++k) {
-        const int idx = min(tid + k * 256, npatch * 4 - 1);
+        const int idx = min(tid + k * NTH, npatch * 4 - 1);
         const int pix = idx >> 2, q = idx & 3;
         lds_a[k] = ((pix / p.pw) * LPWB + pix % p.pw) * APITCH + 8 * q;
         const int iy = m0 - 1 + pix / p.pw, ix = n0 - 1 + pix % p.pw;
@@ -489,10 +495,10 @@ __global__ void __launch_bounds__(256, 1) upconv_bf16_kernel(const ConvParams p)
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn)
                     acc[F][tm][tn] = mfma16<NP>(af[G & 1][tm][PA[pr]], bq[SL][tn][PB[pr]], acc[F][tm][tn]);
-        // the patch of the next chunk is converted into the other LDS buffer under the last three items
-        if constexpr (I >= NITEM - 3)
+        // the patch of the next chunk is converted into the other LDS buffer under the last A_PER_T items
+        if constexpr (I >= NITEM - A_PER_T)
             store_a(min(c + 1, c_end - 1), std::integral_constant<int, 1 - decltype(u_tag)::value>{},
-                    std::integral_constant<int, I - (NITEM - 3)>{});
+                    std::integral_constant<int, I - (NITEM - A_PER_T)>{});
         issue_b(c + (I + RB) / NITEM, std::integral_constant<int, (I + RB) % NITEM>{}, std::integral_constant<int, SL>{});
         if constexpr (I == NITEM - 1) load_a(min(c + 2, c_end - 1));
         __builtin_amdgcn_sched_barrier(0);
@@ -525,13 +531,17 @@ __global__ void __launch_bounds__(256, 1) upconv_bf16_kernel(const ConvParams p)
         }
         store_a(c_begin, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
         store_a(c_begin, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
-        store_a(c_begin, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+        if constexpr (A_PER_T > 2) store_a(c_begin, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
         load_a(min(c_begin + 1, c_end - 1));
-        for (int cg = c_begin; cg < c_end; cg += 2) {
+        // pairs of chunks (LDS buffer = chunk parity = compile time), then the odd one: an exit in the MIDDLE of the
+        // loop body made the register allocator keep the 128 accumulators in two AGPR sets and copy them
+        // (~190 v_accvgpr_mov per 108 MFMAs)
+        int cg = c_begin;
+        for (; cg + 1 < c_end; cg += 2) {
             chunk(cg, std::integral_constant<int, 0>{});
-            if (cg + 1 >= c_end) break;
             chunk(cg + 1, std::integral_constant<int, 1>{});
         }
+        if (cg < c_end) chunk(cg, std::integral_constant<int, 0>{});
     }
 
     // ---- raw stores of the four phases: y_t[2m + (f>>1)][2n + (f&1)], extents (H+1-(f>>1)) x (W+1-(f&1));
@@ -589,12 +599,19 @@ int launch_modconv_bf16(const HfagpModconvArgs* a, Plan& pl, hipStream_t s) {
     // (3x3: one; stride-2 transposed conv and its adjoint: 4 | 2, 2 | 1)
     const ConvParams& p = pl.p;
     if (pl.merged_up) {                 // one block for the four phases (grid.y = 1)
-        if (a->precision == HFAGP_PREC_F16)
-            upconv_bf16_kernel<1><<<pl.grid, 256, bf16_lds_bytes<1, 2>(a->Cin), s>>>(p);
+        if (pl.up_waves == 8) {
+            if (a->precision == HFAGP_PREC_F16)
+                upconv_bf16_kernel<1, 8><<<pl.grid, 512, bf16_lds_bytes<1, 2>(a->Cin), s>>>(p);
+            else if (a->precision == HFAGP_PREC_BF16X3)
+                upconv_bf16_kernel<2, 8><<<pl.grid, 512, bf16_lds_bytes<2, 2>(a->Cin), s>>>(p);
+            else
+                upconv_bf16_kernel<3, 8><<<pl.grid, 512, bf16_lds_bytes<3, 2>(a->Cin), s>>>(p);
+        } else if (a->precision == HFAGP_PREC_F16)
+            upconv_bf16_kernel<1, 4><<<pl.grid, 256, bf16_lds_bytes<1, 2>(a->Cin), s>>>(p);
         else if (a->precision == HFAGP_PREC_BF16X3)
-            upconv_bf16_kernel<2><<<pl.grid, 256, bf16_lds_bytes<2, 2>(a->Cin), s>>>(p);
+            upconv_bf16_kernel<2, 4><<<pl.grid, 256, bf16_lds_bytes<2, 2>(a->Cin), s>>>(p);
         else
-            upconv_bf16_kernel<3><<<pl.grid, 256, bf16_lds_bytes<3, 2>(a->Cin), s>>>(p);
+            upconv_bf16_kernel<3, 4><<<pl.grid, 256, bf16_lds_bytes<3, 2>(a->Cin), s>>>(p);
         return check_launch("modconv_fwd (split bf16, merged up-conv)");
     }
     for (int p0 = 0; p0 < p.nphase;) {
