@@ -48,6 +48,10 @@ def parse():
     ap.add_argument("--precision", default=None, choices=["fp32", "bf16x3", "bf16x6"],
                     help="conv GEMM arithmetic of the headline leg (default: the preset's conv_precision)")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the second render leg on the exact fp32 kernel")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend (nccl = RCCL; gloo + --share-device: developer check of the N > 1 code "
+                         "path on a 1-GPU box, numbers not comparable)")
+    ap.add_argument("--share-device", action="store_true", help="developer: every rank uses cuda:0")
     ap.add_argument("--no-f16-leg", action="store_true",
                     help="skip the legs with the super-resolution / all convs on the single-pass fp16 MFMA path")
     return ap.parse_args()
@@ -161,13 +165,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); no CPU fallback")
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from hfa_gp_amd.config import PRESETS
     from hfa_gp_amd.generator import TriPlaneGenerator
