@@ -28,7 +28,11 @@ struct GradLds {
 
 struct DecGrads { float *w0, *b0, *w1, *b1; };   // [64][32], [64], [33][64], [33]; accumulated with atomics
 
-template <int S, bool PG>
+// MIRROR: the projections of planes 1 and 2 are (x,z) and (z,x) on square planes (EG3D's original axes): their taps
+// are the same texels with row/column swapped and bitwise the same weights, and dL/dfeature is shared by the three
+// planes (the decoder sees their mean), so  d_planes[2][x][z] == d_planes[1][z][x]  exactly.  Plane 2 is then not
+// scattered at all (a third of the atomics, whose issue rate bounds this kernel) and mirror_plane_kernel fills it.
+template <int S, bool PG, bool MIRROR>
 __global__ void __launch_bounds__(256, PG ? 1 : 2)
 raymarch_bwd_tiles_kernel(const RayParams p, float* __restrict__ d_planes, const DecGrads dg) {
     __shared__ TileLds lds_all[4];
@@ -220,7 +224,7 @@ raymarch_bwd_tiles_kernel(const RayParams p, float* __restrict__ d_planes, const
             const int c = lane & 31, hf = lane >> 5;
             float* base = d_planes + (size_t)b * 3 * a.H * a.W * 32 + c;
 #pragma unroll 1
-            for (int pk = 0; pk < 6; ++pk) {
+            for (int pk = 0; pk < (MIRROR ? 4 : 6); ++pk) {
                 const int pl = pk >> 1, k = 2 * (pk & 1) + hf;
                 float* pbase = base + (size_t)pl * a.H * a.W * 32;
                 int cur = -1;
@@ -294,6 +298,30 @@ raymarch_bwd_tiles_kernel(const RayParams p, float* __restrict__ d_planes, const
     }
 }
 
+// d_planes[b][2][x][z][:] = d_planes[b][1][z][x][:]   (one float4 per thread, full 128-byte lines both ways)
+__global__ void __launch_bounds__(256) mirror_plane_kernel(float* __restrict__ d_planes, int B, int N) {
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= (long long)B * N * N * 8) return;
+    const int c4 = (int)(tid & 7);
+    const long long pix = tid >> 3;
+    const int z = (int)(pix % N), x = (int)((pix / N) % N), b = (int)(pix / ((long long)N * N));
+    const float4* src = reinterpret_cast<const float4*>(d_planes + ((((size_t)b * 3 + 1) * N + z) * N + x) * 32);
+    float4* dst = reinterpret_cast<float4*>(d_planes + ((((size_t)b * 3 + 2) * N + x) * N + z) * 32);
+    dst[c4] = src[c4];
+}
+
+template <int S>
+static void launch_tiles(bool pg, bool mirror, unsigned blocks, const RayParams& p, float* d_planes, const DecGrads& dg,
+                         hipStream_t s) {
+    if (pg) {
+        if (mirror) raymarch_bwd_tiles_kernel<S, true, true><<<blocks, 256, 0, s>>>(p, d_planes, dg);
+        else raymarch_bwd_tiles_kernel<S, true, false><<<blocks, 256, 0, s>>>(p, d_planes, dg);
+    } else {
+        if (mirror) raymarch_bwd_tiles_kernel<S, false, true><<<blocks, 256, 0, s>>>(p, d_planes, dg);
+        else raymarch_bwd_tiles_kernel<S, false, false><<<blocks, 256, 0, s>>>(p, d_planes, dg);
+    }
+}
+
 }  // namespace hfagp
 
 using namespace hfagp;
@@ -317,14 +345,14 @@ extern "C" int hfagp_raymarch_bwd(const HfagpRaymarchBwdArgs* a, void* stream) {
     const bool pg = a->d_dec_w0 != nullptr;
     HFAGP_REQUIRE(!pg || (a->d_dec_b0 && a->d_dec_w1 && a->d_dec_b1), HFAGP_EBADARG,
                   "raymarch_bwd: decoder gradients need all four buffers");
-    if (pg) {
-        if (S == 96) raymarch_bwd_tiles_kernel<96, true><<<(unsigned)blocks, 256, 0, s>>>(p, a->d_planes, dg);
-        else if (S == 64) raymarch_bwd_tiles_kernel<64, true><<<(unsigned)blocks, 256, 0, s>>>(p, a->d_planes, dg);
-        else raymarch_bwd_tiles_kernel<32, true><<<(unsigned)blocks, 256, 0, s>>>(p, a->d_planes, dg);
-    } else {
-        if (S == 96) raymarch_bwd_tiles_kernel<96, false><<<(unsigned)blocks, 256, 0, s>>>(p, a->d_planes, dg);
-        else if (S == 64) raymarch_bwd_tiles_kernel<64, false><<<(unsigned)blocks, 256, 0, s>>>(p, a->d_planes, dg);
-        else raymarch_bwd_tiles_kernel<32, false><<<(unsigned)blocks, 256, 0, s>>>(p, a->d_planes, dg);
+    // planes 1 and 2 mirror each other for EG3D's original axes on square planes: scatter plane 1 only
+    const bool mirror = a->fwd.plane_axes == 0 && a->fwd.H == a->fwd.W;
+    if (S == 96) launch_tiles<96>(pg, mirror, (unsigned)blocks, p, a->d_planes, dg, s);
+    else if (S == 64) launch_tiles<64>(pg, mirror, (unsigned)blocks, p, a->d_planes, dg, s);
+    else launch_tiles<32>(pg, mirror, (unsigned)blocks, p, a->d_planes, dg, s);
+    if (mirror) {
+        const long long n = (long long)a->fwd.B * a->fwd.H * a->fwd.W * 8;
+        mirror_plane_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(a->d_planes, a->fwd.B, a->fwd.H);
     }
     return check_launch("raymarch_bwd/tiles");
 }

@@ -275,7 +275,9 @@ typedef struct {
 int hfagp_style_bwd(const HfagpStyleBwdArgs* a, void* stream);
 
 /* backward of hfagp_raymarch_fwd w.r.t. the tri-plane volume: recomputes the forward per ray, then
- * scatters d feat -> d planes with fp32 atomics (d_planes must be zero-initialised by the caller).      */
+ * scatters d feat -> d planes with fp32 atomics (d_planes must be zero-initialised by the caller).
+ * With plane_axes = 0 on square planes, planes 1 (x,z) and 2 (z,x) receive mirrored gradients: only plane 1
+ * is scattered and plane 2 is WRITTEN as its transpose (a third fewer atomics).                            */
 typedef struct {
     HfagpRaymarchArgs fwd;    /* same inputs as the forward call (feat/depth/wsum/tminmax unused) */
     const float* g_feat;      /* [B][R][32] gradient of the composited features */

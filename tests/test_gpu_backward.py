@@ -80,15 +80,17 @@ def test_upsample2d_bwd(dev):
     close(ops.nhwc_to_nchw(ops.upsample2d_bwd(gh, channels_last=True)), x.grad, atol=1e-5)
 
 
-@pytest.mark.parametrize("preset", ["tiny64", "small128", "ffhq512_128"])
-def test_raymarch_bwd_vs_oracle_autograd(dev, preset):
-    """d planes of the fused renderer vs autograd through the oracle's ImportanceRenderer."""
+@pytest.mark.parametrize("preset,axes", [("tiny64", "eg3d_original"), ("small128", "eg3d_original"),
+                                         ("ffhq512_128", "eg3d_original"), ("ffhq512_128", "eg3d_fixed")])
+def test_raymarch_bwd_vs_oracle_autograd(dev, preset, axes):
+    """d planes of the fused renderer vs autograd through the oracle's ImportanceRenderer.  'eg3d_original' takes the
+    mirrored path (plane 2 = transpose of plane 1, not scattered), 'eg3d_fixed' the three-plane scatter."""
     import dataclasses
     from hfa_gp_amd import ops
     from hfa_gp_amd.config import PRESETS
     from hfa_gp_amd.generator import TriPlaneGenerator
     from oracle import eg3d_oracle as O
-    cfg = dataclasses.replace(PRESETS[preset](), neural_rendering_resolution=10, img_resolution=40)
+    cfg = dataclasses.replace(PRESETS[preset](), neural_rendering_resolution=10, img_resolution=40, plane_axes=axes)
     gen = perturb_state(TriPlaneGenerator(cfg, seed=0))
     P = state_cpu(gen)
     gen = gen.to(dev)
