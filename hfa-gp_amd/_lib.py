@@ -126,6 +126,9 @@ SYMBOLS = {
     "hfagp_conv_wgrad": (C.c_int, [C.POINTER(WgradArgs), C.c_void_p]),
     "hfagp_affine_grad": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 4 + [C.c_void_p]),
     "hfagp_channel_sum": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "hfagp_pool_mse_workspace_bytes": (C.c_size_t, []),
+    "hfagp_pool_mse_fwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 4 + [C.c_void_p]),
+    "hfagp_pool_mse_bwd": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 4 + [C.c_void_p]),
     "hfagp_upfirdn2d_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int32] * 12 + [C.c_float, C.c_void_p]),
     "hfagp_bias_act_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64,
                                      C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p]),

@@ -520,3 +520,42 @@ def raymarch_bwd(g_feat: torch.Tensor, planes: torch.Tensor, cam2world, intrinsi
     if decoder_grads:
         return d_planes, dec
     return (d_planes, rec) if return_rec else d_planes
+
+
+# ----------------------------------------------------------------------------- loss side of the fitting step
+class PoolMSE(torch.autograd.Function):
+    """(mean((real - AdaptiveAvgPool2d(size)(img))^2), pooled image) in one pass over `img` [B,C,H,W] (H, W integer
+    multiples of real's h, w); backward = one pass writing d img.  The pooled image is returned for the caller's
+    book-keeping (the reference returns it from gen_update) and carries no gradient."""
+
+    @staticmethod
+    def forward(ctx, img: torch.Tensor, real: torch.Tensor):
+        _chk(img, "img"), _chk(real, "real")
+        b, c, hh, ww = img.shape
+        h, w = real.shape[-2:]
+        f = hh // h
+        if real.shape[:2] != (b, c) or hh != f * h or ww != f * w or f < 1:
+            raise RuntimeError(f"pool_mse: image {tuple(img.shape)} is not an integer multiple of real {tuple(real.shape)}")
+        pooled = torch.empty_like(real)
+        loss = torch.empty((), device=img.device, dtype=torch.float32)
+        ws = torch.empty(L.lib().hfagp_pool_mse_workspace_bytes() // 4, device=img.device, dtype=torch.float32)
+        L.check(L.lib().hfagp_pool_mse_fwd(_ptr(img), _ptr(real), _ptr(pooled), _ptr(loss), _ptr(ws), b * c, h, w, f,
+                                           _stream()), "pool_mse_fwd")
+        ctx.save_for_backward(pooled, real)
+        ctx.shape = (b, c, hh, ww, f)
+        ctx.mark_non_differentiable(pooled)
+        return loss, pooled
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_pooled):
+        pooled, real = ctx.saved_tensors
+        b, c, hh, ww, f = ctx.shape
+        d_img = torch.empty(b, c, hh, ww, device=pooled.device, dtype=torch.float32)
+        L.check(L.lib().hfagp_pool_mse_bwd(_ptr(pooled), _ptr(real), _ptr(g_loss.contiguous().float()), _ptr(d_img), b * c,
+                                           real.shape[-2], real.shape[-1], f, _stream()), "pool_mse_bwd")
+        return d_img, None
+
+
+def pool_mse(img: torch.Tensor, real: torch.Tensor):
+    """→ (l2 loss scalar, pooled image [B,C,h,w])."""
+    return PoolMSE.apply(img, real)

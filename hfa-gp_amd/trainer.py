@@ -25,6 +25,20 @@ from .cam_utils import create_cam2world_matrix, make_label, sample_camera_positi
 from .headnerf import AudioAttNet, AudioNet, HeadNeRF_3DMM, HeadNeRF_Audio, HeadNeRF_final
 
 
+def pooled_l2(face_pool: nn.Module, real_image: torch.Tensor, generated: torch.Tensor, need_pooled_grad: bool):
+    """(l2, pooled image) of the reference's  generated = face_pool(generated); l2 = MSE(real, generated)
+    (trainer_rgb.py:84-86).  On the MI355X with an integer pooling factor and no LPIPS term this is the fused
+    pass of ops.pool_mse (one read of the image forward, one write backward); otherwise PyTorch-ROCm ops."""
+    if (generated.is_cuda and not need_pooled_grad and real_image.dtype == torch.float32
+            and real_image.shape[:2] == generated.shape[:2]
+            and generated.shape[-2] % real_image.shape[-2] == 0 and generated.shape[-1] % real_image.shape[-1] == 0
+            and generated.shape[-2] // real_image.shape[-2] == generated.shape[-1] // real_image.shape[-1]):
+        from . import ops
+        return ops.pool_mse(generated.contiguous(), real_image.contiguous())
+    pooled = face_pool(generated)
+    return F.mse_loss(real_image, pooled, reduction="mean"), pooled
+
+
 def requires_grad(net: nn.Module, flag: bool = True) -> None:
     for p in net.parameters():
         p.requires_grad = flag
@@ -114,8 +128,7 @@ class Trainer(nn.Module):
             generated = self.gen.get_image(latent, label)
         else:
             generated = self.gen(params, label, person_2)
-        generated = self.face_pool(generated)
-        l2 = self.l2_loss(real_image, generated)
+        l2, generated = pooled_l2(self.face_pool, real_image, generated, self.lpips_loss is not None)
         if self.lpips_loss is not None:
             lp = torch.squeeze(self.lpips_loss(real_image, generated)).mean()
         else:
@@ -256,9 +269,9 @@ class AudioTrainer(nn.Module):
     def gen_update(self, real_image, label, params, global_step: int, img_i: int, person_2: bool = False):
         self.gen.train(), self.AudNet.train(), self.AudAttNet.train()
         self.w_optim.zero_grad(), self.optimizer_Aud.zero_grad(), self.optimizer_AudAtt.zero_grad()
-        generated = self.face_pool(self.gen(self._drive(global_step, img_i, self.i_train), label, person_2))
+        generated = self.gen(self._drive(global_step, img_i, self.i_train), label, person_2)
         l2_3dmm = torch.zeros(1, device=self.device)
-        l2 = self.l2_loss(real_image, generated)
+        l2, generated = pooled_l2(self.face_pool, real_image, generated, self.lpips_loss is not None)
         lp = (torch.squeeze(self.lpips_loss(real_image, generated)).mean() if self.lpips_loss is not None
               else torch.zeros((), device=l2.device))
         (l2_3dmm + l2 + lp).backward()

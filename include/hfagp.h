@@ -324,6 +324,18 @@ int hfagp_affine_grad(const float* dstot, const float* w, float* dA, float* db, 
 int hfagp_channel_sum(const float* g, float* partial, float* out, int64_t npix, int32_t C, int32_t nblocks,
                       int32_t accumulate, void* stream);
 
+/* ------------------------------------------------------------------ loss side of the fitting step
+ * trainer_rgb.py:84-86 / trainer_3dmm.py:51-53 / trainer_audio.py:97-99:
+ *   pooled = AdaptiveAvgPool2d((h, w))(img)  with img [BC][f*h][f*w] (NCHW, BC = B*C, integer factor f),
+ *   loss   = mean((real - pooled)^2)          (MSELoss(reduction='mean'); deterministic reduction order)
+ * and its adjoint  d_img = g_loss * 2 (pooled - real) / (BC*h*w * f^2)  (every element of d_img is written).
+ * workspace: hfagp_pool_mse_workspace_bytes() bytes; loss, g_loss: one float on the device.              */
+size_t hfagp_pool_mse_workspace_bytes(void);
+int hfagp_pool_mse_fwd(const float* img, const float* real, float* pooled, float* loss, float* workspace,
+                       int32_t BC, int32_t h, int32_t w, int32_t f, void* stream);
+int hfagp_pool_mse_bwd(const float* pooled, const float* real, const float* g_loss, float* d_img,
+                       int32_t BC, int32_t h, int32_t w, int32_t f, void* stream);
+
 /* ------------------------------------------------------------------ standalone ops (NCHW, test surface) */
 int hfagp_upfirdn2d_fwd(const float* x, const float* f, float* y,
                         int32_t N, int32_t C, int32_t H, int32_t W, int32_t fh, int32_t fw,

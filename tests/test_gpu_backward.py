@@ -223,6 +223,27 @@ def test_rgb_trainer_and_render_harness_on_gpu(dev):
     assert abs(frames[0].float().mean().item() - ref.float().mean().item()) < 8.0
 
 
+@pytest.mark.parametrize("b,c,h,f", [(2, 3, 256, 2), (1, 3, 32, 2), (3, 3, 17, 1), (2, 3, 16, 4), (1, 1, 1, 2)])
+def test_pool_mse_fused_loss(dev, b, c, h, f):
+    """hfagp_pool_mse_fwd / _bwd vs AdaptiveAvgPool2d + MSELoss(mean) and their autograd (trainer_rgb.py:84-86)."""
+    from hfa_gp_amd import ops
+    g = torch.Generator().manual_seed(b * 10 + h)
+    img = torch.randn(b, c, h * f, h * f, generator=g, requires_grad=True)
+    real = (0.5 * torch.randn(b, c, h, h, generator=g)).clamp(-1, 1)
+    pooled_ref = torch.nn.AdaptiveAvgPool2d((h, h))(img)
+    loss_ref = F.mse_loss(real, pooled_ref, reduction="mean")
+    (loss_ref * 1.7).backward()
+    img_d = img.detach().to(dev).requires_grad_(True)
+    loss, pooled = ops.pool_mse(img_d, real.to(dev))
+    assert not pooled.requires_grad
+    close(pooled, pooled_ref.detach(), atol=1e-6)
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) <= 1e-6 + 1e-5 * abs(float(loss_ref.detach()))
+    (loss * 1.7).backward()
+    close(img_d.grad, img.grad, atol=1e-9 + 1e-5 * float(img.grad.abs().max()))
+    loss2, _ = ops.pool_mse(img_d.detach(), real.to(dev))
+    assert torch.equal(loss2, loss.detach()), "fixed reduction order -> bitwise repeatable"
+
+
 def test_audio_trainer_and_batched_reenactment_on_gpu(dev):
     """Audio-driven variant (trainer_audio.py; BASELINE config 5 mechanics): AudioNet (+ AudioAttNet over the
     smoothing window) -> basis -> HIP generator.  One step per branch moves the right optimisers' parameters; the
