@@ -158,6 +158,9 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
     // MFMAs that consume them (item = one tap of one K chunk).
     const char* wb = reinterpret_cast<const char*>(p.wt);
     const int cq8 = p.Cin >> 3;
+    // Cout = 96 (toRGB) runs on the same 128-wide tile: the lanes of its last 32 columns read the first 32 entries of
+    // the NEXT image row (the caller pads the buffer by 512 B for the very last row), their accumulators are never
+    // stored.  (A separate padded pitch for the image cost 66 VGPRs in the 9-tap kernel: spills.)
     const int part_stride = p.wtaps * cq8 * p.Cout;                           // uint4 per part
     unsigned bth[TN];                                                         // per-lane byte offset of a fragment
 #pragma unroll
@@ -589,8 +592,9 @@ static void launch_group(const Plan& pl, int phase0, int nphase, int ntaps, size
 }
 
 int launch_modconv_bf16(const HfagpModconvArgs* a, Plan& pl, hipStream_t s) {
-    HFAGP_REQUIRE(a->Cin % CKB == 0 && a->Cout % BNB == 0, HFAGP_EUNSUPPORTED,
-                  "modconv (split bf16): Cin=%d must be a multiple of %d and Cout=%d of %d", a->Cin, CKB, a->Cout, BNB);
+    HFAGP_REQUIRE(a->Cin % CKB == 0 && (a->Cout % BNB == 0 || (a->Cout % BNB >= 96 && !pl.merged_up)), HFAGP_EUNSUPPORTED,
+                  "modconv (split bf16): Cin=%d must be a multiple of %d and Cout=%d of %d (or 96 mod 128, 512-B tail pad)",
+                  a->Cin, CKB, a->Cout, BNB);
     HFAGP_REQUIRE(pl.bn == BNB && pl.bm == 128, HFAGP_EUNSUPPORTED, "modconv (split bf16): unexpected plan");
     HFAGP_REQUIRE(a->Cin <= 512, HFAGP_EUNSUPPORTED, "modconv (split bf16): Cin=%d > 512 (style image in LDS)", a->Cin);
     HFAGP_REQUIRE(a->precision == HFAGP_PREC_BF16X3 || a->precision == HFAGP_PREC_BF16X6 || a->precision == HFAGP_PREC_F16,

@@ -65,7 +65,7 @@ static inline int make_plan(const HfagpModconvArgs* a, Plan& pl, int ck) {
     int in_h = a->H, in_w = a->W;      // extent of the image(s) the patches are read from
 
     // N tile / wave arrangement
-    if (a->Cout % 128 == 0) pl.bn = 128;
+    if (a->Cout % 128 == 0 || a->precision != HFAGP_PREC_F32) pl.bn = 128;     // 16-bit paths: 128-wide tiles only
     else if (a->Cout % 96 == 0) pl.bn = 96;
     else if (a->Cout % 64 == 0) pl.bn = 64;
     else pl.bn = 32;

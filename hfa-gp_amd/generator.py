@@ -199,8 +199,8 @@ class TriPlaneGenerator(nn.Module):
         prec = self._conv_precision
         if self._sr_conv_precision is not None and id(weight) in self._sr_weight_ids:
             prec = self._sr_conv_precision
-        if transposed and prec == "f16":
-            prec = "bf16x3"
+        if prec == "f16" and (transposed or weight.shape[-1] == 1):
+            prec = "bf16x3"       # gradients and the toRGB products (no fp16 range guard there) stay fp32-class
         nparts = ops.NPARTS[prec]
         if not ops.split_supported(ci, co):
             nparts = 0
@@ -436,6 +436,13 @@ class TriPlaneGenerator(nn.Module):
         """Drop-in for EG3D's TriPlaneGenerator.synthesis.  Differentiable w.r.t. `ws` (the latent-basis fitting of
         HFA-GP) and w.r.t. the generator parameters that require grad (after `tune_generator()`)."""
         self._check_inputs(ws, c, noise_mode)
+        if ws.shape[0] == 0:          # empty batch (ragged last batch of a frame shard): nothing to launch
+            cfg, dev = self.cfg, ws.device
+            r = cfg.neural_rendering_resolution
+            out = {"image": torch.zeros(0, cfg.img_channels, cfg.img_resolution, cfg.img_resolution, device=dev),
+                   "image_raw": torch.zeros(0, 3, r, r, device=dev), "image_depth": torch.zeros(0, 1, r, r, device=dev)}
+            out["image"] = out["image"] + 0.0 * ws.sum()          # keeps the autograd edge to ws
+            return out
         params = [p for n, p in self.named_parameters() if not n.startswith("backbone.mapping.")]
         need_grad = torch.is_grad_enabled() and (ws.requires_grad or any(p.requires_grad for p in params))
         if need_grad:

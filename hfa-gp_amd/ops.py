@@ -66,9 +66,10 @@ PRECISIONS = {"fp32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16x6": PREC_BF16X6, "f
 NPARTS = {"fp32": 0, "f16": 1, "bf16x3": 2, "bf16x6": 3}      # parts of the 16-bit weight image (0: fp32 image)
 
 
-def split_supported(cin: int, cout: int) -> bool:
-    """Shapes the split-bf16 conv path takes (hfagp.h: Cin % 16 == 0, Cout % 128 == 0)."""
-    return cin % 16 == 0 and cout % 128 == 0
+def split_supported(cin: int, cout: int, up: bool = False) -> bool:
+    """Shapes the 16-bit conv paths take (hfagp.h: Cin % 16 == 0 and Cout % 128 == 0, or Cout % 128 >= 96 for the
+    non-upsampling modes: the 96-channel toRGB on a 128-wide tile whose last 32 columns are discarded)."""
+    return cin % 16 == 0 and (cout % 128 == 0 or (cout % 128 >= 96 and not up))
 
 
 def weight_prep_split(weight: torch.Tensor, nparts: int) -> torch.Tensor:
@@ -77,8 +78,10 @@ def weight_prep_split(weight: torch.Tensor, nparts: int) -> torch.Tensor:
     nparts 1: the single-pass fp16 image (float16, HFAGP_PREC_F16)."""
     _chk(weight, "weight")
     co, ci, kh, kw = weight.shape
-    wb = torch.empty(nparts, kh * kw, ci // 8, co, 8, device=weight.device,
-                     dtype=torch.float16 if nparts == 1 else torch.bfloat16)
+    # + 512 B behind the image: with Cout % 128 != 0 the 128-wide tile reads one partial row past it (hfagp.h)
+    numel = nparts * kh * kw * (ci // 8) * co * 8
+    flat = torch.zeros(numel + 256, device=weight.device, dtype=torch.float16 if nparts == 1 else torch.bfloat16)
+    wb = flat[:numel].view(nparts, kh * kw, ci // 8, co, 8)
     L.check(L.lib().hfagp_weight_prep_split(_ptr(weight), wb.data_ptr(), co, ci, kh * kw, nparts, _stream()),
             "weight_prep_split")
     return wb

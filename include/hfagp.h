@@ -114,7 +114,9 @@ int hfagp_weight_prep(const float* weight, float* wt, float* wsq,
 /* split-bf16 weight image for the HFAGP_PREC_BF16X3 / _BF16X6 conv path:
  *   wb [nparts][taps][Cin/8][Cout][8] bf16  <- weight [Cout][Cin][kh][kw],  w = part0 + part1 (+ part2),
  *   each part the round-to-nearest bf16 of the residual left by the parts before it (nparts = 2 or 3).
- *   nparts = 1: the HFAGP_PREC_F16 image, same layout, elements rounded to IEEE fp16.                     */
+ *   nparts = 1: the HFAGP_PREC_F16 image, same layout, elements rounded to IEEE fp16.
+ *   When Cout % 128 != 0 (the 96-channel toRGB) the buffer must extend 512 bytes past the image: the 128-wide
+ *   tile reads (and discards) one partial row beyond it.                                                   */
 int hfagp_weight_prep_split(const float* weight, void* wb, int32_t Cout, int32_t Cin, int32_t taps,
                             int32_t nparts, void* stream);
 
@@ -142,7 +144,8 @@ enum { HFAGP_ACT_LINEAR = 0, HFAGP_ACT_LRELU = 1 };
  *           The arithmetic EG3D's CUDA path uses in its fp16 blocks (super-resolution, sr_num_fp16_res = 4:
  *           SURVEY.md U4) except that tensors stay fp32 in HBM and accumulation is fp32.  The caller keeps
  *           |x * style| below 65504 (EG3D's pre-normalisation of the styles by their max, compensated in dcoef).
- * The 16-bit paths need Cin % 16 == 0 and Cout % 128 == 0 (HFAGP_EUNSUPPORTED otherwise).            */
+ * The 16-bit paths need Cin % 16 == 0 and Cout % 128 == 0 — or, except for HFAGP_CONVT3X3_UP2, Cout % 128 >= 96
+ * (the 96-channel toRGB: computed on a 128-wide tile whose last columns are discarded) — HFAGP_EUNSUPPORTED otherwise.   */
 enum { HFAGP_PREC_F32 = 0, HFAGP_PREC_BF16X3 = 1, HFAGP_PREC_BF16X6 = 2, HFAGP_PREC_F16 = 3 };
 
 typedef struct {

@@ -14,7 +14,7 @@ tot = 0
 for r in csv.DictReader(open(f)):
     ms = float(r["TotalDurationNs"]) / 1e6 / iters
     tot += ms
-    if ms > 0.05:
+    if ms > 0.015:
         print(f"{r['Name'].split('(')[0][:70]:70s} calls/step {int(r['Calls'])/iters:6.1f}  ms/step {ms:7.3f}  avg_us {float(r['AverageNs'])/1e3:8.1f}")
 print("total kernel ms/step", tot)
 PY

@@ -13,6 +13,7 @@ import os
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from tests.util import ROOT, look_at_label, make_inputs, perturb_state, state_cpu
 
@@ -192,6 +193,27 @@ def test_synthesis_layer_f16(dev, b, h, cin, cout, up, ksplit, clamp, xscale):
                         ksplit=ksplit)
     assert torch.isfinite(y).all()
     close(ops.nhwc_to_nchw(y), want, atol=F16_TOL * float(want.abs().max()) + 1e-6)
+
+
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16x6"])
+@pytest.mark.parametrize("b,h,cin,ksplit", [(2, 19, 128, 0), (1, 8, 512, 4), (3, 4, 32, 1)])
+def test_torgb96_on_padded_split_tile(dev, prec, b, h, cin, ksplit):
+    """The 96-channel toRGB (1x1, no demodulation, linear) on the 16-bit kernels: computed on the 128-wide tile, the
+    epilogue drops the last 32 columns."""
+    from hfa_gp_amd import ops
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(b, cin, h, h, generator=g)
+    w = torch.randn(96, cin, 1, 1, generator=g)
+    s = torch.randn(b, cin, generator=g)
+    bias = torch.randn(96, generator=g)
+    want = F.conv2d((x * s[:, :, None, None]).reshape(1, b * cin, h, h),
+                    w.repeat(b, 1, 1, 1), groups=b).reshape(b, 96, h, h) + bias[None, :, None, None]
+    wb = ops.weight_prep_split(w.to(dev), ops.NPARTS[prec])
+    assert wb.shape == (ops.NPARTS[prec], 1, cin // 8, 96, 8) and wb.is_contiguous()
+    y = ops.modconv(ops.nchw_to_nhwc(x.to(dev)), wb, 96, ops.CONV1X1, styles=s.to(dev), bias=bias.to(dev), act="linear",
+                    gain=1.0, ksplit=ksplit)
+    assert y.shape == (b, h, h, 96)
+    close(ops.nhwc_to_nchw(y), want, atol=SPLIT_TOL[prec] * float(want.abs().max()) + 1e-6)
 
 
 def test_split_bf16_rejects_unsupported_shapes(dev):
@@ -405,6 +427,26 @@ def test_full_size_properties(dev):
     x = gen.synthesis(ws[:1], c[:1])["image"]
     y = gen.synthesis(ws[:1], c[:1])["image"]
     assert not torch.equal(x, y)
+
+
+def test_empty_and_odd_batches(dev):
+    """Ragged frame shards: an empty batch returns empty images (no launch), odd batch sizes equal the frames
+    rendered one by one."""
+    from hfa_gp_amd.config import tiny64
+    from hfa_gp_amd.generator import TriPlaneGenerator
+    cfg = tiny64()
+    gen = TriPlaneGenerator(cfg, seed=2).to(dev)
+    ws, c, us, ui = [t.to(dev) for t in make_inputs(cfg, 5, seed=3)]
+    r = cfg.neural_rendering_resolution ** 2
+    out = gen.synthesis(ws[:0], c[:0])
+    assert out["image"].shape == (0, 3, cfg.img_resolution, cfg.img_resolution) and out["image_raw"].shape[0] == 0
+    w0 = ws[:0].clone().requires_grad_(True)
+    gen.synthesis(w0, c[:0])["image"].sum().backward()
+    assert w0.grad.shape == w0.shape
+    full = gen.synthesis(ws, c, u_strat=us, u_imp=ui)["image"]
+    for i in (0, 4):
+        one = gen.synthesis(ws[i:i + 1], c[i:i + 1], u_strat=us[i:i + 1], u_imp=ui[i * r:(i + 1) * r])["image"]
+        close(one, full[i:i + 1], atol=1e-5)
 
 
 def test_state_dict_round_trip_and_headnerf_boundary(dev, tmp_path):
