@@ -111,6 +111,7 @@ SYMBOLS = {
     "hfagp_qr_gram_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "hfagp_style_batch_fwd": (C.c_int, [C.POINTER(StyleArgs), C.c_int32, C.c_void_p]),
     "hfagp_weight_prep_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "hfagp_weight_prep_prec": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "hfagp_modconv_workspace_bytes": (C.c_size_t, [C.POINTER(ModconvArgs)]),
     "hfagp_modconv_fwd": (C.c_int, [C.POINTER(ModconvArgs), C.c_void_p]),
     "hfagp_upfir_epilogue_fwd": (C.c_int, [C.POINTER(UpfirEpilogueArgs), C.c_void_p]),

@@ -50,9 +50,11 @@ class GeneratorConfig:
     # "bf16x3" = operands split into hi+lo bf16, 3 bf16 MFMAs per product, fp32 accumulation (relative error of a
     # layer ~5e-6, i.e. ~200x below the fp16 the reference's CUDA path runs the super-resolution blocks in, U4);
     # "bf16x6" = 3 parts / 6 MFMAs (fp32-class).  Layers the split kernel cannot take run on the exact kernel.
+    # "f16x3" (default) = operands split into hi+lo fp16 (11 + 11 mantissa bits), 3 fp16 MFMAs per product: relative
+    # error of a layer ~1e-6 = the exact kernel's own summation noise, ~5 % slower than "bf16x3".
     # "f16" = operands rounded to fp16, ONE fp16 MFMA per product, fp32 accumulation: the arithmetic of EG3D's own
     # fp16 blocks (relative error of a layer ~3e-4); never the default.
-    conv_precision: str = "bf16x3"
+    conv_precision: str = "f16x3"
     # precision of the two super-resolution blocks when it differs from conv_precision: "f16" reproduces the
     # reference's CUDA defaults (fp32 backbone, fp16 super-resolution: sr_num_fp16_res = 4)
     sr_conv_precision: Optional[str] = None

@@ -43,20 +43,46 @@ __device__ __forceinline__ unsigned pack_f16(float a, float b) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
 }
 
-// one MFMA of the path: NP = 1 is the single-pass fp16 mode (HFAGP_PREC_F16), NP >= 2 the bf16 part products
-template <int NP>
+// operand kinds KD of the kernels below: 1 = one fp16 part (HFAGP_PREC_F16), 2 / 3 = two / three bf16 parts
+// (BF16X3 / BF16X6), 4 = two fp16 parts (F16X3: 11 + 11 mantissa bits, the three products above 2^-22)
+constexpr int kind_parts(int kd) { return kd == 4 ? 2 : kd; }
+constexpr bool kind_f16(int kd) { return kd == 1 || kd == 4; }
+
+__device__ __forceinline__ float f16_lo_back(unsigned u) {       // fp16 in bits 0-15 -> float
+    return (float)__builtin_bit_cast(f16x2, u)[0];
+}
+__device__ __forceinline__ float f16_hi_back(unsigned u) {       // fp16 in bits 16-31 -> float
+    return (float)__builtin_bit_cast(f16x2, u)[1];
+}
+
+// one MFMA of the path: fp16 or bf16 operands
+template <bool F16>
 __device__ __forceinline__ f32x16 mfma16(u32x4 a, u32x4 b, f32x16 c) {
-    if constexpr (NP == 1)
+    if constexpr (F16)
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     else
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// v (4 floats) -> NP x 4 bf16 (two dwords per part); NP = 1: 4 fp16 (round to nearest even)
-template <int NP>
-__device__ __forceinline__ void split4(float4 v, uint2 (&out)[NP]) {
-    if constexpr (NP == 1) {
-        out[0] = make_uint2(pack_f16(v.x, v.y), pack_f16(v.z, v.w));
+// v (4 floats) -> parts x 4 elements (two dwords per part), each part the round-to-nearest 16-bit value of the
+// residual left by the parts before it
+template <int KD>
+__device__ __forceinline__ void split4(float4 v, uint2 (&out)[kind_parts(KD)]) {
+    constexpr int NP = kind_parts(KD);
+    if constexpr (kind_f16(KD)) {
+        // saturating: an activation beyond fp16's range (never seen; the reference clamps its fp16 layers at 256) must
+        // not turn into inf - inf = NaN in the residual
+        constexpr float FMAX = 65504.f;
+        const float cx = __builtin_amdgcn_fmed3f(v.x, -FMAX, FMAX), cy = __builtin_amdgcn_fmed3f(v.y, -FMAX, FMAX);
+        const float cz = __builtin_amdgcn_fmed3f(v.z, -FMAX, FMAX), cw = __builtin_amdgcn_fmed3f(v.w, -FMAX, FMAX);
+        out[0] = make_uint2(pack_f16(cx, cy), pack_f16(cz, cw));
+        if constexpr (NP == 2) {
+            const unsigned lo = out[0].x, hi = out[0].y;
+            out[1] = make_uint2(pack_f16(__builtin_amdgcn_fmed3f(v.x - f16_lo_back(lo), -FMAX, FMAX),
+                                         __builtin_amdgcn_fmed3f(v.y - f16_hi_back(lo), -FMAX, FMAX)),
+                                pack_f16(__builtin_amdgcn_fmed3f(v.z - f16_lo_back(hi), -FMAX, FMAX),
+                                         __builtin_amdgcn_fmed3f(v.w - f16_hi_back(hi), -FMAX, FMAX)));
+        }
         return;
     }
     float r[4] = {v.x, v.y, v.z, v.w};
@@ -73,8 +99,32 @@ __device__ __forceinline__ void split4(float4 v, uint2 (&out)[NP]) {
     }
 }
 
-template <int NP, int TM, int NTAPS>
+// fp16 range guard (EG3D's modulated_conv2d pre-normalises the styles by their max in its fp16 blocks): the styles
+// of the sample are scaled by the power of two 2^-e that brings max|s| into (0.5, 1], so |x * s| <= |x| stays inside
+// fp16's range; the accumulators are scaled back by 2^e on the way out.  Powers of two: both scalings are exact, the
+// result equals the un-normalised arithmetic.  Called by every thread of the block between two barriers.
+template <int NTH>
+__device__ __forceinline__ float style_range_guard(float* Ss, float* red, int cin, int tid) {
+    float m = 0.f;
+    for (int i = tid; i < cin; i += NTH) m = fmaxf(m, fabsf(Ss[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    m = red[0];
+#pragma unroll
+    for (int w = 1; w < NTH / 64; ++w) m = fmaxf(m, red[w]);
+    int e = 0;
+    if (m > 0.f && m < 3.0e38f) (void)frexpf(m, &e);
+    const float down = ldexpf(1.f, -e);
+    for (int i = tid; i < cin; i += NTH) Ss[i] *= down;
+    return ldexpf(1.f, e);
+}
+
+template <int KD, int TM, int NTAPS>
 __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p, const int phase0) {
+    constexpr int NP = kind_parts(KD);
+    constexpr bool F16 = kind_f16(KD);
 #ifndef HFAGP_WAVES_N
 #define HFAGP_WAVES_N 2
 #endif
@@ -118,6 +168,11 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
     float4 ra[A_PER_T];
     const char* xb = reinterpret_cast<const char*>(p.x + ph.in_off + (long long)b * p.x_batch_stride);
     for (int i = tid; i < p.Cin; i += 256) Ss[i] = p.styles ? p.styles[(size_t)b * p.Cin + i] : 1.f;
+    float sback = 1.f;                                   // 2^e of the fp16 range guard (1 for the bf16 kinds)
+    if constexpr (F16) {
+        __syncthreads();
+        sback = style_range_guard<256>(Ss, Ss + p.Cin, p.Cin, tid);
+    }
     unsigned aoff[A_PER_T];
     int lds_a[A_PER_T], soff[A_PER_T];
     float amask[A_PER_T];
@@ -144,7 +199,7 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
             const float m = amask[k];
             const float4 sv = *reinterpret_cast<const float4*>(Ss + chunk * CKB + soff[k]);
             uint2 parts[NP];
-            split4<NP>(make_float4(ra[k].x * (sv.x * m), ra[k].y * (sv.y * m), ra[k].z * (sv.z * m),
+            split4<KD>(make_float4(ra[k].x * (sv.x * m), ra[k].y * (sv.y * m), ra[k].z * (sv.z * m),
                                    ra[k].w * (sv.w * m)), parts);
 #pragma unroll
             for (int q = 0; q < NP; ++q)
@@ -253,7 +308,7 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
                 for (int tm = 0; tm < TMW; ++tm)
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn)
-                        acc[tm][tn] = mfma16<NP>(af[T & 1][tm][PA[pr]], bq[SL][tn][PB[pr]], acc[tm][tn]);
+                        acc[tm][tn] = mfma16<F16>(af[T & 1][tm][PA[pr]], bq[SL][tn][PB[pr]], acc[tm][tn]);
 #pragma unroll
             for (int k = 0; k < A_PER_T; ++k) {
                 const int tk = NT - A_PER_T + k < 0 ? 0 : NT - A_PER_T + k;      // tap that carries slot k
@@ -323,9 +378,9 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
     for (int tn = 0; tn < TN; ++tn) {
         const int co = co0 + (wn * TN + tn) * 32 + l31;
         if (co >= p.Cout) continue;
-        float d = 1.f, bs = 0.f;
+        float d = sback, bs = 0.f;
         if (p.fused) {
-            if (p.dcoef) d = p.dcoef[(size_t)b * p.Cout + co];
+            if (p.dcoef) d = p.dcoef[(size_t)b * p.Cout + co] * sback;
             if (p.bias) bs = p.bias[co];
         }
 #pragma unroll
@@ -349,6 +404,7 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
                     if (n >= ph.mw) continue;
                     float v = acc[tm][tn][8 * rw + q];
                     if (p.fused) v = lrelu_gain_clamp(v * d + bs + nz[q], p.act, p.alpha, p.gain, p.clamp);
+                    else if constexpr (F16) v *= sback;
                     rowp[n * cstep] = v;
                 }
             }
@@ -368,8 +424,10 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
 // channels per block and two waves per SIMD (256 registers each) — the patch is staged once for twice the MFMA
 // work and the second wave of a SIMD covers the barrier / staging bubbles of the first; used when the layer
 // still fills the chip with the larger tile (make_plan).
-template <int NP, int NW>
+template <int KD, int NW>
 __global__ void __launch_bounds__(NW * 64, 1) upconv_bf16_kernel(const ConvParams p) {
+    constexpr int NP = kind_parts(KD);
+    constexpr bool F16 = kind_f16(KD);
     constexpr int NTH = NW * 64;
     constexpr int TM = 2, TN = 1, WN = NW / 2, BM = 128, BNU = WN * TN * 32, PH = BM / PW, NITEM = 9, RB = NP == 1 ? 6 : 3;
     constexpr int LPWB = RowPitch<NP>::value;
@@ -406,6 +464,11 @@ __global__ void __launch_bounds__(NW * 64, 1) upconv_bf16_kernel(const ConvParam
     float4 ra[A_PER_T];
     const char* xb = reinterpret_cast<const char*>(p.x + (long long)b * p.x_batch_stride);
     for (int i = tid; i < p.Cin; i += NTH) Ss[i] = p.styles ? p.styles[(size_t)b * p.Cin + i] : 1.f;
+    float sback = 1.f;
+    if constexpr (F16) {
+        __syncthreads();
+        sback = style_range_guard<NTH>(Ss, Ss + p.Cin, p.Cin, tid);
+    }
     unsigned aoff[A_PER_T];
     int lds_a[A_PER_T], soff[A_PER_T];
     float amask[A_PER_T];
@@ -431,7 +494,7 @@ __global__ void __launch_bounds__(NW * 64, 1) upconv_bf16_kernel(const ConvParam
             const float m = amask[k];
             const float4 sv = *reinterpret_cast<const float4*>(Ss + chunk * CKB + soff[k]);
             uint2 parts[NP];
-            split4<NP>(make_float4(ra[k].x * (sv.x * m), ra[k].y * (sv.y * m), ra[k].z * (sv.z * m),
+            split4<KD>(make_float4(ra[k].x * (sv.x * m), ra[k].y * (sv.y * m), ra[k].z * (sv.z * m),
                                    ra[k].w * (sv.w * m)), parts);
 #pragma unroll
             for (int q = 0; q < NP; ++q)
@@ -497,7 +560,7 @@ __global__ void __launch_bounds__(NW * 64, 1) upconv_bf16_kernel(const ConvParam
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn)
-                    acc[F][tm][tn] = mfma16<NP>(af[G & 1][tm][PA[pr]], bq[SL][tn][PB[pr]], acc[F][tm][tn]);
+                    acc[F][tm][tn] = mfma16<F16>(af[G & 1][tm][PA[pr]], bq[SL][tn][PB[pr]], acc[F][tm][tn]);
         // the patch of the next chunk is converted into the other LDS buffer under the last A_PER_T items
         if constexpr (I >= NITEM - A_PER_T)
             store_a(min(c + 1, c_end - 1), std::integral_constant<int, 1 - decltype(u_tag)::value>{},
@@ -567,7 +630,7 @@ __global__ void __launch_bounds__(NW * 64, 1) upconv_bf16_kernel(const ConvParam
                     for (int q = 0; q < 8; ++q) {
                         const int n = n0 + 8 * (q >> 2) + 4 * h + (q & 3);
                         if (n >= mw) continue;
-                        rowp[2 * n * p.Cout] = acc[f][tm][tn][8 * rw + q];
+                        rowp[2 * n * p.Cout] = F16 ? acc[f][tm][tn][8 * rw + q] * sback : acc[f][tm][tn][8 * rw + q];
                     }
                 }
         }
@@ -577,63 +640,83 @@ __global__ void __launch_bounds__(NW * 64, 1) upconv_bf16_kernel(const ConvParam
 template <int NP, int TM>
 static size_t bf16_lds_bytes(int cin) {
     constexpr int PH = 2 * TM * 32 / PW;
-    return (size_t)2 * NP * (PH + 2) * RowPitch<NP>::value * APITCH + (size_t)cin * sizeof(float);
+    return (size_t)2 * NP * (PH + 2) * RowPitch<NP>::value * APITCH + (size_t)(cin + 8) * sizeof(float);   // + guard scratch
 }
 
-template <int NP>
-static void launch_group(const Plan& pl, int phase0, int nphase, int ntaps, size_t lds, hipStream_t s) {
+template <int KD>
+static void launch_group(const Plan& pl, int phase0, int nphase, int ntaps, int cin, hipStream_t s) {
     const dim3 grid(pl.grid.x, (unsigned)nphase, 1);
+    const size_t lds = bf16_lds_bytes<kind_parts(KD), 2>(cin);
     switch (ntaps) {
-        case 9: modconv_bf16_kernel<NP, 2, 9><<<grid, 256, lds, s>>>(pl.p, phase0); break;
-        case 4: modconv_bf16_kernel<NP, 2, 4><<<grid, 256, lds, s>>>(pl.p, phase0); break;
-        case 2: modconv_bf16_kernel<NP, 2, 2><<<grid, 256, lds, s>>>(pl.p, phase0); break;
-        default: modconv_bf16_kernel<NP, 2, 1><<<grid, 256, lds, s>>>(pl.p, phase0); break;
+        case 9: modconv_bf16_kernel<KD, 2, 9><<<grid, 256, lds, s>>>(pl.p, phase0); break;
+        case 4: modconv_bf16_kernel<KD, 2, 4><<<grid, 256, lds, s>>>(pl.p, phase0); break;
+        case 2: modconv_bf16_kernel<KD, 2, 2><<<grid, 256, lds, s>>>(pl.p, phase0); break;
+        default: modconv_bf16_kernel<KD, 2, 1><<<grid, 256, lds, s>>>(pl.p, phase0); break;
+    }
+}
+
+template <int KD>
+static void launch_up(const Plan& pl, int cin, hipStream_t s) {
+    const size_t lds = bf16_lds_bytes<kind_parts(KD), 2>(cin);
+    if constexpr (KD != 3) {            // (three parts: the 8-wave variant would spill; make_plan never asks for it)
+        if (pl.up_waves == 8) {
+            upconv_bf16_kernel<KD, 8><<<pl.grid, 512, lds, s>>>(pl.p);
+            return;
+        }
+    }
+    upconv_bf16_kernel<KD, 4><<<pl.grid, 256, lds, s>>>(pl.p);
+}
+
+// HFAGP_PREC_* -> operand kind of the kernels (0: not a 16-bit precision)
+static int kind_of(int precision) {
+    switch (precision) {
+        case HFAGP_PREC_F16: return 1;
+        case HFAGP_PREC_BF16X3: return 2;
+        case HFAGP_PREC_BF16X6: return 3;
+        case HFAGP_PREC_F16X3: return 4;
+        default: return 0;
     }
 }
 
 int launch_modconv_bf16(const HfagpModconvArgs* a, Plan& pl, hipStream_t s) {
     HFAGP_REQUIRE(a->Cin % CKB == 0 && (a->Cout % BNB == 0 || (a->Cout % BNB >= 96 && !pl.merged_up)), HFAGP_EUNSUPPORTED,
-                  "modconv (split bf16): Cin=%d must be a multiple of %d and Cout=%d of %d (or 96 mod 128, 512-B tail pad)",
+                  "modconv (16-bit MFMA): Cin=%d must be a multiple of %d and Cout=%d of %d (or 96 mod 128, 512-B tail pad)",
                   a->Cin, CKB, a->Cout, BNB);
-    HFAGP_REQUIRE(pl.bn == BNB && pl.bm == 128, HFAGP_EUNSUPPORTED, "modconv (split bf16): unexpected plan");
-    HFAGP_REQUIRE(a->Cin <= 512, HFAGP_EUNSUPPORTED, "modconv (split bf16): Cin=%d > 512 (style image in LDS)", a->Cin);
-    HFAGP_REQUIRE(a->precision == HFAGP_PREC_BF16X3 || a->precision == HFAGP_PREC_BF16X6 || a->precision == HFAGP_PREC_F16,
-                  HFAGP_EBADARG, "modconv: unknown precision %d", a->precision);
+    HFAGP_REQUIRE(pl.bn == BNB && pl.bm == 128, HFAGP_EUNSUPPORTED, "modconv (16-bit MFMA): unexpected plan");
+    HFAGP_REQUIRE(a->Cin <= 512, HFAGP_EUNSUPPORTED, "modconv (16-bit MFMA): Cin=%d > 512 (style image in LDS)", a->Cin);
+    const int kd = kind_of(a->precision);
+    HFAGP_REQUIRE(kd != 0, HFAGP_EBADARG, "modconv: unknown precision %d", a->precision);
     // the kernel is specialised on the tap count: one launch per run of phases with the same number of taps
     // (3x3: one; stride-2 transposed conv and its adjoint: 4 | 2, 2 | 1)
     const ConvParams& p = pl.p;
     if (pl.merged_up) {                 // one block for the four phases (grid.y = 1)
-        if (pl.up_waves == 8) {
-            if (a->precision == HFAGP_PREC_F16)
-                upconv_bf16_kernel<1, 8><<<pl.grid, 512, bf16_lds_bytes<1, 2>(a->Cin), s>>>(p);
-            else if (a->precision == HFAGP_PREC_BF16X3)
-                upconv_bf16_kernel<2, 8><<<pl.grid, 512, bf16_lds_bytes<2, 2>(a->Cin), s>>>(p);
-            else
-                upconv_bf16_kernel<3, 8><<<pl.grid, 512, bf16_lds_bytes<3, 2>(a->Cin), s>>>(p);
-        } else if (a->precision == HFAGP_PREC_F16)
-            upconv_bf16_kernel<1, 4><<<pl.grid, 256, bf16_lds_bytes<1, 2>(a->Cin), s>>>(p);
-        else if (a->precision == HFAGP_PREC_BF16X3)
-            upconv_bf16_kernel<2, 4><<<pl.grid, 256, bf16_lds_bytes<2, 2>(a->Cin), s>>>(p);
-        else
-            upconv_bf16_kernel<3, 4><<<pl.grid, 256, bf16_lds_bytes<3, 2>(a->Cin), s>>>(p);
-        return check_launch("modconv_fwd (split bf16, merged up-conv)");
+        switch (kd) {
+            case 1: launch_up<1>(pl, a->Cin, s); break;
+            case 2: launch_up<2>(pl, a->Cin, s); break;
+            case 3: launch_up<3>(pl, a->Cin, s); break;
+            default: launch_up<4>(pl, a->Cin, s); break;
+        }
+        return check_launch("modconv_fwd (16-bit MFMA, merged up-conv)");
     }
     for (int p0 = 0; p0 < p.nphase;) {
         int n = 1;
         while (p0 + n < p.nphase && p.phase[p0 + n].ntaps == p.phase[p0].ntaps) ++n;
         const int nt = p.phase[p0].ntaps;
-        HFAGP_REQUIRE(nt == 9 || nt == 4 || nt == 2 || nt == 1, HFAGP_EUNSUPPORTED, "modconv (split bf16): %d taps", nt);
-        if (a->precision == HFAGP_PREC_F16) launch_group<1>(pl, p0, n, nt, bf16_lds_bytes<1, 2>(a->Cin), s);
-        else if (a->precision == HFAGP_PREC_BF16X3) launch_group<2>(pl, p0, n, nt, bf16_lds_bytes<2, 2>(a->Cin), s);
-        else launch_group<3>(pl, p0, n, nt, bf16_lds_bytes<3, 2>(a->Cin), s);
+        HFAGP_REQUIRE(nt == 9 || nt == 4 || nt == 2 || nt == 1, HFAGP_EUNSUPPORTED, "modconv (16-bit MFMA): %d taps", nt);
+        switch (kd) {
+            case 1: launch_group<1>(pl, p0, n, nt, a->Cin, s); break;
+            case 2: launch_group<2>(pl, p0, n, nt, a->Cin, s); break;
+            case 3: launch_group<3>(pl, p0, n, nt, a->Cin, s); break;
+            default: launch_group<4>(pl, p0, n, nt, a->Cin, s); break;
+        }
         p0 += n;
     }
-    return check_launch("modconv_fwd (split bf16)");
+    return check_launch("modconv_fwd (16-bit MFMA)");
 }
 
-// weight [Cout][Cin][taps] -> wb [nparts][taps][Cin/8][Cout][8] bf16 (nparts = 1: fp16); thread = (tap, ci group, co)
+// weight [Cout][Cin][taps] -> wb [parts][taps][Cin/8][Cout][8] bf16 or fp16 (operand kind kd); thread = (tap, ci group, co)
 __global__ void __launch_bounds__(256) weight_prep_split_kernel(const float* __restrict__ w, uint4* __restrict__ wb,
-                                                                int Cout, int Cin, int taps, int nparts) {
+                                                                int Cout, int Cin, int taps, int kd) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int cq8 = Cin >> 3;
     const long long n = (long long)taps * cq8 * Cout;
@@ -644,10 +727,20 @@ __global__ void __launch_bounds__(256) weight_prep_split_kernel(const float* __r
     float r[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) r[e] = w[((size_t)co * Cin + 8 * g + e) * taps + t];
-    if (nparts == 1) {
-        wb[idx] = make_uint4(pack_f16(r[0], r[1]), pack_f16(r[2], r[3]), pack_f16(r[4], r[5]), pack_f16(r[6], r[7]));
+    if (kd == 1 || kd == 4) {
+        unsigned u[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) u[e] = pack_f16(r[2 * e], r[2 * e + 1]);
+        wb[idx] = make_uint4(u[0], u[1], u[2], u[3]);
+        if (kd == 4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                u[e] = pack_f16(r[2 * e] - f16_lo_back(u[e]), r[2 * e + 1] - f16_hi_back(u[e]));
+            wb[n + idx] = make_uint4(u[0], u[1], u[2], u[3]);
+        }
         return;
     }
+    const int nparts = kd;
     for (int q = 0; q < nparts; ++q) {
         unsigned u[4];
 #pragma unroll
@@ -664,14 +757,25 @@ __global__ void __launch_bounds__(256) weight_prep_split_kernel(const float* __r
 
 using namespace hfagp;
 
-extern "C" int hfagp_weight_prep_split(const float* weight, void* wb, int32_t Cout, int32_t Cin, int32_t taps,
-                                       int32_t nparts, void* stream) {
+static int weight_prep_kind(const float* weight, void* wb, int32_t Cout, int32_t Cin, int32_t taps, int kd, void* stream) {
     HFAGP_REQUIRE(weight && wb, HFAGP_EBADARG, "weight_prep_split: null pointer");
-    HFAGP_REQUIRE(Cin % 8 == 0 && Cout > 0 && (taps == 1 || taps == 9) && nparts >= 1 && nparts <= 3,
-                  HFAGP_EUNSUPPORTED, "weight_prep_split: Cin=%d must be a multiple of 8, taps=%d in {1,9}, nparts=%d in {1,2,3}",
-                  Cin, taps, nparts);
+    HFAGP_REQUIRE(Cin % 8 == 0 && Cout > 0 && (taps == 1 || taps == 9), HFAGP_EUNSUPPORTED,
+                  "weight_prep_split: Cin=%d must be a multiple of 8, taps=%d in {1,9}", Cin, taps);
     const long long n = (long long)taps * (Cin / 8) * Cout;
     weight_prep_split_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(
-        weight, reinterpret_cast<uint4*>(wb), Cout, Cin, taps, nparts);
+        weight, reinterpret_cast<uint4*>(wb), Cout, Cin, taps, kd);
     return check_launch("weight_prep_split");
+}
+
+extern "C" int hfagp_weight_prep_split(const float* weight, void* wb, int32_t Cout, int32_t Cin, int32_t taps,
+                                       int32_t nparts, void* stream) {
+    HFAGP_REQUIRE(nparts >= 1 && nparts <= 3, HFAGP_EUNSUPPORTED, "weight_prep_split: nparts=%d in {1,2,3}", nparts);
+    return weight_prep_kind(weight, wb, Cout, Cin, taps, nparts, stream);
+}
+
+extern "C" int hfagp_weight_prep_prec(const float* weight, void* wb, int32_t Cout, int32_t Cin, int32_t taps,
+                                      int32_t precision, void* stream) {
+    const int kd = kind_of(precision);
+    HFAGP_REQUIRE(kd != 0, HFAGP_EBADARG, "weight_prep_prec: precision %d has no 16-bit weight image", precision);
+    return weight_prep_kind(weight, wb, Cout, Cin, taps, kd, stream);
 }

@@ -166,11 +166,12 @@ class TriPlaneGenerator(nn.Module):
     # ----------------------------------------------------------------- caches
     @property
     def conv_precision(self) -> str:
-        """Arithmetic of the conv GEMMs: 'fp32' (exact MFMA), 'bf16x3' or 'bf16x6' (split-bf16 MFMA, fp32
+        """Arithmetic of the conv GEMMs: 'fp32' (exact MFMA), 'bf16x3' / 'bf16x6' / 'f16x3' (split-operand MFMA, fp32
         accumulation; include/hfagp.h HFAGP_PREC_*), 'f16' (single-pass fp16 MFMA, fp32 accumulation: the
-        arithmetic of EG3D's fp16 blocks).  Layers whose shape the 16-bit kernels do not take (Cin % 16,
-        Cout % 128) always run on the exact fp32 kernel; gradient GEMMs of an 'f16' layer run in bf16x3 (a raw
-        gradient has no place in fp16's exponent range without loss scaling)."""
+        arithmetic of EG3D's fp16 blocks).  'f16x3' (the default) splits each operand into two fp16 parts (22 mantissa
+        bits): fp32-class results at the cost of 'bf16x3'.  Layers whose shape the 16-bit kernels do not take
+        (Cin % 16, Cout % 128) always run on the exact fp32 kernel; gradient GEMMs of the fp16 kinds run in bf16x3 (a
+        raw gradient has no place in fp16's exponent range without loss scaling)."""
         return self._conv_precision
 
     @property
@@ -199,18 +200,19 @@ class TriPlaneGenerator(nn.Module):
         prec = self._conv_precision
         if self._sr_conv_precision is not None and id(weight) in self._sr_weight_ids:
             prec = self._sr_conv_precision
-        if prec == "f16" and (transposed or weight.shape[-1] == 1):
-            prec = "bf16x3"       # gradients and the toRGB products (no fp16 range guard there) stay fp32-class
-        nparts = ops.NPARTS[prec]
+        if prec in ("f16", "f16x3") and transposed:
+            prec = "bf16x3"       # gradient GEMMs: a raw gradient needs fp32's exponent range (bf16 parts have it)
+        if prec == "f16" and weight.shape[-1] == 1:
+            prec = "f16x3"        # the toRGB products feed the tri-planes directly: keep them fp32-class
         if not ops.split_supported(ci, co):
-            nparts = 0
-        key = ("G", nparts, transposed, id(weight))
+            prec = "fp32"
+        key = ("G", prec, transposed, id(weight))
         hit = self._prep.get(key)
         if hit is not None and hit[0] == weight._version and hit[1] == weight.data_ptr():
             return hit[2]
         w = weight.detach()
         w = (w.transpose(0, 1) if transposed else w).contiguous()
-        img = ops.weight_prep_split(w, nparts) if nparts else ops.weight_prep(w)[0]
+        img = ops.weight_prep_prec(w, prec) if prec != "fp32" else ops.weight_prep(w)[0]
         self._prep[key] = (weight._version, weight.data_ptr(), img, None)
         return img
 
@@ -255,17 +257,13 @@ class TriPlaneGenerator(nn.Module):
             raise NotImplementedError("noise_mode must be 'const' or 'none' (HFA-GP passes 'const', headnerf.py:112)")
         cout = layer.weight.shape[0]
         gain = math.sqrt(2.0)
-        k_styles, k_dcoef = styles, dcoef
-        if wt.dtype == torch.float16:
-            # EG3D's fp16 guard (modulated_conv2d: styles / max|styles| before the product, undone by the
-            # demodulation): keeps x * style inside fp16's range; the tape keeps the un-normalised pair
-            m = styles.abs().amax(1, keepdim=True)
-            k_styles, k_dcoef = styles / m, dcoef * m
+        k_styles, k_dcoef = styles, dcoef       # (the fp16 kernels apply EG3D's fp16 range guard themselves)
         # algorithmic FLOPs: 2 * B * H_in * W_in * Cin * Cout * 9 (the up-conv is counted in its
         # polyphase / transposed form at INPUT resolution)
         flops = 2.0 * batch * x.shape[1] * x.shape[2] * x.shape[3] * cout * 9
         # which kernel bench.py times
-        key = {torch.float32: "modconv", torch.bfloat16: "modconv_split", torch.float16: "modconv_f16"}[wt.dtype]
+        key = ("modconv" if wt.dtype == torch.float32 else
+               "modconv_f16" if wt.dtype == torch.float16 and wt.shape[0] == 1 else "modconv_split")
         if layer.up == 2:
             yt = self._timed(key, flops, ops.modconv, x, wt, cout, ops.CONVT3X3_UP2, styles=k_styles, batch=batch)
             out = ops.upfir_epilogue(yt, k_dcoef, noise, ns, layer.bias, "lrelu", cfg.lrelu_alpha, gain, conv_clamp)

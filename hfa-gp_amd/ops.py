@@ -61,9 +61,10 @@ def weight_prep(weight: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     return wt, wsq
 
 
-PREC_F32, PREC_BF16X3, PREC_BF16X6, PREC_F16 = 0, 1, 2, 3
-PRECISIONS = {"fp32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16x6": PREC_BF16X6, "f16": PREC_F16}
-NPARTS = {"fp32": 0, "f16": 1, "bf16x3": 2, "bf16x6": 3}      # parts of the 16-bit weight image (0: fp32 image)
+PREC_F32, PREC_BF16X3, PREC_BF16X6, PREC_F16, PREC_F16X3 = 0, 1, 2, 3, 4
+PRECISIONS = {"fp32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16x6": PREC_BF16X6, "f16": PREC_F16, "f16x3": PREC_F16X3}
+NPARTS = {"fp32": 0, "f16": 1, "bf16x3": 2, "bf16x6": 3, "f16x3": 2}   # parts of the 16-bit weight image (0: fp32 image)
+_IMAGE_DTYPE = {"f16": torch.float16, "f16x3": torch.float16, "bf16x3": torch.bfloat16, "bf16x6": torch.bfloat16}
 
 
 def split_supported(cin: int, cout: int, up: bool = False) -> bool:
@@ -72,19 +73,25 @@ def split_supported(cin: int, cout: int, up: bool = False) -> bool:
     return cin % 16 == 0 and (cout % 128 == 0 or (cout % 128 >= 96 and not up))
 
 
-def weight_prep_split(weight: torch.Tensor, nparts: int) -> torch.Tensor:
-    """weight [Cout, Cin, k, k] fp32 → split-bf16 B-operand image [nparts, k*k, Cin/8, Cout, 8] (bfloat16):
-    weight = sum of the parts, each the round-to-nearest bf16 of the residual (nparts 2: BF16X3, 3: BF16X6).
-    nparts 1: the single-pass fp16 image (float16, HFAGP_PREC_F16)."""
+def weight_prep_prec(weight: torch.Tensor, precision: str) -> torch.Tensor:
+    """weight [Cout, Cin, k, k] fp32 → B-operand image [parts, k*k, Cin/8, Cout, 8] of a 16-bit conv precision:
+    'bf16x3' / 'bf16x6' = 2 / 3 bfloat16 parts, 'f16x3' = 2 float16 parts (each part the round-to-nearest value of
+    the residual left by the parts before it), 'f16' = one float16 part."""
     _chk(weight, "weight")
     co, ci, kh, kw = weight.shape
+    nparts = NPARTS[precision]
     # + 512 B behind the image: with Cout % 128 != 0 the 128-wide tile reads one partial row past it (hfagp.h)
     numel = nparts * kh * kw * (ci // 8) * co * 8
-    flat = torch.zeros(numel + 256, device=weight.device, dtype=torch.float16 if nparts == 1 else torch.bfloat16)
+    flat = torch.zeros(numel + 256, device=weight.device, dtype=_IMAGE_DTYPE[precision])
     wb = flat[:numel].view(nparts, kh * kw, ci // 8, co, 8)
-    L.check(L.lib().hfagp_weight_prep_split(_ptr(weight), wb.data_ptr(), co, ci, kh * kw, nparts, _stream()),
-            "weight_prep_split")
+    L.check(L.lib().hfagp_weight_prep_prec(_ptr(weight), wb.data_ptr(), co, ci, kh * kw, PRECISIONS[precision], _stream()),
+            "weight_prep_prec")
     return wb
+
+
+def weight_prep_split(weight: torch.Tensor, nparts: int) -> torch.Tensor:
+    """`weight_prep_prec` by part count: 1 = 'f16', 2 = 'bf16x3', 3 = 'bf16x6'."""
+    return weight_prep_prec(weight, {1: "f16", 2: "bf16x3", 3: "bf16x6"}[nparts])
 
 
 def styles_demod(w: torch.Tensor, affine_w: torch.Tensor, affine_b: torch.Tensor,
@@ -199,11 +206,14 @@ def modconv(x: torch.Tensor, wt: torch.Tensor, cout: int, mode: int, styles: Opt
     b = batch if batch is not None else xb
     a = L.ModconvArgs()
     if wt.dtype in (torch.bfloat16, torch.float16):
-        nparts = (2, 3) if wt.dtype == torch.bfloat16 else (1,)
+        nparts = (2, 3) if wt.dtype == torch.bfloat16 else (1, 2)
         if not (wt.is_cuda and wt.is_contiguous() and wt.dim() == 5 and wt.shape[0] in nparts):
-            raise RuntimeError("modconv: 16-bit weight images must come from weight_prep_split")
+            raise RuntimeError("modconv: 16-bit weight images must come from weight_prep_prec")
         a.x, a.wt = _ptr(x), wt.data_ptr()
-        a.precision = {1: PREC_F16, 2: PREC_BF16X3, 3: PREC_BF16X6}[wt.shape[0]]
+        if wt.dtype == torch.float16:
+            a.precision = PREC_F16 if wt.shape[0] == 1 else PREC_F16X3
+        else:
+            a.precision = PREC_BF16X3 if wt.shape[0] == 2 else PREC_BF16X6
     else:
         a.x, a.wt = _ptr(x), _ptr(_chk(wt, "wt"))
         a.precision = PREC_F32

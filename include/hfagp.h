@@ -119,6 +119,10 @@ int hfagp_weight_prep(const float* weight, float* wt, float* wsq,
  *   tile reads (and discards) one partial row beyond it.                                                   */
 int hfagp_weight_prep_split(const float* weight, void* wb, int32_t Cout, int32_t Cin, int32_t taps,
                             int32_t nparts, void* stream);
+/* the same image selected by HFAGP_PREC_* (F16: 1 fp16 part, BF16X3 / BF16X6: 2 / 3 bf16 parts,
+ * F16X3: 2 fp16 parts = round-to-nearest fp16 of the weight and of its residual)                           */
+int hfagp_weight_prep_prec(const float* weight, void* wb, int32_t Cout, int32_t Cin, int32_t taps,
+                           int32_t precision, void* stream);
 
 /* ------------------------------------------------------------------ modulated conv
  * Implicit-GEMM on v_mfma_f32_32x32x2_f32 (exact fp32).  Input is scaled by
@@ -140,17 +144,20 @@ enum { HFAGP_ACT_LINEAR = 0, HFAGP_ACT_LRELU = 1 };
  *   BF16X3  operands split into 2 bf16 parts (hi+lo), 3 v_mfma_f32_32x32x16_bf16 per product
  *           (hi.hi + lo.hi + hi.lo): relative product error ~2^-16
  *   BF16X6  3 parts, 6 MFMAs per product: relative product error ~2^-23 (fp32 class)
+ *   F16X3   operands split into 2 fp16 parts (11 + 11 mantissa bits), 3 v_mfma_f32_32x32x16_f16 per product
+ *           (hi.hi + lo.hi + hi.lo): relative product error ~2^-22 — fp32 class at the cost of BF16X3
  *   F16     operands rounded to fp16, ONE v_mfma_f32_32x32x16_f16 per product: relative product error ~2^-11.
  *           The arithmetic EG3D's CUDA path uses in its fp16 blocks (super-resolution, sr_num_fp16_res = 4:
  *           SURVEY.md U4) except that tensors stay fp32 in HBM and accumulation is fp32.  The caller keeps
- *           |x * style| below 65504 (EG3D's pre-normalisation of the styles by their max, compensated in dcoef).
+ *           The fp16 kinds keep |x * style| <= |x| inside the kernel (styles scaled by a power of two per sample,
+ *           undone on the accumulators: EG3D's fp16 pre-normalisation, exact); |x| itself must stay below 65504.
  * The 16-bit paths need Cin % 16 == 0 and Cout % 128 == 0 — or, except for HFAGP_CONVT3X3_UP2, Cout % 128 >= 96
  * (the 96-channel toRGB: computed on a 128-wide tile whose last columns are discarded) — HFAGP_EUNSUPPORTED otherwise.   */
-enum { HFAGP_PREC_F32 = 0, HFAGP_PREC_BF16X3 = 1, HFAGP_PREC_BF16X6 = 2, HFAGP_PREC_F16 = 3 };
+enum { HFAGP_PREC_F32 = 0, HFAGP_PREC_BF16X3 = 1, HFAGP_PREC_BF16X6 = 2, HFAGP_PREC_F16 = 3, HFAGP_PREC_F16X3 = 4 };
 
 typedef struct {
     const float* x;           /* [B][H][W][Cin]; x_batch_stride (elements) may be 0 (const)   */
-    const void*  wt;          /* hfagp_weight_prep (F32) or hfagp_weight_prep_split (F16: 1, BF16X3: 2, BF16X6: 3 parts) */
+    const void*  wt;          /* hfagp_weight_prep (F32) or hfagp_weight_prep_prec (16-bit precisions) */
     const float* styles;      /* [B][Cin] or NULL                                             */
     const float* dcoef;       /* [B][Cout] or NULL                                            */
     const float* noise;       /* [Ho][Wo] or NULL                                             */

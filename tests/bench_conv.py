@@ -1,5 +1,5 @@
 """Developer micro-benchmark of one modulated-conv layer (run on the GPU box).
-usage: bench_conv.py B H Cin Cout up [ksplit] [iters] [fp32|bf16x3|bf16x6|f16]"""
+usage: bench_conv.py B H Cin Cout up [ksplit] [iters] [fp32|bf16x3|bf16x6|f16x3|f16]"""
 import math
 import os
 import sys
@@ -20,7 +20,7 @@ def main():
     x = torch.randn(B, H, H, cin, device=dev, generator=g)
     w = torch.randn(cout, cin, 3, 3, device=dev, generator=g)
     wt32, wsq = ops.weight_prep(w)
-    wt = wt32 if prec == "fp32" else ops.weight_prep_split(w, ops.NPARTS[prec])
+    wt = wt32 if prec == "fp32" else ops.weight_prep_prec(w, prec)
     styles = torch.randn(B, cin, device=dev, generator=g)
     dcoef = torch.rand(B, cout, device=dev, generator=g)
     bias = torch.randn(cout, device=dev, generator=g)

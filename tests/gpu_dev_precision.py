@@ -20,7 +20,7 @@ def main():
     gen = gen.to(dev).requires_grad_(False)
     ws, c, us, ui = make_inputs(cfg, 1)
     ref = O.synthesis(P, cfg, ws, c, us, ui)["image"]
-    for prec, sr in (("fp32", None), ("bf16x6", None), ("bf16x3", None), ("bf16x3", "f16"), ("f16", None)):
+    for prec, sr in (("fp32", None), ("bf16x6", None), ("f16x3", None), ("bf16x3", None), ("bf16x3", "f16"), ("f16", None)):
         gen.conv_precision, gen.sr_conv_precision = prec, sr
         prec = prec if sr is None else f"{prec}+{sr} SR"
         out = gen.synthesis(ws.to(dev), c.to(dev), u_strat=us.to(dev), u_imp=ui.to(dev))["image"].cpu()

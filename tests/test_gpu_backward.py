@@ -112,14 +112,15 @@ def test_raymarch_bwd_vs_oracle_autograd(dev, preset, axes):
 
 
 @pytest.mark.parametrize("preset,batch,prec", [("tiny64", 2, "fp32"), ("tiny14", 1, "fp32"), ("small128", 2, "fp32"),
-                                               ("small128", 2, "bf16x3"), ("small128", 1, "bf16x6")])
+                                               ("small128", 2, "bf16x3"), ("small128", 1, "bf16x6"),
+                                               ("small128", 2, "f16x3")])
 def test_synthesis_backward_vs_oracle_autograd(dev, preset, batch, prec):
     """dL/d ws for L = <image, G> + <image_raw, G_raw>, generator frozen (BASELINE config 3 mechanics)."""
     from hfa_gp_amd.config import PRESETS
     from hfa_gp_amd.generator import TriPlaneGenerator
     from oracle import eg3d_oracle as O
     cfg = dataclasses.replace(PRESETS[preset](), conv_precision=prec)
-    k = {"fp32": 1.0, "bf16x6": 1.0, "bf16x3": 5.0}[prec]
+    k = {"fp32": 1.0, "bf16x6": 1.0, "bf16x3": 5.0, "f16x3": 5.0}[prec]     # (f16x3: gradient GEMMs run in bf16x3)
     gen = perturb_state(TriPlaneGenerator(cfg, seed=0)).requires_grad_(False)
     P = state_cpu(gen)
     gen = gen.to(dev)

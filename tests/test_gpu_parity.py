@@ -4,8 +4,8 @@ golden vectors.  Needs an MI355X:  python -m pytest tests -m gpu
 Tolerances.  Tensors and accumulation are fp32.  With conv_precision 'fp32' the conv GEMMs run on the exact-f32
 MFMA; north_star's bar is MSE <= 1e-3 on [-1,1] images; the internal bar used here is max-abs <= 1e-4
  — measured errors are ~5e-6, the slack covers fp32 summation-order differences (MFMA k-order,
-split-K, wave scans vs cumprod).  The split-bf16 conv paths ('bf16x3' = the preset default, 'bf16x6') are held to
-E2E_ATOL / SPLIT_TOL below (measured: ~5e-6 relative per layer for bf16x3, fp32-level for bf16x6)."""
+split-K, wave scans vs cumprod).  The split-operand conv paths ('f16x3' = the preset default, 'bf16x3', 'bf16x6') are
+held to E2E_ATOL / SPLIT_TOL below (measured: ~5e-6 relative per layer for bf16x3, fp32-level for f16x3 / bf16x6)."""
 import dataclasses
 import math
 import os
@@ -116,10 +116,11 @@ def test_synthesis_layer(dev, b, h, cin, cout, up, ksplit, clamp):
     close(ops.nhwc_to_nchw(y), want, atol=2e-5)
 
 
-SPLIT_TOL = {"bf16x3": 5e-5, "bf16x6": 4e-6}     # relative to max|ref|: product error ~2^-16 / ~2^-23, fp32 sums
+# relative to max|ref|: product error ~2^-16 (bf16x3) / ~2^-23 (bf16x6) / ~2^-22 (f16x3), fp32 sums
+SPLIT_TOL = {"bf16x3": 5e-5, "bf16x6": 4e-6, "f16x3": 4e-6}
 
 
-@pytest.mark.parametrize("prec", ["bf16x3", "bf16x6"])
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16x6", "f16x3"])
 @pytest.mark.parametrize("b,h,cin,cout,up,ksplit,clamp", [
     (2, 17, 32, 128, 1, 0, None), (1, 33, 16, 256, 1, 1, 0.8), (1, 8, 64, 128, 1, 3, None),
     (2, 9, 48, 128, 2, 0, None), (1, 16, 64, 256, 2, 3, 0.9), (1, 1, 16, 128, 1, 0, None)])
@@ -135,11 +136,13 @@ def test_synthesis_layer_split_bf16(dev, prec, b, h, cin, cout, up, ksplit, clam
     want = O.synthesis_layer(x, w, P, "L", up, O.fir_kernel(), "const", clamp, 0.2, True, 1e-8)
     D = {k: v.to(dev) for k, v in P.items()}
     _, wsq = ops.weight_prep(D["L.weight"])
-    wb = ops.weight_prep_split(D["L.weight"], 2 if prec == "bf16x3" else 3)
-    assert wb.dtype == torch.bfloat16 and wb.shape == (2 if prec == "bf16x3" else 3, 9, cin // 8, cout, 8)
-    # the parts sum back to the weight to 2^-16 / 2^-24
+    wb = ops.weight_prep_prec(D["L.weight"], prec)
+    assert wb.dtype == (torch.float16 if prec == "f16x3" else torch.bfloat16)
+    assert wb.shape == (ops.NPARTS[prec], 9, cin // 8, cout, 8)
+    # the parts sum back to the weight to 2^-16 (bf16 hi+lo) / 2^-22 (fp16 hi+lo) / 2^-23 (three bf16 parts)
     back = wb.float().sum(0).permute(2, 1, 3, 0).reshape(cout, cin, 3, 3)
-    assert float((back - D["L.weight"]).abs().max()) <= (2.0 ** -16 if prec == "bf16x3" else 2.0 ** -23) * float(D["L.weight"].abs().max())
+    bits = {"bf16x3": -16, "f16x3": -22, "bf16x6": -23}[prec]
+    assert float((back - D["L.weight"]).abs().max()) <= 2.0 ** bits * float(D["L.weight"].abs().max())
     styles, dcoef = ops.styles_demod(w.to(dev), D["L.affine.weight"], D["L.affine.bias"], wsq)
     xh = ops.nchw_to_nhwc(x.to(dev))
     if up == 2:
@@ -161,8 +164,8 @@ F16_TOL = 6e-3      # relative to max|ref| (which a conv_clamp caps): operands r
     (1, 12, 32, 128, 1, 0, None, 200.0)])
 def test_synthesis_layer_f16(dev, b, h, cin, cout, up, ksplit, clamp, xscale):
     """The single-pass fp16 MFMA path (HFAGP_PREC_F16: the arithmetic of EG3D's fp16 blocks) of the same layer,
-    with EG3D's style pre-normalisation; xscale 200 = activations at the conv_clamp level, styles x 40: the
-    un-normalised product would leave fp16's range."""
+    with the kernel's fp16 range guard (EG3D's style pre-normalisation as an exact power-of-two scaling); xscale 200 =
+    activations at the conv_clamp level, styles x 40: the un-normalised product would leave fp16's range."""
     from hfa_gp_amd import ops
     from oracle import eg3d_oracle as O
     res = h * up
@@ -181,9 +184,7 @@ def test_synthesis_layer_f16(dev, b, h, cin, cout, up, ksplit, clamp, xscale):
     back = wb.float()[0].permute(2, 1, 3, 0).reshape(cout, cin, 3, 3)
     assert torch.equal(back, D["L.weight"].half().float())            # round-to-nearest-even, like torch
     styles, dcoef = ops.styles_demod(w.to(dev), D["L.affine.weight"], D["L.affine.bias"], wsq)
-    m = styles.abs().amax(1, keepdim=True)
-    styles, dcoef = styles / m, dcoef * m
-    xh = ops.nchw_to_nhwc(x.to(dev))
+    xh = ops.nchw_to_nhwc(x.to(dev))      # (the range guard on the styles is inside the kernel)
     if up == 2:
         yt = ops.modconv(xh, wb, cout, ops.CONVT3X3_UP2, styles=styles, ksplit=ksplit)
         y = ops.upfir_epilogue(yt, dcoef, D["L.noise_const"], 0.37, D["L.bias"], clamp=clamp)
@@ -195,7 +196,7 @@ def test_synthesis_layer_f16(dev, b, h, cin, cout, up, ksplit, clamp, xscale):
     close(ops.nhwc_to_nchw(y), want, atol=F16_TOL * float(want.abs().max()) + 1e-6)
 
 
-@pytest.mark.parametrize("prec", ["bf16x3", "bf16x6"])
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16x6", "f16x3"])
 @pytest.mark.parametrize("b,h,cin,ksplit", [(2, 19, 128, 0), (1, 8, 512, 4), (3, 4, 32, 1)])
 def test_torgb96_on_padded_split_tile(dev, prec, b, h, cin, ksplit):
     """The 96-channel toRGB (1x1, no demodulation, linear) on the 16-bit kernels: computed on the 128-wide tile, the
@@ -208,7 +209,7 @@ def test_torgb96_on_padded_split_tile(dev, prec, b, h, cin, ksplit):
     bias = torch.randn(96, generator=g)
     want = F.conv2d((x * s[:, :, None, None]).reshape(1, b * cin, h, h),
                     w.repeat(b, 1, 1, 1), groups=b).reshape(b, 96, h, h) + bias[None, :, None, None]
-    wb = ops.weight_prep_split(w.to(dev), ops.NPARTS[prec])
+    wb = ops.weight_prep_prec(w.to(dev), prec)
     assert wb.shape == (ops.NPARTS[prec], 1, cin // 8, 96, 8) and wb.is_contiguous()
     y = ops.modconv(ops.nchw_to_nhwc(x.to(dev)), wb, 96, ops.CONV1X1, styles=s.to(dev), bias=bias.to(dev), act="linear",
                     gain=1.0, ksplit=ksplit)
@@ -332,13 +333,14 @@ def test_raymarch_edge_cases(dev):
 
 # ----------------------------------------------------------------------------- end to end
 # image-level tolerance per conv precision (images are in [-1, 1]; the planes reach a few units)
-E2E_ATOL = {"fp32": 1e-5, "bf16x6": 2e-5, "bf16x3": 2e-4}
+E2E_ATOL = {"fp32": 1e-5, "bf16x6": 2e-5, "bf16x3": 2e-4, "f16x3": 2e-5}
 
 
 @pytest.mark.parametrize("preset,batch,prec", [("tiny64", 1, "fp32"), ("tiny64", 3, "fp32"), ("tiny14", 2, "fp32"),
                                                ("small128", 2, "fp32"), ("small128", 2, "bf16x3"),
                                                ("ffhq512_128", 1, "fp32"), ("ffhq512_128", 1, "bf16x3"),
-                                               ("ffhq512_128", 1, "bf16x6")])
+                                               ("ffhq512_128", 1, "bf16x6"), ("ffhq512_128", 1, "f16x3"),
+                                               ("small128", 2, "f16x3")])
 def test_synthesis_vs_oracle(dev, preset, batch, prec):
     """BASELINE configs 1 (tiny64 plumbing case) and 2 (512^2, 96 samples) against the oracle, for the exact
     fp32 conv kernel and for the split-bf16 ones."""
@@ -393,8 +395,8 @@ def test_synthesis_f16_blocks_vs_oracle(dev, sr_only):
     r = cfg.plane_resolution
     planes = out["planes"].permute(0, 1, 4, 2, 3).reshape(1, 96, r, r)
     if sr_only:     # the backbone is untouched: the default precision's tolerance
-        close(planes, ref["planes"], atol=E2E_ATOL["bf16x3"] * max(1.0, float(ref["planes"].abs().max())))
-        close(out["image_raw"], ref["image_raw"], atol=E2E_ATOL["bf16x3"])
+        close(planes, ref["planes"], atol=E2E_ATOL[cfg.conv_precision] * max(1.0, float(ref["planes"].abs().max())))
+        close(out["image_raw"], ref["image_raw"], atol=E2E_ATOL[cfg.conv_precision])
     err = (out["image"].cpu() - ref["image"])
     assert err.pow(2).mean().item() <= 1e-5, err.pow(2).mean().item()
     assert err.abs().max().item() <= 3e-2, err.abs().max().item()
@@ -414,7 +416,7 @@ def test_full_size_properties(dev):
     assert torch.equal(a["image"], b["image"]), "no atomics / fixed reduction order -> bitwise repeatable"
     one = gen.synthesis(ws[2:], c[2:], u_strat=us[2:], u_imp=ui[2 * r:])
     # the split-K factor of the small layers depends on the batch size, so this is equal to fp32
-    # summation order, not bitwise (the preset's default conv arithmetic is bf16x3)
+    # summation order, not bitwise (the preset's default conv arithmetic is f16x3)
     close(one["image"], a["image"][2:], atol=1e-4)
     close(one["image_raw"], a["image_raw"][2:], atol=1e-4)
     assert a["image"].shape == (3, 3, 512, 512) and a["image_raw"].shape == (3, 3, 128, 128)

@@ -15,7 +15,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 @pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="hipcc not available")
 @pytest.mark.parametrize("src,patterns", [
-    ("modconv_bf16.hip", [r"modconv_bf16_kernelILi[12]E", r"upconv_bf16_kernelILi[12]E"]),
+    ("modconv_bf16.hip", [r"modconv_bf16_kernelILi[124]E", r"upconv_bf16_kernelILi[124]E"]),
     ("modconv.hip", [r"modconv_kernelI"]),
 ])
 def test_conv_kernels_do_not_spill(tmp_path, src, patterns):
