@@ -102,23 +102,18 @@ __device__ __forceinline__ void split4(float4 v, uint2 (&out)[kind_parts(KD)]) {
 // fp16 range guard (EG3D's modulated_conv2d pre-normalises the styles by their max in its fp16 blocks): the styles
 // of the sample are scaled by the power of two 2^-e that brings max|s| into (0.5, 1], so |x * s| <= |x| stays inside
 // fp16's range; the accumulators are scaled back by 2^e on the way out.  Powers of two: both scalings are exact, the
-// result equals the un-normalised arithmetic.  Called by every thread of the block between two barriers.
-template <int NTH>
-__device__ __forceinline__ float style_range_guard(float* Ss, float* red, int cin, int tid) {
-    float m = 0.f;
-    for (int i = tid; i < cin; i += NTH) m = fmaxf(m, fabsf(Ss[i]));
+// result equals the un-normalised arithmetic.  Every wave reduces the (L2-resident, <= 2 KB) style vector on its own:
+// no LDS traffic, no barrier.  Returns 2^-e, *back = 2^e.
+__device__ __forceinline__ float style_range_guard(const float* styles, int cin, int lane, float* back) {
+    float m = styles ? 0.f : 1.f;
+    if (styles)
+        for (int i = lane; i < cin; i += 64) m = fmaxf(m, fabsf(styles[i]));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((tid & 63) == 0) red[tid >> 6] = m;
-    __syncthreads();
-    m = red[0];
-#pragma unroll
-    for (int w = 1; w < NTH / 64; ++w) m = fmaxf(m, red[w]);
     int e = 0;
     if (m > 0.f && m < 3.0e38f) (void)frexpf(m, &e);
-    const float down = ldexpf(1.f, -e);
-    for (int i = tid; i < cin; i += NTH) Ss[i] *= down;
-    return ldexpf(1.f, e);
+    *back = ldexpf(1.f, e);
+    return ldexpf(1.f, -e);
 }
 
 template <int KD, int TM, int NTAPS>
@@ -168,11 +163,8 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
     float4 ra[A_PER_T];
     const char* xb = reinterpret_cast<const char*>(p.x + ph.in_off + (long long)b * p.x_batch_stride);
     for (int i = tid; i < p.Cin; i += 256) Ss[i] = p.styles ? p.styles[(size_t)b * p.Cin + i] : 1.f;
-    float sback = 1.f;                                   // 2^e of the fp16 range guard (1 for the bf16 kinds)
-    if constexpr (F16) {
-        __syncthreads();
-        sback = style_range_guard<256>(Ss, Ss + p.Cin, p.Cin, tid);
-    }
+    float sback = 1.f, sdown = 1.f;                      // 2^e, 2^-e of the fp16 range guard (1 for the bf16 kinds)
+    if constexpr (F16) sdown = style_range_guard(p.styles ? p.styles + (size_t)b * p.Cin : nullptr, p.Cin, lane, &sback);
     unsigned aoff[A_PER_T];
     int lds_a[A_PER_T], soff[A_PER_T];
     float amask[A_PER_T];
@@ -184,7 +176,7 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
         const int iy = m0 + p.dymin + pix / p.pw, ix = n0 + p.dxmin + pix % p.pw;
         const bool inside = iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
         aoff[k] = inside ? (unsigned)((iy * p.in_w + ix) * p.Cin + 4 * q) * 4u : 0u;     // bytes, < 2^32 per image
-        amask[k] = inside ? 1.f : 0.f;
+        amask[k] = inside ? sdown : 0.f;          // zero padding and the fp16 range guard in one factor
         soff[k] = 4 * q;
     }
     auto load_a = [&](int chunk) __attribute__((always_inline)) {
@@ -464,11 +456,8 @@ __global__ void __launch_bounds__(NW * 64, 1) upconv_bf16_kernel(const ConvParam
     float4 ra[A_PER_T];
     const char* xb = reinterpret_cast<const char*>(p.x + (long long)b * p.x_batch_stride);
     for (int i = tid; i < p.Cin; i += NTH) Ss[i] = p.styles ? p.styles[(size_t)b * p.Cin + i] : 1.f;
-    float sback = 1.f;
-    if constexpr (F16) {
-        __syncthreads();
-        sback = style_range_guard<NTH>(Ss, Ss + p.Cin, p.Cin, tid);
-    }
+    float sback = 1.f, sdown = 1.f;
+    if constexpr (F16) sdown = style_range_guard(p.styles ? p.styles + (size_t)b * p.Cin : nullptr, p.Cin, lane, &sback);
     unsigned aoff[A_PER_T];
     int lds_a[A_PER_T], soff[A_PER_T];
     float amask[A_PER_T];
@@ -480,7 +469,7 @@ __global__ void __launch_bounds__(NW * 64, 1) upconv_bf16_kernel(const ConvParam
         const int iy = m0 - 1 + pix / p.pw, ix = n0 - 1 + pix % p.pw;
         const bool inside = iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
         aoff[k] = inside ? (unsigned)((iy * p.in_w + ix) * p.Cin + 4 * q) * 4u : 0u;
-        amask[k] = inside ? 1.f : 0.f;
+        amask[k] = inside ? sdown : 0.f;          // zero padding and the fp16 range guard in one factor
         soff[k] = 4 * q;
     }
     auto load_a = [&](int chunk) __attribute__((always_inline)) {
