@@ -151,28 +151,40 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p) {
 }
 
 // dW[co][ci][tap] = sum_ks slab[ks][tap(widx)][ci][co]  -  W[co][ci][tap] * sum_b dd[b][co] d[b][co]^3 s[b][ci]^2
+// thread = one (tap, ci, co) element, co fastest (coalesced slab reads); the slab loop is 8-way unrolled with
+// independent partial sums (fixed order -> deterministic).  The first version looped over the taps inside a thread:
+// the 128-channel layers (ksplit 128) had 64 blocks of 1152 dependent loads each — 2.7 ms per tuned fitting step.
+// (Routing the stores through an LDS transpose so that they follow the parameter layout was measured: no gain, the
+// slab reads bound this kernel.)
+struct WTaps9 { WTap t[9]; };
+
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ slabs, const float* __restrict__ weight,
                                                            const float* __restrict__ dd, const float* __restrict__ dcoef,
                                                            const float* __restrict__ styles, float* __restrict__ dW,
-                                                           int ksplit, int ntaps, int Cin, int Cout, int B, int wtaps, WTap t0,
-                                                           WTap t1, WTap t2, WTap t3, WTap t4, WTap t5, WTap t6,
-                                                           WTap t7, WTap t8) {
-    const WTap taps[9] = {t0, t1, t2, t3, t4, t5, t6, t7, t8};
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // over Cin * Cout, co fastest (coalesced slab reads)
+                                                           int ksplit, int ntaps, int Cin, int Cout, int B, int wtaps,
+                                                           const WTaps9 taps) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // over Cin * Cout, co fastest
     if (idx >= Cin * Cout) return;
+    const int t = blockIdx.y;
     const int co = idx % Cout, ci = idx / Cout;
     float dem = 0.f;
     if (dd)
         for (int b = 0; b < B; ++b) {
-            const float d = dcoef[(size_t)b * Cout + co], s = styles[(size_t)b * Cin + ci];
-            dem += dd[(size_t)b * Cout + co] * d * d * d * s * s;
+            const float d = dcoef[(size_t)b * Cout + co], sv = styles[(size_t)b * Cin + ci];
+            dem += dd[(size_t)b * Cout + co] * d * d * d * sv * sv;
         }
-    for (int t = 0; t < ntaps; ++t) {
-        float acc = 0.f;
-        for (int k = 0; k < ksplit; ++k) acc += slabs[(((size_t)k * ntaps + t) * Cin + ci) * Cout + co];
-        const size_t wi = ((size_t)co * Cin + ci) * wtaps + taps[t].widx;
-        dW[wi] = acc - weight[wi] * dem;
+    const float* src = slabs + ((size_t)t * Cin + ci) * Cout + co;
+    const size_t kstride = (size_t)ntaps * Cin * Cout;
+    float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int k = 0;
+    for (; k + 8 <= ksplit; k += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) part[u] += src[(size_t)(k + u) * kstride];
     }
+    for (; k < ksplit; ++k) part[0] += src[(size_t)k * kstride];
+    const float acc = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
+    const size_t wi = ((size_t)co * Cin + ci) * wtaps + taps.t[t].widx;
+    dW[wi] = acc - weight[wi] * dem;
 }
 
 // dA[i][k] = wgain * sum_b dstot[b][i] * w[b][k];  db[i] = sum_b dstot[b][i]   (accumulating)
@@ -237,11 +249,11 @@ static int run_wgrad(WgradParams& p, const HfagpWgradArgs* a, hipStream_t s) {
     wgrad_kernel<NT, SHARE><<<grid, 256, lds, s>>>(p);
     int rc = check_launch("conv_wgrad");
     if (rc != HFAGP_OK) return rc;
-    const int n = a->Cin * a->Cout;
-    wgrad_reduce_kernel<<<(n + 255) / 256, 256, 0, s>>>(a->workspace, a->weight, a->dd, a->dcoef, a->styles, a->dweight,
-                                                       a->ksplit, NT, a->Cin, a->Cout, a->B, a->mode == HFAGP_CONV1X1 ? 1 : 9,
-                                                       p.tap[0], p.tap[1], p.tap[2], p.tap[3], p.tap[4], p.tap[5], p.tap[6],
-                                                       p.tap[7], p.tap[8]);
+    WTaps9 taps;
+    for (int t = 0; t < 9; ++t) taps.t[t] = p.tap[t];
+    const dim3 rgrid((unsigned)((a->Cin * a->Cout + 255) / 256), (unsigned)NT);
+    wgrad_reduce_kernel<<<rgrid, 256, 0, s>>>(a->workspace, a->weight, a->dd, a->dcoef, a->styles, a->dweight, a->ksplit, NT,
+                                              a->Cin, a->Cout, a->B, a->mode == HFAGP_CONV1X1 ? 1 : 9, taps);
     return check_launch("conv_wgrad/reduce");
 }
 
