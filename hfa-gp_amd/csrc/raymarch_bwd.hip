@@ -16,8 +16,8 @@ namespace hfagp {
 
 struct TileLds {
     float df[16 * 32];        // dL/dfeature of the 16 samples, [sample][channel]
-    int   idx[16 * 12];       // texel index of every tap, [sample][plane*4 + tap]
-    float wgt[16 * 12];       // bilinear weight / 3
+    __attribute__((aligned(16))) int   idx[12 * 16];       // texel index of every tap, [plane*4 + tap][sample]
+    __attribute__((aligned(16))) float wgt[12 * 16];       // bilinear weight / 3
 };
 
 // decoder-weight gradients (PG): per-tile operand images for the sample-contracting products
@@ -32,11 +32,18 @@ struct DecGrads { float *w0, *b0, *w1, *b1; };   // [64][32], [64], [33][64], [3
 // are the same texels with row/column swapped and bitwise the same weights, and dL/dfeature is shared by the three
 // planes (the decoder sees their mean), so  d_planes[2][x][z] == d_planes[1][z][x]  exactly.  Plane 2 is then not
 // scattered at all (a third of the atomics, whose issue rate bounds this kernel) and mirror_plane_kernel fills it.
+// Waves per workgroup: 6 without the decoder gradients — the three weight images (43 KB) are shared by the block, so
+// 6 waves need 64 KB and two workgroups = 3 waves per SIMD fit a CU (4-wave blocks: 57.6 KB each, 2 per SIMD);
+// 4 with them (PG: 13 KB more per wave, one workgroup per CU).
+template <bool PG> struct BwdWaves { static constexpr int value = PG ? 4 : 6; };
+
 template <int S, bool PG, bool MIRROR>
-__global__ void __launch_bounds__(256, PG ? 1 : 2)
+__global__ void __launch_bounds__(BwdWaves<PG>::value * 64, PG ? 1 : 2)
 raymarch_bwd_tiles_kernel(const RayParams p, float* __restrict__ d_planes, const DecGrads dg) {
-    __shared__ TileLds lds_all[4];
-    __shared__ GradLds glds_all[PG ? 4 : 1];
+    constexpr int NWB = BwdWaves<PG>::value, NTHB = NWB * 64;
+    __shared__ TileLds lds_all[NWB];
+    // (sized 1 float instead of one GradLds when the decoder gradients are off: 13 KB less -> 3 workgroups per CU)
+    __shared__ __attribute__((aligned(16))) float glds_raw[PG ? 4 * sizeof(GradLds) / sizeof(float) : 1];
     // A operands of the two backward products, lane-linear ([step][lane]: conflict-free ds_read_b32), shared by
     // the 4 waves:  w1t[mt][ot*4+r][lane] = W1[1 + 16ot + 4g + r][16mt + j] * g1
     //               w0t[ft][mt*4+r][lane] = W0[16mt + 4g + r][16ft + j] * g0
@@ -57,18 +64,18 @@ raymarch_bwd_tiles_kernel(const RayParams p, float* __restrict__ d_planes, const
     }
     {
         const float g0 = a.decoder_lr_mul * 0.17677669529663687f, g1 = a.decoder_lr_mul * 0.125f;
-        for (int i = threadIdx.x; i < 4 * 8 * 64; i += 256) {
+        for (int i = threadIdx.x; i < 4 * 8 * 64; i += NTHB) {
             const int l = i & 63, st = (i >> 6) & 7, mt = i >> 9, jj = l & 15, gg = l >> 4;
             w1t[i] = a.dec_w1[(1 + 16 * (st >> 2) + 4 * gg + (st & 3)) * 64 + 16 * mt + jj] * g1;
         }
-        for (int i = threadIdx.x; i < 2 * 16 * 64; i += 256) {
+        for (int i = threadIdx.x; i < 2 * 16 * 64; i += NTHB) {
             const int l = i & 63, st = (i >> 6) & 15, ft = i >> 10, jj = l & 15, gg = l >> 4;
             w0t[i] = a.dec_w0[(16 * (st >> 2) + 4 * gg + (st & 3)) * 32 + 16 * ft + jj] * g0;
         }
         __syncthreads();
     }
 
-    GradLds& gl = glds_all[PG ? wave : 0];
+    GradLds& gl = reinterpret_cast<GradLds*>(glds_raw)[PG ? wave : 0];      // never dereferenced unless PG
     f32x4 aw1[2][4], aw0[4][2];                      // PG: dW1c tiles [ct][kt], dW0 tiles [kt][ft]
     float s_dO[2][4], s_dp[4][4], s_sw[4][4], s_ds = 0.f;
     if constexpr (PG) {
@@ -87,7 +94,7 @@ raymarch_bwd_tiles_kernel(const RayParams p, float* __restrict__ d_planes, const
     }
 
     const long long ntiles = (long long)p.total_rays * NT;
-    for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long long)gridDim.x * 4) {
+    for (long long tile = (long long)blockIdx.x * NWB + wave; tile < ntiles; tile += (long long)gridDim.x * NWB) {
         const int ray = __builtin_amdgcn_readfirstlane((int)(tile / NT));        // wave-uniform -> scalar registers
         const int tt = __builtin_amdgcn_readfirstlane((int)(tile % NT));
         const int b = ray / R, rr = ray % R;
@@ -206,11 +213,11 @@ raymarch_bwd_tiles_kernel(const RayParams p, float* __restrict__ d_planes, const
         }
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)                 // lane (j, g = pl) publishes plane pl's taps of sample j
-            if (g == pl) {
+            if (g == pl) {                             // tap-major [plane*4 + tap][sample]: the scatter reads 16 samples as b128
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    lds.idx[j * 12 + pl * 4 + k] = taps[pl].idx[k];
-                    lds.wgt[j * 12 + pl * 4 + k] = taps[pl].w[k] * 0.3333333333333333f;
+                    lds.idx[(pl * 4 + k) * 16 + j] = taps[pl].idx[k];
+                    lds.wgt[(pl * 4 + k) * 16 + j] = taps[pl].w[k] * 0.3333333333333333f;
                 }
             }
         WAVE_SYNC();
@@ -223,17 +230,29 @@ raymarch_bwd_tiles_kernel(const RayParams p, float* __restrict__ d_planes, const
         {
             const int c = lane & 31, hf = lane >> 5;
             float* base = d_planes + (size_t)b * 3 * a.H * a.W * 32 + c;
+            float dfc[16];                             // dL/dfeature[sample][c] of the tile: read once, used by every tap
+#pragma unroll
+            for (int sm = 0; sm < 16; ++sm) dfc[sm] = lds.df[sm * 32 + c];
 #pragma unroll 1
             for (int pk = 0; pk < (MIRROR ? 4 : 6); ++pk) {
                 const int pl = pk >> 1, k = 2 * (pk & 1) + hf;
                 float* pbase = base + (size_t)pl * a.H * a.W * 32;
+                float wv[16];
+                int tv[16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {          // the 16 samples of this tap: 4 + 4 ds_read_b128 (half-wave broadcast)
+                    const float4 w4 = *reinterpret_cast<const float4*>(&lds.wgt[(pl * 4 + k) * 16 + 4 * q]);
+                    const int4 t4 = *reinterpret_cast<const int4*>(&lds.idx[(pl * 4 + k) * 16 + 4 * q]);
+                    wv[4 * q] = w4.x; wv[4 * q + 1] = w4.y; wv[4 * q + 2] = w4.z; wv[4 * q + 3] = w4.w;
+                    tv[4 * q] = t4.x; tv[4 * q + 1] = t4.y; tv[4 * q + 2] = t4.z; tv[4 * q + 3] = t4.w;
+                }
                 int cur = -1;
                 float run = 0.f;
-#pragma unroll 4
+#pragma unroll
                 for (int sm = 0; sm < 16; ++sm) {
-                    const float wgt = lds.wgt[sm * 12 + pl * 4 + k];
-                    const int t = lds.idx[sm * 12 + pl * 4 + k];
-                    const float v = lds.df[sm * 32 + c] * wgt;
+                    const float wgt = wv[sm];
+                    const int t = tv[sm];
+                    const float v = dfc[sm] * wgt;
                     if (wgt != 0.f) {
                         if (t == cur) {
                             run += v;
@@ -314,11 +333,11 @@ template <int S>
 static void launch_tiles(bool pg, bool mirror, unsigned blocks, const RayParams& p, float* d_planes, const DecGrads& dg,
                          hipStream_t s) {
     if (pg) {
-        if (mirror) raymarch_bwd_tiles_kernel<S, true, true><<<blocks, 256, 0, s>>>(p, d_planes, dg);
-        else raymarch_bwd_tiles_kernel<S, true, false><<<blocks, 256, 0, s>>>(p, d_planes, dg);
+        if (mirror) raymarch_bwd_tiles_kernel<S, true, true><<<blocks, BwdWaves<true>::value * 64, 0, s>>>(p, d_planes, dg);
+        else raymarch_bwd_tiles_kernel<S, true, false><<<blocks, BwdWaves<true>::value * 64, 0, s>>>(p, d_planes, dg);
     } else {
-        if (mirror) raymarch_bwd_tiles_kernel<S, false, true><<<blocks, 256, 0, s>>>(p, d_planes, dg);
-        else raymarch_bwd_tiles_kernel<S, false, false><<<blocks, 256, 0, s>>>(p, d_planes, dg);
+        if (mirror) raymarch_bwd_tiles_kernel<S, false, true><<<blocks, BwdWaves<false>::value * 64, 0, s>>>(p, d_planes, dg);
+        else raymarch_bwd_tiles_kernel<S, false, false><<<blocks, BwdWaves<false>::value * 64, 0, s>>>(p, d_planes, dg);
     }
 }
 
@@ -338,11 +357,12 @@ extern "C" int hfagp_raymarch_bwd(const HfagpRaymarchBwdArgs* a, void* stream) {
     if (rc != HFAGP_OK) return rc;
     const int S = a->fwd.Sc + a->fwd.Sf;
     const long long ntiles = (long long)p.total_rays * (S / 16);
-    long long blocks = (ntiles + 3) / 4;
-    const long long cap = (long long)kNumCU * 2 * 8;
-    if (blocks > cap) blocks = cap;
     DecGrads dg{a->d_dec_w0, a->d_dec_b0, a->d_dec_w1, a->d_dec_b1};
     const bool pg = a->d_dec_w0 != nullptr;
+    const int nwb = pg ? BwdWaves<true>::value : BwdWaves<false>::value;
+    long long blocks = (ntiles + nwb - 1) / nwb;
+    const long long cap = (long long)kNumCU * 2 * 8;
+    if (blocks > cap) blocks = cap;
     HFAGP_REQUIRE(!pg || (a->d_dec_b0 && a->d_dec_w1 && a->d_dec_b1), HFAGP_EBADARG,
                   "raymarch_bwd: decoder gradients need all four buffers");
     // planes 1 and 2 mirror each other for EG3D's original axes on square planes: scatter plane 1 only
