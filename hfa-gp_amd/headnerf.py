@@ -26,6 +26,20 @@ from .generator import load_G_official
 
 FLIP_COLUMNS = [1, 2, 5, 6, 9, 10]      # headnerf.py:108,132,201,214,261,274
 NUM_WS = 14                               # headnerf.py:55
+_FLIP_SIGN = {}                           # (device, dtype) -> [25] tensor of +-1
+
+
+def flip_label_(label: torch.Tensor) -> torch.Tensor:
+    """`label[:, [1,2,5,6,9,10]] *= -1` IN PLACE on the caller's tensor (the side effect callers of the reference
+    see), as one multiplication by a cached sign vector: no host-built index tensor, so it is also legal inside a
+    HIP-graph capture."""
+    key = (label.device, label.dtype, label.shape[-1])
+    sign = _FLIP_SIGN.get(key)
+    if sign is None:
+        sign = torch.ones(label.shape[-1], dtype=label.dtype)
+        sign[FLIP_COLUMNS] = -1
+        sign = _FLIP_SIGN[key] = sign.to(label.device)
+    return label.mul_(sign)
 
 
 def load_bases(device, base_dir, dim_shape):
@@ -85,7 +99,7 @@ class _LatentBasis(nn.Module):
         return out.view(weights.shape[0], -1, self.dim) + delta.view(-1, self.dim)
 
     def get_image(self, latent: torch.Tensor, label: torch.Tensor) -> torch.Tensor:
-        label[:, FLIP_COLUMNS] *= -1                     # in place, on the caller's tensor
+        flip_label_(label)                               # in place, on the caller's tensor
         return self.generator.synthesis(latent, c=label, noise_mode="const")["image"]
 
 
@@ -123,7 +137,7 @@ class HeadNeRF_final(_LatentBasis):
         return self.encoder(image)          # (weights, pose) when out_pose
 
     def forward(self, image, label, person_2=False):
-        label[:, FLIP_COLUMNS] *= -1
+        flip_label_(label)
         if self.out_pose:
             weights, pose = self.encoder(image)
         else:
@@ -163,7 +177,7 @@ class _ParamDriven(_LatentBasis):
         return self.weights_3dmm(params)
 
     def forward(self, params, label, person_2=False):
-        label[:, FLIP_COLUMNS] *= -1
+        flip_label_(label)
         latent = self.get_latent(self.weights_3dmm(params), person_2)
         return self.generator.synthesis(latent, c=label, noise_mode="const")["image"]
 
