@@ -13,7 +13,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhfagp_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 c_float_p = C.c_void_p  # device pointers travel as integers
 
@@ -92,7 +92,7 @@ class StyleBwdArgs(C.Structure):
 
 class WgradArgs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("x", "styles", "g", "weight", "dd", "dcoef", "dweight", "workspace")] + \
-        [(n, C.c_int32) for n in ("B", "H", "W", "Cin", "Cout", "mode", "ksplit")]
+        [(n, C.c_int32) for n in ("B", "H", "W", "Cin", "Cout", "mode", "ksplit", "precision")]
 
 
 class RaymarchBwdArgs(C.Structure):

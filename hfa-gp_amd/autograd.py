@@ -134,8 +134,11 @@ class _Backward:
         if x.shape[0] != g.shape[-4]:                      # b4: the learned constant is shared by the batch
             x = x.expand(g.shape[-4], -1, -1, -1).contiguous()
         mode = ops.CONVT3X3_UP2 if rec["up"] == 2 else ops.CONV3X3
+        # gradient GEMMs follow the generator's precision class: exact fp32 MFMA when conv_precision is "fp32", else
+        # split-bf16 (the 3x3 layers with 64-multiple channels; bf16 parts keep a gradient's exponent range)
+        wprec = "fp32" if self.gen.conv_precision == "fp32" else "bf16x3"
         self._acc(layer.weight, ops.conv_wgrad(x, rec["styles"], g, layer.weight, mode, dd=rec["dd"].contiguous(),
-                                               dcoef=rec["dcoef"]))
+                                               dcoef=rec["dcoef"], precision=wprec))
         self._acc(layer.bias, sums_out[:, 4].sum(0))
         if rec["producer"]["noise"] is not None:
             self._acc(layer.noise_strength, sums_out[:, 5].sum())

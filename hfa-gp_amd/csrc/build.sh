@@ -6,7 +6,7 @@ out="${here}/../libhfagp_hip.so"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function)
 objs=()
-for src in elementwise modconv modconv_bf16 raymarch backward raymarch_bwd wgrad qr loss; do
+for src in elementwise modconv modconv_bf16 raymarch backward raymarch_bwd wgrad wgrad_bf16 qr loss; do
     obj="${here}/${src}.o"
     if [[ ! -f "$obj" || "${here}/${src}.hip" -nt "$obj" || "${here}/common.h" -nt "$obj" || "${here}/modconv_plan.h" -nt "$obj" || "${here}/../../include/hfagp.h" -nt "$obj" ]]; then
         "$HIPCC" "${FLAGS[@]}" ${HFAGP_EXTRA_FLAGS:-} -c "${here}/${src}.hip" -o "$obj" &

@@ -234,6 +234,8 @@ __global__ void __launch_bounds__(256) channel_sum_final_kernel(const float* __r
 
 }  // namespace hfagp
 
+namespace hfagp { int launch_wgrad3x3_bf16(const HfagpWgradArgs* a, hipStream_t s); }      // wgrad_bf16.hip
+
 using namespace hfagp;
 
 template <int NT, int SHARE>
@@ -278,6 +280,19 @@ int hfagp_conv_wgrad(const HfagpWgradArgs* a, void* stream) {
     if (a->mode == HFAGP_CONV3X3) {
         p.gH = a->H; p.gW = a->W;
         for (int t = 0; t < 9; ++t) p.tap[t] = WTap{(signed char)(t / 3 - 1), (signed char)(t % 3 - 1), 0, 0, (signed char)t};
+        if (a->precision == HFAGP_PREC_BF16X3 && a->Cin % 64 == 0 && a->Cout % 64 == 0) {
+            // split-bf16 MFMA kernel (slab t = tap t, like the taps above), then the shared reducer
+            int rc = launch_wgrad3x3_bf16(a, s);
+            if (rc != HFAGP_OK) return rc;
+            WTaps9 taps;
+            for (int t = 0; t < 9; ++t) taps.t[t] = p.tap[t];
+            const dim3 rgrid((unsigned)((a->Cin * a->Cout + 255) / 256), 9u);
+            wgrad_reduce_kernel<<<rgrid, 256, 0, s>>>(a->workspace, a->weight, a->dd, a->dcoef, a->styles, a->dweight, a->ksplit,
+                                                      9, a->Cin, a->Cout, a->B, 9, taps);
+            return check_launch("conv_wgrad/reduce");
+        }
+        HFAGP_REQUIRE(a->precision == HFAGP_PREC_F32 || a->precision == HFAGP_PREC_BF16X3, HFAGP_EBADARG,
+                      "conv_wgrad: precision %d (F32 or BF16X3)", a->precision);
         return run_wgrad<9, 1>(p, a, s);
     }
     if (a->mode == HFAGP_CONV1X1) {

@@ -465,21 +465,26 @@ def style_bwd(ds: torch.Tensor, dd: Optional[torch.Tensor], styles: torch.Tensor
 
 
 def conv_wgrad(x: torch.Tensor, styles: Optional[torch.Tensor], g: torch.Tensor, weight: torch.Tensor, mode: int,
-               dd: Optional[torch.Tensor] = None, dcoef: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Weight gradient of a modulated conv (see include/hfagp.h): returns dweight like `weight`."""
+               dd: Optional[torch.Tensor] = None, dcoef: Optional[torch.Tensor] = None,
+               precision: str = "fp32") -> torch.Tensor:
+    """Weight gradient of a modulated conv (see include/hfagp.h): returns dweight like `weight`.  precision 'bf16x3':
+    the 3x3 mode with Cin, Cout multiples of 64 runs on the split-bf16 MFMA kernel (everything else stays fp32)."""
     _chk(x, "x")
     _chk(g, "g")
     b, h, w, cin = x.shape
     cout = weight.shape[0]
     a = L.WgradArgs()
     dweight = torch.empty_like(weight)
-    units = b * ((h + 1) // 2) * ((w + 15) // 16)
+    split16 = precision == "bf16x3" and mode == CONV3X3 and cin % 64 == 0 and cout % 64 == 0
+    rows = 4 if split16 else 2                         # position tile of the kernel that will run: rows x 16
+    units = b * ((h + rows - 1) // rows) * ((w + 15) // 16)
     tiles = ((cin + 63) // 64) * ((cout + 63) // 64)
     # one resident block per CU (117 KB of LDS): aim at a whole number of rounds over the 256 CUs
     ksplit = max(1, min(units, max(512 // tiles, 1), 256))
     a.x, a.styles, a.g = _ptr(x), _ptr(styles), _ptr(g)
     a.weight, a.dd, a.dcoef, a.dweight = _ptr(_chk(weight.detach(), "weight")), _ptr(dd), _ptr(dcoef), _ptr(dweight)
     a.B, a.H, a.W, a.Cin, a.Cout, a.mode, a.ksplit = b, h, w, cin, cout, mode, ksplit
+    a.precision = PREC_BF16X3 if precision == "bf16x3" else PREC_F32
     ws = torch.empty(L.lib().hfagp_wgrad_workspace_bytes(C.byref(a)) // 4, device=x.device, dtype=torch.float32)
     a.workspace = _ptr(ws)
     L.check(L.lib().hfagp_conv_wgrad(C.byref(a), _stream()), "conv_wgrad")

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define HFAGP_ABI_VERSION 2
+#define HFAGP_ABI_VERSION 3
 
 enum { HFAGP_OK = 0, HFAGP_EBADARG = -1, HFAGP_EUNSUPPORTED = -2, HFAGP_ELAUNCH = -3 };
 
@@ -321,6 +321,8 @@ typedef struct {
     float*       workspace;   /* >= hfagp_wgrad_workspace_bytes() */
     int32_t B, H, W, Cin, Cout, mode;
     int32_t ksplit;           /* number of split-K slabs over (b, position tiles); >= 1 */
+    int32_t precision;        /* HFAGP_PREC_F32 (exact fp32 MFMA) or HFAGP_PREC_BF16X3: the 3x3 mode with Cin, Cout    */
+                              /* multiples of 64 then runs on the split-bf16 MFMA kernel, every other case stays fp32 */
 } HfagpWgradArgs;
 
 size_t hfagp_wgrad_workspace_bytes(const HfagpWgradArgs* a);

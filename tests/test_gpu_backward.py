@@ -316,6 +316,27 @@ def test_conv_weight_gradient(dev, b, h, cin, cout, mode):
     close(dw, w.grad, atol=1e-4 * w.grad.abs().max().item(), rtol=1e-4)
 
 
+@pytest.mark.parametrize("b,h,w_,cin,cout", [(2, 21, 21, 64, 128), (1, 8, 40, 128, 64), (3, 5, 3, 64, 64), (1, 33, 16, 192, 128)])
+def test_conv_weight_gradient_split_bf16(dev, b, h, w_, cin, cout):
+    """The 3x3 weight gradient on the split-bf16 MFMA kernel (wgrad_bf16.hip; ragged position tiles, several channel
+    tiles, several split-K slabs) vs autograd; products carry 2^-16, sums are fp32."""
+    from hfa_gp_amd import ops
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(b, cin, h, w_, generator=g)
+    s = torch.randn(b, cin, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g, requires_grad=True)
+    y = F.conv2d(x * s[:, :, None, None], w, padding=1)
+    gy = torch.randn(y.shape, generator=g) * 1e-6            # gradients are small numbers: bf16 parts keep the exponent
+    y.backward(gy)
+    xh, gh = ops.nchw_to_nhwc(x.to(dev)), ops.nchw_to_nhwc(gy.to(dev))
+    dw = ops.conv_wgrad(xh, s.to(dev), gh, w.detach().to(dev), ops.CONV3X3, precision="bf16x3")
+    exact = ops.conv_wgrad(xh, s.to(dev), gh, w.detach().to(dev), ops.CONV3X3)
+    scale = w.grad.abs().max().item()
+    close(exact, w.grad, atol=1e-4 * scale, rtol=1e-4)
+    close(dw, w.grad, atol=1e-4 * scale, rtol=1e-4)
+    assert not torch.equal(dw, exact), "the split kernel did not run"
+
+
 @pytest.mark.parametrize("preset,batch,prec", [("tiny64", 2, "fp32"), ("tiny14", 1, "fp32"), ("small128", 1, "fp32"),
                                                ("small128", 1, "bf16x3")])
 def test_generator_parameter_gradients_vs_oracle_autograd(dev, preset, batch, prec):
