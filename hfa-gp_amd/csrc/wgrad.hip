@@ -60,29 +60,37 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p) {
 
     const int units = p.B * p.tiles_h * p.tiles_w;
     const int u_begin = (int)(((long long)units * ks) / p.ksplit), u_end = (int)(((long long)units * (ks + 1)) / p.ksplit);
-    float4 ra[STG], rb[STG];
+    // Staging loads are unconditional (an out-of-range slot reads element 0 and is multiplied by a 0 mask when it is
+    // committed) and nothing in fetch() consumes a loaded value, so the loads of tile u+1 stay in flight under the MFMAs
+    // of tile u; the style is applied at commit time.  (Not for the nine-accumulator variant: the extra staging
+    // registers made it spill — it applies style and mask in fetch() as before.)
+    constexpr bool DEFER = NT != 9;
+    float4 ra[STG], rb[STG], rs[DEFER ? STG : 1];
+    float ma[DEFER ? STG : 1], mb[DEFER ? STG : 1];
 
     auto fetch = [&](int u) {
         const int tw = u % p.tiles_w, th = (u / p.tiles_w) % p.tiles_h, b = u / (p.tiles_w * p.tiles_h);
         const int m0 = th * TPH, n0 = tw * TPW;
 #pragma unroll
         for (int k = 0; k < STG; ++k) {
-            const int idx = tid + k * 256;
+            const int idx = min(tid + k * 256, PPH * PPW * 16 - 1);
             const int pix = idx >> 4, q = idx & 15;
             const int iy = m0 - 1 + pix / PPW, ix = n0 - 1 + pix % PPW;
-            float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
-            if (idx < PPH * PPW * 16) {
-                if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && ci0 + 4 * q < p.Cin) {
-                    va = *reinterpret_cast<const float4*>(p.x + (((size_t)b * p.H + iy) * p.W + ix) * p.Cin + ci0 + 4 * q);
-                    if (p.styles) {
-                        const float4 sv = *reinterpret_cast<const float4*>(p.styles + (size_t)b * p.Cin + ci0 + 4 * q);
-                        va.x *= sv.x; va.y *= sv.y; va.z *= sv.z; va.w *= sv.w;
-                    }
-                }
-                if (iy >= 0 && iy < p.gH && ix >= 0 && ix < p.gW && co0 + 4 * q < p.Cout)
-                    vb = *reinterpret_cast<const float4*>(p.g + (((size_t)b * p.gH + iy) * p.gW + ix) * p.Cout + co0 + 4 * q);
+            const bool oka = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && ci0 + 4 * q < p.Cin;
+            const bool okb = iy >= 0 && iy < p.gH && ix >= 0 && ix < p.gW && co0 + 4 * q < p.Cout;
+            const float4 va = *reinterpret_cast<const float4*>(p.x + (oka ? (((size_t)b * p.H + iy) * p.W + ix) * p.Cin + ci0 + 4 * q : 0));
+            const float4 vb = *reinterpret_cast<const float4*>(p.g + (okb ? (((size_t)b * p.gH + iy) * p.gW + ix) * p.Cout + co0 + 4 * q : 0));
+            const float4 sv = (p.styles && oka) ? *reinterpret_cast<const float4*>(p.styles + (size_t)b * p.Cin + ci0 + 4 * q)
+                                                : make_float4(1.f, 1.f, 1.f, 1.f);
+            if constexpr (DEFER) {
+                ma[k] = oka ? 1.f : 0.f;
+                mb[k] = okb ? 1.f : 0.f;
+                ra[k] = va; rb[k] = vb; rs[k] = sv;
+            } else {
+                const float fa = oka ? 1.f : 0.f, fb = okb ? 1.f : 0.f;
+                ra[k] = make_float4(va.x * (sv.x * fa), va.y * (sv.y * fa), va.z * (sv.z * fa), va.w * (sv.w * fa));
+                rb[k] = make_float4(vb.x * fb, vb.y * fb, vb.z * fb, vb.w * fb);
             }
-            ra[k] = va; rb[k] = vb;
         }
     };
     auto commit = [&](int buf) {
@@ -92,8 +100,16 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p) {
         for (int k = 0; k < STG; ++k) {
             const int idx = tid + k * 256;
             if (idx < PPH * PPW * 16) {
-                *reinterpret_cast<float4*>(As + (idx >> 4) * WS + 4 * (idx & 15)) = ra[k];
-                *reinterpret_cast<float4*>(Bs + (idx >> 4) * WS + 4 * (idx & 15)) = rb[k];
+                if constexpr (DEFER) {
+                    const float m = ma[k];
+                    *reinterpret_cast<float4*>(As + (idx >> 4) * WS + 4 * (idx & 15)) =
+                        make_float4(ra[k].x * (rs[k].x * m), ra[k].y * (rs[k].y * m), ra[k].z * (rs[k].z * m), ra[k].w * (rs[k].w * m));
+                    *reinterpret_cast<float4*>(Bs + (idx >> 4) * WS + 4 * (idx & 15)) =
+                        make_float4(rb[k].x * mb[k], rb[k].y * mb[k], rb[k].z * mb[k], rb[k].w * mb[k]);
+                } else {
+                    *reinterpret_cast<float4*>(As + (idx >> 4) * WS + 4 * (idx & 15)) = ra[k];
+                    *reinterpret_cast<float4*>(Bs + (idx >> 4) * WS + 4 * (idx & 15)) = rb[k];
+                }
             }
         }
     };

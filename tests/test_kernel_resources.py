@@ -18,6 +18,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     ("modconv_bf16.hip", [r"modconv_bf16_kernelILi[124]E", r"upconv_bf16_kernelILi[124]E"]),
     ("modconv.hip", [r"modconv_kernelI"]),
     ("wgrad_bf16.hip", [r"wgrad3x3_bf16_kernel"]),
+    ("wgrad.hip", [r"wgrad_kernelI"]),
 ])
 def test_conv_kernels_do_not_spill(tmp_path, src, patterns):
     out = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c",
