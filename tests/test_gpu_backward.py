@@ -341,7 +341,8 @@ def test_conv_weight_gradient_split_bf16(dev, b, h, w_, cin, cout):
                                                ("small128", 1, "bf16x3")])
 def test_generator_parameter_gradients_vs_oracle_autograd(dev, preset, batch, prec):
     """tune_generator() mode: dL/d(every generator parameter) and dL/d ws against autograd through the oracle.
-    (Only the bwd-data GEMMs follow conv_precision; the weight-gradient GEMMs are always exact fp32.)"""
+    (The bwd-data GEMMs follow conv_precision — bf16x3 for the fp16 kinds; the 3x3 weight-gradient GEMMs run on split
+    bf16 unless conv_precision is 'fp32'; the parity / 1x1 ones are always exact fp32.)"""
     from hfa_gp_amd.config import PRESETS
     from hfa_gp_amd.generator import TriPlaneGenerator
     from oracle import eg3d_oracle as O
