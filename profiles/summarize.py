@@ -58,6 +58,19 @@ def main():
         for k, (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
             print(f"| {k} | {n} | {v / n * 1024 / 1e6:.2f} |")
             traffic.setdefault(k, {})[counter] = v / n * 1024          # bytes per launch, as reported (KiB units)
+    # matrix-pipe utilisation per kernel: SQ_VALU_MFMA_BUSY_CYCLES counts busy cycles summed over the 1024 SIMDs
+    # (= 32 x N_mfma for a 32x32x16 16-bit MFMA); GRBM_GUI_ACTIVE is summed over the 8 XCDs
+    f = find(os.path.join(out, "pmc_mfma"), "*counter_collection.csv")
+    if f:
+        agg = defaultdict(lambda: defaultdict(float))
+        for r in csv.DictReader(open(f)):
+            agg[short(r["Kernel_Name"])][r["Counter_Name"]] += float(r["Counter_Value"])
+        print("\n## MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs), summed over the kernel's launches\n")
+        print("| kernel | MFMA instructions | MFMA busy |\n|---|---|---|")
+        for k, c in sorted(agg.items(), key=lambda kv: -kv[1].get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)):
+            busy, act = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), c.get("GRBM_GUI_ACTIVE", 0.0)
+            if busy > 0 and act > 0:
+                print(f"| {k} | {c.get('SQ_INSTS_MFMA', 0.0):.3g} | {busy / (128.0 * act):.3f} |")
     # HBM/fabric bytes per launch for bench.py's `traffic` field: FETCH_SIZE doubled (gfx950 reports half of a wide
     # coalesced read, MI355X_MICROARCH.md section HBM) + WRITE_SIZE
     batch = 8
