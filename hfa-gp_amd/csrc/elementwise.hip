@@ -267,26 +267,29 @@ constexpr int kTorgbMaxOut = 4;
 // epilogue of one (pixel, output channel c): bias, (pre-clamp copy), clamp, + upsample2d(rgb_in), store.
 // The 8 lanes of a pixel all hold the reduced sums; lane c finishes channel c, so the 4-tap skip gathers of the
 // channels run side by side instead of one lane walking all of them.
-__device__ __forceinline__ void torgb_finish(const HfagpTorgbArgs& a, int b, int pix, int c, float acc) {
-    const int HW = a.H * a.W;
+// upsample2d(rgb_in) at output pixel `pix`, channel c (0 when there is no previous image): four unconditional loads
+// (clamped addresses + zeroed weights).
+__device__ __forceinline__ float torgb_skip(const HfagpTorgbArgs& a, int b, int pix, int c) {
+    if (!a.rgb_in) return 0.f;
     const int Y = pix / a.W, X = pix % a.W;
+    const int Hi = a.H >> 1, Wi = a.W >> 1;
+    int y0, y1, x0, x1; float wy0, wy1, wx0, wx1;
+    up2_taps(Y, y0, y1, wy0, wy1);
+    up2_taps(X, x0, x1, wx0, wx1);
+    const float* src = a.rgb_in + ((size_t)b * a.Cout + c) * Hi * Wi;
+    const float my0 = y0 >= 0 ? wy0 : 0.f, my1 = y1 < Hi ? wy1 : 0.f;
+    const float mx0 = x0 >= 0 ? wx0 : 0.f, mx1 = x1 < Wi ? wx1 : 0.f;
+    const int cy0 = max(y0, 0), cy1 = min(y1, Hi - 1), cx0 = max(x0, 0), cx1 = min(x1, Wi - 1);
+    return my0 * (mx0 * src[cy0 * Wi + cx0] + mx1 * src[cy0 * Wi + cx1]) +
+           my1 * (mx0 * src[cy1 * Wi + cx0] + mx1 * src[cy1 * Wi + cx1]);
+}
+
+__device__ __forceinline__ void torgb_finish(const HfagpTorgbArgs& a, int b, int pix, int c, float acc, float skip) {
+    const int HW = a.H * a.W;
     float v = acc + a.bias[c];
     if (a.y_pre) a.y_pre[((size_t)b * a.Cout + c) * HW + pix] = v;      // before the clamp: backward mask
     if (a.clamp >= 0.f) v = fminf(fmaxf(v, -a.clamp), a.clamp);
-    if (a.rgb_in) {
-        const int Hi = a.H >> 1, Wi = a.W >> 1;
-        int y0, y1, x0, x1; float wy0, wy1, wx0, wx1;
-        up2_taps(Y, y0, y1, wy0, wy1);
-        up2_taps(X, x0, x1, wx0, wx1);
-        const float* src = a.rgb_in + ((size_t)b * a.Cout + c) * Hi * Wi;
-        // clamped addresses + zeroed weights: four unconditional loads
-        const float my0 = y0 >= 0 ? wy0 : 0.f, my1 = y1 < Hi ? wy1 : 0.f;
-        const float mx0 = x0 >= 0 ? wx0 : 0.f, mx1 = x1 < Wi ? wx1 : 0.f;
-        const int cy0 = max(y0, 0), cy1 = min(y1, Hi - 1), cx0 = max(x0, 0), cx1 = min(x1, Wi - 1);
-        v += my0 * (mx0 * src[cy0 * Wi + cx0] + mx1 * src[cy0 * Wi + cx1]) +
-             my1 * (mx0 * src[cy1 * Wi + cx0] + mx1 * src[cy1 * Wi + cx1]);
-    }
-    a.rgb_out[((size_t)b * a.Cout + c) * HW + pix] = v;
+    a.rgb_out[((size_t)b * a.Cout + c) * HW + pix] = v + skip;
 }
 
 // Cin = 32*KQ: lane `sub` of a pixel owns the channel quads sub, sub+8, ...; its slice of the modulated weight
@@ -294,14 +297,15 @@ __device__ __forceinline__ void torgb_finish(const HfagpTorgbArgs& a, int b, int
 // and the weight set-up is paid once per 32*kTorgbIter pixels.
 constexpr int kTorgbIter = 8;
 
-template <int KQ>
+// NO = number of output accumulators kept per lane (3 for RGB: a quarter fewer weight registers and FMAs than 4)
+template <int KQ, int NO>
 __global__ void __launch_bounds__(256) torgb_reg_kernel(HfagpTorgbArgs a) {
     const int b = blockIdx.y;
     const int sub = threadIdx.x & 7;
     const int HW = a.H * a.W;
-    float4 w[kTorgbMaxOut][KQ];
+    float4 w[NO][KQ];
 #pragma unroll
-    for (int c = 0; c < kTorgbMaxOut; ++c)
+    for (int c = 0; c < NO; ++c)
 #pragma unroll
         for (int i = 0; i < KQ; ++i) {
             w[c][i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -324,19 +328,27 @@ __global__ void __launch_bounds__(256) torgb_reg_kernel(HfagpTorgbArgs a) {
         const int pn = min(pix + 32, HW - 1);
 #pragma unroll
         for (int i = 0; i < KQ; ++i) vn[i] = xb[(size_t)pn * cq + 8 * i];
-        float acc[kTorgbMaxOut] = {0.f, 0.f, 0.f, 0.f};
+        float acc[NO];
+#pragma unroll
+        for (int c = 0; c < NO; ++c) acc[c] = 0.f;
 #pragma unroll
         for (int i = 0; i < KQ; ++i)
 #pragma unroll
-            for (int c = 0; c < kTorgbMaxOut; ++c)
+            for (int c = 0; c < NO; ++c)
                 acc[c] += v[i].x * w[c][i].x + v[i].y * w[c][i].y + v[i].z * w[c][i].z + v[i].w * w[c][i].w;
 #pragma unroll
-        for (int c = 0; c < kTorgbMaxOut; ++c) {
+        for (int c = 0; c < NO; ++c) {
             acc[c] += __shfl_xor(acc[c], 1);
             acc[c] += __shfl_xor(acc[c], 2);
             acc[c] += __shfl_xor(acc[c], 4);
         }
-        if (sub < a.Cout) torgb_finish(a, b, pix, sub, sub == 0 ? acc[0] : sub == 1 ? acc[1] : sub == 2 ? acc[2] : acc[3]);
+        if (sub < a.Cout) {
+            float mine = acc[0];
+#pragma unroll
+            for (int c = 1; c < NO; ++c) mine = sub == c ? acc[c] : mine;
+            torgb_finish(a, b, pix, sub, mine, torgb_skip(a, b, pix, sub));   // (issuing the skip loads before the
+                                                                              // reduction was measured: slower)
+        }
 #pragma unroll
         for (int i = 0; i < KQ; ++i) v[i] = vn[i];
     }
@@ -370,7 +382,8 @@ __global__ void __launch_bounds__(256) torgb_kernel(HfagpTorgbArgs a) {
         acc[c] += __shfl_xor(acc[c], 2);
         acc[c] += __shfl_xor(acc[c], 4);
     }
-    if (sub < a.Cout) torgb_finish(a, b, pix, sub, sub == 0 ? acc[0] : sub == 1 ? acc[1] : sub == 2 ? acc[2] : acc[3]);
+    if (sub < a.Cout)
+        torgb_finish(a, b, pix, sub, sub == 0 ? acc[0] : sub == 1 ? acc[1] : sub == 2 ? acc[2] : acc[3], torgb_skip(a, b, pix, sub));
 }
 
 // ---------------------------------------------------------------- generic upfirdn2d (NCHW, test surface)
@@ -526,9 +539,9 @@ int hfagp_torgb_fwd(const HfagpTorgbArgs* a, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const dim3 rgrid((HW + 32 * kTorgbIter - 1) / (32 * kTorgbIter), a->B);
     switch (a->Cin) {
-        case 64:  torgb_reg_kernel<2><<<rgrid, 256, 0, s>>>(*a); break;
-        case 128: torgb_reg_kernel<4><<<rgrid, 256, 0, s>>>(*a); break;
-        case 256: torgb_reg_kernel<8><<<rgrid, 256, 0, s>>>(*a); break;
+        case 64:  if (a->Cout <= 3) torgb_reg_kernel<2, 3><<<rgrid, 256, 0, s>>>(*a); else torgb_reg_kernel<2, 4><<<rgrid, 256, 0, s>>>(*a); break;
+        case 128: if (a->Cout <= 3) torgb_reg_kernel<4, 3><<<rgrid, 256, 0, s>>>(*a); else torgb_reg_kernel<4, 4><<<rgrid, 256, 0, s>>>(*a); break;
+        case 256: if (a->Cout <= 3) torgb_reg_kernel<8, 3><<<rgrid, 256, 0, s>>>(*a); else torgb_reg_kernel<8, 4><<<rgrid, 256, 0, s>>>(*a); break;
         default: {
             dim3 grid((HW + 31) / 32, a->B);
             const size_t lds = (size_t)a->Cout * a->Cin * sizeof(float);
