@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--train-batch", type=int, default=2, help="frames per fitting step per GPU")
     ap.add_argument("--train-steps", type=int, default=6)
     ap.add_argument("--no-sweep", action="store_true",
-                    help="skip the batch-size sweeps (render B = 1, 4; fitting step B = 1, 4; SURVEY.md section 8d)")
+                    help="skip the batch-size sweeps (render B = 1, 4, 16; fitting step B = 1, 4; SURVEY.md section 8d)")
     ap.add_argument("--cpu-runs", type=int, default=2)
     ap.add_argument("--precision", default=None, choices=["fp32", "f16x3", "bf16x3", "bf16x6"],
                     help="conv GEMM arithmetic of the headline leg (default: the preset's conv_precision)")
@@ -228,7 +228,7 @@ def main():
         return dt, timing
 
     def sweep_leg(b, precision, steps=20, warmup=3):
-        """batch sizes 1 and 4 beside the headline's; per-step HIP event pairs."""
+        """batch sizes 1, 4 (and 16) beside the headline's 8; per-step HIP event pairs."""
         gen.conv_precision, gen.sr_conv_precision = precision, None
         w_, c_, us_, ui_ = [t.to(dev) for t in make_inputs(cfg, b, seed=10 + rank)]
         for _ in range(warmup):
@@ -256,7 +256,7 @@ def main():
         dt16, _ = render_leg("f16")
     sweep = None
     if not args.no_sweep:
-        sweep = {str(b): sweep_leg(b, prec) for b in (1, 4) if b != B}
+        sweep = {str(b): sweep_leg(b, prec) for b in (1, 4, 16) if b != B}
     dt, timing = render_leg(prec)
 
     def agg(key, table=None):
