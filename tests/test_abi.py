@@ -73,3 +73,24 @@ def test_product_path_refuses_cpu_tensors():
     g = TriPlaneGenerator(tiny64())
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         g.synthesis(torch.zeros(1, g.cfg.num_ws, 512), torch.zeros(1, 25))
+
+
+def test_header_is_valid_c_and_a_plain_c_caller_links(lib, tmp_path):
+    """include/hfagp.h compiles as C99 (pedantic) and a plain-C program links against the in-tree library and drives
+    its host-side entry points (examples/c_abi_smoke.c) — the boundary is a C ABI, not a Python extension."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc not available")
+    lib.lib()
+    src = os.path.join(ROOT, "examples", "c_abi_smoke.c")
+    exe = str(tmp_path / "c_abi_smoke")
+    libdir = os.path.dirname(lib.LIB_PATH)
+    cmd = [gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), src,
+           "-L", libdir, "-lhfagp_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    out = subprocess.run(cmd, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert f"abi {lib.ABI_VERSION}" in run.stdout and "null pointer" in run.stdout and "multiple of" in run.stdout
