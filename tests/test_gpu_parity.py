@@ -196,6 +196,33 @@ def test_synthesis_layer_f16(dev, b, h, cin, cout, up, ksplit, clamp, xscale):
     close(ops.nhwc_to_nchw(y), want, atol=F16_TOL * float(want.abs().max()) + 1e-6)
 
 
+@pytest.mark.parametrize("xscale,sscale,tol", [(200.0, 40.0, 4e-6), (1e-3, 1.0, 1e-4), (1.0, 1e-4, 4e-6), (3e4, 1e3, 4e-6)])
+def test_f16x3_range_guard(dev, xscale, sscale, tol):
+    """The default precision at the edges of fp16's range: activations at the clamp level with large styles (the raw
+    product would overflow), tiny activations (|x| ~ 1e-3: the lo parts are fp16 subnormals, bits below 2^-25 ABSOLUTE
+    are lost, so a tensor that is tiny everywhere keeps ~14 bits — measured 4e-5 relative; in a real layer such inputs
+    sit beside O(1) ones and their absolute error vanishes), tiny styles (scaled UP by the guard), activations of 3e4
+    (just inside fp16's range)."""
+    from hfa_gp_amd import ops
+    g = torch.Generator().manual_seed(23)
+    b, cin, cout, h = 2, 64, 128, 12
+    x = torch.randn(b, cin, h, h, generator=g) * xscale
+    if xscale > 1e4:
+        x = x.clamp(-6e4, 6e4)
+    w = torch.randn(cout, cin, 3, 3, generator=g)
+    s = (torch.randn(b, cin, generator=g) + 1.5) * sscale
+    want = F.conv2d((x * s[:, :, None, None]).reshape(1, b * cin, h, h).double(), w.repeat(b, 1, 1, 1).double(),
+                    padding=1, groups=b).reshape(b, cout, h, h)
+    wb = ops.weight_prep_prec(w.to(dev), "f16x3")
+    y = ops.nhwc_to_nchw(ops.modconv(ops.nchw_to_nhwc(x.to(dev)), wb, cout, ops.CONV3X3, styles=s.to(dev)))
+    yt = ops.nhwc_to_nchw(ops.modconv(ops.nchw_to_nhwc(x.to(dev)), wb, cout, ops.CONVT3X3_UP2, styles=s.to(dev)))
+    want_t = F.conv_transpose2d((x * s[:, :, None, None]).double(), w.transpose(0, 1).double(), stride=2)
+    assert torch.isfinite(y).all() and torch.isfinite(yt).all()
+    for got, ref in ((y, want), (yt, want_t)):
+        err = (got.cpu().double() - ref).abs().max().item()
+        assert err <= tol * ref.abs().max().item(), (err, ref.abs().max().item())
+
+
 @pytest.mark.parametrize("prec", ["bf16x3", "bf16x6", "f16x3"])
 @pytest.mark.parametrize("b,h,cin,ksplit", [(2, 19, 128, 0), (1, 8, 512, 4), (3, 4, 32, 1)])
 def test_torgb96_on_padded_split_tile(dev, prec, b, h, cin, ksplit):
