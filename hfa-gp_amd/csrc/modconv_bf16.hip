@@ -1,17 +1,22 @@
-// Modulated convolution on v_mfma_f32_32x32x16_bf16 with SPLIT operands (gfx950): every fp32 operand is the sum
-// of NP bf16 parts (NP = 2: hi + lo, NP = 3: hi + mid + lo) and a product is the sum of the part products whose
-// weight is above 2^-16 (NP = 2: hi.hi + lo.hi + hi.lo) or 2^-24 (NP = 3: six products), accumulated in fp32.
-// The bf16 matrix pipe is 16x the fp32 one, so BF16X3 has 5.3x and BF16X6 2.7x the MFMA ceiling of the exact
-// kernel (modconv.hip) at a relative product error of ~2^-16 / ~2^-23.
+// Modulated convolution on the 16-bit matrix pipe (v_mfma_f32_32x32x16_{f16,bf16}, gfx950) with SPLIT operands:
+// every fp32 operand is the sum of 16-bit parts, each the round-to-nearest value of the residual left by the parts
+// before it, and a product is the sum of the part products above the target weight, accumulated in fp32.  Operand
+// kinds (template parameter KD):
+//   KD = 4  F16X3 (default)  fp16 hi + lo (11 + 11 mantissa bits), hi.hi + lo.hi + hi.lo:      ~2^-22 per product
+//   KD = 2  BF16X3           bf16 hi + lo ( 8 +  8 bits),          the same three products:      ~2^-16
+//   KD = 3  BF16X6           bf16 hi + mid + lo,                   six products:                 ~2^-23
+//   KD = 1  F16              one fp16 rounding,                    ONE product (EG3D's fp16 blocks): ~2^-11
+// The 16-bit pipe is 16x the fp32 one, so the 3-product kinds have 5.3x the MFMA ceiling of the exact kernel
+// (modconv.hip).  The fp16 kinds carry a range guard (style_range_guard) and a saturating split.
 //
 //   same implicit GEMM as modconv.hip: M = 8x16 output positions, N = 128 output channels, K = taps x Cin in
 //   chunks of 16 channels (= one MFMA K step).  The activations are read as fp32, scaled by the style, split and
-//   written to LDS as bf16 part images [part][position][16 ch] (32 B per position, the two 16-B halves XOR-swizzled
-//   by bit 3 of the position so that a ds_read_b128 of 16 consecutive positions touches 16 distinct 16-B slots).
-//   The weights are pre-split (hfagp_weight_prep_split) into [part][tap][Cin/8][Cout][8], which is the B-operand
-//   fragment order: a lane's 8 K values are one 16-B load / one ds_read_b128.
-//   A K chunk is consumed in steps of up to 3 taps; the B image of the next step and the A patch of the next chunk
-//   are prefetched into registers under the MFMAs and written to the other LDS buffer before the step's barrier.
+//   written to LDS as part images [part][position][16 ch + 16 B pad] (48-B pitch, row pitch 32 positions: every
+//   16-lane group of a ds_read_b128 covers 16 distinct 16-B slots).
+//   The weights are pre-split (hfagp_weight_prep_prec) into [part][tap][Cin/8][Cout][8], which is the B-operand
+//   fragment order: a lane's 8 K values are one 16-B load, straight from L2 into the fragment registers through a
+//   ring that stays 3 (F16: 6) taps ahead of the MFMAs.  The patch of the next chunk is converted under the last
+//   taps of the current one into the other LDS buffer: one barrier per chunk.
 #include <type_traits>
 #include "modconv_plan.h"
 
