@@ -196,6 +196,35 @@ def test_synthesis_layer_f16(dev, b, h, cin, cout, up, ksplit, clamp, xscale):
     close(ops.nhwc_to_nchw(y), want, atol=F16_TOL * float(want.abs().max()) + 1e-6)
 
 
+@pytest.mark.parametrize("prec", ["fp32", "f16x3", "bf16x3", "f16"])
+@pytest.mark.parametrize("b,h,w_,cin,cout", [(2, 9, 21, 32, 128), (1, 37, 5, 64, 256), (8, 96, 128, 16, 128), (3, 1, 17, 16, 128)])
+def test_conv_non_square_and_all_modes(dev, prec, b, h, w_, cin, cout):
+    """The C-ABI conv takes H != W: 3x3, stride-2 transposed (merged 4- and 8-wave up-conv kernels: the (8, 96, 128)
+    case crosses the 8-wave threshold) and 1x1, for every precision, against torch's convolutions in fp64."""
+    from hfa_gp_amd import ops
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(b, cin, h, w_, generator=g)
+    w3 = torch.randn(cout, cin, 3, 3, generator=g)
+    w1 = torch.randn(96, cin, 1, 1, generator=g)
+    s = torch.randn(b, cin, generator=g)
+    xs = (x * s[:, :, None, None]).double()
+    tol = {"fp32": 2e-6, "f16x3": 4e-6, "bf16x3": 5e-5, "f16": 6e-3}[prec]
+
+    def image(w):
+        return ops.weight_prep(w.to(dev))[0] if prec == "fp32" else ops.weight_prep_prec(w.to(dev), prec)
+    xh, sd = ops.nchw_to_nhwc(x.to(dev)), s.to(dev)
+    cases = [(ops.CONV3X3, w3, cout, F.conv2d(xs, w3.double(), padding=1)),
+             (ops.CONVT3X3_UP2, w3, cout, F.conv_transpose2d(xs, w3.transpose(0, 1).double(), stride=2)),
+             (ops.CONV1X1, w1, 96, F.conv2d(xs, w1.double()))]
+    for mode, w, co, want in cases:
+        if prec != "fp32" and not ops.split_supported(cin, co, up=mode == ops.CONVT3X3_UP2):
+            continue
+        y = ops.nhwc_to_nchw(ops.modconv(xh, image(w), co, mode, styles=sd)).cpu().double()
+        assert y.shape == want.shape
+        err = (y - want).abs().max().item()
+        assert err <= tol * want.abs().max().item() + 1e-9, (mode, err, want.abs().max().item())
+
+
 @pytest.mark.parametrize("xscale,sscale,tol", [(200.0, 40.0, 4e-6), (1e-3, 1.0, 1e-4), (1.0, 1e-4, 4e-6), (3e4, 1e3, 4e-6)])
 def test_f16x3_range_guard(dev, xscale, sscale, tol):
     """The default precision at the edges of fp16's range: activations at the clamp level with large styles (the raw
