@@ -244,6 +244,9 @@ def main():
         return p
 
     prec = args.precision or cfg.conv_precision
+    # the headline leg first, exactly as the contract words it (W warm-up steps, then K timed steps); the secondary
+    # legs (other precisions, batch sweep) follow
+    dt, timing = render_leg(prec)
     dt32 = timing32 = dtb3 = None
     if prec != "fp32" and not args.no_fp32_leg:
         dt32, timing32 = render_leg("fp32")
@@ -257,7 +260,7 @@ def main():
     sweep = None
     if not args.no_sweep:
         sweep = {str(b): sweep_leg(b, prec) for b in (1, 4, 16) if b != B}
-    dt, timing = render_leg(prec)
+    gen.conv_precision, gen.sr_conv_precision = prec, None
 
     def agg(key, table=None):
         evs = (timing if table is None else table).get(key, [])
