@@ -250,7 +250,10 @@ __global__ void __launch_bounds__(256) channel_sum_final_kernel(const float* __r
 
 }  // namespace hfagp
 
-namespace hfagp { int launch_wgrad3x3_bf16(const HfagpWgradArgs* a, hipStream_t s); }      // wgrad_bf16.hip
+namespace hfagp {      // wgrad_bf16.hip
+int launch_wgrad3x3_bf16(const HfagpWgradArgs* a, hipStream_t s);
+int launch_wgrad_parity_bf16(const HfagpWgradArgs* a, const float* g_par, int parity, hipStream_t s);
+}
 
 using namespace hfagp;
 
@@ -323,11 +326,24 @@ int hfagp_conv_wgrad(const HfagpWgradArgs* a, void* stream) {
         const long long img = (long long)a->B * p.gH * p.gW * a->Cout;
         static const int taps_of[4][4] = {{0, 2, 6, 8}, {1, 7, -1, -1}, {3, 5, -1, -1}, {4, -1, -1, -1}};
         static const int ntaps_of[4] = {4, 2, 2, 1};
+        const bool split16 = a->precision == HFAGP_PREC_BF16X3 && a->Cin % 64 == 0 && a->Cout % 64 == 0;
         for (int ph = 0; ph < 4; ++ph) {
             p.g = a->g + ph * img;
             for (int k = 0; k < ntaps_of[ph]; ++k) {
                 const int t = taps_of[ph][k], ti = t / 3, tj = t % 3;
                 p.tap[k] = WTap{0, 0, (signed char)(ti >> 1), (signed char)(tj >> 1), (signed char)t};
+            }
+            if (split16) {      // split-bf16 MFMA kernel (tap slots in the order of taps_of[ph]), then the shared reducer
+                int rc = launch_wgrad_parity_bf16(a, p.g, ph, s);
+                if (rc != HFAGP_OK) return rc;
+                WTaps9 taps;
+                for (int t = 0; t < 9; ++t) taps.t[t] = p.tap[t];
+                const dim3 rgrid((unsigned)((a->Cin * a->Cout + 255) / 256), (unsigned)ntaps_of[ph]);
+                wgrad_reduce_kernel<<<rgrid, 256, 0, s>>>(a->workspace, a->weight, a->dd, a->dcoef, a->styles, a->dweight,
+                                                          a->ksplit, ntaps_of[ph], a->Cin, a->Cout, a->B, 9, taps);
+                rc = check_launch("conv_wgrad/reduce");
+                if (rc != HFAGP_OK) return rc;
+                continue;
             }
             const int rc = ntaps_of[ph] == 4 ? run_wgrad<4, 2>(p, a, s) : ntaps_of[ph] == 2 ? run_wgrad<2, 2>(p, a, s)
                                                                                           : run_wgrad<1, 2>(p, a, s);

@@ -469,14 +469,15 @@ def conv_wgrad(x: torch.Tensor, styles: Optional[torch.Tensor], g: torch.Tensor,
                dd: Optional[torch.Tensor] = None, dcoef: Optional[torch.Tensor] = None,
                precision: str = "fp32") -> torch.Tensor:
     """Weight gradient of a modulated conv (see include/hfagp.h): returns dweight like `weight`.  precision 'bf16x3':
-    the 3x3 mode with Cin, Cout multiples of 64 runs on the split-bf16 MFMA kernel (everything else stays fp32)."""
+    the 3x3 and up-sampling modes with Cin, Cout multiples of 64 run on the split-bf16 MFMA kernel (the 1x1 mode and
+    other shapes stay fp32)."""
     _chk(x, "x")
     _chk(g, "g")
     b, h, w, cin = x.shape
     cout = weight.shape[0]
     a = L.WgradArgs()
     dweight = torch.empty_like(weight)
-    split16 = precision == "bf16x3" and mode == CONV3X3 and cin % 64 == 0 and cout % 64 == 0
+    split16 = precision == "bf16x3" and mode in (CONV3X3, CONVT3X3_UP2) and cin % 64 == 0 and cout % 64 == 0
     rows = 4 if split16 else 2                         # position tile of the kernel that will run: rows x 16
     units = b * ((h + rows - 1) // rows) * ((w + 15) // 16)
     tiles = ((cin + 63) // 64) * ((cout + 63) // 64)

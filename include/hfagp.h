@@ -321,8 +321,8 @@ typedef struct {
     float*       workspace;   /* >= hfagp_wgrad_workspace_bytes() */
     int32_t B, H, W, Cin, Cout, mode;
     int32_t ksplit;           /* number of split-K slabs over (b, position tiles); >= 1 */
-    int32_t precision;        /* HFAGP_PREC_F32 (exact fp32 MFMA) or HFAGP_PREC_BF16X3: the 3x3 mode with Cin, Cout    */
-                              /* multiples of 64 then runs on the split-bf16 MFMA kernel, every other case stays fp32 */
+    int32_t precision;        /* HFAGP_PREC_F32 (exact fp32 MFMA) or HFAGP_PREC_BF16X3: modes 0 and 1 with Cin, Cout    */
+                              /* multiples of 64 then run on the split-bf16 MFMA kernel, every other case stays fp32   */
 } HfagpWgradArgs;
 
 size_t hfagp_wgrad_workspace_bytes(const HfagpWgradArgs* a);

@@ -337,6 +337,29 @@ def test_conv_weight_gradient_split_bf16(dev, b, h, w_, cin, cout):
     assert not torch.equal(dw, exact), "the split kernel did not run"
 
 
+@pytest.mark.parametrize("b,h,w_,cin,cout", [(2, 11, 11, 64, 128), (1, 8, 21, 128, 64), (3, 3, 5, 64, 64), (1, 32, 16, 128, 128)])
+def test_upconv_weight_gradient_split_bf16(dev, b, h, w_, cin, cout):
+    """The weight gradient of the up-sampling conv on the split-bf16 MFMA kernel (four parity launches, the shifted
+    operand is the gradient image) vs autograd through the oracle's transposed conv + FIR."""
+    from hfa_gp_amd import ops
+    from oracle import eg3d_oracle as O
+    g = torch.Generator().manual_seed(19)
+    x = torch.randn(b, cin, h, w_, generator=g)
+    s = torch.randn(b, cin, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g, requires_grad=True)
+    y = O._conv_up2(x * s[:, :, None, None], w, O.fir_kernel())
+    gy = torch.randn(y.shape, generator=g) * 1e-5
+    y.backward(gy)
+    xh = ops.nchw_to_nhwc(x.to(dev))
+    gph = ops.upfir_bwd(ops.nchw_to_nhwc(gy.to(dev)))
+    dw = ops.conv_wgrad(xh, s.to(dev), gph, w.detach().to(dev), ops.CONVT3X3_UP2, precision="bf16x3")
+    exact = ops.conv_wgrad(xh, s.to(dev), gph, w.detach().to(dev), ops.CONVT3X3_UP2)
+    scale = w.grad.abs().max().item()
+    close(exact, w.grad, atol=1e-4 * scale, rtol=1e-4)
+    close(dw, w.grad, atol=1e-4 * scale, rtol=1e-4)
+    assert not torch.equal(dw, exact), "the split kernel did not run"
+
+
 @pytest.mark.parametrize("preset,batch,prec", [("tiny64", 2, "fp32"), ("tiny14", 1, "fp32"), ("small128", 1, "fp32"),
                                                ("small128", 1, "bf16x3")])
 def test_generator_parameter_gradients_vs_oracle_autograd(dev, preset, batch, prec):
