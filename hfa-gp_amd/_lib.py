@@ -95,6 +95,12 @@ class WgradArgs(C.Structure):
         [(n, C.c_int32) for n in ("B", "H", "W", "Cin", "Cout", "mode", "ksplit", "precision")]
 
 
+class StyleBwdItem(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("ds", "dd", "styles", "dcoef", "wsq", "affine_w", "dstot", "dw")] + \
+        [(n, C.c_int32) for n in ("B", "Cin", "Cout", "w_dim", "dw_stride", "ds_stride", "dd_stride")] + \
+        [("style_gain", C.c_float)]
+
+
 class RaymarchBwdArgs(C.Structure):
     _fields_ = [("fwd", RaymarchArgs), ("g_feat", C.c_void_p), ("d_planes", C.c_void_p), ("rec", C.c_void_p),
                 ("d_dec_w0", C.c_void_p), ("d_dec_b0", C.c_void_p), ("d_dec_w1", C.c_void_p), ("d_dec_b1", C.c_void_p)]
@@ -122,6 +128,7 @@ SYMBOLS = {
     "hfagp_upsample2d_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "hfagp_planes_to_nhwc": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p]),
     "hfagp_style_bwd": (C.c_int, [C.POINTER(StyleBwdArgs), C.c_void_p]),
+    "hfagp_style_batch_bwd": (C.c_int, [C.POINTER(StyleBwdItem), C.c_int32, C.c_void_p]),
     "hfagp_raymarch_bwd": (C.c_int, [C.POINTER(RaymarchBwdArgs), C.c_void_p]),
     "hfagp_wgrad_workspace_bytes": (C.c_size_t, [C.POINTER(WgradArgs)]),
     "hfagp_conv_wgrad": (C.c_int, [C.POINTER(WgradArgs), C.c_void_p]),

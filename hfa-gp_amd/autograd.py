@@ -33,6 +33,7 @@ class _Backward:
     def __init__(self, gen, tape, d_ws: torch.Tensor, ws: torch.Tensor, param_grads: bool):
         self.gen, self.tape, self.d_ws, self.ws, self.pg = gen, tape, d_ws, ws, param_grads
         self.grads = {}            # id(parameter) -> gradient (only when the generator is being tuned)
+        self.pending = []          # style gradients of the whole pass: (item for ops.style_bwd_batch, affine module)
 
     def _acc(self, param: torch.Tensor, g: torch.Tensor):
         key = id(param)
@@ -84,11 +85,10 @@ class _Backward:
         if next_layer_rec is not None:
             next_layer_rec["ds"] = sums[:, 0]
         ds_rgb = sums[:, 2] if rgb["small"] else sums[:, 1]
-        dstot = ops.style_bwd(ds_rgb, None, rgb["styles"], None, None, tr.affine.weight, self.d_ws[:, rgb["row"]],
-                              1.0 / math.sqrt(cin), accumulate=True)
+        self.pending.append(((ds_rgb, None, rgb["styles"], None, None, tr.affine.weight, rgb["row"],
+                              1.0 / math.sqrt(cin)), tr.affine))
         c1["dd"] = sums[:, 3]
         if self.pg:
-            self.affine_grads(tr.affine, dstot, rgb["row"])
             if rgb["small"]:
                 co = tr.weight.shape[0]
                 dw = (sums[:, 6:6 + co] * rgb["styles"][:, None, :]).sum(0)          # [Co, C]: tiny host-side glue
@@ -144,11 +144,17 @@ class _Backward:
             self._acc(layer.noise_strength, sums_out[:, 5].sum())
 
     def finish_layer(self, rec: dict):
-        """ds (from the pass over the layer's input) and dd (from the pass over its output) are both known."""
-        dstot = ops.style_bwd(rec["ds"], rec["dd"], rec["styles"], rec["dcoef"], rec["wsq"],
-                              rec["layer"].affine.weight, self.d_ws[:, rec["row"]], 1.0, accumulate=True)
+        """ds (from the pass over the layer's input) and dd (from the pass over its output) are both known: queue the
+        layer's style gradient (all of them run in two launches at the end of the pass, `flush_styles`)."""
+        self.pending.append(((rec["ds"], rec["dd"], rec["styles"], rec["dcoef"], rec["wsq"], rec["layer"].affine.weight,
+                              rec["row"], 1.0), rec["layer"].affine))
+
+    def flush_styles(self):
+        dstots = ops.style_bwd_batch([it for it, _ in self.pending], self.d_ws)
         if self.pg:
-            self.affine_grads(rec["layer"].affine, dstot, rec["row"])
+            for (it, affine), dstot in zip(self.pending, dstots):
+                self.affine_grads(affine, dstot, it[6])
+        self.pending = []
 
 
 class SynthesisFn(torch.autograd.Function):
@@ -217,6 +223,7 @@ class SynthesisFn(torch.autograd.Function):
             if nxt is not None:
                 bw.finish_layer(nxt)
             dxs, nxt = dxs_new, c0
+        bw.flush_styles()
         ctx.tape = None
         pgrads = tuple(bw.grads.get(id(p)) if p.requires_grad else None for p in ctx.params)
         return (d_ws, None, None, None, None) + pgrads

@@ -312,6 +312,61 @@ __global__ void __launch_bounds__(256) style_bwd_dw_kernel(const float* __restri
     }
 }
 
+// ---------------------------------------------------------------- all style gradients of a backward pass, batched
+// The per-layer calls (52 launches of ~5-9 us per fitting step, each fed by tiny `.contiguous()` copies of strided
+// views) become two launches: item = one affine layer; ds / dd are read with a row stride; the d_ws rows are
+// accumulated by ONE block per (row, sample, 64 columns) that walks the items of its row in order (several layers
+// share a ws row: deterministic, no race).
+constexpr int kStyleBwdBatch = 32;
+struct StyleBwdBatch {
+    HfagpStyleBwdItem it[kStyleBwdBatch];
+    int row_start[kStyleBwdBatch + 1];     // items are sorted by dw pointer: row r owns items [row_start[r], row_start[r+1])
+};
+
+__global__ void __launch_bounds__(256) style_bwd_ds_batch_kernel(const StyleBwdBatch t) {
+    const HfagpStyleBwdItem& a = t.it[blockIdx.y];
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= a.B * a.Cin) return;
+    const int b = wave / a.Cin, i = wave % a.Cin;
+    float acc = 0.f;
+    if (a.dd)
+        for (int o = lane; o < a.Cout; o += 64) {
+            const float d = a.dcoef[(size_t)b * a.Cout + o];
+            acc += a.dd[(size_t)b * a.dd_stride + o] * d * d * d * a.wsq[(size_t)o * a.Cin + i];
+        }
+    for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m);
+    if (lane == 0) a.dstot[wave] = (a.ds[(size_t)b * a.ds_stride + i] - a.styles[wave] * acc) * a.style_gain;
+}
+
+__global__ void __launch_bounds__(256) style_bwd_dw_batch_kernel(const StyleBwdBatch t) {
+    __shared__ float red[4][64];
+    const int row = blockIdx.z, b = blockIdx.y, k = blockIdx.x * 64 + (threadIdx.x & 63), ig = threadIdx.x >> 6;
+    const int i0 = t.row_start[row], i1 = t.row_start[row + 1];
+    const HfagpStyleBwdItem& first = t.it[i0];
+    float acc = 0.f;
+    if (k < first.w_dim)
+        for (int it = i0; it < i1; ++it) {
+            const HfagpStyleBwdItem& a = t.it[it];
+            float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            int i = ig;
+            for (; i + 28 < a.Cin; i += 32) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    part[u] += a.dstot[(size_t)b * a.Cin + i + 4 * u] * a.affine_w[(size_t)(i + 4 * u) * a.w_dim + k];
+            }
+            for (; i < a.Cin; i += 4) part[0] += a.dstot[(size_t)b * a.Cin + i] * a.affine_w[(size_t)i * a.w_dim + k];
+            acc += ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
+        }
+    red[ig][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (ig == 0 && k < first.w_dim) {
+        const float v = (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) *
+                        rsqrtf((float)first.w_dim);
+        float* dst = first.dw + (size_t)b * first.dw_stride + k;
+        *dst += v;
+    }
+}
+
 }  // namespace hfagp
 
 using namespace hfagp;
@@ -361,6 +416,27 @@ int hfagp_planes_to_nhwc(const float* pm, float* y, int32_t B, int32_t H, int32_
     const long long total = (long long)B * H * W * (3 * Cp / 4);
     planes_to_nhwc_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(pm, y, B, H, W, Cp);
     return check_launch("planes_to_nhwc");
+}
+
+int hfagp_style_batch_bwd(const HfagpStyleBwdItem* items, int32_t n, void* stream) {
+    HFAGP_REQUIRE(items && n >= 1 && n <= kStyleBwdBatch, HFAGP_EBADARG, "style_batch_bwd: 1..%d items", kStyleBwdBatch);
+    StyleBwdBatch t;
+    int max_waves = 0, nrows = 0;
+    for (int i = 0; i < n; ++i) {
+        const HfagpStyleBwdItem& a = items[i];
+        HFAGP_REQUIRE(a.ds && a.styles && a.affine_w && a.dstot && a.dw, HFAGP_EBADARG, "style_batch_bwd: null pointer (item %d)", i);
+        HFAGP_REQUIRE(!a.dd || (a.dcoef && a.wsq && a.Cout > 0), HFAGP_EBADARG, "style_batch_bwd: dd needs dcoef and wsq (item %d)", i);
+        HFAGP_REQUIRE(a.B == items[0].B && a.w_dim == items[0].w_dim, HFAGP_EBADARG, "style_batch_bwd: B / w_dim differ (item %d)", i);
+        HFAGP_REQUIRE(i == 0 || a.dw >= items[i - 1].dw, HFAGP_EBADARG, "style_batch_bwd: items must be sorted by dw (item %d)", i);
+        t.it[i] = a;
+        if (i == 0 || a.dw != items[i - 1].dw) t.row_start[nrows++] = i;
+        max_waves = a.B * a.Cin > max_waves ? a.B * a.Cin : max_waves;
+    }
+    t.row_start[nrows] = n;
+    hipStream_t s = (hipStream_t)stream;
+    style_bwd_ds_batch_kernel<<<dim3((max_waves + 3) / 4, n), 256, 0, s>>>(t);
+    style_bwd_dw_batch_kernel<<<dim3((items[0].w_dim + 63) / 64, items[0].B, nrows), 256, 0, s>>>(t);
+    return check_launch("style_batch_bwd");
 }
 
 int hfagp_style_bwd(const HfagpStyleBwdArgs* a, void* stream) {

@@ -465,6 +465,46 @@ def style_bwd(ds: torch.Tensor, dd: Optional[torch.Tensor], styles: torch.Tensor
     return dstot
 
 
+def style_bwd_batch(items, d_ws: torch.Tensor):
+    """All style gradients of a backward pass in two launches.  ``items``: list of (ds [B,Cin] view, dd [B,Cout] view |
+    None, styles, dcoef | None, wsq | None, affine_w, row, style_gain); ds / dd may be strided row views (unit inner
+    stride) of the reduction tensors.  Accumulates into d_ws[:, row]; returns the dstot [B, Cin] of every item, in the
+    order given."""
+    order = sorted(range(len(items)), key=lambda i: items[i][6])          # by ws row = by dw pointer
+    out = [None] * len(items)
+    for c0 in range(0, len(order), 32):
+        chunk = order[c0:c0 + 32]
+        # a ws row must not straddle two launches (its accumulation is one block's job): cut the chunk at a row boundary
+        while c0 + len(chunk) < len(order) and len(chunk) > 1 and items[chunk[-1]][6] == items[order[c0 + len(chunk)]][6]:
+            chunk = chunk[:-1]
+        if len(chunk) != len(order[c0:c0 + 32]):
+            return _style_bwd_each(items, d_ws)                            # (never with <= 32 layers: ffhq has 26)
+        arr = (L.StyleBwdItem * len(chunk))()
+        for j, i in enumerate(chunk):
+            ds, dd, styles, dcoef, wsq, affine_w, row, gain = items[i]
+            if ds.stride(-1) != 1 or (dd is not None and dd.stride(-1) != 1):
+                raise RuntimeError("style_bwd_batch: ds / dd need unit inner stride")
+            b, cin = styles.shape
+            dstot = torch.empty(b, cin, device=styles.device, dtype=torch.float32)
+            a = arr[j]
+            a.ds, a.dd, a.styles, a.dcoef, a.wsq = ds.data_ptr(), (dd.data_ptr() if dd is not None else None), _ptr(styles), \
+                _ptr(dcoef), _ptr(wsq)
+            a.affine_w, a.dstot = _ptr(affine_w), _ptr(dstot)
+            a.dw = d_ws.data_ptr() + row * d_ws.stride(1) * 4
+            a.B, a.Cin, a.Cout = b, cin, (dd.shape[1] if dd is not None else 0)
+            a.w_dim, a.dw_stride = affine_w.shape[1], d_ws.stride(0)
+            a.ds_stride, a.dd_stride = ds.stride(0), (dd.stride(0) if dd is not None else 0)
+            a.style_gain = gain
+            out[i] = dstot
+        L.check(L.lib().hfagp_style_batch_bwd(arr, len(chunk), _stream()), "style_batch_bwd")
+    return out
+
+
+def _style_bwd_each(items, d_ws):
+    return [style_bwd(ds, dd, styles, dcoef, wsq, affine_w, d_ws[:, row], gain, accumulate=True)
+            for ds, dd, styles, dcoef, wsq, affine_w, row, gain in items]
+
+
 def conv_wgrad(x: torch.Tensor, styles: Optional[torch.Tensor], g: torch.Tensor, weight: torch.Tensor, mode: int,
                dd: Optional[torch.Tensor] = None, dcoef: Optional[torch.Tensor] = None,
                precision: str = "fp32") -> torch.Tensor:

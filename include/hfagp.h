@@ -284,6 +284,24 @@ typedef struct {
 
 int hfagp_style_bwd(const HfagpStyleBwdArgs* a, void* stream);
 
+/* the same for every affine layer of a backward pass in two launches (at most 32 items, sorted by `dw`: layers that
+ * share a row of d ws are accumulated in item order by one block, so the result is deterministic).  ds / dd are read
+ * with a row stride (elements), so the reductions of hfagp_pointwise_bwd can be passed without a copy; every dw row
+ * is accumulated into (+=).                                                                                  */
+typedef struct {
+    const float* ds;          /* [B][Cin], row stride ds_stride */
+    const float* dd;          /* [B][Cout], row stride dd_stride, or NULL (no demodulation) */
+    const float* styles;      /* [B][Cin] */
+    const float* dcoef;       /* [B][Cout] or NULL */
+    const float* wsq;         /* [Cout][Cin] or NULL */
+    const float* affine_w;    /* [Cin][w_dim] */
+    float*       dstot;       /* out [B][Cin] */
+    float*       dw;          /* row of d ws: dw[b * dw_stride + k] += ... */
+    int32_t B, Cin, Cout, w_dim, dw_stride, ds_stride, dd_stride;
+    float style_gain;
+} HfagpStyleBwdItem;
+int hfagp_style_batch_bwd(const HfagpStyleBwdItem* items, int32_t n, void* stream);
+
 /* backward of hfagp_raymarch_fwd w.r.t. the tri-plane volume: recomputes the forward per ray, then
  * scatters d feat -> d planes with fp32 atomics (d_planes must be zero-initialised by the caller).
  * With plane_axes = 0 on square planes, planes 1 (x,z) and 2 (z,x) receive mirrored gradients: only plane 1
