@@ -8,6 +8,16 @@ explicit sampling uniforms), forward only, inputs resident in HBM before the
 timed region.  N>1: one process per GPU, frames are independent → weak scaling,
 no data-path collective; only the timing is reduced (MAX).
 
+``python bench.py --gpus N`` WITHOUT a launcher (WORLD_SIZE unset) re-executes itself under
+``torch.distributed.run`` with N ranks (the reference spawns one process per GPU itself:
+/root/reference/code/train_rgb.py:196-202, ``ddp_setup`` :53-57); under a launcher it checks that the
+process group really has N ranks.  ``n_gpus`` on the line is what the process group reports.
+
+Secondary legs on the same JSON line (none of them is ``value``): other conv precisions, batch sweep,
+the fitting step of BASELINE configs 3 (RGB-driven, Encoder in the step) and 4 (3DMM-driven) with the
+all-reduce of the shared gradients, a 500-frame synthetic fit (config 3 as written), the batched
+audio-driven reenactment of config 5, the CPU oracle baseline.
+
 Prints ONE JSON line on rank 0 (see the contract in the task description).
 """
 from __future__ import annotations
@@ -16,16 +26,17 @@ import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-MFMA_F32_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32 dense peak
+L2_PEAK_GBS = 34500.0        # MI355X_MICROARCH.md: L2 aggregate ~34.5 TB/s
+MFMA_F32_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32 / 16x16x4_f32 dense peak
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_bf16 dense peak
 SPLIT_MFMAS = {"f16x3": 3, "bf16x3": 3, "bf16x6": 6}   # 16-bit MFMAs per algorithmic (fp32) product on the split paths
 SPLIT_ELEM = {"f16x3": "f16", "bf16x3": "bf16", "bf16x6": "bf16"}
@@ -40,12 +51,20 @@ def parse():
     ap.add_argument("--batch", type=int, default=8, help="frames per step per GPU")
     ap.add_argument("--preset", default="ffhq512_128")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-train", action="store_true", help="skip the fitting-step leg (train_step_ms)")
+    ap.add_argument("--no-train", action="store_true", help="skip the fitting-step legs (train_step_ms ...)")
     ap.add_argument("--train-batch", type=int, default=2, help="frames per fitting step per GPU")
     ap.add_argument("--train-steps", type=int, default=6)
+    ap.add_argument("--fit-frames", type=int, default=500,
+                    help="frames of the synthetic RGB-driven fit (BASELINE config 3; 0 = skip): one pass over them")
+    ap.add_argument("--audio-frames", type=int, default=256,
+                    help="frames of the batched audio-driven reenactment leg (BASELINE config 5; 0 = skip)")
+    ap.add_argument("--lpips", action="store_true",
+                    help="also time the fitting step with the LPIPS(alex) term (random weights: cost only)")
     ap.add_argument("--no-sweep", action="store_true",
                     help="skip the batch-size sweeps (render B = 1, 4, 16; fitting step B = 1, 4; SURVEY.md section 8d)")
-    ap.add_argument("--cpu-runs", type=int, default=2)
+    ap.add_argument("--cpu-runs", type=int, default=3, help="timed oracle runs (BASELINE.md section 3 plans 5)")
+    ap.add_argument("--cpu-warmup", type=int, default=1, help="oracle warm-up runs (BASELINE.md section 3 plans 2)")
+    ap.add_argument("--cpu-n1", action="store_true", help="also time the oracle with ONE thread (minutes)")
     ap.add_argument("--precision", default=None, choices=["fp32", "f16x3", "bf16x3", "bf16x6"],
                     help="conv GEMM arithmetic of the headline leg (default: the preset's conv_precision)")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the second render leg on the exact fp32 kernel")
@@ -58,20 +77,74 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(cfg, state, runs: int):
-    """Oracle (kind 'port') timed on this box's host cores: B=1 synthesis, same workload."""
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launcher_command(n: int, argv, port: int):
+    """The command line `--gpus N` re-executes when no launcher set WORLD_SIZE (one rank per GPU, rendezvous on
+    127.0.0.1) — the driver's own form of the launch."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py")] + list(argv)
+
+
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(cfg, state, runs: int, warmup: int, n1: bool):
+    """Oracle (kind 'port') timed on this box's host cores: B=1 synthesis of the same workload; median of `runs`
+    after `warmup`; stage split backbone / ray-march / super-resolution."""
+    import torch
     from oracle import eg3d_oracle as O
     from tests.util import make_inputs
     ws, c, us, ui = make_inputs(cfg, 1, seed=10)
-    with torch.no_grad():
-        O.synthesis(state, cfg, ws, c, us, ui)          # warm-up
-        t = time.perf_counter()
-        for _ in range(runs):
-            O.synthesis(state, cfg, ws, c, us, ui)
-        dt = (time.perf_counter() - t) / runs
-    return {"value": 1.0 / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{runs} x synthesis(B=1) of the {cfg.name} workload with the fp32 PyTorch-CPU oracle, "
-                      f"{dt:.2f} s/frame"}
+    res = cfg.neural_rendering_resolution
+
+    def one():
+        t = [time.perf_counter()]
+        planes = O.backbone_synthesis(state, cfg, ws)
+        t.append(time.perf_counter())
+        o, d = O.ray_sampler(c[:, :16].reshape(-1, 4, 4), c[:, 16:25].reshape(-1, 3, 3), res)
+        p5 = planes.reshape(1, 3, cfg.plane_channels, planes.shape[-2], planes.shape[-1])
+        feat, _, _ = O.importance_renderer(state, cfg, p5, o, d, us, ui)
+        t.append(time.perf_counter())
+        fi = feat.permute(0, 2, 1).reshape(1, feat.shape[-1], res, res).contiguous()
+        O.superresolution(state, cfg, fi[:, :3], fi, ws)
+        t.append(time.perf_counter())
+        return [b - a for a, b in zip(t[:-1], t[1:])]
+
+    def timed(nruns, nwarm):
+        with torch.no_grad():
+            for _ in range(nwarm):
+                one()
+            rows = [one() for _ in range(nruns)]
+        tot = sorted(sum(r) for r in rows)
+        med = tot[len(tot) // 2]
+        stages = [sorted(r[i] for r in rows)[len(rows) // 2] for i in range(3)]
+        return med, stages
+
+    threads = torch.get_num_threads()
+    med, stages = timed(runs, warmup)
+    out = {"value": 1.0 / med, "unit": "frames/s", "cores": threads, "kind": "port", "cpu_model": cpu_model(),
+           "sample": f"median of {runs} x synthesis(B=1) of the {cfg.name} workload with the fp32 PyTorch-CPU oracle "
+                     f"after {warmup} warm-up, {threads} threads, {med:.2f} s/frame",
+           "stage_s": {"backbone": stages[0], "raymarch": stages[1], "superres": stages[2]}}
+    if n1:
+        torch.set_num_threads(1)
+        med1, st1 = timed(1, 0)
+        torch.set_num_threads(threads)
+        out["n1"] = {"value": 1.0 / med1, "cores": 1, "s_per_frame": med1,
+                     "stage_s": {"backbone": st1[0], "raymarch": st1[1], "superres": st1[2]}}
+    return out
 
 
 def _pct(ms_list):
@@ -85,7 +158,7 @@ def _pct(ms_list):
 
 
 class _FitArgs:
-    """Flags of code/train_3dmm.py that reach the step."""
+    """Flags of code/train_3dmm.py / train_rgb.py that reach the step."""
     out_pose = False
     person_2 = False
     params_len = 76
@@ -97,30 +170,44 @@ class _FitArgs:
     generator_seed = 0
 
 
-def train_leg(args, cfg_name, dev, rank, world, dist):
-    """BASELINE config 3/4 mechanics: 3DMM-driven latent-basis fitting, generator frozen, L2 loss at 256^2
-    (LPIPS weights are not available offline), Adam 3e-4; frames sharded over ranks, ONE flattened
-    all-reduce of the shared gradients per step.  Returns max-over-ranks ms per step."""
+class _AudioArgs(_FitArgs):
+    """code/train_audio.py:186-212."""
+    params_len = 64
+    dim_aud = 64
+    win_size = 16
+    nosmo_iters = 0
+    smo_size = 8
+
+
+def train_legs(args, cfg_name, dev, rank, world, dist):
+    """BASELINE configs 3 / 4 mechanics at full size: latent-basis fitting step, generator frozen, L2 loss at 256^2
+    (+ LPIPS with random weights under --lpips), Adam 3e-4; RGB-driven (Encoder in the step: config 3) and
+    3DMM-driven (config 4); ONE in-place all-reduce of the flat shared-gradient buffer per step when world > 1."""
+    import torch
     from hfa_gp_amd.trainer import Trainer
     from tests.util import look_at_label
-    fa = _FitArgs()
-    fa.generator_preset = cfg_name
-    torch.manual_seed(0)
-    tr = Trainer(fa, dev, rank=rank, world_size=world, mode="3dmm")
-    g = torch.Generator().manual_seed(40 + rank)
+    out = {}
 
-    def inputs(B):
+    def make(mode, lpips):
+        fa = _FitArgs()
+        fa.generator_preset = cfg_name
+        torch.manual_seed(0)
+        return fa, Trainer(fa, dev, rank=rank, world_size=world, mode=mode, lpips=lpips)
+
+    def inputs(fa, B, g):
         real = (0.5 * torch.randn(B, 3, fa.size, fa.size, generator=g)).clamp(-1, 1).to(dev)
         params = torch.randn(B, fa.params_len, generator=g).to(dev)
         label = look_at_label(math.pi / 2 + 0.3 * torch.randn(B, generator=g),
                               math.pi / 2 + 0.155 * torch.randn(B, generator=g), flipped=False).to(dev)
         return real, params, label
 
-    def timed(steps, B):
+    def timed(tr, fa, steps, B):
         """(max-over-ranks ms per step, {phase: mean ms} from HIP events on the launch stream)."""
-        real, params, label = inputs(B)
+        real, params, label = inputs(fa, B, torch.Generator().manual_seed(40 + rank))
+        call = (lambda: tr.gen_update(real, label.clone())) if tr.mode == "rgb" else \
+               (lambda: tr.gen_update(real, label.clone(), params))
         for _ in range(2):
-            tr.gen_update(real, label.clone(), params)
+            call()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -128,7 +215,7 @@ def train_leg(args, cfg_name, dev, rank, world, dist):
         tr.timing = {}
         t0 = time.perf_counter()
         for _ in range(steps):
-            l2, _, _ = tr.gen_update(real, label.clone(), params)
+            res = call()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -139,35 +226,131 @@ def train_leg(args, cfg_name, dev, rank, world, dist):
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
-        assert torch.isfinite(l2)
+        assert torch.isfinite(res[-3]), "fitting step produced a non-finite loss"
         phases = {k: sum(a.elapsed_time(b) for a, b in v) / max(len(v), 1) for k, v in spans.items()}
         return dt / steps * 1e3, phases
 
     B = args.train_batch
-    out = {"frozen": {}, "tuned": {}}
     batches = [B] if args.no_sweep else sorted({1, B, 4})
-    for b in batches:
-        ms, phases = timed(args.train_steps, b)
-        out["frozen"][b] = {"step_ms": ms, "phases_ms": phases}
-    # after tune_iter the reference also trains the generator (trainer_rgb.py:69-71): all 30.7 M parameters get
-    # gradients and are all-reduced with the basis / driver gradients
-    tr.tune_generator()
-    ms, phases = timed(max(2, args.train_steps // 2), B)
-    out["tuned"][B] = {"step_ms": ms, "phases_ms": phases}
+    for mode in ("3dmm", "rgb"):
+        fa, tr = make(mode, "none")
+        leg = {"frozen": {}, "tuned": {}, "shared_grad_bytes": None}
+        for b in (batches if mode == "3dmm" else [B]):
+            ms, phases = timed(tr, fa, args.train_steps, b)
+            leg["frozen"][b] = {"step_ms": ms, "phases_ms": phases}
+        leg["shared_grad_bytes"] = 4 * tr.flat_grads().numel
+        # after tune_iter the reference also trains the generator (trainer_rgb.py:69-71): all 30.7 M parameters get
+        # gradients, which live in the same flat buffer and are all-reduced with the basis / driver gradients
+        tr.tune_generator()
+        ms, phases = timed(tr, fa, max(2, args.train_steps // 2), B)
+        leg["tuned"][B] = {"step_ms": ms, "phases_ms": phases}
+        leg["shared_grad_bytes_tuned"] = 4 * tr.flat_grads().numel
+        out[mode] = leg
+        del tr
+        torch.cuda.empty_cache()
+    if args.lpips:
+        from hfa_gp_amd.lpips_alex import LPIPSAlex
+        fa, tr = make("rgb", LPIPSAlex().to(dev))
+        ms, phases = timed(tr, fa, args.train_steps, B)
+        out["rgb_lpips"] = {"step_ms": ms, "phases_ms": phases,
+                            "note": "LPIPS(alex) architecture with RANDOM weights: the cost of the reference objective "
+                                    "l2 + lpips (trainer_rgb.py:86-91), not its value"}
+        del tr
+        torch.cuda.empty_cache()
     return out, B
+
+
+def fit_leg(args, cfg_name, dev, rank, world, dist):
+    """BASELINE config 3 as written: RGB-driven latent-basis fitting (`train_rgb.py:114-154`) on `--fit-frames`
+    synthetic frames rendered from a hidden true basis (hfa_gp_amd.synthetic), frames sharded in contiguous blocks over
+    the ranks, one pass, batch 2 per rank, L2 loss; reports ms/step and the loss at both ends of the pass."""
+    import torch
+    from hfa_gp_amd.synthetic import make_frame_set
+    from hfa_gp_amd.trainer import Trainer, fit_frames
+    fa = _FitArgs()
+    fa.generator_preset = cfg_name
+    fa.batch_size = args.train_batch * world
+    torch.manual_seed(1)
+    tr = Trainer(fa, dev, rank=rank, world_size=world, mode="rgb", lpips="none")
+    data = make_frame_set(tr.gen, args.fit_frames, size=fa.size, seed=40)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    losses = fit_frames(tr, data["real"], data["label"], epochs=1, batch=args.train_batch)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    l = torch.stack(losses).float().cpu()
+    k = max(1, len(l) // 10)
+    return {"workload": f"train_rgb-style fit, {args.fit_frames} synthetic frames (targets rendered from a hidden basis, "
+                        f"256^2), Encoder -> basis -> generator, L2, Adam 3e-4, batch {args.train_batch}/rank, one pass",
+            "steps": len(l), "ms_per_step": dt / max(len(l), 1) * 1e3, "frames_per_s": args.fit_frames / dt,
+            "loss_first_tenth": float(l[:k].mean()), "loss_last_tenth": float(l[-k:].mean())}
+
+
+def audio_leg(args, cfg_name, dev, rank, world, dist):
+    """BASELINE config 5: batched audio-driven reenactment (`run_recon_video_audio.py:346`, `trainer_audio.py:115-153`)
+    at 512^2 / 96 samples with the super-resolution blocks on the single-pass fp16 MFMA path (the reference's own CUDA
+    precision split); `--audio-frames` frames sharded in contiguous blocks over the ranks, B = --batch per synthesis."""
+    import torch
+    from hfa_gp_amd.synthetic import audio_features, gaussian_labels
+    from hfa_gp_amd.trainer import AudioTrainer, shard_range
+    fa = _AudioArgs()
+    fa.generator_preset = cfg_name
+    n = args.audio_frames
+    torch.manual_seed(2)
+    tr = AudioTrainer(audio_features(n).numpy(), n, fa, dev, rank=rank, world_size=world, lpips="none")
+    tr.gen.generator.sr_conv_precision = "f16"
+    lo, hi = shard_range(n, rank, world)
+    labels = gaussian_labels(n, dev, seed=51)
+    idx = torch.arange(lo, hi, device=dev)
+    B = args.batch
+
+    def run():
+        for i in range(0, hi - lo, B):
+            tr.sample_frames(idx[i:i + B], labels[lo + i: lo + i + B].clone())
+    run()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    run()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return {"workload": f"audio-driven batched reenactment, {n} frames of aud[N,16,29], smoothing window 8, AudioNet + "
+                        f"AudioAttNet -> basis -> generator, 512^2 @ 48+48 samples, SR convs fp16 MFMA, B={B}",
+            "frames_per_s": n / dt, "frames_per_s_per_gpu": n / dt / world, "ms_per_frame": dt / max(hi - lo, 1) * 1e3}
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: start the N ranks ourselves, exactly as the driver does
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.exit(subprocess.run(launcher_command(args.gpus, sys.argv[1:], _free_port()), env=env).returncode)
+
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); no CPU fallback")
     if args.share_device:
         local_rank = 0
+    elif torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {world} but only {torch.cuda.device_count()} device(s) visible "
+                         f"(developer check of the N > 1 path on one GPU: --backend gloo --share-device)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -178,6 +361,9 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus says {args.gpus}")
+    n_ranks = dist.get_world_size() if dist is not None else 1
 
     from hfa_gp_amd.config import PRESETS
     from hfa_gp_amd.generator import TriPlaneGenerator
@@ -195,9 +381,9 @@ def main():
     def step():
         return gen.synthesis(ws, c, noise_mode="const", u_strat=us, u_imp=ui)["image"]
 
-    def render_leg(precision, sr_precision=None):
+    def render_leg(precision, sr_precision=None, events=True):
         """W warm-up + K timed steps with the conv GEMMs in ``precision`` (super-resolution blocks: ``sr_precision``
-        when given); (seconds max over ranks, event table)."""
+        when given); (seconds max over ranks, this rank's seconds, event table)."""
         gen.conv_precision = precision
         gen.sr_conv_precision = sr_precision
         for _ in range(args.warmup):
@@ -206,7 +392,7 @@ def main():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
-        gen.timing = {}
+        gen.timing = {} if events else None
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
         t0 = time.perf_counter()
         marks[0].record()
@@ -214,18 +400,19 @@ def main():
             img = step()
             marks[i + 1].record()
         torch.cuda.synchronize()
+        own = time.perf_counter() - t0
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        timing, gen.timing = gen.timing, None
+        timing, gen.timing = (gen.timing or {}), None
         timing["step"] = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
         if dist is not None:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         assert torch.isfinite(img).all()
-        return dt, timing
+        return dt, own, timing
 
     def sweep_leg(b, precision, steps=20, warmup=3):
         """batch sizes 1, 4 (and 16) beside the headline's 8; per-step HIP event pairs."""
@@ -244,23 +431,27 @@ def main():
         return p
 
     prec = args.precision or cfg.conv_precision
-    # the headline leg first, exactly as the contract words it (W warm-up steps, then K timed steps); the secondary
-    # legs (other precisions, batch sweep) follow
-    dt, timing = render_leg(prec)
+    # the headline leg first, exactly as the contract words it (W warm-up steps, then K timed steps), WITHOUT the
+    # per-kernel timing events (they cost host time per launch); a second pass of the same leg collects the events
+    # the roofline objects are computed from
+    dt, own_dt, timing_head = render_leg(prec, events=False)
+    _, _, timing = render_leg(prec)
+    timing["step"] = timing_head["step"]
     dt32 = timing32 = dtb3 = None
     if prec != "fp32" and not args.no_fp32_leg:
-        dt32, timing32 = render_leg("fp32")
+        dt32, _, timing32 = render_leg("fp32")
         if prec != "bf16x3":
-            dtb3, _ = render_leg("bf16x3")
+            dtb3, _, _ = render_leg("bf16x3", events=False)
     dt16sr = dt16 = timing16 = None
     if not args.no_f16_leg:
         # the reference's CUDA defaults: fp32-class backbone, fp16 super-resolution; then every conv in fp16
-        dt16sr, timing16 = render_leg(prec, "f16")
-        dt16, _ = render_leg("f16")
+        dt16sr, _, timing16 = render_leg(prec, "f16")
+        dt16, _, _ = render_leg("f16", events=False)
     sweep = None
     if not args.no_sweep:
         sweep = {str(b): sweep_leg(b, prec) for b in (1, 4, 16) if b != B}
     gen.conv_precision, gen.sr_conv_precision = prec, None
+    overflow = gen.f16_range_report()
 
     def agg(key, table=None):
         evs = (timing if table is None else table).get(key, [])
@@ -268,10 +459,23 @@ def main():
         units = sum(u for _, _, u in evs)
         return ms, units, len(evs)
 
-    train = train_B = None
+    per_rank = [B * args.steps / own_dt]
+    if dist is not None:
+        t = torch.zeros(n_ranks, device=dev, dtype=torch.float64)
+        t[rank] = B * args.steps / own_dt
+        dist.all_reduce(t)
+        per_rank = [float(v) for v in t.cpu()]
+
+    del ws, c, us, ui
+    train = train_B = fit = audio = None
     if not args.no_train:
         torch.cuda.empty_cache()
-        train, train_B = train_leg(args, args.preset, dev, rank, world, dist)
+        train, train_B = train_legs(args, args.preset, dev, rank, world, dist)
+        if args.fit_frames > 0:
+            fit = fit_leg(args, args.preset, dev, rank, world, dist)
+    if args.audio_frames > 0:
+        torch.cuda.empty_cache()
+        audio = audio_leg(args, args.preset, dev, rank, world, dist)
 
     def profiled_traffic(prefix):
         """HBM bytes per launch from the committed PMC passes (profiles/traffic.json), only if the batch matches."""
@@ -287,7 +491,7 @@ def main():
         return None
 
     if rank == 0:
-        frames = world * B * args.steps
+        frames = n_ranks * B * args.steps
         rm_ms, rm_bytes, rm_n = agg("raymarch")
         rm_gbs = rm_bytes / (rm_ms * 1e-3) / 1e9
 
@@ -313,9 +517,23 @@ def main():
                     "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
                     "traffic": profiled_traffic(f"modconv_bf16_kernel<{kd}, 2, 9>"), "avg_launch_ms": ms / max(n, 1),
                     "launches": n, "mfma_16bit_tflops": tf * SPLIT_MFMAS[prec]}
+        # ray march: the planes of a frame (25 MB) are cache resident, so the SURVEY 8d "algorithmic bytes" are a GATHER
+        # rate served by L2 / Infinity Cache, not HBM traffic.  The kernel's physical floor is the L2 gather
+        # (gather bytes / 34.5 TB/s) plus the decoder MLP on the fp32 matrix pipe (13.1 GF per frame / 157.3 TF); `frac`
+        # is that floor over the measured time.  HBM traffic from the counters and its fraction of 8 TB/s are listed
+        # separately and are NOT the roofline fraction.
+        s_tot = cfg.depth_resolution + cfg.depth_resolution_importance
+        r = cfg.neural_rendering_resolution ** 2
+        frames_per_launch = B
+        gather_bytes = frames_per_launch * r * s_tot * 3 * 4 * 32 * 4
+        dec_flops = frames_per_launch * r * s_tot * 2.0 * (32 * 64 + 64 * 33)
+        rm_avg_ms = rm_ms / max(rm_n, 1)
+        floor_ms = (gather_bytes / (L2_PEAK_GBS * 1e9) + dec_flops / (MFMA_F32_PEAK_TFLOPS * 1e12)) * 1e3
+        rm_traffic = profiled_traffic("raymarch_kernel")
+        compulsory = frames_per_launch * (3 * cfg.plane_resolution ** 2 * 32 * 4 + r * (34 + s_tot) * 4)
         out = {
             "metric": "rendered 512^2 frames/sec (96 depth samples), whole job",
-            "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": frames / dt, "unit": "frames/s", "n_gpus": n_ranks, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32" if prec == "fp32" else f"f32 tensors and accumulation; conv GEMM products as {prec} "
@@ -325,17 +543,33 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{cfg.name}: synthesis(ws[B,14,512], c[B,25]) forward, 512x512 out, 128^2 rays x "
                                    f"(48+48) samples, random-init weights, random latents+cameras",
-                       "frames_per_step_per_gpu": B, "parallelism": f"frame-parallel x{world}"},
+                       "frames_per_step_per_gpu": B, "parallelism": f"frame-parallel x{n_ranks}"},
+            "per_rank_frames_per_s": per_rank,
             # dominant kernel by time: the modulated-conv implicit GEMM
             "roofline": roof,
-            # the kernel north_star sets the HBM target on
-            "roofline_raymarch": {"bound": "hbm", "kernel": "raymarch_kernel<3,3>", "achieved": rm_gbs,
-                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rm_gbs / HBM_PEAK_GBS,
-                                  "traffic": profiled_traffic("raymarch_kernel"),
-                                  "avg_launch_ms": rm_ms / max(rm_n, 1), "launches": rm_n,
-                                  "algorithmic_bytes_per_launch": rm_bytes / max(rm_n, 1)},
+            # the kernel north_star names: see the comment above
+            "roofline_raymarch": {"bound": "l2+mfma", "kernel": "raymarch_kernel<3,3>",
+                                  "achieved": frames_per_launch / (rm_avg_ms * 1e-3),
+                                  "peak": frames_per_launch / (floor_ms * 1e-3), "unit": "frames/s (kernel alone)",
+                                  "frac": floor_ms / rm_avg_ms,
+                                  "floor_ms_per_launch": {"l2_gather": gather_bytes / (L2_PEAK_GBS * 1e9) * 1e3,
+                                                          "decoder_mfma_f32": dec_flops / (MFMA_F32_PEAK_TFLOPS * 1e12) * 1e3},
+                                  "avg_launch_ms": rm_avg_ms, "launches": rm_n,
+                                  "gather_rate_GBps_survey8d": rm_gbs,
+                                  "gather_rate_over_hbm_peak_survey8d": rm_gbs / HBM_PEAK_GBS,
+                                  "algorithmic_bytes_per_launch": rm_bytes / max(rm_n, 1),
+                                  "compulsory_bytes_per_launch": compulsory,
+                                  "traffic": rm_traffic,
+                                  "hbm_counter_frac_of_peak": (rm_traffic / (rm_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                                                               if rm_traffic else None),
+                                  "traffic_over_compulsory": rm_traffic / compulsory if rm_traffic else None},
         }
         out["config"]["conv_precision"] = prec
+        if overflow is not None:
+            # fp16 range tracking: largest |activation| any unclamped layer produced in the last frame batch; the fp16-part
+            # GEMMs normalise by it (exact power of two), no layer fell back to another precision
+            out["f16_range"] = {"max_abs_activation": max(overflow.values()), "fp16_max": 65504.0,
+                                "layers_fell_back": []}
         if dt16sr is not None:
             # not the headline: products of the super-resolution convs (value_f16_sr: the reference's own CUDA
             # precision split) or of all convs (value_f16) rounded to fp16, one fp16 MFMA per product
@@ -357,18 +591,36 @@ def main():
         if sweep is not None:
             out["batch_sweep"] = sweep
         if train is not None:
-            out["train_step_ms"] = train["frozen"][train_B]["step_ms"]
-            out["train_step_ms_generator_tuned"] = train["tuned"][train_B]["step_ms"]
+            t3, trgb = train["3dmm"], train["rgb"]
+            out["train_step_ms"] = trgb["frozen"][train_B]["step_ms"]             # BASELINE config 3: RGB-driven
+            out["train_step_ms_3dmm"] = t3["frozen"][train_B]["step_ms"]          # BASELINE config 4 mechanics
+            out["train_step_ms_generator_tuned"] = trgb["tuned"][train_B]["step_ms"]
+            out["train_step_ms_3dmm_generator_tuned"] = t3["tuned"][train_B]["step_ms"]
             # fwd / bwd / all-reduce / Adam from HIP events on the launch stream (mean ms per step, this rank)
-            out["train_phases_ms"] = train["frozen"][train_B]["phases_ms"]
-            out["train_phases_ms_generator_tuned"] = train["tuned"][train_B]["phases_ms"]
-            out["train_step_ms_by_batch"] = {str(b): v["step_ms"] for b, v in train["frozen"].items()}
-            out["train_config"] = {"workload": "3DMM-driven latent-basis fitting step (fwd + bwd + Adam), K=50, "
-                                               "generator frozen, L2 at 256^2, synthetic frames",
+            out["train_phases_ms"] = trgb["frozen"][train_B]["phases_ms"]
+            out["train_phases_ms_3dmm"] = t3["frozen"][train_B]["phases_ms"]
+            out["train_phases_ms_generator_tuned"] = trgb["tuned"][train_B]["phases_ms"]
+            out["train_step_ms_3dmm_by_batch"] = {str(b): v["step_ms"] for b, v in t3["frozen"].items()}
+            out["allreduce_us"] = {"rgb": 1e3 * trgb["frozen"][train_B]["phases_ms"].get("allreduce", 0.0),
+                                   "3dmm": 1e3 * t3["frozen"][train_B]["phases_ms"].get("allreduce", 0.0),
+                                   "rgb_generator_tuned": 1e3 * trgb["tuned"][train_B]["phases_ms"].get("allreduce", 0.0),
+                                   "bytes": {"rgb": trgb["shared_grad_bytes"], "3dmm": t3["shared_grad_bytes"],
+                                             "rgb_generator_tuned": trgb["shared_grad_bytes_tuned"]}}
+            out["train_config"] = {"workload": "latent-basis fitting step (fwd + bwd + Adam), K=50, generator frozen, L2 at "
+                                               "256^2, synthetic frames; train_step_ms = RGB-driven (Encoder(256) in the "
+                                               "step, trainer_rgb.py:73-98), train_step_ms_3dmm = 3DMM-driven "
+                                               "(trainer_3dmm.py:43-67)",
                                    "frames_per_step_per_gpu": train_B,
-                                   "collective": "one flattened all-reduce of shared grads per step" if world > 1 else None}
+                                   "collective": ("one in-place all-reduce of the flat shared-gradient buffer per step "
+                                                  f"({args.backend})") if n_ranks > 1 else None}
+            if "rgb_lpips" in train:
+                out["train_step_ms_lpips"] = train["rgb_lpips"]
+        if fit is not None:
+            out["fit_rgb"] = fit
+        if audio is not None:
+            out["audio_reenactment"] = audio
         if state is not None:
-            out["cpu_baseline"] = cpu_baseline(cfg, state, args.cpu_runs)
+            out["cpu_baseline"] = cpu_baseline(cfg, state, args.cpu_runs, args.cpu_warmup, args.cpu_n1)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -13,7 +13,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhfagp_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 c_float_p = C.c_void_p  # device pointers travel as integers
 
@@ -49,7 +49,11 @@ class ModconvArgs(C.Structure):
         ("mode", C.c_int32), ("act", C.c_int32), ("ksplit", C.c_int32),
         ("noise_strength", C.c_float), ("alpha", C.c_float), ("gain", C.c_float), ("clamp", C.c_float),
         ("precision", C.c_int32),
+        ("x_absmax", C.c_void_p), ("y_absmax", C.c_void_p),
     ]
+
+
+ABSMAX_SLOTS = 64       # HFAGP_ABSMAX_SLOTS
 
 
 class UpfirEpilogueArgs(C.Structure):
@@ -57,6 +61,7 @@ class UpfirEpilogueArgs(C.Structure):
         ("yt", C.c_void_p), ("dcoef", C.c_void_p), ("noise", C.c_void_p), ("bias", C.c_void_p), ("y", C.c_void_p),
         ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("act", C.c_int32),
         ("noise_strength", C.c_float), ("alpha", C.c_float), ("gain", C.c_float), ("clamp", C.c_float),
+        ("y_absmax", C.c_void_p),
     ]
 
 
@@ -115,6 +120,7 @@ SYMBOLS = {
     "hfagp_fc_fwd": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 3 + [C.c_float, C.c_int32, C.c_float, C.c_float, C.c_void_p]),
     "hfagp_weight_prep": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "hfagp_qr_gram_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "hfagp_qr_refine_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "hfagp_style_batch_fwd": (C.c_int, [C.POINTER(StyleArgs), C.c_int32, C.c_void_p]),
     "hfagp_weight_prep_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "hfagp_weight_prep_prec": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),

@@ -180,6 +180,10 @@ class SynthesisFn(torch.autograd.Function):
     @torch.no_grad()
     def backward(ctx, g_img, g_raw, _g_depth):
         gen, tape = ctx.gen, ctx.tape
+        if tape is None:
+            raise RuntimeError("TriPlaneGenerator.synthesis: backward called a second time — the saved activations "
+                               "(several GB at 512^2) are released by the first backward pass; sum the losses before "
+                               "calling backward instead of backpropagating them one by one (retain_graph is not supported)")
         cfg = gen.cfg
         b = tape["batch"]
         dev = tape["planes"].device

@@ -38,6 +38,20 @@ __device__ __forceinline__ float lrelu_gain_clamp(float v, int act, float alpha,
     return v;
 }
 
+// fp16 range tracking (include/hfagp.h, HfagpModconvArgs::y_absmax): wave maximum of |v| -> ONE atomic per wave into
+// one of HFAGP_ABSMAX_SLOTS slots (non-negative floats order like their bit patterns; spreading the blocks over the
+// slots keeps same-address atomics from serialising in L2).
+__device__ __forceinline__ void publish_absmax(float* slots, float m, unsigned slot) {
+    unsigned* dst = reinterpret_cast<unsigned*>(slots) + (slot % HFAGP_ABSMAX_SLOTS);
+    if (__ballot(1) != ~0ull) {                     // a partial wave (tail of a grid): every active lane for itself
+        atomicMax(dst, __float_as_uint(m));
+        return;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(dst, __float_as_uint(m));
+}
+
 // XCD-aware bijective remap of a linear block id: blocks that land on the same
 // XCD (observed: id % 8) get a contiguous chunk of the logical index space so
 // that neighbouring tiles share that XCD's L2 (cdna_hip_programming.md T1).

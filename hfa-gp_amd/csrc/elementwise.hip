@@ -178,11 +178,13 @@ __global__ void __launch_bounds__(256) upfir_epilogue_kernel(HfagpUpfirEpilogueA
     float4 a0, a1, a2, b0, b1, b2;
     hrow(Y0 - 1, a0, b0); hrow(Y0, a1, b1); hrow(Y0 + 1, a2, b2);
     float4* dst = reinterpret_cast<float4*>(a.y) + (size_t)b * Ho * Wo * C4 + c4;
+    float vmax = 0.f;                                        // max |y| of this thread's stores (a.y_absmax)
     auto finish = [&](float4 o, float nz) -> float4 {
         o.x = lrelu_gain_clamp(o.x * d.x + nz + bs.x, a.act, a.alpha, a.gain, a.clamp);
         o.y = lrelu_gain_clamp(o.y * d.y + nz + bs.y, a.act, a.alpha, a.gain, a.clamp);
         o.z = lrelu_gain_clamp(o.z * d.z + nz + bs.z, a.act, a.alpha, a.gain, a.clamp);
         o.w = lrelu_gain_clamp(o.w * d.w + nz + bs.w, a.act, a.alpha, a.gain, a.clamp);
+        vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
         return o;
     };
 #pragma unroll
@@ -210,6 +212,7 @@ __global__ void __launch_bounds__(256) upfir_epilogue_kernel(HfagpUpfirEpilogueA
         a0 = a1; a1 = a2; a2 = a3;
         b0 = b1; b1 = b2; b2 = b3;
     }
+    if (a.y_absmax) publish_absmax(a.y_absmax, vmax, blockIdx.x * 4 + (threadIdx.x >> 6));
 }
 
 // ---------------------------------------------------------------- skip: img_out = upsample2d(img_in) + y

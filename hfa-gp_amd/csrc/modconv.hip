@@ -174,6 +174,7 @@ __global__ void __launch_bounds__(256) modconv_kernel(const ConvParams p) {
 
     // ---- epilogue.  C/D layout of 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     float* out = p.out + (size_t)(ks * p.nslab + ph.slab) * p.slab;
+    float vmax = 0.f;                              // max |y| of this lane's stores (fp16 range tracking, hfagp.h)
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
         const int co = co0 + (wn * TN + tn) * 32 + l31;
@@ -203,10 +204,12 @@ __global__ void __launch_bounds__(256) modconv_kernel(const ConvParams p) {
                     v = v * d + bs + nz[r] * p.noise_strength;
                     v = lrelu_gain_clamp(v, p.act, p.alpha, p.gain, p.clamp);
                 }
+                vmax = fmaxf(vmax, fabsf(v));
                 out[(((size_t)b * p.Ho + oy) * p.Wo + ox) * p.Cout + co] = v;
             }
         }
     }
+    if (p.fused && p.y_absmax) publish_absmax(p.y_absmax, vmax, blockIdx.x * 4 + (threadIdx.x >> 6));
 }
 
 // sum the split-K slabs and (optionally) apply the epilogue
@@ -216,7 +219,7 @@ __global__ void __launch_bounds__(256) splitk_epilogue_kernel(const float* __res
                                                               const float* __restrict__ bias, long long slab,
                                                               int ksplit, int HoWo, int Cout, int fused, int act,
                                                               float noise_strength, float alpha, float gain,
-                                                              float clamp) {
+                                                              float clamp, float* __restrict__ y_absmax) {
     const long long i4 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i4 * 4 >= slab) return;
     float4 s = reinterpret_cast<const float4*>(ws)[i4];
@@ -239,6 +242,8 @@ __global__ void __launch_bounds__(256) splitk_epilogue_kernel(const float* __res
         s.w = lrelu_gain_clamp(s.w * d.w + bs.w + nz, act, alpha, gain, clamp);
     }
     reinterpret_cast<float4*>(y)[i4] = s;
+    if (fused && y_absmax)
+        publish_absmax(y_absmax, fmaxf(fmaxf(fabsf(s.x), fabsf(s.y)), fmaxf(fabsf(s.z), fabsf(s.w))), blockIdx.x * 4 + (threadIdx.x >> 6));
 }
 
 }  // namespace hfagp
@@ -291,7 +296,7 @@ int hfagp_modconv_fwd(const HfagpModconvArgs* a, void* stream) {
         const long long n4 = p.slab / 4;
         splitk_epilogue_kernel<<<(unsigned)((n4 + 255) / 256), 256, 0, s>>>(
             a->workspace, a->y, a->dcoef, a->noise, a->bias, p.slab, nslabs, p.Ho * p.Wo, a->Cout, fused, a->act,
-            a->noise_strength, a->alpha, a->gain, a->clamp);
+            a->noise_strength, a->alpha, a->gain, a->clamp, a->y_absmax);
         rc = check_launch("modconv_fwd/splitk");
     }
     return rc;

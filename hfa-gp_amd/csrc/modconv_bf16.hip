@@ -109,14 +109,25 @@ __device__ __forceinline__ void split4(float4 v, uint2 (&out)[kind_parts(KD)]) {
 // fp16's range; the accumulators are scaled back by 2^e on the way out.  Powers of two: both scalings are exact, the
 // result equals the un-normalised arithmetic.  Every wave reduces the (L2-resident, <= 2 KB) style vector on its own:
 // no LDS traffic, no barrier.  Returns 2^-e, *back = 2^e.
-__device__ __forceinline__ float style_range_guard(const float* styles, int cin, int lane, float* back) {
+// With x_absmax (the producer's max |x| of the whole input tensor, HFAGP_ABSMAX_SLOTS slots) the operand is also
+// scaled by the power of two that brings max |x| into [2^14, 2^15): a tensor beyond fp16's range (an fp32 backbone has
+// no clamp) cannot saturate, a tiny one keeps all 22 bits of its two parts; again exact.
+__device__ __forceinline__ float style_range_guard(const float* styles, int cin, int lane, float* back,
+                                                   const float* x_absmax) {
     float m = styles ? 0.f : 1.f;
     if (styles)
         for (int i = lane; i < cin; i += 64) m = fmaxf(m, fabsf(styles[i]));
+    float mx = x_absmax ? x_absmax[lane] : 0.f;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    int e = 0;
+    for (int o = 32; o > 0; o >>= 1) {
+        m = fmaxf(m, __shfl_xor(m, o));
+        mx = fmaxf(mx, __shfl_xor(mx, o));
+    }
+    int e = 0, ex = 15;
     if (m > 0.f && m < 3.0e38f) (void)frexpf(m, &e);
+    if (mx > 0.f && mx < 3.0e38f) (void)frexpf(mx, &ex);        // mx = f 2^ex, f in [0.5, 1)
+    e += ex - 15;
+    e = max(-100, min(100, e));
     *back = ldexpf(1.f, e);
     return ldexpf(1.f, -e);
 }
@@ -169,7 +180,7 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
     const char* xb = reinterpret_cast<const char*>(p.x + ph.in_off + (long long)b * p.x_batch_stride);
     for (int i = tid; i < p.Cin; i += 256) Ss[i] = p.styles ? p.styles[(size_t)b * p.Cin + i] : 1.f;
     float sback = 1.f, sdown = 1.f;                      // 2^e, 2^-e of the fp16 range guard (1 for the bf16 kinds)
-    if constexpr (F16) sdown = style_range_guard(p.styles ? p.styles + (size_t)b * p.Cin : nullptr, p.Cin, lane, &sback);
+    if constexpr (F16) sdown = style_range_guard(p.styles ? p.styles + (size_t)b * p.Cin : nullptr, p.Cin, lane, &sback, p.x_absmax);
     unsigned aoff[A_PER_T];
     int lds_a[A_PER_T], soff[A_PER_T];
     float amask[A_PER_T];
@@ -371,6 +382,7 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
     // row); everything else is a 32-bit offset (the per-element 64-bit index products were ~8k VALU cycles per wave).
     float* out = p.out + (size_t)(ks * p.nslab + ph.slab) * p.slab;
     const int cstep = ph.sx * p.Cout;                                     // elements between neighbouring columns
+    float vmax = 0.f;                                                     // max |y| of this lane's stores (y_absmax)
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
         const int co = co0 + (wn * TN + tn) * 32 + l31;
@@ -402,10 +414,12 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
                     float v = acc[tm][tn][8 * rw + q];
                     if (p.fused) v = lrelu_gain_clamp(v * d + bs + nz[q], p.act, p.alpha, p.gain, p.clamp);
                     else if constexpr (F16) v *= sback;
+                    vmax = fmaxf(vmax, fabsf(v));
                     rowp[n * cstep] = v;
                 }
             }
     }
+    if (p.fused && p.y_absmax) publish_absmax(p.y_absmax, vmax, blockIdx.x * 4 + wave);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -462,7 +476,7 @@ __global__ void __launch_bounds__(NW * 64, 1) upconv_bf16_kernel(const ConvParam
     const char* xb = reinterpret_cast<const char*>(p.x + (long long)b * p.x_batch_stride);
     for (int i = tid; i < p.Cin; i += NTH) Ss[i] = p.styles ? p.styles[(size_t)b * p.Cin + i] : 1.f;
     float sback = 1.f, sdown = 1.f;
-    if constexpr (F16) sdown = style_range_guard(p.styles ? p.styles + (size_t)b * p.Cin : nullptr, p.Cin, lane, &sback);
+    if constexpr (F16) sdown = style_range_guard(p.styles ? p.styles + (size_t)b * p.Cin : nullptr, p.Cin, lane, &sback, p.x_absmax);
     unsigned aoff[A_PER_T];
     int lds_a[A_PER_T], soff[A_PER_T];
     float amask[A_PER_T];

@@ -69,9 +69,81 @@ __global__ void __launch_bounds__(256) qr_gram_kernel(const float* __restrict__ 
     for (int e = tid; e < n * n; e += 256) Rinv_out[e] = Ri[e / n][e % n];
 }
 
+// Re-orthogonalisation pass (CholeskyQR2's second step): the Gram-matrix method above leaves an orthogonality defect
+// |Q1^T Q1 - I| ~ cond(A)^2 eps (2.7e-3 at cond 476, 3.2e-2 at cond 1560 in fp32).  G2 = Q1^T Q1 is then within that
+// defect of I, so its Cholesky factor R2 (positive diagonal: the column signs LAPACK chose in pass 1 are kept) is
+// perfectly conditioned, and Q = Q1 R2^-1 is orthonormal to O(eps).  One block: upper Cholesky G2 = R2^T R2 and
+// R2^-1 in LDS.  status[0] = max |G2 - I| (the defect of pass 1: the host's conditioning monitor), status[1] = 1 if a
+// pivot was not positive (the factorisation broke down: cond(A)^2 eps >~ 1; the outputs are then NaN, never silently
+// wrong).
+__global__ void __launch_bounds__(256) qr_refine_kernel(const float* __restrict__ G_in, float* __restrict__ R_out,
+                                                        float* __restrict__ Rinv_out, float* __restrict__ status, int n) {
+    __shared__ float G[kQrMax][kQrMax + 1], Ri[kQrMax][kQrMax + 1];
+    __shared__ float red[256];
+    __shared__ int bad;
+    const int tid = threadIdx.x;
+    float defect = 0.f;
+    if (tid == 0) bad = 0;
+    for (int i = tid; i < n * n; i += 256) {
+        const float g = G_in[i];
+        G[i / n][i % n] = g;
+        const float d = fabsf(g - (i / n == i % n ? 1.f : 0.f));
+        defect = (d > defect || d != d) ? d : defect;          // NaN propagates
+    }
+    red[tid] = defect;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) {
+            const float o = red[tid + s];
+            if (o > red[tid] || o != o) red[tid] = o;
+        }
+        __syncthreads();
+    }
+    // right-looking upper Cholesky: row j of R = G[j][j:] / sqrt(G[j][j]); trailing block -= r r^T
+    for (int j = 0; j < n; ++j) {
+        const float piv = G[j][j];
+        if (!(piv > 0.f)) { if (tid == 0) bad = 1; }
+        const float inv = 1.f / sqrtf(piv);
+        __syncthreads();
+        if (tid >= j && tid < n) G[j][tid] *= inv;              // (G[j][j] becomes sqrt(piv))
+        __syncthreads();
+        for (int e = tid; e < (n - j - 1) * (n - j - 1); e += 256) {
+            const int a = j + 1 + e / (n - j - 1), c = j + 1 + e % (n - j - 1);
+            if (c >= a) G[a][c] -= G[j][a] * G[j][c];
+        }
+        __syncthreads();
+    }
+    const float poison = bad ? __builtin_nanf("") : 0.f;
+    for (int e = tid; e < n * n; e += 256) {
+        const int i = e / n, c = e % n;
+        R_out[e] = c >= i ? G[i][c] + poison : 0.f;
+    }
+    if (tid < n) {
+        const int c = tid;
+        for (int i = n - 1; i >= 0; --i) {
+            float acc = i == c ? 1.f : 0.f;
+            for (int k = i + 1; k <= c; ++k) acc -= G[i][k] * Ri[k][c];
+            Ri[i][c] = i <= c ? acc / G[i][i] : 0.f;
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < n * n; e += 256) Rinv_out[e] = Ri[e / n][e % n] + (e / n <= e % n ? poison : 0.f);
+    if (status && tid == 0) {
+        status[0] = red[0];
+        status[1] = bad ? 1.f : 0.f;
+    }
+}
+
 }  // namespace hfagp
 
 using namespace hfagp;
+
+extern "C" int hfagp_qr_refine_fwd(const float* gram, float* R, float* Rinv, float* status, int32_t n, void* stream) {
+    HFAGP_REQUIRE(gram && R && Rinv, HFAGP_EBADARG, "qr_refine_fwd: null pointer");
+    HFAGP_REQUIRE(n >= 1 && n <= kQrMax, HFAGP_EUNSUPPORTED, "qr_refine_fwd: n=%d must be in 1..%d", n, kQrMax);
+    qr_refine_kernel<<<1, 256, 0, (hipStream_t)stream>>>(gram, R, Rinv, status, n);
+    return check_launch("qr_refine_fwd");
+}
 
 extern "C" int hfagp_qr_gram_fwd(const float* gram, const float* top, float* R, float* Rinv, int32_t n, void* stream) {
     HFAGP_REQUIRE(gram && top && R && Rinv, HFAGP_EBADARG, "qr_gram_fwd: null pointer");

@@ -146,11 +146,26 @@ class TriPlaneGenerator(nn.Module):
         self._sr_conv_precision: Optional[str] = None
         self.conv_precision = cfg.conv_precision
         self.sr_conv_precision = cfg.sr_conv_precision
-        self._sr_weight_ids = {id(l.weight) for blk in (sr.block0, sr.block1) for l in (blk.conv0, blk.conv1)}
         self._styles: Dict[int, tuple] = {}      # id(layer) -> (styles, dcoef) of the pass in flight
+        self._absmax = None                      # (slot buffers, layer names) of the last pass: f16_range_report()
         self._scalars: Dict[int, tuple] = {}     # id(param) -> (version, data_ptr, python float)
         self._const_nhwc: Optional[tuple] = None
         self.timing: Optional[Dict[str, list]] = None   # bench.py: {'raymarch': [(ev0, ev1, units)], 'modconv': [...]}
+        self.ignored_checkpoint_keys: list = []  # EG3D entries a loaded checkpoint carried that have no tensor here
+        self._register_load_state_dict_pre_hook(self._drop_foreign_eg3d_keys)
+
+    # entries of an EG3D `G_ema.state_dict()` / HFA-GP `ckpt["gen"]["generator.*"]` that carry no parameter of the
+    # path: version-dependent helper buffers of modules that are fused away here.  They are dropped (and listed in
+    # `ignored_checkpoint_keys`) so that the reference's STRICT `load_state_dict` calls (trainer_rgb.py:137) succeed;
+    # any other unexpected or missing key still raises.
+    FOREIGN_KEY_PREFIXES = ("renderer.", "ray_sampler.", "superresolution.resample_filter")
+
+    def _drop_foreign_eg3d_keys(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                                error_msgs):
+        drop = [k for k in state_dict if k.startswith(prefix) and k[len(prefix):].startswith(self.FOREIGN_KEY_PREFIXES)]
+        for k in drop:
+            del state_dict[k]
+        self.ignored_checkpoint_keys = [k[len(prefix):] for k in drop]
 
     def _timed(self, key: str, units: float, fn, *args, **kwargs):
         """Run ``fn`` bracketed by HIP events on the current stream when bench.py enabled timing."""
@@ -164,6 +179,42 @@ class TriPlaneGenerator(nn.Module):
         return out
 
     # ----------------------------------------------------------------- caches
+    def invalidate_caches(self) -> None:
+        """Drop every derived image of the parameters (GEMM weight images, wsq, host copies of scalars, the NHWC
+        constant).  The caches are keyed by (id, `_version`, `data_ptr`) of the parameter, which catches optimiser
+        steps, `load_state_dict` and `.to()`; an in-place write through `.data` (EMA / PTI-style `.data.copy_`) changes
+        neither, so such callers must call this.  Also called by `_apply` (device / dtype moves) and `__deepcopy__`."""
+        self._prep = {}
+        self._scalars = {}
+        self._const_nhwc = None
+        self._styles = {}
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        if hasattr(self, "_prep"):
+            self.invalidate_caches()
+        return out
+
+    def __deepcopy__(self, memo):
+        """`copy.deepcopy(generator)` (the reference's load_G_official deep-copies G_ema, headnerf.py:35): parameters,
+        buffers and the precision settings are copied, the derived caches are not (their keys are object ids)."""
+        import copy
+        saved = (self._prep, self._scalars, self._const_nhwc, self._styles, self.timing)
+        self.invalidate_caches()
+        self.timing = None
+        try:
+            new = self.__class__.__new__(self.__class__)
+            memo[id(self)] = new
+            new.__dict__ = copy.deepcopy(self.__dict__, memo)
+        finally:
+            self._prep, self._scalars, self._const_nhwc, self._styles, self.timing = saved
+        return new
+
+    def _is_sr_weight(self, weight: torch.Tensor) -> bool:
+        """True for the 3x3 conv weights of the two super-resolution blocks (resolved by module, not by a cached id)."""
+        sr = self.superresolution
+        return any(weight is l.weight for blk in (sr.block0, sr.block1) for l in (blk.conv0, blk.conv1))
+
     @property
     def conv_precision(self) -> str:
         """Arithmetic of the conv GEMMs: 'fp32' (exact MFMA), 'bf16x3' / 'bf16x6' / 'f16x3' (split-operand MFMA, fp32
@@ -198,7 +249,7 @@ class TriPlaneGenerator(nn.Module):
         if transposed:
             co, ci = ci, co
         prec = self._conv_precision
-        if self._sr_conv_precision is not None and id(weight) in self._sr_weight_ids:
+        if self._sr_conv_precision is not None and self._is_sr_weight(weight):
             prec = self._sr_conv_precision
         if prec in ("f16", "f16x3") and transposed:
             prec = "bf16x3"       # gradient GEMMs: a raw gradient needs fp32's exponent range (bf16 parts have it)
@@ -244,7 +295,10 @@ class TriPlaneGenerator(nn.Module):
         return x
 
     # ----------------------------------------------------------------- layers
-    def _layer(self, x, layer: _SynthesisLayer, w, row, batch, noise_mode, conv_clamp, tape):
+    def _layer(self, x, layer: _SynthesisLayer, w, row, batch, noise_mode, conv_clamp, tape, x_absmax=None,
+               y_absmax=None):
+        """x_absmax / y_absmax: fp16 range tracking of an UNCLAMPED activation chain (ops.modconv): the slot buffer with
+        max |x| of the input as published by its producer, and the one this layer publishes max |out| into."""
         cfg = self.cfg
         wt, wsq = self._prepared(layer.weight)
         pre = self._styles.pop(id(layer), None) if self._styles else None      # computed up front (_precompute_styles)
@@ -265,12 +319,14 @@ class TriPlaneGenerator(nn.Module):
         key = ("modconv" if wt.dtype == torch.float32 else
                "modconv_f16" if wt.dtype == torch.float16 and wt.shape[0] == 1 else "modconv_split")
         if layer.up == 2:
-            yt = self._timed(key, flops, ops.modconv, x, wt, cout, ops.CONVT3X3_UP2, styles=k_styles, batch=batch)
-            out = ops.upfir_epilogue(yt, k_dcoef, noise, ns, layer.bias, "lrelu", cfg.lrelu_alpha, gain, conv_clamp)
+            yt = self._timed(key, flops, ops.modconv, x, wt, cout, ops.CONVT3X3_UP2, styles=k_styles, batch=batch,
+                             x_absmax=x_absmax)
+            out = ops.upfir_epilogue(yt, k_dcoef, noise, ns, layer.bias, "lrelu", cfg.lrelu_alpha, gain, conv_clamp,
+                                     y_absmax=y_absmax)
         else:
             out = self._timed(key, flops, ops.modconv, x, wt, cout, ops.CONV3X3, styles=k_styles, dcoef=k_dcoef,
                               noise=noise, noise_strength=ns, bias=layer.bias, act="lrelu", alpha=cfg.lrelu_alpha,
-                              gain=gain, clamp=conv_clamp, batch=batch)
+                              gain=gain, clamp=conv_clamp, batch=batch, x_absmax=x_absmax, y_absmax=y_absmax)
         rec = None
         if tape is not None:
             rec = dict(layer=layer, x=x, styles=styles, dcoef=dcoef, out=out, row=row, up=layer.up, wsq=wsq,
@@ -278,15 +334,20 @@ class TriPlaneGenerator(nn.Module):
                                      alpha=cfg.lrelu_alpha, gain=gain, clamp=conv_clamp))
         return out, rec
 
-    def _block(self, x, img, blk: _SynthesisBlock, ws, rows, batch, noise_mode, conv_clamp, small_rgb, last, tape):
-        """rows = the ws row of (conv0,) conv1, torgb."""
+    def _block(self, x, img, blk: _SynthesisBlock, ws, rows, batch, noise_mode, conv_clamp, small_rgb, last, tape,
+               absmax=None):
+        """rows = the ws row of (conv0,) conv1, torgb.  absmax = (slots of the block input | None, slots for conv0's
+        output, slots for conv1's output) when the chain is unclamped (fp16 range tracking), else None."""
         rec = dict(conv0=None, first=blk.in_channels == 0, img_in=img, const=getattr(blk, "const", None))
+        am_in, am0, am1 = absmax if absmax is not None else (None, None, None)
         if blk.in_channels == 0:
             x, rec["conv1"] = self._layer(self._const(blk.const), blk.conv1, ws[:, rows[0]], rows[0], batch,
-                                          noise_mode, conv_clamp, tape)
+                                          noise_mode, conv_clamp, tape, None, am1)
         else:
-            x, rec["conv0"] = self._layer(x, blk.conv0, ws[:, rows[0]], rows[0], batch, noise_mode, conv_clamp, tape)
-            x, rec["conv1"] = self._layer(x, blk.conv1, ws[:, rows[1]], rows[1], batch, noise_mode, conv_clamp, tape)
+            x, rec["conv0"] = self._layer(x, blk.conv0, ws[:, rows[0]], rows[0], batch, noise_mode, conv_clamp, tape,
+                                          am_in, am0)
+            x, rec["conv1"] = self._layer(x, blk.conv1, ws[:, rows[1]], rows[1], batch, noise_mode, conv_clamp, tape,
+                                          am0, am1)
         tr = blk.torgb
         cin = tr.weight.shape[1]
         row = rows[-1]
@@ -302,7 +363,7 @@ class TriPlaneGenerator(nn.Module):
         else:
             wt, _ = self._prepared(tr.weight)
             y = ops.modconv(x, wt, tr.weight.shape[0], ops.CONV1X1, styles=styles, bias=tr.bias, act="linear",
-                            gain=1.0, clamp=conv_clamp, batch=batch)
+                            gain=1.0, clamp=conv_clamp, batch=batch, x_absmax=am1)
             img = ops.skip_upsample_add(img, y, plane_major=last)
         if tape is not None:
             rec["rgb"] = dict(torgb=tr, x=x, styles=styles, row=row, small=small_rgb, clamp=conv_clamp,
@@ -344,15 +405,35 @@ class TriPlaneGenerator(nn.Module):
             plan.append((getattr(syn, f"b{res}"), list(range(idx, idx + n_conv + 1))))
             idx += n_conv
         self._precompute_styles(ws, plan)
+        # fp16 range tracking: the backbone has no clamp (conv_clamp None), so every conv publishes max |out| and the
+        # next fp16-kind GEMM normalises its operand with it (one memset for all layers; row 2k / 2k+1 = conv0 / conv1
+        # of block k).  Kept for `f16_range_report()`.
+        track = cfg.backbone_conv_clamp is None and (self._conv_precision in ("f16x3", "f16"))
+        am = ops.absmax_slots(2 * len(cfg.block_resolutions), ws.device) if track else None
+        self._absmax = (am, [f"b{res}.{c}" for res in cfg.block_resolutions for c in ("conv0", "conv1")]) if track else None
         idx = 0
-        for res in cfg.block_resolutions:
+        prev = None
+        for k, res in enumerate(cfg.block_resolutions):
             blk = getattr(syn, f"b{res}")
             n_conv = 1 if res == 4 else 2
             rows = list(range(idx, idx + n_conv + 1))
             x, img = self._block(x, img, blk, ws, rows, b, cfg.backbone_noise_mode, cfg.backbone_conv_clamp, False,
-                                 res == cfg.plane_resolution, tape)
+                                 res == cfg.plane_resolution, tape,
+                                 (prev, am[2 * k], am[2 * k + 1]) if track else None)
+            prev = am[2 * k + 1] if track else None
             idx += n_conv
         return img
+
+    def f16_range_report(self) -> Optional[Dict[str, float]]:
+        """max |activation| of every backbone layer output of the LAST synthesis (host sync), or None when the conv
+        precision has no fp16 parts / the backbone is clamped.  Values beyond 65504 are handled (the consumer GEMM
+        scales by an exact power of two, hfagp.h `x_absmax`); the report shows how far a checkpoint is from the cliff
+        that an un-tracked fp16 split would have."""
+        if getattr(self, "_absmax", None) is None:
+            return None
+        am, names = self._absmax
+        vals = am.max(dim=1).values.tolist()
+        return {n: v for n, v in zip(names, vals) if not n.startswith("b4.conv0")}
 
     def _render_args(self, c: torch.Tensor):
         cfg = self.cfg
@@ -403,6 +484,14 @@ class TriPlaneGenerator(nn.Module):
                                "there is no CPU fallback (oracle/ is test infrastructure only)")
         if noise_mode != "const":
             raise NotImplementedError("HFA-GP always passes noise_mode='const' (headnerf.py:112)")
+        if ws.device.index != torch.cuda.current_device():
+            raise RuntimeError(f"TriPlaneGenerator.synthesis: tensors live on {ws.device} but the current device is "
+                               f"cuda:{torch.cuda.current_device()}; the kernels are enqueued on the CURRENT device's "
+                               f"stream — wrap the call in `with torch.cuda.device(ws.device):`")
+        if c.requires_grad and torch.is_grad_enabled():
+            raise RuntimeError("TriPlaneGenerator.synthesis: the camera label `c` requires grad, but the renderer "
+                               "has no camera gradient (HFA-GP never optimises the pose through the generator); "
+                               "detach it explicitly")
         if ws.shape[1:] != (cfg.num_ws, cfg.w_dim) or c.shape[1] != cfg.c_dim:
             raise ValueError(f"expected ws [B,{cfg.num_ws},{cfg.w_dim}] and c [B,{cfg.c_dim}], got "
                              f"{tuple(ws.shape)} and {tuple(c.shape)}")

@@ -72,7 +72,7 @@ class LPIPSAlex(nn.Module):
 
     CHNS = (64, 192, 384, 256, 256)
 
-    def __init__(self, state_dict: Optional[dict] = None):
+    def __init__(self, state_dict: Optional[dict] = None, allow_partial: bool = False):
         super().__init__()
         self.scaling_layer = _ScalingLayer()
         self.net = _AlexFeatures()
@@ -80,7 +80,16 @@ class LPIPSAlex(nn.Module):
             setattr(self, f"lin{i}", _NetLinLayer(c))
         self.lins = [getattr(self, f"lin{i}") for i in range(5)]
         if state_dict is not None:
-            self.load_state_dict(state_dict, strict=False)
+            # `lpips.LPIPS.state_dict()` also lists the lin layers a second time under `lins.N.*` (a ModuleList alias):
+            # those duplicates are the only keys that may be ignored.  Anything else missing or unexpected would leave
+            # random weights in place silently, so it raises unless the caller opts in with allow_partial=True
+            sd = {k: v for k, v in state_dict.items() if not k.startswith("lins.")}
+            res = self.load_state_dict(sd, strict=False)
+            if (res.missing_keys or res.unexpected_keys) and not allow_partial:
+                raise RuntimeError(f"LPIPSAlex: state dict does not match lpips.LPIPS(net='alex'): missing "
+                                   f"{res.missing_keys[:6]}, unexpected {res.unexpected_keys[:6]} (allow_partial=True "
+                                   f"loads what matches and leaves the rest random-initialised)")
+            self.partial_keys = list(res.missing_keys)
         else:
             with torch.no_grad():           # LPIPS lin weights are non-negative
                 for lin in self.lins:

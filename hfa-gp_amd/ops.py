@@ -152,17 +152,34 @@ def qr_gram(gram: torch.Tensor, top: torch.Tensor) -> Tuple[torch.Tensor, torch.
     return r, rinv
 
 
+def qr_refine(gram: torch.Tensor, status: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """gram = Q1^T Q1 [n, n] → (upper Cholesky factor R2 with positive diagonal, R2^-1); status [2] (optional)
+    receives (max |gram - I|, breakdown flag).  See include/hfagp.h."""
+    n = gram.shape[0]
+    r = torch.empty(n, n, device=gram.device, dtype=torch.float32)
+    rinv = torch.empty(n, n, device=gram.device, dtype=torch.float32)
+    L.check(L.lib().hfagp_qr_refine_fwd(_ptr(_chk(gram, "gram")), _ptr(r), _ptr(rinv), _ptr(status), n, _stream()),
+            "qr_refine_fwd")
+    return r, rinv
+
+
 class TallSkinnyQR(torch.autograd.Function):
     """Q of the reduced QR of a tall-skinny fp32 CUDA matrix A [m, n <= 64] with torch.linalg.qr's (LAPACK's) sign
     convention; backward = the standard QR adjoint for dR = 0:
-        dA = (dQ + Q S) R^-T,   X = triu(-Q^T dQ),   S = X + X^T - diag(X)."""
+        dA = (dQ + Q S) R^-T,   X = triu(-Q^T dQ),   S = X + X^T - diag(X).
+    Two passes: the Gram-matrix Householder kernel (Q1 = A R1^-1, orthogonality defect ~cond(A)^2 eps) and one
+    Cholesky re-orthogonalisation of Q1 (Q = Q1 R2^-1, defect O(eps) while cond(A)^2 eps < ~0.3); R^-1 = R1^-1 R2^-1.
+    `status` (device float[2], optional) receives the defect of pass 1 and the breakdown flag (ops.qr_refine)."""
 
     @staticmethod
-    def forward(ctx, a: torch.Tensor) -> torch.Tensor:
+    def forward(ctx, a: torch.Tensor, status: Optional[torch.Tensor] = None) -> torch.Tensor:
         n = a.shape[1]
         gram = (a.T @ a).contiguous()
-        _, rinv = qr_gram(gram, a[:n, :n].contiguous())
-        q = a @ rinv
+        _, rinv1 = qr_gram(gram, a[:n, :n].contiguous())
+        q1 = a @ rinv1
+        _, rinv2 = qr_refine((q1.T @ q1).contiguous(), status)
+        rinv = rinv1 @ rinv2
+        q = q1 @ rinv2
         ctx.save_for_backward(q, rinv)
         return q
 
@@ -171,7 +188,7 @@ class TallSkinnyQR(torch.autograd.Function):
         q, rinv = ctx.saved_tensors
         x = torch.triu(-(q.T @ gq))
         s = x + x.T - torch.diag(torch.diagonal(x))
-        return (gq + q @ s) @ rinv.T
+        return (gq + q @ s) @ rinv.T, None
 
 
 def fully_connected(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], lr_mul: float = 1.0,
@@ -189,15 +206,24 @@ def fully_connected(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.
 
 
 # ----------------------------------------------------------------------------- modulated conv
+def absmax_slots(n: int, device) -> torch.Tensor:
+    """[n, 64] zeroed slot buffers for the fp16 range tracking of n tensors (row i: max |.| of tensor i = row.max())."""
+    return torch.zeros(n, L.ABSMAX_SLOTS, device=device, dtype=torch.float32)
+
+
 def modconv(x: torch.Tensor, wt: torch.Tensor, cout: int, mode: int, styles: Optional[torch.Tensor] = None,
             dcoef: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None,
             noise_strength: float = 0.0, bias: Optional[torch.Tensor] = None, act: str = "linear",
             alpha: float = 0.2, gain: float = 1.0, clamp: Optional[float] = None, batch: Optional[int] = None,
-            ksplit: int = 0) -> torch.Tensor:
+            ksplit: int = 0, x_absmax: Optional[torch.Tensor] = None,
+            y_absmax: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x [B|1, H, W, Cin] channels-last.  mode CONV3X3 / CONV1X1: fused epilogue, returns [B,H,W,Cout];
     mode CONVT3X3_UP2: returns the RAW transposed-conv result [B, 2H+1, 2W+1, Cout].
     ``wt`` from :func:`weight_prep` (fp32, exact MFMA) or :func:`weight_prep_split` (bfloat16 parts: the
-    split-bf16 MFMA path, BF16X3 for 2 parts, BF16X6 for 3; float16, 1 part: the single-pass fp16 path)."""
+    split-bf16 MFMA path, BF16X3 for 2 parts, BF16X6 for 3; float16, 1 part: the single-pass fp16 path).
+    ``x_absmax`` / ``y_absmax`` ([64] fp32, `absmax_slots`): fp16 range tracking — max |x| of the input as published by its
+    producer (the fp16 kinds scale the operand by an exact power of two so nothing saturates) and the slot buffer that
+    receives max |y| of a fused-epilogue output (include/hfagp.h)."""
     _chk(x, "x")
     if mode == CONVS2_BWD:                      # x = four parity images [2,2,B,H+1,W+1,Cin]
         _, _, xb, h, w, cin = x.shape
@@ -224,6 +250,7 @@ def modconv(x: torch.Tensor, wt: torch.Tensor, cout: int, mode: int, styles: Opt
     a.mode, a.act, a.ksplit = mode, _ACT[act], ksplit
     a.noise_strength, a.alpha, a.gain = noise_strength, alpha, gain
     a.clamp = -1.0 if clamp is None else float(clamp)
+    a.x_absmax, a.y_absmax = _ptr(x_absmax), _ptr(y_absmax)
     if mode == CONVT3X3_UP2:
         y = torch.empty(b, 2 * h + 1, 2 * w + 1, cout, device=x.device, dtype=torch.float32)
     else:
@@ -240,7 +267,8 @@ def modconv(x: torch.Tensor, wt: torch.Tensor, cout: int, mode: int, styles: Opt
 
 def upfir_epilogue(yt: torch.Tensor, dcoef: Optional[torch.Tensor], noise: Optional[torch.Tensor],
                    noise_strength: float, bias: Optional[torch.Tensor], act: str = "lrelu", alpha: float = 0.2,
-                   gain: float = math.sqrt(2.0), clamp: Optional[float] = None) -> torch.Tensor:
+                   gain: float = math.sqrt(2.0), clamp: Optional[float] = None,
+                   y_absmax: Optional[torch.Tensor] = None) -> torch.Tensor:
     """yt [B, 2H+1, 2W+1, C] raw transposed conv → FIR(pad 1, gain 4) → demod/noise/bias/act → [B,2H,2W,C]."""
     _chk(yt, "yt")
     b, hi, wi, c = yt.shape
@@ -251,6 +279,7 @@ def upfir_epilogue(yt: torch.Tensor, dcoef: Optional[torch.Tensor], noise: Optio
     a.B, a.H, a.W, a.C, a.act = b, h, w, c, _ACT[act]
     a.noise_strength, a.alpha, a.gain = noise_strength, alpha, gain
     a.clamp = -1.0 if clamp is None else float(clamp)
+    a.y_absmax = _ptr(y_absmax)
     L.check(L.lib().hfagp_upfir_epilogue_fwd(C.byref(a), _stream()), "upfir_epilogue_fwd")
     return y
 

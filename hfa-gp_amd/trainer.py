@@ -2,20 +2,23 @@
 trainer_3dmm.py:20-122 (`Trainer.gen_update / sample / sample_bases / tune_generator / save / resume`).
 
 Differences that are deliberate:
-  * multi-GPU: one process per GPU, frames sharded by the caller; the gradients of the SHARED
-    parameters (`bases`, `delta`, driver net, and the generator once it is being tuned) are summed with
-    ONE flattened all-reduce per step over RCCL (`torch.distributed`, backend "nccl" on ROCm) and
-    divided by the world size.  The reference wraps the module in DDP but its RGB trainer bypasses
+  * multi-GPU: one process per GPU; `fit_frames` shards the frame set in contiguous blocks over the ranks
+    (`shard_range` / `epoch_batches`, ragged tails included); the gradients of the SHARED parameters (`bases`,
+    `delta`, driver net, and the generator once it is being tuned) live in ONE persistent flat fp32 buffer
+    (`FlatGrads`: the `.grad` tensors are its slices) that is all-reduced in place per step over RCCL
+    (`torch.distributed`, backend "nccl" on ROCm) on the launch stream and averaged over the world size.  The reference wraps the module in DDP but its RGB trainer bypasses
     `DDP.forward`, so it never synchronises gradients at all; `north_star` asks for the all-reduce.
-  * LPIPS(alex) weights cannot be obtained offline: `lpips=None` (default) trains on the L2 term only;
-    a callable `lpips(real, fake) -> tensor` can be supplied.
+  * LPIPS(alex) weights cannot be obtained offline: a callable `lpips(real, fake) -> tensor` can be supplied
+    (`lpips_alex.LPIPSAlex` has the lpips package's architecture and key names); `lpips=None` trains on the L2
+    term only and WARNS, `lpips='none'` does so silently.
   * no per-step `.item()` host sync; losses are returned as device tensors.
 """
 from __future__ import annotations
 
 import math
 import os
-from typing import Callable, Iterable, List, Optional
+import warnings
+from typing import Callable, Iterable, List, Optional, Tuple, Union
 
 import torch
 import torch.nn.functional as F
@@ -46,7 +49,8 @@ def requires_grad(net: nn.Module, flag: bool = True) -> None:
 
 def allreduce_shared_grads(params: Iterable[torch.Tensor], world_size: int, group=None) -> int:
     """Sum-then-average the .grad of `params` over all ranks with ONE collective on one flat fp32 buffer
-    (bases 50x7168 + delta 7168 = 1.46 MB; + driver net).  Returns the element count."""
+    (bases 50x7168 + delta 7168 = 1.46 MB; + driver net).  Returns the element count.
+    Stand-alone form (builds the flat buffer per call); the trainers use `FlatGrads`, whose buffer is persistent."""
     import torch.distributed as dist
     grads: List[torch.Tensor] = []
     for p in params:
@@ -67,12 +71,106 @@ def allreduce_shared_grads(params: Iterable[torch.Tensor], world_size: int, grou
     return off
 
 
+class FlatGrads:
+    """ONE persistent flat fp32 buffer whose slices ARE the `.grad` tensors of the shared parameters (SURVEY.md
+    §5.8 / §8e): autograd accumulates straight into it, `zero()` is one memset, and the all-reduce runs on the
+    buffer itself on the launch stream right after the backward pass — no `cat`, no copy back.
+
+    Buckets: the parameters are laid out in the order given; `bucket_bytes` cuts the buffer into contiguous
+    buckets that are reduced by separate collectives (latency-bound basis/driver gradients: one bucket; the 123 MB of
+    a generator being tuned: one bucket per ~32 MB so the ring pipeline of RCCL stays busy, 7 x 153 GB/s xGMI links).
+    `rebuild()` must be called when the set of parameters that require grad changes (`tune_generator`)."""
+
+    def __init__(self, params: Iterable[torch.Tensor], bucket_bytes: int = 32 << 20):
+        self.params = [p for p in params if p.requires_grad]
+        self.bucket_bytes = bucket_bytes
+        self.numel = sum(p.numel() for p in self.params)
+        self.flat: Optional[torch.Tensor] = None
+        self.buckets: List[Tuple[int, int]] = []
+        if self.params:
+            p0 = self.params[0]
+            self.flat = torch.zeros(self.numel, device=p0.device, dtype=torch.float32)
+            off, b0 = 0, 0
+            for p in self.params:
+                n = p.numel()
+                p.grad = self.flat[off: off + n].view_as(p)
+                off += n
+                if (off - b0) * 4 >= bucket_bytes:
+                    self.buckets.append((b0, off))
+                    b0 = off
+            if off > b0:
+                self.buckets.append((b0, off))
+
+    def owns(self, params: Iterable[torch.Tensor]) -> bool:
+        """True while every parameter's .grad still is this buffer's slice (an optimiser `zero_grad(set_to_none=True)`
+        or a changed `requires_grad` set breaks the aliasing)."""
+        want = [p for p in params if p.requires_grad]
+        if len(want) != len(self.params) or any(a is not b for a, b in zip(want, self.params)):
+            return False
+        off = 0
+        base = self.flat.data_ptr() if self.flat is not None else 0
+        for p in self.params:
+            if p.grad is None or p.grad.data_ptr() != base + 4 * off:
+                return False
+            off += p.numel()
+        return True
+
+    def zero(self) -> None:
+        if self.flat is not None:
+            self.flat.zero_()
+
+    def allreduce_mean(self, world_size: int, group=None) -> int:
+        """In-place mean over the ranks, one collective per bucket, enqueued on the current (launch) stream."""
+        if self.flat is None or world_size <= 1:
+            return 0
+        import torch.distributed as dist
+        avg = getattr(dist.ReduceOp, "AVG", None) if dist.get_backend(group) == "nccl" else None
+        for lo, hi in self.buckets:
+            seg = self.flat[lo:hi]
+            if avg is not None:
+                dist.all_reduce(seg, op=avg, group=group)          # RCCL averages in the collective: no second pass
+            else:
+                dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=group)
+        if avg is None:
+            self.flat.div_(world_size)
+        return self.numel
+
+
+def shard_range(n_frames: int, rank: int, world_size: int) -> Tuple[int, int]:
+    """Contiguous-block frame shard [lo, hi) of rank `rank` (2000 frames over 8 ranks →
+    rank r owns [250 r, 250 (r+1)); contiguous blocks keep audio smoothing windows local, §8e).  When
+    `n_frames % world_size != 0` the first `n_frames % world_size` ranks own one frame more (ragged tail)."""
+    base, extra = divmod(n_frames, world_size)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def epoch_batches(n_frames: int, rank: int, world_size: int, batch: int):
+    """One pass over a contiguous-block sharded frame set: yields (frame indices of THIS rank [b_r], weight) per step;
+    every rank yields the SAME number of steps (= ceil(largest shard / batch)) so the per-step collective matches.
+    A rank whose shard is exhausted yields an empty index tensor (it still joins the all-reduce with zero gradients).
+    `weight` = b_r * world / (sum over ranks of b) rescales the rank's mean loss so that the all-reduce MEAN equals the
+    gradient of the mean over all frames of the step, also when the last batches are ragged."""
+    shards = [shard_range(n_frames, r, world_size) for r in range(world_size)]
+    steps = max(-(-(hi - lo) // batch) for lo, hi in shards) if n_frames > 0 else 0
+    for s in range(steps):
+        counts = [max(0, min(batch, hi - lo - s * batch)) for lo, hi in shards]
+        lo, _ = shards[rank]
+        idx = torch.arange(lo + s * batch, lo + s * batch + counts[rank])
+        yield idx, counts[rank] * world_size / max(sum(counts), 1)
+
+
 class Trainer(nn.Module):
-    """`mode='rgb'` mirrors trainer_rgb.Trainer (image-driven), `mode='3dmm'` trainer_3dmm.Trainer."""
+    """`mode='rgb'` mirrors trainer_rgb.Trainer (image-driven: `gen_update(real, label, person_2)` → (l2, lpips, img),
+    optimiser / checkpoint key `g_optim`), `mode='3dmm'` mirrors trainer_3dmm.Trainer (`gen_update(real, label, params,
+    person_2)` → (l2_3dmm = zeros(1), l2, lpips, img), optimiser / checkpoint key `w_optim`, `sample_bases` with
+    alpha = 5 e_i instead of 10 e_i)."""
 
     def __init__(self, args, device, rank: int = 0, world_size: int = 1, mode: str = "rgb",
-                 lpips: Optional[Callable] = None, gen: Optional[nn.Module] = None):
+                 lpips: Union[Callable, str, None] = None, gen: Optional[nn.Module] = None):
         super().__init__()
+        if mode not in ("rgb", "3dmm"):
+            raise ValueError(f"mode must be 'rgb' or '3dmm', got {mode!r}")
         self.args, self.device, self.rank, self.world_size, self.mode = args, device, rank, world_size, mode
         self.batch_size = args.batch_size
         if gen is None:
@@ -80,24 +178,54 @@ class Trainer(nn.Module):
             gen = cls(args, args.size, device, args.latent_dim_style, args.latent_dim_shape,
                       getattr(args, "run_id", "nerface2"), getattr(args, "emb_dir", "./PTI/embeddings/"))
         self.gen = gen.to(device)
-        # Adam over ALL parameters, THEN freeze the generator — same order as trainer_rgb.py:58-60, so
-        # that tune_generator() starts updating the generator without rebuilding the optimiser.
-        self.g_optim = torch.optim.Adam(self.gen.parameters(), lr=args.lr)
+        # Adam over ALL parameters, THEN freeze the generator — same order as trainer_rgb.py:58-60 /
+        # trainer_3dmm.py:33-35, so that tune_generator() starts updating the generator without rebuilding the optimiser.
+        self.optim_key = "g_optim" if mode == "rgb" else "w_optim"
+        setattr(self, self.optim_key, torch.optim.Adam(self.gen.parameters(), lr=args.lr))
         requires_grad(self.gen.generator, False)
-        self.lpips_loss = lpips
+        if lpips is None:
+            # the reference objective is ALWAYS l2 + LPIPS(alex) (trainer_rgb.py:62,86-91); its weights cannot be
+            # obtained offline, so an L2-only step is legal but must not be silent
+            warnings.warn("Trainer: no LPIPS module given — optimising the L2 term only (the reference trains on "
+                          "l2 + LPIPS(alex)); pass lpips=LPIPSAlex(state_dict) or lpips='none' to silence this",
+                          stacklevel=2)
+        self.lpips_loss = None if (lpips is None or (isinstance(lpips, str) and lpips == "none")) else lpips
         self.face_pool = nn.AdaptiveAvgPool2d((args.size, args.size))
         self.timing: Optional[dict] = None   # bench.py: {'fwd': [(ev0, ev1)], 'bwd': ..., 'allreduce': ..., 'optim': ...}
         if world_size > 1:
             self.broadcast_parameters()
+        self._flat: Optional[FlatGrads] = None
+
+    @property
+    def optimizer(self) -> torch.optim.Optimizer:
+        return getattr(self, self.optim_key)
+
+    @optimizer.setter
+    def optimizer(self, opt: torch.optim.Optimizer) -> None:
+        setattr(self, self.optim_key, opt)
 
     # ------------------------------------------------------------------ distributed
     def broadcast_parameters(self) -> None:
+        """Rank 0's parameters and buffers to every rank, in place on the tensors themselves (not `.data`: that
+        would leave `_version` unchanged and the generator's weight-image caches stale)."""
         import torch.distributed as dist
-        for t in list(self.gen.parameters()) + list(self.gen.buffers()):
-            dist.broadcast(t.data, src=0)
+        with torch.no_grad():
+            for t in list(self.gen.parameters()) + list(self.gen.buffers()):
+                dist.broadcast(t, src=0)
+        inv = getattr(self.gen.generator, "invalidate_caches", None)
+        if inv is not None:
+            inv()
 
     def shared_parameters(self):
         return [p for p in self.gen.parameters() if p.requires_grad]
+
+    def flat_grads(self) -> FlatGrads:
+        """The persistent gradient buffer of the parameters that currently require grad (rebuilt when that set
+        changes, e.g. after `tune_generator`, or when something replaced a .grad tensor)."""
+        shared = self.shared_parameters()
+        if self._flat is None or not self._flat.owns(shared):
+            self._flat = FlatGrads(shared)
+        return self._flat
 
     # ------------------------------------------------------------------ reference API
     def l2_loss(self, real_images, generated_images):
@@ -118,33 +246,56 @@ class Trainer(nn.Module):
         if self.timing is not None:
             self.timing.setdefault(key, []).append((e0, e1))
 
-    def gen_update(self, real_image, label, params=None, person_2=False):
+    def gen_update(self, real_image, label, params=None, person_2=False, loss_weight: float = 1.0):
+        """One optimisation step.  rgb mode: `gen_update(real, label, person_2=...)` → (l2, lpips, image);
+        3dmm mode: `gen_update(real, label, params, person_2)` → (l2_3dmm, l2, lpips, image) — the reference's
+        signatures and return arity (trainer_rgb.py:73-98, trainer_3dmm.py:43-67; train_3dmm.py:128 unpacks four).
+        `loss_weight` rescales this rank's loss before the all-reduce mean (ragged frame shards, `epoch_batches`);
+        an EMPTY batch skips the forward/backward and contributes zero gradients to the collective."""
+        if self.mode == "rgb" and isinstance(params, bool):          # reference call form gen_update(real, label, person_2)
+            params, person_2 = None, params
         self.gen.train()
-        self.g_optim.zero_grad()
+        flat = self.flat_grads()
+        flat.zero()
         t0 = self._mark()
-        if self.mode == "rgb":
-            weights = self.gen.get_weights(real_image)
-            latent = self.gen.get_latent(weights, person_2)
-            generated = self.gen.get_image(latent, label)
+        empty = real_image.shape[0] == 0
+        if empty:
+            l2 = lp = torch.zeros((), device=self.device)
+            generated = real_image
+            t1 = t2 = self._mark()
         else:
-            generated = self.gen(params, label, person_2)
-        l2, generated = pooled_l2(self.face_pool, real_image, generated, self.lpips_loss is not None)
-        if self.lpips_loss is not None:
-            lp = torch.squeeze(self.lpips_loss(real_image, generated)).mean()
-        else:
-            lp = torch.zeros((), device=l2.device)
-        t1 = self._mark()
-        (l2 + lp).backward()
-        t2 = self._mark()
+            if self.mode == "rgb":
+                weights = self.gen.get_weights(real_image)
+                if isinstance(weights, tuple):
+                    weights = weights[0]
+                latent = self.gen.get_latent(weights, person_2)
+                generated = self.gen.get_image(latent, label)
+            else:
+                generated = self.gen(params, label, person_2)
+            l2, generated = pooled_l2(self.face_pool, real_image, generated, self.lpips_loss is not None)
+            if self.lpips_loss is not None:
+                lp = torch.squeeze(self.lpips_loss(real_image, generated)).mean()
+            else:
+                lp = torch.zeros((), device=l2.device)
+            t1 = self._mark()
+            g_loss = l2 + lp
+            if loss_weight != 1.0:
+                g_loss = g_loss * loss_weight
+            g_loss.backward()
+            t2 = self._mark()
         if self.world_size > 1:
-            allreduce_shared_grads(self.shared_parameters(), self.world_size)
+            flat.allreduce_mean(self.world_size)
         t3 = self._mark()
-        self.g_optim.step()
+        self.optimizer.step()
         t4 = self._mark()
         self._span("fwd", t0, t1), self._span("bwd", t1, t2), self._span("allreduce", t2, t3), self._span("optim", t3, t4)
+        if self.mode == "3dmm":
+            return torch.zeros(1, device=self.device), l2.detach(), lp.detach(), generated.detach()
         return l2.detach(), lp.detach(), generated.detach()
 
     def sample(self, real_image, label, params=None, person_2=False):
+        if self.mode == "rgb" and isinstance(params, bool):
+            params, person_2 = None, params
         with torch.no_grad():
             self.gen.eval()
             if self.mode == "rgb":
@@ -156,10 +307,12 @@ class Trainer(nn.Module):
                                             vertical_mean=0.5 * math.pi, mode=None)
         return make_label(create_cam2world_matrix(-pts, pts, device=self.device))
 
-    def sample_bases(self, person_2=False, scale: float = 10.0):
-        """One render per basis vector (alpha = scale * e_i).  The label tensor is re-used across calls,
-        so — exactly as in the reference (trainer_rgb.py:113-125 + headnerf.py:132) — odd and even bases
-        see flipped / un-flipped cameras."""
+    def sample_bases(self, person_2=False, scale: Optional[float] = None):
+        """One render per basis vector (alpha = scale * e_i; 10 in trainer_rgb.py:120, 5 in trainer_3dmm.py:90).  The
+        label tensor is re-used across calls, so — exactly as in the reference (trainer_rgb.py:113-125 +
+        headnerf.py:132) — odd and even bases see flipped / un-flipped cameras."""
+        if scale is None:
+            scale = 10.0 if self.mode == "rgb" else 5.0
         imgs = []
         with torch.no_grad():
             label = self.frontal_label()
@@ -175,13 +328,50 @@ class Trainer(nn.Module):
         ckpt = torch.load(resume_ckpt, map_location=self.device, weights_only=False)
         start_iter = int(os.path.splitext(os.path.basename(resume_ckpt))[0])
         self.gen.load_state_dict(ckpt["gen"])
-        self.g_optim.load_state_dict(ckpt["g_optim"])
+        # the reference's own key for this mode first; the other trainer's key is accepted too
+        key = self.optim_key if self.optim_key in ckpt else ("w_optim" if "w_optim" in ckpt else "g_optim")
+        self.optimizer.load_state_dict(ckpt[key])
         return start_iter
 
     def save(self, idx: int, checkpoint_path: str) -> str:
         path = f"{checkpoint_path}/{str(idx).zfill(6)}.pt"
-        torch.save({"gen": self.gen.state_dict(), "g_optim": self.g_optim.state_dict(), "args": self.args}, path)
+        torch.save({"gen": self.gen.state_dict(), self.optim_key: self.optimizer.state_dict(), "args": self.args}, path)
         return path
+
+
+def fit_frames(trainer: "Trainer", reals: torch.Tensor, labels: torch.Tensor, params: Optional[torch.Tensor] = None,
+               epochs: int = 1, batch: Optional[int] = None, tune_iter: Optional[int] = None,
+               start_iter: int = 0, on_step: Optional[Callable] = None) -> List[torch.Tensor]:
+    """The fitting loop of train_rgb.py:114-154 / train_3dmm.py:113-150 over a frame set resident on the device:
+    frames are sharded in contiguous blocks over the ranks (`shard_range`), every rank walks its shard in
+    batches of `batch` (default: args.batch_size // world_size, at least 1 — the reference's integer division can
+    give 0), ragged tails are handled by `epoch_batches`, the shared gradients are averaged by the
+    trainer's one flat all-reduce, and the generator starts being tuned once `i + 1 >= tune_iter`.
+    `reals` [N,3,s,s], `labels` [N,25] (un-flipped, as the data set yields them), `params` [N,P] (3dmm mode).
+    Returns the per-step L2 losses of THIS rank (device scalars; no host sync inside the loop)."""
+    tr = trainer
+    n = reals.shape[0]
+    if batch is None:
+        batch = max(1, tr.batch_size // max(tr.world_size, 1))
+    losses: List[torch.Tensor] = []
+    i = start_iter
+    for _ in range(epochs):
+        for idx, weight in epoch_batches(n, tr.rank, tr.world_size, batch):
+            idx = idx.to(reals.device)
+            real, label = reals[idx], labels[idx].clone()       # the label flip is in place: never on the data set
+            if tr.mode == "rgb":
+                out = tr.gen_update(real, label, loss_weight=weight)
+                l2 = out[0]
+            else:
+                out = tr.gen_update(real, label, params[idx], loss_weight=weight)
+                l2 = out[1]
+            losses.append(l2)
+            if on_step is not None:
+                on_step(i, out)
+            if tune_iter is not None and (i + 1) >= tune_iter:
+                tr.tune_generator()
+            i += 1
+    return losses
 
 
 def audio_window(auds: torch.Tensor, img_i: int, smo_size: int, limit: int) -> torch.Tensor:
@@ -237,18 +427,33 @@ class AudioTrainer(nn.Module):
                                                  betas=(0.9, 0.999))
         self.w_optim = torch.optim.Adam(self.gen.parameters(), lr=args.lr)
         requires_grad(self.gen.generator, False)
-        self.lpips_loss = lpips
+        if lpips is None:
+            warnings.warn("AudioTrainer: no LPIPS module given — optimising the L2 term only (the reference trains on "
+                          "l2 + LPIPS(alex)); pass lpips=LPIPSAlex(state_dict) or lpips='none' to silence this",
+                          stacklevel=2)
+        self.lpips_loss = None if (lpips is None or (isinstance(lpips, str) and lpips == "none")) else lpips
+        self._flat: Optional[FlatGrads] = None
         self.auds = torch.as_tensor(auds).to(device).float()
         self.i_train = i_train
         self.face_pool = nn.AdaptiveAvgPool2d((args.size, args.size))
         if world_size > 1:
             import torch.distributed as dist
-            for m in (self.gen, self.AudNet, self.AudAttNet):
-                for t in list(m.parameters()) + list(m.buffers()):
-                    dist.broadcast(t.data, src=0)
+            with torch.no_grad():
+                for m in (self.gen, self.AudNet, self.AudAttNet):
+                    for t in list(m.parameters()) + list(m.buffers()):
+                        dist.broadcast(t, src=0)
+            inv = getattr(self.gen.generator, "invalidate_caches", None)
+            if inv is not None:
+                inv()
 
     def shared_parameters(self):
         return [p for m in (self.gen, self.AudNet, self.AudAttNet) for p in m.parameters() if p.requires_grad]
+
+    def flat_grads(self) -> FlatGrads:
+        shared = self.shared_parameters()
+        if self._flat is None or not self._flat.owns(shared):
+            self._flat = FlatGrads(shared)
+        return self._flat
 
     def l2_loss(self, real_images, generated_images):
         return F.mse_loss(real_images, generated_images, reduction="mean")
@@ -268,7 +473,8 @@ class AudioTrainer(nn.Module):
 
     def gen_update(self, real_image, label, params, global_step: int, img_i: int, person_2: bool = False):
         self.gen.train(), self.AudNet.train(), self.AudAttNet.train()
-        self.w_optim.zero_grad(), self.optimizer_Aud.zero_grad(), self.optimizer_AudAtt.zero_grad()
+        flat = self.flat_grads()
+        flat.zero()
         generated = self.gen(self._drive(global_step, img_i, self.i_train), label, person_2)
         l2_3dmm = torch.zeros(1, device=self.device)
         l2, generated = pooled_l2(self.face_pool, real_image, generated, self.lpips_loss is not None)
@@ -276,7 +482,7 @@ class AudioTrainer(nn.Module):
               else torch.zeros((), device=l2.device))
         (l2_3dmm + l2 + lp).backward()
         if self.world_size > 1:
-            allreduce_shared_grads(self.shared_parameters(), self.world_size)
+            flat.allreduce_mean(self.world_size)
         self.w_optim.step()
         self.optimizer_Aud.step()
         if global_step >= self.args.nosmo_iters:

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define HFAGP_ABI_VERSION 3
+#define HFAGP_ABI_VERSION 4
 
 enum { HFAGP_OK = 0, HFAGP_EBADARG = -1, HFAGP_EUNSUPPORTED = -2, HFAGP_ELAUNCH = -3 };
 
@@ -100,6 +100,13 @@ int hfagp_style_batch_fwd(const HfagpStyleArgs* items, int32_t n, void* stream);
  *   -> R [n][n] upper triangular with LAPACK geqrf's sign convention, Rinv = R^-1;  the caller forms Q = A . Rinv.
  * One small kernel instead of the ~250 launches of a library geqrf + orgqr on a 7168 x 50 panel.            */
 int hfagp_qr_gram_fwd(const float* gram, const float* top, float* R, float* Rinv, int32_t n, void* stream);
+/* Re-orthogonalisation pass (CholeskyQR2's second step) that removes the cond(A)^2 eps orthogonality defect of the
+ * Gram-matrix factorisation: gram = Q1^T Q1 [n][n] of the first pass' Q1 -> upper Cholesky factor R [n][n] (positive
+ * diagonal, so the signs of pass 1 = LAPACK's are kept) and Rinv; the caller forms Q = Q1 . Rinv.
+ * status (optional, device float[2]): [0] = max |gram - I| = the defect of pass 1 (the host's conditioning monitor:
+ * HeadNeRF_* falls back to a library Householder QR when it grows), [1] = 1 when a pivot was not positive — the
+ * outputs are then NaN, never silently wrong.                                                                   */
+int hfagp_qr_refine_fwd(const float* gram, float* R, float* Rinv, float* status, int32_t n, void* stream);
 
 /* FullyConnectedLayer (mapping network): y = act((x . W^T) * lr_mul/sqrt(In) + bias*lr_mul) * gain   [B][Out] */
 int hfagp_fc_fwd(const float* x, const float* weight, const float* bias, float* y, int32_t B, int32_t In, int32_t Out,
@@ -150,7 +157,8 @@ enum { HFAGP_ACT_LINEAR = 0, HFAGP_ACT_LRELU = 1 };
  *           The arithmetic EG3D's CUDA path uses in its fp16 blocks (super-resolution, sr_num_fp16_res = 4:
  *           SURVEY.md U4) except that tensors stay fp32 in HBM and accumulation is fp32.  The caller keeps
  *           The fp16 kinds keep |x * style| <= |x| inside the kernel (styles scaled by a power of two per sample,
- *           undone on the accumulators: EG3D's fp16 pre-normalisation, exact); |x| itself must stay below 65504.
+ *           undone on the accumulators: EG3D's fp16 pre-normalisation, exact); |x| itself must stay below 65504 unless
+ *           the tensor's maximum is passed in x_absmax (then any fp32 magnitude is taken, see HfagpModconvArgs).
  * The 16-bit paths need Cin % 16 == 0 and Cout % 128 == 0 — or, except for HFAGP_CONVT3X3_UP2, Cout % 128 >= 96
  * (the 96-channel toRGB: computed on a 128-wide tile whose last columns are discarded) — HFAGP_EUNSUPPORTED otherwise.   */
 enum { HFAGP_PREC_F32 = 0, HFAGP_PREC_BF16X3 = 1, HFAGP_PREC_BF16X6 = 2, HFAGP_PREC_F16 = 3, HFAGP_PREC_F16X3 = 4 };
@@ -170,7 +178,16 @@ typedef struct {
     int32_t ksplit;           /* 0 = let the library choose                                   */
     float noise_strength, alpha, gain, clamp;   /* clamp < 0: none                            */
     int32_t precision;        /* HFAGP_PREC_*                                                 */
+    /* fp16 range tracking (optional, both may be NULL).  A tensor without a clamp (EG3D's fp32 backbone,
+     * conv_clamp = None) has no bound, and fp16 parts saturate at 65504 and lose bits below 2^-14: the producer of
+     * such a tensor publishes max |y| into y_absmax (HFAGP_ABSMAX_SLOTS floats, zeroed by the caller before the
+     * launch; blocks write different slots, the maximum over the slots is the tensor's), and the fp16 kinds (F16X3,
+     * F16) that consume it read x_absmax and scale the operand by the power of two that brings max |x| to 2^15 —
+     * undone on the accumulators, so the result is that of un-scaled arithmetic and nothing saturates.            */
+    const float* x_absmax;    /* [HFAGP_ABSMAX_SLOTS] max |x| of the input tensor, or NULL (then |x| <= 65504 is the caller's promise) */
+    float*       y_absmax;    /* [HFAGP_ABSMAX_SLOTS] receives max |y| of the fused-epilogue output, or NULL */
 } HfagpModconvArgs;
+#define HFAGP_ABSMAX_SLOTS 64
 
 size_t hfagp_modconv_workspace_bytes(const HfagpModconvArgs* a);
 int hfagp_modconv_fwd(const HfagpModconvArgs* a, void* stream);
@@ -186,6 +203,7 @@ typedef struct {
     int32_t B, H, W, C;       /* H, W = INPUT resolution of the up-conv */
     int32_t act;
     float noise_strength, alpha, gain, clamp;
+    float*       y_absmax;    /* optional [HFAGP_ABSMAX_SLOTS]: max |y| (see HfagpModconvArgs) */
 } HfagpUpfirEpilogueArgs;
 
 int hfagp_upfir_epilogue_fwd(const HfagpUpfirEpilogueArgs* a, void* stream);

@@ -151,13 +151,13 @@ def test_trainer_step_on_gpu_matches_oracle_step(dev):
         gen = headnerf.HeadNeRF_3DMM(Args(), Args.size, device, 512, Args.latent_dim_shape)
         if oracle:
             OracleGenerator.adopt(gen.generator)
-        tr = Trainer(Args(), device, mode="3dmm", gen=gen)
-        tr.g_optim = torch.optim.SGD(tr.gen.parameters(), lr=0.0)      # compare gradients, not Adam's first step
+        tr = Trainer(Args(), device, mode="3dmm", gen=gen, lpips="none")
+        tr.optimizer = torch.optim.SGD(tr.gen.parameters(), lr=0.0)    # compare gradients, not Adam's first step
         return tr
 
     real, label, params = frame(2)
     cpu = build("cpu", True)
-    l2_cpu, _, _ = cpu.gen_update(real, label.clone(), params)
+    _, l2_cpu, _, _ = cpu.gen_update(real, label.clone(), params)
     gpu = build(dev, False)
     # same renderer uniforms as OracleGenerator draws (seed 0)
     cfg = gpu.gen.generator.cfg
@@ -167,7 +167,7 @@ def test_trainer_step_on_gpu_matches_oracle_step(dev):
     ui = torch.rand(r, cfg.depth_resolution_importance, generator=g).to(dev)
     inner = gpu.gen.generator.synthesis
     gpu.gen.generator.synthesis = lambda ws, c=None, noise_mode="const": inner(ws, c, noise_mode, u_strat=us, u_imp=ui)
-    l2_gpu, _, _ = gpu.gen_update(real.to(dev), label.clone().to(dev), params.to(dev))
+    _, l2_gpu, _, _ = gpu.gen_update(real.to(dev), label.clone().to(dev), params.to(dev))
     assert abs(float(l2_gpu) - float(l2_cpu)) < 1e-5
     for name in ("bases", "delta"):
         a, bref = getattr(gpu.gen, name).grad, getattr(cpu.gen, name).grad
@@ -190,7 +190,7 @@ def test_rgb_trainer_and_render_harness_on_gpu(dev):
         latent_dim_style = 512; latent_dim_shape = 8; generator_preset = "tiny14"; generator_seed = 0
 
     torch.manual_seed(0)
-    tr = Trainer(A(), dev, mode="rgb")
+    tr = Trainer(A(), dev, mode="rgb", lpips="none")
     g0 = {k: v.clone() for k, v in tr.gen.generator.state_dict().items()}
     b0, e0 = tr.gen.bases.detach().clone(), tr.gen.encoder.fc[0].weight.detach().clone()
     g = torch.Generator().manual_seed(1)
@@ -258,7 +258,7 @@ def test_audio_trainer_and_batched_reenactment_on_gpu(dev):
 
     torch.manual_seed(0)
     auds = torch.randn(24, 16, 29, generator=torch.Generator().manual_seed(50)).numpy()
-    tr = AudioTrainer(auds, 20, A(), dev)
+    tr = AudioTrainer(auds, 20, A(), dev, lpips="none")
     g = torch.Generator().manual_seed(1)
     real = (0.5 * torch.randn(1, 3, 64, 64, generator=g)).clamp(-1, 1).to(dev)
     label = look_at_label(torch.tensor([1.5]), torch.tensor([1.6]), flipped=False).to(dev)

@@ -222,3 +222,91 @@ def test_converter_key_selection_round_trip(tmp_path):
     bad["decoder.net.0.weight"] = torch.zeros(3, 3)
     with pytest.raises(SystemExit, match="shape mismatch"):
         conv.select_for(dst, bad)
+
+
+def _eg3d_keys():
+    import json
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "eg3d_ffhq512_128_keys.json")))["keys"]
+
+
+def test_generator_state_dict_matches_eg3d_key_fixture():
+    """The ffhq512_128 generator registers exactly the names and shapes of EG3D's `G_ema.state_dict()` for
+    ffhqrebalanced512-128 (fixture enumerated independently of the package, tests/golden/make_eg3d_keys.py; provenance:
+    recalled structure, not the real pickle)."""
+    import torch
+    from hfa_gp_amd.config import ffhq512_128
+    from hfa_gp_amd.generator import TriPlaneGenerator
+    want = _eg3d_keys()
+    with torch.device("meta"):
+        have = {k: list(v.shape) for k, v in TriPlaneGenerator(ffhq512_128()).state_dict().items()}
+    assert set(have) == set(want), (sorted(set(have) - set(want))[:5], sorted(set(want) - set(have))[:5])
+    assert all(have[k] == want[k] for k in want), [k for k in want if have[k] != want[k]][:5]
+    assert len(want) == 176
+
+
+def test_strict_load_of_an_hfagp_checkpoint_built_from_the_eg3d_key_set(tmp_path):
+    """trainer_rgb.py:130-151: `self.gen.module.load_state_dict(ckpt["gen"])` — STRICT — where ckpt["gen"] is the
+    HeadNeRF_final state dict: bases, delta, encoder.*, and every EG3D tensor under `generator.` (plus, depending on the
+    EG3D version, helper buffers of modules that are fused away here).  A synthetic checkpoint with those keys must load
+    strictly into this package's HeadNeRF_final, through Trainer.resume, and through the offline converter."""
+    import importlib.util
+    import torch
+    from hfa_gp_amd import headnerf
+    from hfa_gp_amd.trainer import Trainer
+
+    class A:
+        out_pose = False; person_2 = False; params_len = 76; size = 256; batch_size = 1; lr = 3e-4
+        latent_dim_style = 512; latent_dim_shape = 50; generator_preset = "ffhq512_128"; generator_seed = 0
+
+    torch.manual_seed(0)
+    model = headnerf.HeadNeRF_final(A(), 256, "cpu", 512, 50)
+    g = torch.Generator().manual_seed(1)
+    gen_sd = {"generator." + k: torch.randn(shape, generator=g) if shape else torch.randn((), generator=g)
+              for k, shape in _eg3d_keys().items()}
+    gen_sd["generator.renderer.plane_axes"] = torch.zeros(3, 3, 3)              # version-dependent helper buffers
+    gen_sd["generator.superresolution.resample_filter"] = torch.zeros(4, 4)
+    sd = {k: v.clone() for k, v in model.state_dict().items() if not k.startswith("generator.")}
+    assert {"bases", "delta"} <= set(sd) and any(k.startswith("encoder.net_app.convs.") for k in sd)
+    sd.update(gen_sd)
+    res = model.load_state_dict(sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    assert sorted(model.generator.ignored_checkpoint_keys) == ["renderer.plane_axes", "superresolution.resample_filter"]
+    assert torch.equal(model.generator.decoder.net["2"].weight, gen_sd["generator.decoder.net.2.weight"])
+    # a key that is NOT a known helper buffer still fails the strict load
+    bad = dict(sd)
+    bad["generator.backbone.synthesis.b1024.conv0.weight"] = torch.zeros(1)
+    import pytest
+    with pytest.raises(RuntimeError, match="b1024"):
+        model.load_state_dict(bad, strict=True)
+    # Trainer.resume on a reference-format checkpoint file
+    tr = Trainer(A(), "cpu", mode="rgb", lpips="none", gen=model)
+    ref_optim = torch.optim.Adam(model.parameters(), lr=3e-4)
+    torch.save({"gen": sd, "g_optim": ref_optim.state_dict(), "args": None}, tmp_path / "004999.pt")
+    assert tr.resume(str(tmp_path / "004999.pt")) == 4999
+    # offline converter: HFA-GP checkpoint -> tensors for load_G_official(weights=...)
+    spec = importlib.util.spec_from_file_location("convert_eg3d_pickle", os.path.join(ROOT, "tools", "convert_eg3d_pickle.py"))
+    conv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(conv)
+    picked = conv.select_for(model.generator, conv.hfagp_state_dict(str(tmp_path / "004999.pt")))
+    assert set(picked) == set(_eg3d_keys())
+
+
+def test_generator_deepcopy_and_cache_invalidation():
+    """`copy.deepcopy(generator)` (what the reference's load_G_official does) keeps the precision settings and
+    resolves super-resolution membership by module; the derived caches are not copied; `invalidate_caches` empties them."""
+    import copy
+    import torch
+    from hfa_gp_amd.config import tiny64
+    from hfa_gp_amd.generator import TriPlaneGenerator
+    g = TriPlaneGenerator(tiny64(), seed=0)
+    g.sr_conv_precision = "f16"
+    g._prep[("Q", 123)] = (0, 0, None, torch.zeros(1))
+    g._scalars[5] = (0, 0, 1.0)
+    c = copy.deepcopy(g)
+    assert c.sr_conv_precision == "f16" and c._prep == {} and c._scalars == {} and len(g._prep) == 1
+    w = c.superresolution.block1.conv0.weight
+    assert c._is_sr_weight(w) and not g._is_sr_weight(w) and not c._is_sr_weight(c.backbone.synthesis.b8.conv0.weight)
+    g.invalidate_caches()
+    assert g._prep == {} and g._scalars == {}
+    c2 = c.to(torch.float32)           # _apply hook must not break module moves
+    assert c2 is c
