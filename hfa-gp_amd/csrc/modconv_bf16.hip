@@ -139,6 +139,12 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
 #ifndef HFAGP_WAVES_N
 #define HFAGP_WAVES_N 2
 #endif
+#ifndef HFAGP_LOADA_EARLY
+#define HFAGP_LOADA_EARLY 1
+#endif
+#ifndef HFAGP_B_EARLY
+#define HFAGP_B_EARLY 1
+#endif
     // wave grid WM x WN over the 128 x 128 block tile; TM here is the M tiles per wave for WN = 2
     constexpr int WN = HFAGP_WAVES_N, WM = 4 / WN, TN = 4 / WN, TMW = 4 / WM, BM = 128, PH = BM / PW;
     static_assert(TM == 2, "block tile is 128 positions");
@@ -264,6 +270,7 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
     // compile-time ring slot and the whole group is straight-line code.
     auto run = [&](auto nt_tag) __attribute__((always_inline)) {
         constexpr int NT = decltype(nt_tag)::value;
+        constexpr bool EARLY_A = HFAGP_LOADA_EARLY && NT == 9;
 #ifndef HFAGP_RB9
 #define HFAGP_RB9 3
 #endif
@@ -308,7 +315,17 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
             // this buffer: the next chunk's patch is published by the barrier in between)
             // (sched_barrier: without it the scheduler sinks every load to just before its first use to save
             // registers, i.e. it undoes the look-ahead)
+#ifndef HFAGP_ABL_NOA            // (HFAGP_ABL_*: developer ablation builds, tools/dev/conv_ablation.sh — never in the product)
             if constexpr (T + 1 < NT) read_a(u_tag, std::integral_constant<int, T + 1>{});
+#endif
+#if HFAGP_B_EARLY && !defined(HFAGP_ABL_NOB)
+            {   // B fragments of the item RB-1 ahead, into the slot the PREVIOUS item has just finished with: issued in
+                // front of this item's MFMAs, so the youngest load at the loop's back edge (where hipcc drains vmcnt
+                // to 0) is a whole item old instead of brand new
+                constexpr int TE = (T + RB - 1) % NT, DCE = (T + RB - 1) / NT, SLE = (UU * NT + T + RB - 1) % RB;
+                issue_b(c + DCE, std::integral_constant<int, TE>{}, std::integral_constant<int, SLE>{});
+            }
+#endif
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int pr = 0; pr < NPROD; ++pr)
@@ -317,6 +334,7 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn)
                         acc[tm][tn] = mfma16<F16>(af[T & 1][tm][PA[pr]], bq[SL][tn][PB[pr]], acc[tm][tn]);
+#ifndef HFAGP_ABL_NOSTAGE
 #pragma unroll
             for (int k = 0; k < A_PER_T; ++k) {
                 const int tk = NT - A_PER_T + k < 0 ? 0 : NT - A_PER_T + k;      // tap that carries slot k
@@ -326,14 +344,32 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
                     if (k == 2) store_a(min(c + 1, c_end - 1), std::integral_constant<int, 1 - UU>{}, std::integral_constant<int, 2>{});
                 }
             }
+#endif
             // refill the slot with the item RB ahead
             constexpr int T2 = (T + RB) % NT, DC = (T + RB) / NT;
+#if !HFAGP_B_EARLY && !defined(HFAGP_ABL_NOB)
             issue_b(c + DC, std::integral_constant<int, T2>{}, std::integral_constant<int, SL>{});
-            if constexpr (T == NT - 1) load_a(min(c + 2, c_end - 1));
+#endif
+#ifndef HFAGP_ABL_NOSTAGE
+            // 9 taps: the patch of chunk c+1 is fetched at the FIRST tap of chunk c and converted under its last taps, so
+            // nothing but B fragments is in flight at the loop's back edge, where hipcc drains vmcnt to 0 (its wait-count
+            // analysis is conservative at loop headers) — with the fetch at the last tap that drain waited for HBM.
+            // Fewer taps: fetch at the last tap for chunk c+2 (a whole chunk of cover).
+            if constexpr (EARLY_A) {
+                if constexpr (T == 0) load_a(min(c + 1, c_end - 1));
+            } else {
+                if constexpr (T == NT - 1) load_a(min(c + 2, c_end - 1));
+            }
+#endif
             __builtin_amdgcn_sched_barrier(0);
         };
         auto chunk = [&](int c, auto u_tag) __attribute__((always_inline)) {
+#ifndef HFAGP_ABL_NOBAR
             __syncthreads();                                // publishes the patch of chunk c
+#endif
+#ifdef HFAGP_ABL_NOA
+            if (c == c_begin)
+#endif
             read_a(u_tag, std::integral_constant<int, 0>{});
             __builtin_amdgcn_sched_barrier(0);
             item(c, u_tag, std::integral_constant<int, 0>{});
@@ -356,18 +392,21 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
         store_a(c_begin, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
         store_a(c_begin, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
         store_a(c_begin, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
-        load_a(min(c_begin + 1, c_end - 1));
+        if constexpr (!EARLY_A) load_a(min(c_begin + 1, c_end - 1));
         // prologue: the first RB items
         issue_b(c_begin + 0 / NT, std::integral_constant<int, 0 % NT>{}, std::integral_constant<int, 0>{});
-        issue_b(c_begin + 1 / NT, std::integral_constant<int, 1 % NT>{}, std::integral_constant<int, 1>{});
-        if constexpr (RB > 2)
+        // (HFAGP_B_EARLY: the item itself issues the fragments RB-1 ahead, so the prologue stops one item short)
+        constexpr int NPRO = HFAGP_B_EARLY ? RB - 1 : RB;
+        if constexpr (NPRO > 1)
+            issue_b(c_begin + 1 / NT, std::integral_constant<int, 1 % NT>{}, std::integral_constant<int, 1>{});
+        if constexpr (NPRO > 2)
             issue_b(c_begin + 2 / NT, std::integral_constant<int, 2 % NT>{}, std::integral_constant<int, 2>{});
-        if constexpr (RB > 3)
+        if constexpr (NPRO > 3)
             issue_b(c_begin + 3 / NT, std::integral_constant<int, 3 % NT>{}, std::integral_constant<int, 3>{});
-        if constexpr (RB > 4) {
+        if constexpr (NPRO > 4)
             issue_b(c_begin + 4 / NT, std::integral_constant<int, 4 % NT>{}, std::integral_constant<int, 4>{});
+        if constexpr (NPRO > 5)
             issue_b(c_begin + 5 / NT, std::integral_constant<int, 5 % NT>{}, std::integral_constant<int, 5>{});
-        }
         static_assert((U * NT) % RB == 0, "ring slots must repeat every iteration");
         for (int cg = c_begin; cg < c_end; cg += U) {
             chunk(cg, std::integral_constant<int, 0>{});

@@ -56,9 +56,11 @@ __global__ void __launch_bounds__(256, 2) raymarch_kernel(const RayParams p) {
     DecoderRegs dec;
     load_decoder(a, j, g, dec);
 
-    for (int ray = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave); ray < p.total_rays; ray += gridDim.x * 4) {
-        const int b = ray / R, rr = ray % R;                 // wave-uniform -> scalar registers
-        const int pi = rr / a.res, pj = rr % a.res;
+    const RaySchedule sch = ray_schedule(p.total_rays, wave);
+    for (int seq = __builtin_amdgcn_readfirstlane((int)sch.begin); seq < (int)sch.end; seq += sch.stride) {
+        int b, pi, pj;                                         // wave-uniform -> scalar registers
+        ray_of(seq, a.res, b, pi, pj);
+        const int ray = __builtin_amdgcn_readfirstlane(b * R + pi * a.res + pj);   // index into the [B][R] tensors
         float o3[3], d3[3];
         ray_setup(a, b, pi, pj, o3, d3);
 
@@ -258,15 +260,14 @@ __global__ void __launch_bounds__(256, 2) raymarch_kernel(const RayParams p) {
                 float q1 = __shfl_up(ds1, 1);
                 const float ds0_63 = __shfl(ds0, 63);
                 if (lane == 0) q1 = ds0_63;
+                // records in DEPTH order (sorted position, not sample id): a 16-sample tile of pass 2 is then a contiguous
+                // piece of the ray, so consecutive samples land on the same or neighbouring texels — the importance samples
+                // cluster at the surface — and the scatter's run merging folds them into one atomic per texel line
                 float* rec = p.rec + (size_t)ray * S * 4;
-                if (lane < S) {
-                    const int id = lds.sid[lane];
-                    *reinterpret_cast<float4*>(rec + id * 4) = make_float4(lds.ts[lane], 0.5f * (p0 + w0), 0.5f * (q0 + ds0), 0.f);
-                }
-                if (lane + 64 < S) {
-                    const int id = lds.sid[lane + 64];
-                    *reinterpret_cast<float4*>(rec + id * 4) = make_float4(lds.ts[lane + 64], 0.5f * (p1 + w1), 0.5f * (q1 + ds1), 0.f);
-                }
+                if (lane < S)
+                    *reinterpret_cast<float4*>(rec + lane * 4) = make_float4(lds.ts[lane], 0.5f * (p0 + w0), 0.5f * (q0 + ds0), 0.f);
+                if (lane + 64 < S)
+                    *reinterpret_cast<float4*>(rec + (lane + 64) * 4) = make_float4(lds.ts[lane + 64], 0.5f * (p1 + w1), 0.5f * (q1 + ds1), 0.f);
             }
         }
         WAVE_SYNC();

