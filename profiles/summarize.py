@@ -32,8 +32,8 @@ def main():
                       f"B={d['config']['frames_per_step_per_gpu']}, conv precision {d['config'].get('conv_precision')}; "
                       f"{d['roofline']['kernel']} {d['roofline']['achieved']:.1f} TFLOP/s "
                       f"({d['roofline']['frac']:.3f} of {d['roofline']['peak']:.0f}){extra}; raymarch "
-                      f"{d['roofline_raymarch']['achieved']:.0f} GB/s algorithmic ({d['roofline_raymarch']['frac']:.3f} of 8 TB/s), "
-                      f"{d['roofline_raymarch']['avg_launch_ms']:.3f} ms/launch\n")
+                      f"{d['roofline_raymarch']['avg_launch_ms']:.3f} ms/launch = {d['roofline_raymarch']['frac']:.3f} of its "
+                      f"L2-gather + decoder-MFMA floor (gather rate {d['roofline_raymarch']['gather_rate_GBps_survey8d']:.0f} GB/s)\n")
     stats = find(os.path.join(out, "trace"), "*kernel_stats.csv")
     if stats:
         print("## kernel stats (rocprofv3 --kernel-trace --stats), bench command\n")

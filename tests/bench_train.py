@@ -17,17 +17,19 @@ def main():
     iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
-    tr = Trainer(Args(), dev, mode="3dmm")
+    mode = sys.argv[3] if len(sys.argv) > 3 else "3dmm"
+    tr = Trainer(Args(), dev, mode=mode, lpips="none")
     g = torch.Generator().manual_seed(1)
     real = (0.5 * torch.randn(B, 3, 256, 256, generator=g)).clamp(-1, 1).to(dev)
     params = torch.randn(B, 76, generator=g).to(dev)
     label0 = look_at_label(1.57 + 0.3 * torch.randn(B, generator=g), 1.57 + 0.15 * torch.randn(B, generator=g), flipped=False).to(dev)
+    step = (lambda: tr.gen_update(real, label0.clone())) if mode == "rgb" else (lambda: tr.gen_update(real, label0.clone(), params))
     for _ in range(2):
-        tr.gen_update(real, label0.clone(), params)
+        step()
     torch.cuda.synchronize()
     t = time.perf_counter()
     for _ in range(iters):
-        l2, _, _ = tr.gen_update(real, label0.clone(), params)
+        l2 = step()[-3]
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t) / iters
     print(f"train step B={B}: {dt*1e3:.2f} ms/step ({dt/B*1e3:.2f} ms/frame), l2={float(l2):.4f}, "

@@ -5,10 +5,10 @@ R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}"
 tag="${1:-render}"; steps="${2:-20}"; shift 2 || true
 out="$R/gpurun_out/prof_$tag"; mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o bench -- python "$R/bench.py" --steps "$steps" --warmup 3 --no-cpu-baseline --no-train --no-sweep --no-fp32-leg --no-f16-leg "$@" > "$out/trace.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o bench -- python "$R/bench.py" --steps "$steps" --warmup 3 --no-cpu-baseline --no-train --no-sweep --no-fp32-leg --no-f16-leg --audio-frames 0 "$@" > "$out/trace.log" 2>&1
 python - "$out" "$steps" <<'PY'
 import csv, glob, os, sys
-out, iters = sys.argv[1], int(sys.argv[2]) + 3
+out, iters = sys.argv[1], 2 * (int(sys.argv[2]) + 3)      # bench.py runs the headline leg twice (plain, then with events)
 f = sorted(glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True))[0]
 tot = 0
 for r in csv.DictReader(open(f)):
