@@ -56,6 +56,9 @@ def parse():
     ap.add_argument("--train-steps", type=int, default=6)
     ap.add_argument("--fit-frames", type=int, default=500,
                     help="frames of the synthetic RGB-driven fit (BASELINE config 3; 0 = skip): one pass over them")
+    ap.add_argument("--fit3dmm-frames-per-rank", type=int, default=250,
+                    help="frames per rank of the frame-sharded 3DMM-driven fit (BASELINE config 4: 2000 frames on 8 GPUs; "
+                         "0 = skip)")
     ap.add_argument("--audio-frames", type=int, default=256,
                     help="frames of the batched audio-driven reenactment leg (BASELINE config 5; 0 = skip)")
     ap.add_argument("--lpips", action="store_true",
@@ -187,6 +190,7 @@ def train_legs(args, cfg_name, dev, rank, world, dist):
     from hfa_gp_amd.trainer import Trainer
     from tests.util import look_at_label
     out = {}
+    torch.backends.cudnn.benchmark = True        # MIOpen picks its fastest kernels for the RGB driver's (Encoder) convs
 
     def make(mode, lpips):
         fa = _FitArgs()
@@ -258,6 +262,40 @@ def train_legs(args, cfg_name, dev, rank, world, dist):
         del tr
         torch.cuda.empty_cache()
     return out, B
+
+
+def fit3dmm_leg(args, cfg_name, dev, rank, world, dist):
+    """BASELINE config 4 as written: 3DMM-driven fitting (`train_3dmm.py:85-128`) of 250 x world synthetic frames (8 GPUs:
+    the 2000 frames of the config) sharded in contiguous blocks — rank r owns [250 r, 250 (r + 1)) — batch 2 per rank,
+    one in-place all-reduce of the flat shared-gradient buffer per step; one pass."""
+    import torch
+    from hfa_gp_amd.synthetic import make_frame_set
+    from hfa_gp_amd.trainer import Trainer, fit_frames, shard_range
+    fa = _FitArgs()
+    fa.generator_preset = cfg_name
+    fa.batch_size = args.train_batch * world
+    n = args.fit3dmm_frames_per_rank * world
+    torch.manual_seed(3)
+    tr = Trainer(fa, dev, rank=rank, world_size=world, mode="3dmm", lpips="none")
+    # every rank renders only its own shard of the targets (the data set is synthetic: same seed -> same frames)
+    lo, hi = shard_range(n, rank, world)
+    full = make_frame_set(tr.gen, n, size=fa.size, seed=44, params_len=fa.params_len, only=(lo, hi))
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    losses = fit_frames(tr, full["real"], full["label"], full["params"], epochs=1, batch=args.train_batch)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    l = torch.stack(losses).float().cpu()
+    k = max(1, len(l) // 10)
+    return {"workload": f"train_3dmm-style fit, {n} synthetic frames = {args.fit3dmm_frames_per_rank} per rank in contiguous "
+                        f"blocks (rank r owns [{args.fit3dmm_frames_per_rank} r, {args.fit3dmm_frames_per_rank} (r+1))), "
+                        f"Weights_3DMM -> basis -> generator, L2, Adam 3e-4, batch {args.train_batch}/rank, one pass",
+            "steps": len(l), "ms_per_step": dt / max(len(l), 1) * 1e3, "frames_per_s": n / dt,
+            "loss_first_tenth": float(l[:k].mean()), "loss_last_tenth": float(l[-k:].mean())}
 
 
 def fit_leg(args, cfg_name, dev, rank, world, dist):
@@ -467,12 +505,15 @@ def main():
         per_rank = [float(v) for v in t.cpu()]
 
     del ws, c, us, ui
-    train = train_B = fit = audio = None
+    train = train_B = fit = fit3 = audio = None
     if not args.no_train:
         torch.cuda.empty_cache()
         train, train_B = train_legs(args, args.preset, dev, rank, world, dist)
         if args.fit_frames > 0:
             fit = fit_leg(args, args.preset, dev, rank, world, dist)
+            torch.cuda.empty_cache()
+        if args.fit3dmm_frames_per_rank > 0:
+            fit3 = fit3dmm_leg(args, args.preset, dev, rank, world, dist)
     if args.audio_frames > 0:
         torch.cuda.empty_cache()
         audio = audio_leg(args, args.preset, dev, rank, world, dist)
@@ -617,6 +658,8 @@ def main():
                 out["train_step_ms_lpips"] = train["rgb_lpips"]
         if fit is not None:
             out["fit_rgb"] = fit
+        if fit3 is not None:
+            out["fit_3dmm_sharded"] = fit3
         if audio is not None:
             out["audio_reenactment"] = audio
         if state is not None:

@@ -33,11 +33,29 @@ class _Backward:
     def __init__(self, gen, tape, d_ws: torch.Tensor, ws: torch.Tensor, param_grads: bool):
         self.gen, self.tape, self.d_ws, self.ws, self.pg = gen, tape, d_ws, ws, param_grads
         self.grads = {}            # id(parameter) -> gradient (only when the generator is being tuned)
+        self.by_id = {}            # id(parameter) -> parameter
+        self.released = set()      # ids already handed to the gradient sink
         self.pending = []          # style gradients of the whole pass: (item for ops.style_bwd_batch, affine module)
 
     def _acc(self, param: torch.Tensor, g: torch.Tensor):
         key = id(param)
         self.grads[key] = g if key not in self.grads else self.grads[key] + g
+        self.by_id[key] = param
+
+    def release_ready(self):
+        """Hand the parameter gradients computed so far to the generator's gradient sink (a multi-GPU trainer's
+        bucketed all-reduce, trainer.BucketedAllReduce): each parameter is accumulated exactly once per pass, so
+        whatever is in `grads` is final.  The sink adds the gradient into the parameter's .grad slice and may start
+        the collective of a finished bucket while the rest of the backward pass is still being enqueued; released
+        parameters get None from autograd.  Without a sink nothing happens and autograd receives every gradient."""
+        sink = getattr(self.gen, "_grad_sink", None)
+        if sink is None:
+            return
+        for key in list(self.grads):
+            prm = self.by_id[key]
+            if prm.requires_grad and prm.grad is not None:
+                sink(prm, self.grads.pop(key))
+                self.released.add(key)
 
     def affine_grads(self, affine, dstot: torch.Tensor, row: int):
         dA = torch.zeros_like(affine.weight)
@@ -196,7 +214,9 @@ class SynthesisFn(torch.autograd.Function):
         # ---- super-resolution, block1 then block0
         sr1, sr0 = tape["sr"][1], tape["sr"][0]
         dxs, c0rec, g_rgb = bw.block(sr1, g_img, None, None, None)
+        bw.release_ready()
         dxs, c0rec0, g_rgb_raw = bw.block(sr0, g_rgb, dxs, c0rec["styles"], c0rec)
+        bw.release_ready()
         bw.finish_layer(c0rec)
         # ---- feature image: consumer = SR block0.conv0, plus the first 3 channels through image_raw
         feat_img = tape["feat_img"]
@@ -216,6 +236,7 @@ class SynthesisFn(torch.autograd.Function):
             net = gen.decoder.net
             for prm, g in zip((net["0"].weight, net["0"].bias, net["2"].weight, net["2"].bias), dec):
                 bw._acc(prm, g)
+            bw.release_ready()
         else:
             d_planes = rb
         # ---- backbone, last block first
@@ -227,7 +248,9 @@ class SynthesisFn(torch.autograd.Function):
             if nxt is not None:
                 bw.finish_layer(nxt)
             dxs, nxt = dxs_new, c0
+            bw.release_ready()
         bw.flush_styles()
+        bw.release_ready()
         ctx.tape = None
         pgrads = tuple(bw.grads.get(id(p)) if p.requires_grad else None for p in ctx.params)
         return (d_ws, None, None, None, None) + pgrads

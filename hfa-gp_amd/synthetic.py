@@ -33,10 +33,11 @@ def gaussian_labels(n: int, device, seed: int = 20, r: float = 2.7) -> torch.Ten
 
 @torch.no_grad()
 def make_frame_set(model, n: int, size: int = 256, seed: int = 40, params_len: Optional[int] = None,
-                   render_batch: int = 8, alpha_scale: float = 1.0) -> Dict[str, torch.Tensor]:
+                   render_batch: int = 8, alpha_scale: float = 1.0, only: Optional[tuple] = None) -> Dict[str, torch.Tensor]:
     """`model`: a HeadNeRF_* module (its generator renders the targets; its own basis is NOT the hidden one).
     Returns {'real' [n,3,size,size], 'label' [n,25] un-flipped, 'alpha' [n,K], 'params' [n,P] | absent,
-    'true_bases' [K,14*dim], 'true_delta' [14*dim]}."""
+    'true_bases' [K,14*dim], 'true_delta' [14*dim]}.  `only = (lo, hi)`: render only the targets of frames [lo, hi) (a rank's
+    shard; the other rows of 'real' stay zero — the frame set itself is identical on every rank)."""
     dev = next(model.parameters()).device
     k, dim = model.dim_shape, model.dim
     g = torch.Generator().manual_seed(seed)
@@ -46,13 +47,15 @@ def make_frame_set(model, n: int, size: int = 256, seed: int = 40, params_len: O
     label = gaussian_labels(n, dev, seed=seed + 1)
     q = torch.linalg.qr((true_bases + 1e-8).T, mode="reduced")[0]
     ws = (alpha @ q.T).view(n, 14, dim) + true_delta.view(14, dim)
-    reals = []
-    for i in range(0, n, render_batch):
-        lab = label[i:i + render_batch].clone()
+    lo, hi = only if only is not None else (0, n)
+    real = torch.zeros(n, 3, size, size, device=dev)
+    for i in range(lo, hi, render_batch):
+        e = min(hi, i + render_batch)
+        lab = label[i:e].clone()
         lab[:, [1, 2, 5, 6, 9, 10]] *= -1                     # what get_image feeds the generator (headnerf.py:132)
-        img = model.generator.synthesis(ws[i:i + render_batch].contiguous(), c=lab, noise_mode="const")["image"]
-        reals.append(F.adaptive_avg_pool2d(img, (size, size)).clamp(-1, 1))
-    out = {"real": torch.cat(reals), "label": label, "alpha": alpha, "true_bases": true_bases, "true_delta": true_delta}
+        img = model.generator.synthesis(ws[i:e].contiguous(), c=lab, noise_mode="const")["image"]
+        real[i:e] = F.adaptive_avg_pool2d(img, (size, size)).clamp(-1, 1)
+    out = {"real": real, "label": label, "alpha": alpha, "true_bases": true_bases, "true_delta": true_delta}
     if params_len is not None:
         m = torch.randn(params_len, k, generator=g).to(dev) / math.sqrt(params_len)      # alpha* = params @ M
         out["params"] = alpha @ torch.linalg.pinv(m)

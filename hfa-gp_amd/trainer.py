@@ -136,6 +136,71 @@ class FlatGrads:
         return self.numel
 
 
+class BucketedAllReduce:
+    """Overlaps the all-reduce of `FlatGrads` buckets with the rest of the backward pass (when the
+    generator is tuned the shared gradients are 123 MB — bandwidth-bound on xGMI — and should travel while the
+    backward pass is still running).  A bucket's collective is started (async, on RCCL's own stream, ordered after the
+    launch stream) as soon as the LAST of its parameters has its final gradient:
+      * generator parameters: `SynthesisFn.backward` hands them to `generator._grad_sink` block by block
+        (autograd.py `release_ready`), in the order super-resolution -> decoder -> backbone 256 ... 4 -> affine layers;
+      * everything else (basis, driver net): `register_post_accumulate_grad_hook`.
+    `finish()` starts whatever is left (parameters that got no gradient this step), waits, and averages."""
+
+    def __init__(self, flat: FlatGrads, world_size: int, group=None):
+        import torch.distributed as dist
+        self.flat, self.world, self.group = flat, world_size, group
+        self.avg = getattr(dist.ReduceOp, "AVG", None) if dist.get_backend(group) == "nccl" else None
+        self.bucket_of = {}
+        self.size = [0] * len(flat.buckets)
+        off, b = 0, 0
+        for p in flat.params:
+            while off >= flat.buckets[b][1]:
+                b += 1
+            self.bucket_of[id(p)] = b
+            self.size[b] += 1
+            off += p.numel()
+        self.reset()
+
+    def reset(self):
+        self.left = list(self.size)
+        self.works = [None] * len(self.size)
+        self.order = []                # buckets in the order their collectives were started (tests / diagnostics)
+
+    def _launch(self, b: int):
+        import torch.distributed as dist
+        lo, hi = self.flat.buckets[b]
+        op = self.avg if self.avg is not None else dist.ReduceOp.SUM
+        self.works[b] = dist.all_reduce(self.flat.flat[lo:hi], op=op, group=self.group, async_op=True)
+        self.order.append(b)
+
+    def on_grad(self, p: torch.Tensor):
+        b = self.bucket_of.get(id(p))
+        if b is None or self.works[b] is not None:
+            return
+        self.left[b] -= 1
+        if self.left[b] == 0:
+            self._launch(b)
+
+    def sink(self, p: torch.Tensor, g: torch.Tensor):
+        """generator._grad_sink: accumulate into the flat slice, then count the parameter as ready."""
+        p.grad.add_(g.view_as(p.grad))
+        self.on_grad(p)
+
+    def finish(self):
+        for b in range(len(self.size)):
+            if self.works[b] is None:
+                self._launch(b)
+        for w in self.works:
+            w.wait()
+        if self.avg is None:
+            self.flat.flat.div_(self.world)
+        n = self.flat.numel
+        order = self.order
+        self.reset()
+        self.last_order = order
+        return n
+
+
 def shard_range(n_frames: int, rank: int, world_size: int) -> Tuple[int, int]:
     """Contiguous-block frame shard [lo, hi) of rank `rank` (2000 frames over 8 ranks →
     rank r owns [250 r, 250 (r+1)); contiguous blocks keep audio smoothing windows local, §8e).  When
@@ -158,6 +223,60 @@ def epoch_batches(n_frames: int, rank: int, world_size: int, batch: int):
         lo, _ = shards[rank]
         idx = torch.arange(lo + s * batch, lo + s * batch + counts[rank])
         yield idx, counts[rank] * world_size / max(sum(counts), 1)
+
+
+def _readiness_order(*modules: nn.Module) -> List[torch.Tensor]:
+    """Trainable parameters of `modules` ordered by when the backward pass finishes their gradients (see
+    Trainer.shared_parameters)."""
+    first, affine, rest, seen = [], [], [], set()
+    for m in modules:
+        gen = getattr(m, "generator", None)
+        if gen is not None:
+            named = dict(gen.named_parameters())
+            sr = [n for n in named if n.startswith("superresolution.block1.")] + \
+                 [n for n in named if n.startswith("superresolution.block0.")]
+            dec = [n for n in named if n.startswith("decoder.")]
+            bb = [n for n in named if n.startswith("backbone.synthesis.")]
+            res = sorted({int(n.split(".")[2][1:]) for n in bb}, reverse=True)
+            bb = [n for r in res for n in bb if n.split(".")[2] == f"b{r}"]
+            other = [n for n in named if n not in set(sr) | set(dec) | set(bb)]
+            for n in sr + dec + bb + other:
+                p = named[n]
+                if p.requires_grad and id(p) not in seen:
+                    seen.add(id(p))
+                    (affine if ".affine." in n else first).append(p)
+        for p in m.parameters():
+            if p.requires_grad and id(p) not in seen:
+                seen.add(id(p))
+                rest.append(p)
+    return first + affine + rest
+
+
+def _install_grad_hooks(trainer, modules) -> None:
+    """Route final gradients to the trainer's CURRENT BucketedAllReduce (looked up at call time: the bucketer is rebuilt
+    when the set of trainable parameters changes).  Installed once per parameter / generator."""
+    def current():
+        return getattr(trainer, "_bucketer", None)
+    for m in modules:
+        for p in m.parameters():
+            if getattr(p, "_hfagp_hooked", False) or not p.requires_grad:
+                continue                       # (frozen now: hooked when it becomes trainable and the buffer is rebuilt)
+            p._hfagp_hooked = True
+
+            def hook(param, _cur=current):
+                b = _cur()
+                if b is not None:
+                    b.on_grad(param)
+            p.register_post_accumulate_grad_hook(hook)
+        gen = getattr(m, "generator", None)
+        if gen is not None and getattr(gen, "_grad_sink", None) is None:
+            def sink(param, grad, _cur=current):
+                b = _cur()
+                if b is not None:
+                    b.sink(param, grad)
+                else:
+                    param.grad.add_(grad.view_as(param.grad))
+            gen._grad_sink = sink
 
 
 class Trainer(nn.Module):
@@ -217,7 +336,11 @@ class Trainer(nn.Module):
             inv()
 
     def shared_parameters(self):
-        return [p for p in self.gen.parameters() if p.requires_grad]
+        """Parameters whose gradients are shared by the ranks, in FLAT-BUFFER order = the order in which the backward
+        pass finishes them, so that contiguous buckets complete early: generator tensors as `SynthesisFn.backward`
+        releases them (super-resolution, decoder, backbone 256 ... 4; the affine layers, whose gradients come out of the
+        batched style adjoint at the very end, last), then basis / driver parameters (finished after the generator)."""
+        return _readiness_order(self.gen)
 
     def flat_grads(self) -> FlatGrads:
         """The persistent gradient buffer of the parameters that currently require grad (rebuilt when that set
@@ -225,7 +348,18 @@ class Trainer(nn.Module):
         shared = self.shared_parameters()
         if self._flat is None or not self._flat.owns(shared):
             self._flat = FlatGrads(shared)
+            self._bucketer = None
         return self._flat
+
+    def _overlap(self, flat: FlatGrads) -> Optional[BucketedAllReduce]:
+        """The bucketed, backward-overlapped all-reduce of `flat` (world_size > 1 only)."""
+        # (force_collective: tests run the multi-rank code path in a 1-rank process group)
+        if (self.world_size <= 1 and not getattr(self, "force_collective", False)) or flat.flat is None:
+            return None
+        if getattr(self, "_bucketer", None) is None:
+            self._bucketer = BucketedAllReduce(flat, self.world_size)
+            _install_grad_hooks(self, [self.gen])
+        return self._bucketer
 
     # ------------------------------------------------------------------ reference API
     def l2_loss(self, real_images, generated_images):
@@ -257,6 +391,7 @@ class Trainer(nn.Module):
         self.gen.train()
         flat = self.flat_grads()
         flat.zero()
+        bucketer = self._overlap(flat)
         t0 = self._mark()
         empty = real_image.shape[0] == 0
         if empty:
@@ -283,8 +418,8 @@ class Trainer(nn.Module):
                 g_loss = g_loss * loss_weight
             g_loss.backward()
             t2 = self._mark()
-        if self.world_size > 1:
-            flat.allreduce_mean(self.world_size)
+        if bucketer is not None:
+            bucketer.finish()          # (most buckets are already in flight: started from inside the backward pass)
         t3 = self._mark()
         self.optimizer.step()
         t4 = self._mark()
@@ -447,13 +582,22 @@ class AudioTrainer(nn.Module):
                 inv()
 
     def shared_parameters(self):
-        return [p for m in (self.gen, self.AudNet, self.AudAttNet) for p in m.parameters() if p.requires_grad]
+        return _readiness_order(self.gen, self.AudNet, self.AudAttNet)
 
     def flat_grads(self) -> FlatGrads:
         shared = self.shared_parameters()
         if self._flat is None or not self._flat.owns(shared):
             self._flat = FlatGrads(shared)
+            self._bucketer = None
         return self._flat
+
+    def _overlap(self, flat: FlatGrads) -> Optional[BucketedAllReduce]:
+        if self.world_size <= 1 or flat.flat is None:
+            return None
+        if getattr(self, "_bucketer", None) is None:
+            self._bucketer = BucketedAllReduce(flat, self.world_size)
+            _install_grad_hooks(self, [self.gen, self.AudNet, self.AudAttNet])
+        return self._bucketer
 
     def l2_loss(self, real_images, generated_images):
         return F.mse_loss(real_images, generated_images, reduction="mean")
@@ -475,14 +619,15 @@ class AudioTrainer(nn.Module):
         self.gen.train(), self.AudNet.train(), self.AudAttNet.train()
         flat = self.flat_grads()
         flat.zero()
+        bucketer = self._overlap(flat)
         generated = self.gen(self._drive(global_step, img_i, self.i_train), label, person_2)
         l2_3dmm = torch.zeros(1, device=self.device)
         l2, generated = pooled_l2(self.face_pool, real_image, generated, self.lpips_loss is not None)
         lp = (torch.squeeze(self.lpips_loss(real_image, generated)).mean() if self.lpips_loss is not None
               else torch.zeros((), device=l2.device))
         (l2_3dmm + l2 + lp).backward()
-        if self.world_size > 1:
-            flat.allreduce_mean(self.world_size)
+        if bucketer is not None:
+            bucketer.finish()
         self.w_optim.step()
         self.optimizer_Aud.step()
         if global_step >= self.args.nosmo_iters:

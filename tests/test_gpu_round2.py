@@ -394,3 +394,48 @@ def test_plain_c_host_launches_kernels(dev, tmp_path):
     assert out.returncode == 0, out.stderr
     run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0 and "c_abi_kernel OK" in run.stdout, run.stdout + run.stderr
+
+
+def test_bucketed_allreduce_sink_matches_plain_autograd_on_gpu(dev):
+    """The multi-GPU gradient path on one GPU (1-rank gloo group): with the generator being tuned, `SynthesisFn.backward`
+    hands its parameter gradients to the trainer's bucketed all-reduce block by block (they are ADDED into the flat
+    buffer, autograd gets None) and the buckets' collectives start in readiness order — super-resolution first, the affine
+    layers and the basis / driver last.  The resulting .grad of every parameter must equal the plain autograd path."""
+    import torch.distributed as dist
+    from hfa_gp_amd.synthetic import make_frame_set
+    from hfa_gp_amd.trainer import FlatGrads, Trainer
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(_free_port())
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        grads = {}
+        for overlapped in (False, True):
+            torch.manual_seed(0)
+            tr = Trainer(FitArgs(), dev, mode="3dmm", lpips="none")
+            tr.optimizer = torch.optim.SGD(tr.gen.parameters(), lr=0.0)
+            tr.tune_generator()
+            tr.force_collective = overlapped
+            if overlapped:                      # small buckets so that several collectives are started
+                flat = tr._flat = FlatGrads(tr.shared_parameters(), bucket_bytes=64 << 10)
+                tr._bucketer = None
+            data = make_frame_set(tr.gen, 2, size=FitArgs.size, seed=42, params_len=76)
+            cfg = tr.gen.generator.cfg
+            r = cfg.neural_rendering_resolution ** 2
+            us = torch.rand(2, r, cfg.depth_resolution, device=dev, generator=torch.Generator(dev).manual_seed(1))
+            ui = torch.rand(2 * r, cfg.depth_resolution_importance, device=dev, generator=torch.Generator(dev).manual_seed(2))
+            inner = tr.gen.generator.synthesis
+            tr.gen.generator.synthesis = lambda ws, c=None, noise_mode="const": inner(ws, c, noise_mode, u_strat=us, u_imp=ui)
+            tr.gen_update(data["real"], data["label"].clone(), data["params"])
+            grads[overlapped] = {n: p.grad.detach().clone() for n, p in tr.gen.named_parameters() if p.grad is not None}
+            if overlapped:
+                order = tr._bucketer.last_order
+                assert len(order) == len(tr._flat.buckets) > 4 and order[0] == 0, order
+                names = {id(p): n for n, p in tr.gen.named_parameters()}
+                first = names[id(tr._flat.params[0])]
+                assert first.startswith("generator.superresolution.block1."), first
+                assert names[id(tr._flat.params[-1])].startswith(("weights_3dmm.", "bases", "delta"))
+        assert set(grads[True]) == set(grads[False])
+        for n, gref in grads[False].items():
+            got = grads[True][n]
+            assert (got - gref).abs().max().item() <= 1e-5 * gref.abs().max().item() + 1e-9, n
+    finally:
+        dist.destroy_process_group()
