@@ -228,7 +228,7 @@ def epoch_batches(n_frames: int, rank: int, world_size: int, batch: int):
 def _readiness_order(*modules: nn.Module) -> List[torch.Tensor]:
     """Trainable parameters of `modules` ordered by when the backward pass finishes their gradients (see
     Trainer.shared_parameters)."""
-    first, affine, rest, seen = [], [], [], set()
+    first, affine, rest, idle, seen = [], [], [], [], set()
     for m in modules:
         gen = getattr(m, "generator", None)
         if gen is not None:
@@ -240,16 +240,25 @@ def _readiness_order(*modules: nn.Module) -> List[torch.Tensor]:
             res = sorted({int(n.split(".")[2][1:]) for n in bb}, reverse=True)
             bb = [n for r in res for n in bb if n.split(".")[2] == f"b{r}"]
             other = [n for n in named if n not in set(sr) | set(dec) | set(bb)]
+            cfg = getattr(gen, "cfg", None)
+
+            def unused(n):        # never on the synthesis path: no gradient ever arrives, so they must not hold a bucket back
+                if n.startswith("backbone.mapping."):
+                    return True
+                if n.endswith(".noise_strength") and cfg is not None:
+                    mode = cfg.sr_noise_mode if n.startswith("superresolution.") else cfg.backbone_noise_mode
+                    return mode == "none"
+                return False
             for n in sr + dec + bb + other:
                 p = named[n]
                 if p.requires_grad and id(p) not in seen:
                     seen.add(id(p))
-                    (affine if ".affine." in n else first).append(p)
+                    (idle if unused(n) else affine if ".affine." in n else first).append(p)
         for p in m.parameters():
             if p.requires_grad and id(p) not in seen:
                 seen.add(id(p))
                 rest.append(p)
-    return first + affine + rest
+    return first + affine + rest + idle
 
 
 def _install_grad_hooks(trainer, modules) -> None:
