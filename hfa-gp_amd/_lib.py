@@ -14,7 +14,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # (HFAGP_LIB_PATH: developer override, used by the ablation builds of tools/dev/ — the product loads the in-tree library)
 LIB_PATH = os.environ.get("HFAGP_LIB_PATH") or os.path.join(_HERE, "libhfagp_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 c_float_p = C.c_void_p  # device pointers travel as integers
 
@@ -51,6 +51,7 @@ class ModconvArgs(C.Structure):
         ("noise_strength", C.c_float), ("alpha", C.c_float), ("gain", C.c_float), ("clamp", C.c_float),
         ("precision", C.c_int32),
         ("x_absmax", C.c_void_p), ("y_absmax", C.c_void_p),
+        ("rgb_w", C.c_void_p), ("rgb_part", C.c_void_p),
     ]
 
 
@@ -80,6 +81,11 @@ class TorgbArgs(C.Structure):
         ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32),
         ("clamp", C.c_float),
     ]
+
+
+class TorgbFinishArgs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("part", "bias", "rgb_in", "rgb_out", "y_pre")] + \
+        [(n, C.c_int32) for n in ("nparts", "B", "H", "W", "Cout")] + [("clamp", C.c_float)]
 
 
 class PointwiseBwdArgs(C.Structure):
@@ -130,6 +136,8 @@ SYMBOLS = {
     "hfagp_upfir_epilogue_fwd": (C.c_int, [C.POINTER(UpfirEpilogueArgs), C.c_void_p]),
     "hfagp_skip_upsample_add": (C.c_int, [C.POINTER(SkipArgs), C.c_void_p]),
     "hfagp_torgb_fwd": (C.c_int, [C.POINTER(TorgbArgs), C.c_void_p]),
+    "hfagp_torgb_finish_fwd": (C.c_int, [C.POINTER(TorgbFinishArgs), C.c_void_p]),
+    "hfagp_modconv_rgb_parts": (C.c_int32, [C.POINTER(ModconvArgs)]),
     "hfagp_pointwise_bwd": (C.c_int, [C.POINTER(PointwiseBwdArgs), C.c_void_p]),
     "hfagp_upfir_bwd": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p]),
     "hfagp_upsample2d_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),

@@ -389,6 +389,26 @@ __global__ void __launch_bounds__(256) torgb_kernel(HfagpTorgbArgs a) {
         torgb_finish(a, b, pix, sub, sub == 0 ? acc[0] : sub == 1 ? acc[1] : sub == 2 ? acc[2] : acc[3], torgb_skip(a, b, pix, sub));
 }
 
+// second half of the fused toRGB: one thread per pixel sums the partial images, then bias / clamp / skip per channel
+__global__ void __launch_bounds__(256) torgb_finish_kernel(HfagpTorgbFinishArgs f) {
+    const int HW = f.H * f.W;
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= (long long)f.B * HW) return;
+    const int b = (int)(tid / HW), pix = (int)(tid % HW);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = 0; q < f.nparts; ++q) {
+        const float4 v = reinterpret_cast<const float4*>(f.part)[((size_t)q * f.B + b) * HW + pix];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z;
+    }
+    HfagpTorgbArgs a{};                       // torgb_skip / torgb_finish read these fields only
+    a.bias = f.bias; a.rgb_in = f.rgb_in; a.rgb_out = f.rgb_out; a.y_pre = f.y_pre;
+    a.H = f.H; a.W = f.W; a.Cout = f.Cout; a.clamp = f.clamp;
+    const float s3[3] = {acc.x, acc.y, acc.z};
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        if (c < f.Cout) torgb_finish(a, b, pix, c, s3[c], torgb_skip(a, b, pix, c));
+}
+
 // ---------------------------------------------------------------- generic upfirdn2d (NCHW, test surface)
 __global__ void __launch_bounds__(256) upfirdn2d_kernel(const float* __restrict__ x, const float* __restrict__ f,
                                                         float* __restrict__ y, int NC, int H, int W, int fh, int fw,
@@ -552,6 +572,15 @@ int hfagp_torgb_fwd(const HfagpTorgbArgs* a, void* stream) {
         }
     }
     return check_launch("torgb");
+}
+
+int hfagp_torgb_finish_fwd(const HfagpTorgbFinishArgs* a, void* stream) {
+    HFAGP_REQUIRE(a && a->part && a->bias && a->rgb_out, HFAGP_EBADARG, "torgb_finish: null pointer");
+    HFAGP_REQUIRE(a->Cout >= 1 && a->Cout <= 3 && a->nparts >= 1 && a->H % 2 == 0 && a->W % 2 == 0, HFAGP_EUNSUPPORTED,
+                  "torgb_finish: Cout=%d (max 3), nparts=%d", a->Cout, a->nparts);
+    const long long total = (long long)a->B * a->H * a->W;
+    torgb_finish_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(*a);
+    return check_launch("torgb_finish");
 }
 
 int hfagp_upfirdn2d_fwd(const float* x, const float* f, float* y, int32_t N, int32_t C, int32_t H, int32_t W,

@@ -261,6 +261,8 @@ size_t hfagp_modconv_workspace_bytes(const HfagpModconvArgs* a) {
     return pl.ws_bytes;
 }
 
+int32_t hfagp_modconv_rgb_parts(const HfagpModconvArgs* a) { return a ? ((a->Cout + 127) / 128) * 2 : 0; }
+
 int hfagp_modconv_fwd(const HfagpModconvArgs* a, void* stream) {
     int rc = validate(a, ck_of(a));
     if (rc != HFAGP_OK) return rc;
@@ -268,6 +270,12 @@ int hfagp_modconv_fwd(const HfagpModconvArgs* a, void* stream) {
     rc = make_plan(a, pl, ck_of(a));
     if (rc != HFAGP_OK) return rc;
     ConvParams& p = pl.p;
+    HFAGP_REQUIRE((a->rgb_w == nullptr) == (a->rgb_part == nullptr), HFAGP_EBADARG, "modconv: rgb_w and rgb_part go together");
+    HFAGP_REQUIRE(!a->rgb_part || (a->precision != HFAGP_PREC_F32 && p.ksplit * p.nslab == 1 && p.fused && a->Cout % 128 == 0 &&
+                                   (a->mode == HFAGP_CONV3X3 || a->mode == HFAGP_CONV1X1)),
+                  HFAGP_EUNSUPPORTED, "modconv: the fused toRGB needs a 16-bit precision, mode 0 / 2, Cout %% 128 == 0 and no "
+                                      "split-K (workspace_bytes() == 0); got precision %d mode %d Cout %d ksplit %d",
+                  a->precision, a->mode, a->Cout, p.ksplit);
     hipStream_t s = (hipStream_t)stream;
     const int nslabs = p.ksplit * p.nslab;
     if (nslabs > 1) {

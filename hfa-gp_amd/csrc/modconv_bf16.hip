@@ -422,10 +422,24 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
     float* out = p.out + (size_t)(ks * p.nslab + ph.slab) * p.slab;
     const int cstep = ph.sx * p.Cout;                                     // elements between neighbouring columns
     float vmax = 0.f;                                                     // max |y| of this lane's stores (y_absmax)
+    // fused toRGB (hfagp.h rgb_w / rgb_part): rgbp[position][r] collects y[co] * rgb_w[r][co] over this lane's channels
+    constexpr bool RGB = NTAPS == 9 || NTAPS == 1;
+    const bool do_rgb = RGB && p.fused && p.rgb_part != nullptr;
+    float rgbp[RGB ? TMW * 16 * 3 : 1];
+    if constexpr (RGB) {
+#pragma unroll
+        for (int i = 0; i < TMW * 16 * 3; ++i) rgbp[i] = 0.f;
+    }
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
         const int co = co0 + (wn * TN + tn) * 32 + l31;
         if (co >= p.Cout) continue;
+        float rw3[3] = {0.f, 0.f, 0.f};
+        if constexpr (RGB)
+            if (do_rgb) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) rw3[r] = p.rgb_w[((size_t)b * 3 + r) * p.Cout + co];
+            }
         float d = sback, bs = 0.f;
         if (p.fused) {
             if (p.dcoef) d = p.dcoef[(size_t)b * p.Cout + co] * sback;
@@ -455,10 +469,45 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
                     else if constexpr (F16) v *= sback;
                     vmax = fmaxf(vmax, fabsf(v));
                     rowp[n * cstep] = v;
+                    if constexpr (RGB) {
+#pragma unroll
+                        for (int r = 0; r < 3; ++r)
+                            rgbp[((tm * 2 + rw) * 8 + q) * 3 + r] = fmaf(v, rw3[r], rgbp[((tm * 2 + rw) * 8 + q) * 3 + r]);
+                    }
                 }
             }
     }
     if (p.fused && p.y_absmax) publish_absmax(p.y_absmax, vmax, blockIdx.x * 4 + wave);
+    if constexpr (RGB) {
+        if (do_rgb) {
+            // reduce-scatter over the 32 channel lanes: at the step with lane bit m the lane keeps one half of its values
+            // and adds the partner's copy of that half; after 5 steps lane l31 owns the 3 sums of position l31
+            // (position index = (tm*2 + rw)*8 + q, exactly the order of rgbp): 93 exchanges instead of 5 x 96
+            int n = TMW * 16 * 3;
+#pragma unroll
+            for (int m = 16; m >= 1; m >>= 1) {
+                n >>= 1;
+                const bool up = (l31 & m) != 0;
+#pragma unroll
+                for (int i = 0; i < TMW * 16 * 3 / 2; ++i) {
+                    if (i < n) {
+                        const float keep = up ? rgbp[i + n] : rgbp[i];
+                        const float give = up ? rgbp[i] : rgbp[i + n];
+                        rgbp[i] = keep + __shfl_xor(give, m);
+                    }
+                }
+            }
+            const int pos = l31;                                  // (tm*2 + rw)*8 + q
+            const int tm = pos >> 4, rw = (pos >> 3) & 1, q = pos & 7;
+            const int m = m0 + 2 * (wm * TMW + tm) + rw, nn = n0 + 8 * (q >> 2) + 4 * h + (q & 3);
+            if (m < ph.mh && nn < ph.mw) {
+                const int part = tn_blk * WN + wn;
+                float4* dst = reinterpret_cast<float4*>(p.rgb_part) +
+                              (((size_t)part * p.B + b) * p.Ho + (ph.sy * m + ph.oy0)) * p.Wo + (ph.sx * nn + ph.ox0);
+                *dst = make_float4(rgbp[0], rgbp[1], rgbp[2], 0.f);
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------

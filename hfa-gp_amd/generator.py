@@ -148,6 +148,7 @@ class TriPlaneGenerator(nn.Module):
         self.sr_conv_precision = cfg.sr_conv_precision
         self._styles: Dict[int, tuple] = {}      # id(layer) -> (styles, dcoef) of the pass in flight
         self._absmax = None                      # (slot buffers, layer names) of the last pass: f16_range_report()
+        self._rgb_part = None                    # partial toRGB sums of the conv just run (fused toRGB, ops.modconv)
         self._scalars: Dict[int, tuple] = {}     # id(param) -> (version, data_ptr, python float)
         self._const_nhwc: Optional[tuple] = None
         self.timing: Optional[Dict[str, list]] = None   # bench.py: {'raymarch': [(ev0, ev1, units)], 'modconv': [...]}
@@ -296,7 +297,7 @@ class TriPlaneGenerator(nn.Module):
 
     # ----------------------------------------------------------------- layers
     def _layer(self, x, layer: _SynthesisLayer, w, row, batch, noise_mode, conv_clamp, tape, x_absmax=None,
-               y_absmax=None):
+               y_absmax=None, rgb=None):
         """x_absmax / y_absmax: fp16 range tracking of an UNCLAMPED activation chain (ops.modconv): the slot buffer with
         max |x| of the input as published by its producer, and the one this layer publishes max |out| into."""
         cfg = self.cfg
@@ -324,9 +325,17 @@ class TriPlaneGenerator(nn.Module):
             out = ops.upfir_epilogue(yt, k_dcoef, noise, ns, layer.bias, "lrelu", cfg.lrelu_alpha, gain, conv_clamp,
                                      y_absmax=y_absmax)
         else:
+            # rgb = (toRGB weight [3, Cout], toRGB styles [B, Cout]): form the block's toRGB sums in this conv's epilogue
+            # when the kernel can (ops.fused_torgb_supported); the caller finishes them with ops.torgb_finish
+            rgb_w = None
+            if rgb is not None and ops.fused_torgb_supported(x, wt, cout, batch):
+                rgb_w = (rgb[1][:, None, :] * rgb[0][None]).contiguous()
             out = self._timed(key, flops, ops.modconv, x, wt, cout, ops.CONV3X3, styles=k_styles, dcoef=k_dcoef,
                               noise=noise, noise_strength=ns, bias=layer.bias, act="lrelu", alpha=cfg.lrelu_alpha,
-                              gain=gain, clamp=conv_clamp, batch=batch, x_absmax=x_absmax, y_absmax=y_absmax)
+                              gain=gain, clamp=conv_clamp, batch=batch, x_absmax=x_absmax, y_absmax=y_absmax,
+                              rgb_w=rgb_w)
+            if rgb_w is not None:
+                out, self._rgb_part = out
         rec = None
         if tape is not None:
             rec = dict(layer=layer, x=x, styles=styles, dcoef=dcoef, out=out, row=row, up=layer.up, wsq=wsq,
@@ -340,26 +349,33 @@ class TriPlaneGenerator(nn.Module):
         output, slots for conv1's output) when the chain is unclamped (fp16 range tracking), else None."""
         rec = dict(conv0=None, first=blk.in_channels == 0, img_in=img, const=getattr(blk, "const", None))
         am_in, am0, am1 = absmax if absmax is not None else (None, None, None)
-        if blk.in_channels == 0:
-            x, rec["conv1"] = self._layer(self._const(blk.const), blk.conv1, ws[:, rows[0]], rows[0], batch,
-                                          noise_mode, conv_clamp, tape, None, am1)
-        else:
-            x, rec["conv0"] = self._layer(x, blk.conv0, ws[:, rows[0]], rows[0], batch, noise_mode, conv_clamp, tape,
-                                          am_in, am0)
-            x, rec["conv1"] = self._layer(x, blk.conv1, ws[:, rows[1]], rows[1], batch, noise_mode, conv_clamp, tape,
-                                          am0, am1)
         tr = blk.torgb
         cin = tr.weight.shape[1]
         row = rows[-1]
         pre = self._styles.pop(id(tr), None) if self._styles else None
         styles = pre[0] if pre is not None else ops.styles_demod(ws[:, row], tr.affine.weight, tr.affine.bias, None,
                                                                  1.0 / math.sqrt(cin))[0]
+        # a 3-channel toRGB (super-resolution blocks) rides in the epilogue of conv1 where the kernel allows it
+        rgb = (tr.weight.detach().reshape(tr.weight.shape[0], cin), styles) if (small_rgb and tr.weight.shape[0] <= 3) else None
+        self._rgb_part = None
+        if blk.in_channels == 0:
+            x, rec["conv1"] = self._layer(self._const(blk.const), blk.conv1, ws[:, rows[0]], rows[0], batch,
+                                          noise_mode, conv_clamp, tape, None, am1, rgb)
+        else:
+            x, rec["conv0"] = self._layer(x, blk.conv0, ws[:, rows[0]], rows[0], batch, noise_mode, conv_clamp, tape,
+                                          am_in, am0)
+            x, rec["conv1"] = self._layer(x, blk.conv1, ws[:, rows[1]], rows[1], batch, noise_mode, conv_clamp, tape,
+                                          am0, am1, rgb)
         y = y_pre = None
         if small_rgb:
             if tape is not None and conv_clamp is not None:
                 y_pre = torch.empty(batch, tr.weight.shape[0], x.shape[1], x.shape[2], device=x.device)
-            img = ops.torgb_small(x, tr.weight.detach().reshape(tr.weight.shape[0], cin), styles, tr.bias, img,
-                                  conv_clamp, y_pre)
+            if self._rgb_part is not None:
+                img = ops.torgb_finish(self._rgb_part, tr.bias, img, conv_clamp, y_pre)
+                self._rgb_part = None
+            else:
+                img = ops.torgb_small(x, tr.weight.detach().reshape(tr.weight.shape[0], cin), styles, tr.bias, img,
+                                      conv_clamp, y_pre)
         else:
             wt, _ = self._prepared(tr.weight)
             y = ops.modconv(x, wt, tr.weight.shape[0], ops.CONV1X1, styles=styles, bias=tr.bias, act="linear",

@@ -216,14 +216,16 @@ def modconv(x: torch.Tensor, wt: torch.Tensor, cout: int, mode: int, styles: Opt
             noise_strength: float = 0.0, bias: Optional[torch.Tensor] = None, act: str = "linear",
             alpha: float = 0.2, gain: float = 1.0, clamp: Optional[float] = None, batch: Optional[int] = None,
             ksplit: int = 0, x_absmax: Optional[torch.Tensor] = None,
-            y_absmax: Optional[torch.Tensor] = None) -> torch.Tensor:
+            y_absmax: Optional[torch.Tensor] = None, rgb_w: Optional[torch.Tensor] = None):
     """x [B|1, H, W, Cin] channels-last.  mode CONV3X3 / CONV1X1: fused epilogue, returns [B,H,W,Cout];
     mode CONVT3X3_UP2: returns the RAW transposed-conv result [B, 2H+1, 2W+1, Cout].
     ``wt`` from :func:`weight_prep` (fp32, exact MFMA) or :func:`weight_prep_split` (bfloat16 parts: the
     split-bf16 MFMA path, BF16X3 for 2 parts, BF16X6 for 3; float16, 1 part: the single-pass fp16 path).
     ``x_absmax`` / ``y_absmax`` ([64] fp32, `absmax_slots`): fp16 range tracking — max |x| of the input as published by its
     producer (the fp16 kinds scale the operand by an exact power of two so nothing saturates) and the slot buffer that
-    receives max |y| of a fused-epilogue output (include/hfagp.h)."""
+    receives max |y| of a fused-epilogue output (include/hfagp.h).
+    ``rgb_w`` [B, 3, Cout] (toRGB weight x its styles): fused toRGB — returns (y, rgb_part [parts, B, H, W, 4]) for
+    `torgb_finish`; only where `fused_torgb_supported` says so."""
     _chk(x, "x")
     if mode == CONVS2_BWD:                      # x = four parity images [2,2,B,H+1,W+1,Cin]
         _, _, xb, h, w, cin = x.shape
@@ -261,8 +263,37 @@ def modconv(x: torch.Tensor, wt: torch.Tensor, cout: int, mode: int, styles: Opt
     if nbytes:
         ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
         a.workspace = _ptr(ws)
+    part = None
+    if rgb_w is not None:
+        part = torch.empty(L.lib().hfagp_modconv_rgb_parts(C.byref(a)), b, h, w, 4, device=x.device, dtype=torch.float32)
+        a.rgb_w, a.rgb_part = _ptr(_chk(rgb_w, "rgb_w")), _ptr(part)
     L.check(L.lib().hfagp_modconv_fwd(C.byref(a), _stream()), "modconv_fwd")
-    return y
+    return y if rgb_w is None else (y, part)
+
+
+def fused_torgb_supported(x: torch.Tensor, wt: torch.Tensor, cout: int, batch: int) -> bool:
+    """Whether `modconv(..., mode=CONV3X3, rgb_w=...)` can form the toRGB sums in its epilogue: 16-bit weight image,
+    Cout a multiple of 128, and a grid large enough that the library does not split K (then the epilogue lives in the
+    reducer): the library's own rule, 2 x 256 CUs blocks of 8 x 16 positions x 128 channels."""
+    if wt.dtype == torch.float32 or cout % 128 != 0:
+        return False
+    h, w = x.shape[1], x.shape[2]
+    return batch * ((h + 7) // 8) * ((w + 15) // 16) * (cout // 128) >= 512
+
+
+def torgb_finish(part: torch.Tensor, bias: torch.Tensor, rgb_in: Optional[torch.Tensor], clamp: Optional[float],
+                 y_pre: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """rgb_part of a fused-toRGB conv -> NCHW image: clamp(sum of parts + bias) + upsample2d(rgb_in)."""
+    nparts, b, h, w, _ = part.shape
+    cout = bias.shape[0]
+    out = torch.empty(b, cout, h, w, device=part.device, dtype=torch.float32)
+    a = L.TorgbFinishArgs()
+    a.part, a.bias, a.rgb_out, a.y_pre = _ptr(part), _ptr(_chk(bias, "bias")), _ptr(out), _ptr(y_pre)
+    a.rgb_in = _ptr(_chk(rgb_in, "rgb_in")) if rgb_in is not None else None
+    a.nparts, a.B, a.H, a.W, a.Cout = nparts, b, h, w, cout
+    a.clamp = -1.0 if clamp is None else float(clamp)
+    L.check(L.lib().hfagp_torgb_finish_fwd(C.byref(a), _stream()), "torgb_finish_fwd")
+    return out
 
 
 def upfir_epilogue(yt: torch.Tensor, dcoef: Optional[torch.Tensor], noise: Optional[torch.Tensor],

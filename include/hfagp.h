@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define HFAGP_ABI_VERSION 4
+#define HFAGP_ABI_VERSION 5
 
 enum { HFAGP_OK = 0, HFAGP_EBADARG = -1, HFAGP_EUNSUPPORTED = -2, HFAGP_ELAUNCH = -3 };
 
@@ -186,7 +186,16 @@ typedef struct {
      * undone on the accumulators, so the result is that of un-scaled arithmetic and nothing saturates.            */
     const float* x_absmax;    /* [HFAGP_ABSMAX_SLOTS] max |x| of the input tensor, or NULL (then |x| <= 65504 is the caller's promise) */
     float*       y_absmax;    /* [HFAGP_ABSMAX_SLOTS] receives max |y| of the fused-epilogue output, or NULL */
+    /* fused toRGB of a block's last conv (optional, both or none; 16-bit precisions, modes 0 / 2 without split-K —
+     * hfagp_modconv_workspace_bytes() == 0): while the output tile is still in registers the block also forms
+     *   rgb[r] = sum_co y[co] * rgb_w[b][r][co]     (r < 3; rgb_w = toRGB weight * its styles, Cout entries per r)
+     * over ITS output channels and writes the partial sums to rgb_part; hfagp_torgb_finish_fwd adds the parts, the
+     * bias, the clamp and the up-sampled previous image.  Saves the separate toRGB pass over the activation.    */
+    const float* rgb_w;       /* [B][3][Cout] or NULL */
+    float*       rgb_part;    /* [hfagp_modconv_rgb_parts()][B][H][W][4] floats (3 used), written, or NULL */
 } HfagpModconvArgs;
+/* number of partial-sum images a call with rgb_part writes: (Cout / 128) x 2 */
+int32_t hfagp_modconv_rgb_parts(const HfagpModconvArgs* a);
 #define HFAGP_ABSMAX_SLOTS 64
 
 size_t hfagp_modconv_workspace_bytes(const HfagpModconvArgs* a);
@@ -237,6 +246,19 @@ typedef struct {
 } HfagpTorgbArgs;
 
 int hfagp_torgb_fwd(const HfagpTorgbArgs* a, void* stream);
+
+/* second half of the fused toRGB (HfagpModconvArgs::rgb_part): rgb_out[b][c][y][x] (NCHW) =
+ * clamp(sum_p part[p][b][y][x][c] + bias[c]) + upsample2d(rgb_in)[b][c][y][x]                         */
+typedef struct {
+    const float* part;        /* [nparts][B][H][W][4] */
+    const float* bias;        /* [Cout] */
+    const float* rgb_in;      /* NCHW [B][Cout][H/2][W/2] or NULL */
+    float*       rgb_out;     /* NCHW [B][Cout][H][W] */
+    float*       y_pre;       /* optional NCHW [B][Cout][H][W]: value before the clamp (backward mask) */
+    int32_t nparts, B, H, W, Cout;   /* Cout <= 3 */
+    float clamp;
+} HfagpTorgbFinishArgs;
+int hfagp_torgb_finish_fwd(const HfagpTorgbFinishArgs* a, void* stream);
 
 /* ------------------------------------------------------------------ backward pass (generator frozen: d/d ws)
  * GEMM-shaped parts reuse hfagp_modconv_fwd (modes 3, 4 and 2 with transposed weights).               */

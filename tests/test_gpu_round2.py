@@ -441,3 +441,41 @@ def test_bucketed_allreduce_sink_matches_plain_autograd_on_gpu(dev):
             assert (got - gref).abs().max().item() <= 1e-5 * gref.abs().max().item() + 1e-9, n
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("prec,cout,h", [("f16x3", 128, 192), ("f16", 256, 136), ("bf16x3", 128, 180)])
+def test_fused_torgb_in_conv_epilogue(dev, prec, cout, h):
+    """The 3-channel toRGB of a super-resolution block formed in the epilogue of its conv1 (rgb_w / rgb_part +
+    hfagp_torgb_finish_fwd) equals the stand-alone toRGB pass over the stored activation (ops.torgb_small): same bias,
+    clamp, pre-clamp output and up-sampled skip image; ragged tiles (h not a multiple of the 8 x 16 patch)."""
+    from hfa_gp_amd import ops
+    g = torch.Generator().manual_seed(41)
+    b, cin = 4, 64
+    x = torch.randn(b, h, h, cin, generator=g).to(dev)
+    w = torch.randn(cout, cin, 3, 3, generator=g).to(dev)
+    s = (torch.randn(b, cin, generator=g) + 1.0).to(dev)
+    dcoef = torch.rand(b, cout, generator=g).to(dev) + 0.5
+    bias = torch.randn(cout, generator=g).to(dev)
+    w_rgb = torch.randn(3, cout, generator=g).to(dev)
+    s_rgb = (torch.randn(b, cout, generator=g) / math.sqrt(cout)).to(dev)
+    b_rgb = torch.randn(3, generator=g).to(dev)
+    prev = torch.randn(b, 3, h // 2, h // 2, generator=g).to(dev)
+    wb = ops.weight_prep_prec(w, prec)
+    assert ops.fused_torgb_supported(x, wb, cout, b)
+    kw = dict(styles=s, dcoef=dcoef, bias=bias, act="lrelu", gain=math.sqrt(2), clamp=256.0)
+    y_ref = ops.modconv(x, wb, cout, ops.CONV3X3, **kw)
+    pre_ref = torch.empty(b, 3, h, h, device=dev)
+    rgb_ref = ops.torgb_small(y_ref, w_rgb, s_rgb, b_rgb, prev, 2.0, pre_ref)
+    y, part = ops.modconv(x, wb, cout, ops.CONV3X3, rgb_w=(s_rgb[:, None, :] * w_rgb[None]).contiguous(), **kw)
+    assert torch.equal(y, y_ref) and part.shape == (2 * cout // 128, b, h, h, 4)
+    pre = torch.empty(b, 3, h, h, device=dev)
+    rgb = ops.torgb_finish(part, b_rgb, prev, 2.0, pre)
+    scale = pre_ref.abs().max().item()
+    # (fp32 sums in a different order: lane pairs, a butterfly over 32 lanes, then the parts)
+    assert (pre - pre_ref).abs().max().item() <= 1e-5 * scale, ((pre - pre_ref).abs().max().item(), scale)
+    assert (rgb - rgb_ref).abs().max().item() <= 1e-5 * scale
+    # a grid too small for the library's no-split-K rule is reported as unsupported, and the call itself refuses
+    xs = x[:1, :8, :8].contiguous()
+    assert not ops.fused_torgb_supported(xs, wb, cout, 1)
+    with pytest.raises(RuntimeError, match="split-K"):
+        ops.modconv(xs, wb, cout, ops.CONV3X3, rgb_w=(s_rgb[:1, None, :] * w_rgb[None]).contiguous(), styles=s[:1])
