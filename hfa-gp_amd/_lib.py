@@ -29,6 +29,7 @@ class RaymarchArgs(C.Structure):
         ("Sc", C.c_int32), ("Sf", C.c_int32), ("plane_axes", C.c_int32), ("white_back", C.c_int32),
         ("ray_start", C.c_double), ("ray_end", C.c_double),
         ("box_warp", C.c_float), ("decoder_lr_mul", C.c_float),
+        ("planes_absmax", C.c_void_p),
     ]
 
 
@@ -71,6 +72,7 @@ class SkipArgs(C.Structure):
     _fields_ = [
         ("img_in", C.c_void_p), ("y", C.c_void_p), ("img_out", C.c_void_p),
         ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("plane_major", C.c_int32),
+        ("out_absmax", C.c_void_p),
     ]
 
 

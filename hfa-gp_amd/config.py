@@ -58,6 +58,10 @@ class GeneratorConfig:
     # precision of the two super-resolution blocks when it differs from conv_precision: "f16" reproduces the
     # reference's CUDA defaults (fp32 backbone, fp16 super-resolution: sr_num_fp16_res = 4)
     sr_conv_precision: Optional[str] = None
+    # arithmetic of the decoder MLP inside the ray marcher: "f16x3" = split fp16 operands on the 16-bit matrix pipe
+    # (3 MFMAs per product, ~2^-22: fp32-class; operands scaled into fp16's range by exact powers of two from a bound on
+    # |planes| that the plane-writing kernel publishes), "fp32" = the exact fp32 matrix instructions (5x the pipe time)
+    decoder_precision: str = "f16x3"
     # ---- mapping network (never called by HFA-GP) ---------------
     z_dim: int = 512
     mapping_layers: int = 2
@@ -106,6 +110,7 @@ class GeneratorConfig:
         assert self.depth_resolution_importance % 16 == 0 and self.depth_resolution_importance <= 64
         assert self.plane_channels == 32, "decoder / ray-march kernel are written for 32 features"
         assert self.plane_axes in ("eg3d_original", "eg3d_fixed")
+        assert self.decoder_precision in ("fp32", "f16x3")
 
 
 def ffhq512_128() -> GeneratorConfig:

@@ -260,6 +260,9 @@ __global__ void __launch_bounds__(256) skip_kernel(HfagpSkipArgs a) {
     } else {
         reinterpret_cast<float4*>(a.img_out)[tid] = o;
     }
+    if (a.out_absmax)
+        publish_absmax(a.out_absmax, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))),
+                       blockIdx.x * 4 + (threadIdx.x >> 6));
 }
 
 // ---------------------------------------------------------------- toRGB (few output channels) + skip

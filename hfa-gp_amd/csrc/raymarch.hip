@@ -22,6 +22,7 @@
 //     transmittance / CDF scans are wavefront shuffle scans; the 48+48 merge is a rank count.
 //   * final colour = sum_j omega_j c_j with omega_j = (w_{j-1} + w_j)/2 — algebraically the
 //     midpoint rule of MipRayMarcher2, without forming the 95 midpoint colours.
+#include <type_traits>
 #include "raymarch_common.h"
 
 namespace hfagp {
@@ -42,7 +43,10 @@ struct WaveLds {
 // GRADS = false: the forward renderer.  GRADS = true: first half of the backward pass — the same forward
 // per ray, then the compositing adjoint, emitting one record (depth, omega, d sigma) per sample for
 // raymarch_bwd_tiles_kernel (raymarch_bwd.hip).
-template <int NC, int NF, bool GRADS>
+// DEC16: the decoder MLP on the 16-bit matrix pipe with split fp16 operands (raymarch_common.h decoder_fwd16; needs
+// HfagpRaymarchArgs::planes_absmax) instead of the exact fp32 matrix instructions — which were 0.9 of the 2.0 ms of an
+// 8-frame launch.
+template <int NC, int NF, bool GRADS, bool DEC16>
 __global__ void __launch_bounds__(256, 2) raymarch_kernel(const RayParams p) {
     using L = WaveLds<NC, NF>;
     constexpr int SC = L::SC, SF = L::SF, S = L::S;
@@ -53,8 +57,14 @@ __global__ void __launch_bounds__(256, 2) raymarch_kernel(const RayParams p) {
     const int j = lane & 15, g = lane >> 4;
     const int R = a.res * a.res;
 
-    DecoderRegs dec;
-    load_decoder(a, j, g, dec);
+    typename std::conditional<DEC16, Dec16Regs, DecoderRegs>::type dec;
+    if constexpr (DEC16) {
+        DecoderRegs dec32;
+        load_decoder(a, j, g, dec32);
+        make_dec16(dec32, a.planes_absmax, lane, dec);
+    } else {
+        load_decoder(a, j, g, dec);
+    }
 
     const RaySchedule sch = ray_schedule(p.total_rays, wave);
     for (int seq = __builtin_amdgcn_readfirstlane((int)sch.begin); seq < (int)sch.end; seq += sch.stride) {
@@ -93,7 +103,8 @@ __global__ void __launch_bounds__(256, 2) raymarch_kernel(const RayParams p) {
             }
             f32x4 h[4], o[2];
             float sigma;
-            decoder_fwd<false>(dec, f, h, h, sigma, o);
+            if constexpr (DEC16) decoder_fwd16<false>(dec, f, h, h, sigma, o);
+            else decoder_fwd<false>(dec, f, h, h, sigma, o);
             if (g == 0) lds.sig[s] = sigma;
 #pragma unroll
             for (int ot = 0; ot < 2; ++ot) {
@@ -294,28 +305,34 @@ __global__ void __launch_bounds__(256, 2) raymarch_kernel(const RayParams p) {
     }
 }
 
-template <int NC, int NF, bool GRADS>
+template <int NC, int NF, bool GRADS, bool DEC16>
 static int launch(const RayParams& p, hipStream_t s) {
     const size_t lds = 4 * sizeof(WaveLds<NC, NF>);
     int blocks = (p.total_rays + 3) / 4;
     const int cap = kNumCU * 2 * 4;          // 2 resident workgroups per CU, a few rounds each
     if (blocks > cap) blocks = cap;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&raymarch_kernel<NC, NF, GRADS>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&raymarch_kernel<NC, NF, GRADS, DEC16>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             set_error("raymarch: cannot raise dynamic LDS to %zu bytes: %s", lds, hipGetErrorString(e));
             return HFAGP_ELAUNCH;
         }
     }
-    raymarch_kernel<NC, NF, GRADS><<<blocks, 256, lds, s>>>(p);
+    raymarch_kernel<NC, NF, GRADS, DEC16><<<blocks, 256, lds, s>>>(p);
     return check_launch(GRADS ? "raymarch_bwd/samples" : "raymarch_fwd");
 }
 
-int launch_raymarch(const RayParams& p, bool grads, hipStream_t s) {
+template <bool GRADS, bool DEC16>
+static int launch_n(const RayParams& p, hipStream_t s) {
     const int n = p.a.Sc / 16;
-    if (grads) return n == 3 ? launch<3, 3, true>(p, s) : n == 2 ? launch<2, 2, true>(p, s) : launch<1, 1, true>(p, s);
-    return n == 3 ? launch<3, 3, false>(p, s) : n == 2 ? launch<2, 2, false>(p, s) : launch<1, 1, false>(p, s);
+    return n == 3 ? launch<3, 3, GRADS, DEC16>(p, s) : n == 2 ? launch<2, 2, GRADS, DEC16>(p, s) : launch<1, 1, GRADS, DEC16>(p, s);
+}
+
+int launch_raymarch(const RayParams& p, bool grads, hipStream_t s) {
+    const bool dec16 = p.a.planes_absmax != nullptr;
+    if (grads) return dec16 ? launch_n<true, true>(p, s) : launch_n<true, false>(p, s);
+    return dec16 ? launch_n<false, true>(p, s) : launch_n<false, false>(p, s);
 }
 
 }  // namespace hfagp

@@ -203,8 +203,12 @@ __device__ __forceinline__ void gather8(const HfagpRaymarchArgs& a, int b, int g
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const unsigned off = ((unsigned)taps[pl].idx[k] * 32u + 8u * g) * 4u;      // < 2^32: one plane
+#ifndef HFAGP_ABL_NOGATHER  // (developer ablation: texel loads compiled out)
             v0[k] = *reinterpret_cast<const float4*>(base + off);
             v1[k] = *reinterpret_cast<const float4*>(base + off + 16);
+#else
+            v0[k] = make_float4((float)off, 1.f, 2.f, 3.f); v1[k] = v0[k];
+#endif
         }
         const float v[4][8] = {{v0[0].x, v0[0].y, v0[0].z, v0[0].w, v1[0].x, v1[0].y, v1[0].z, v1[0].w},
                                {v0[1].x, v0[1].y, v0[1].z, v0[1].w, v1[1].x, v1[1].y, v1[1].z, v1[1].w},
@@ -267,8 +271,12 @@ __device__ __forceinline__ void decoder_fwd(const DecoderRegs& w, const float f[
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         h[mt] = f32x4{w.b0c[mt][0], w.b0c[mt][1], w.b0c[mt][2], w.b0c[mt][3]};
+#ifndef HFAGP_ABL_NODEC     // (developer ablation: decoder MFMAs compiled out)
 #pragma unroll
         for (int t = 0; t < 8; ++t) h[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w0a[mt][t], f[t], h[mt], 0, 0, 0);
+#else
+        h[mt][0] += f[mt] + f[mt + 4];
+#endif
     }
     float sg = 0.f;
 #pragma unroll
@@ -288,8 +296,187 @@ __device__ __forceinline__ void decoder_fwd(const DecoderRegs& w, const float f[
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+            for (int r = 0; r < 4; ++r) {
+#ifndef HFAGP_ABL_NODEC
                 o[ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w1a[ot][mt * 4 + r], h[mt][r], o[ot], 0, 0, 0);
+#else
+                o[ot][r] += h[mt][r];
+#endif
+            }
+    }
+}
+
+// ---------------------------------------------------------------- the decoder on the 16-bit matrix pipe
+// v_mfma_f32_16x16x32_f16 with SPLIT operands (fp16 hi + lo parts, products hi.hi + lo.hi + hi.lo: ~2^-22, the F16X3
+// arithmetic of the conv kernels): layer 1 is ONE K step of 32 features (4 M tiles x 3 products = 12 MFMAs instead of
+// 32 fp32 ones at twice the issue time each), layer 2 two K steps of 32 hidden units (12 instead of 32).  The operand
+// layouts are those of the fp32 version: B = the lane's 8 gathered channels k = 8g + c; the C registers of layer 1
+// (rows 16mt + 4g + r) are the B operand of layer 2 with K step ks <-> tiles mt = 2ks, 2ks + 1 (k = 4 (mt & 1) + r) and
+// the weight columns permuted to match.
+// fp16 has 5 exponent bits, so every operand is scaled by an exact power of two into [.., 2^14]: the features by the
+// caller's bound on |planes| (HfagpRaymarchArgs::planes_absmax), the hidden units by max_i (|b0_i| + sum_k |W0_ik| M),
+// the weights by their own maxima; the accumulators are scaled back with one multiply.  Results equal the un-scaled
+// arithmetic; values more than 2^18 below their tensor's bound lose low bits only (absolute error < bound * 2^-40).
+typedef _Float16 f16x8r __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8r __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2r __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2r __attribute__((ext_vector_type(2)));
+typedef float f32x2r __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4r __attribute__((ext_vector_type(4)));
+
+// 8 floats -> hi / lo fp16 parts (each part: 4 dwords of 2 halves), lo = fp16(v - float(hi))
+__device__ __forceinline__ void split8_f16(const float v[8], u32x4r& hi, u32x4r& lo) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x2r x = {v[2 * q], v[2 * q + 1]};
+        const f16x2r hh = __builtin_convertvector(x, f16x2r);
+        const f32x2r r = {v[2 * q] - (float)hh[0], v[2 * q + 1] - (float)hh[1]};
+        hi[q] = __builtin_bit_cast(unsigned, hh);
+        lo[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2r));
+    }
+}
+// the same with bfloat16 parts (gradients: a raw gradient needs fp32's exponent range; ~2^-16 per product)
+__device__ __forceinline__ void split8_bf16(const float v[8], u32x4r& hi, u32x4r& lo) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x2r x = {v[2 * q], v[2 * q + 1]};
+        const unsigned hh = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2r));
+        const f32x2r r = {v[2 * q] - __builtin_bit_cast(float, hh << 16), v[2 * q + 1] - __builtin_bit_cast(float, hh & 0xffff0000u)};
+        hi[q] = hh;
+        lo[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2r));
+    }
+}
+__device__ __forceinline__ f32x4 mfma3_f16(u32x4r ah, u32x4r al, u32x4r bh, u32x4r bl, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8r, ah), __builtin_bit_cast(f16x8r, bh), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8r, al), __builtin_bit_cast(f16x8r, bh), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8r, ah), __builtin_bit_cast(f16x8r, bl), c, 0, 0, 0);
+    return c;
+}
+__device__ __forceinline__ f32x4 mfma3_bf16(u32x4r ah, u32x4r al, u32x4r bh, u32x4r bl, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8r, ah), __builtin_bit_cast(bf16x8r, bh), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8r, al), __builtin_bit_cast(bf16x8r, bh), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8r, ah), __builtin_bit_cast(bf16x8r, bl), c, 0, 0, 0);
+    return c;
+}
+
+// wave-wide max of a non-negative value (all 64 lanes)
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+// 2^-e with e chosen so that bound * 2^-e lies in (2^13, 2^14] (1 when the bound is 0 / not finite)
+__device__ __forceinline__ float down_scale(float bound, float* up) {
+    int e = 14;
+    if (bound > 0.f && bound < 3.0e38f) (void)frexpf(bound, &e);      // bound = f 2^e, f in [0.5, 1)
+    e = max(-60, min(60, e - 14));
+    *up = ldexpf(1.f, e);
+    return ldexpf(1.f, -e);
+}
+
+struct Dec16Regs {
+    u32x4r w0h[4], w0l[4];            // layer 1 A operands (M tile mt): W0[16mt + j][8g + c] * sW0, hi / lo
+    u32x4r w1h[2][2], w1l[2][2];      // layer 2 A operands (colour tile ot, K step ks): W1[1+16ot+j][16(2ks+(c>>2)) + 4g + (c&3)] * sW1
+    float b0c[4][4], wsig[4][4], b1c[2][4];
+    float bsig;
+    float sF, sH;                     // down-scales of the features / hidden units
+    float u1, u2;                     // up-scales of the layer-1 / layer-2 accumulators
+};
+
+// from the fp32 register image + the bound M on |planes| (max over the HFAGP_ABSMAX_SLOTS slots)
+__device__ __forceinline__ void make_dec16(const DecoderRegs& w, const float* planes_absmax, int lane, Dec16Regs& d) {
+    const float M = wave_max(planes_absmax[lane]);
+    float m0 = 0.f, m1 = 0.f, rs = 0.f, hb = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        float row = 0.f;                                   // sum_k |W0[16mt + j][k]| over this lane's 8 columns ...
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            m0 = fmaxf(m0, fabsf(w.w0a[mt][t]));
+            row += fabsf(w.w0a[mt][t]);
+        }
+        row += __shfl_xor(row, 16);                        // ... and over the four column groups g
+        row += __shfl_xor(row, 32);
+        rs = fmaxf(rs, row);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hb = fmaxf(hb, fabsf(w.b0c[mt][r]));
+    }
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) m1 = fmaxf(m1, fabsf(w.w1a[ot][k]));
+    m0 = wave_max(m0); m1 = wave_max(m1); rs = wave_max(rs); hb = wave_max(hb);
+    float uF, uH, uW0, uW1;
+    d.sF = down_scale(M, &uF);
+    d.sH = down_scale(hb + rs * M, &uH);                   // softplus(x) <= |x| + log 2 < bound + 1: the margin of 2^14 covers it
+    const float sW0 = down_scale(m0, &uW0), sW1 = down_scale(m1, &uW1);
+    d.u1 = uF * uW0;
+    d.u2 = uH * uW1;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        float v[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] = w.w0a[mt][t] * sW0;
+        split8_f16(v, d.w0h[mt], d.w0l[mt]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { d.b0c[mt][r] = w.b0c[mt][r]; d.wsig[mt][r] = w.wsig[mt][r]; }
+    }
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            float v[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] = w.w1a[ot][8 * ks + c] * sW1;      // (mt = 2ks + (c>>2), r = c&3) -> index 4mt + r
+            split8_f16(v, d.w1h[ot][ks], d.w1l[ot][ks]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d.b1c[ot][r] = w.b1c[ot][r];
+    }
+    d.bsig = w.bsig;
+}
+
+// drop-in for decoder_fwd: same inputs / outputs / register layouts
+template <bool KEEP_PRE>
+__device__ __forceinline__ void decoder_fwd16(const Dec16Regs& w, const float f[8], f32x4 hp[4], f32x4 h[4],
+                                              float& sigma, f32x4 o[2]) {
+    u32x4r fh, fl;
+    {
+        float fs[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) fs[t] = f[t] * w.sF;
+        split8_f16(fs, fh, fl);
+    }
+    float sg = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const f32x4 acc = mfma3_f16(w.w0h[mt], w.w0l[mt], fh, fl, f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float pre = fmaf(acc[r], w.u1, w.b0c[mt][r]);
+            if (KEEP_PRE) hp[mt][r] = pre;
+            h[mt][r] = softplus_f(pre);
+            sg = fmaf(h[mt][r], w.wsig[mt][r], sg);
+        }
+    }
+    sg += __shfl_xor(sg, 16);
+    sg += __shfl_xor(sg, 32);
+    sigma = sg + w.bsig;
+    u32x4r hh[2], hl[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        float hs[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) hs[c] = h[2 * ks + (c >> 2)][c & 3] * w.sH;
+        split8_f16(hs, hh[ks], hl[ks]);
+    }
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot) {
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) acc = mfma3_f16(w.w1h[ot][ks], w.w1l[ot][ks], hh[ks], hl[ks], acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[ot][r] = fmaf(acc[r], w.u2, w.b1c[ot][r]);
     }
 }
 

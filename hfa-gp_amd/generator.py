@@ -149,6 +149,7 @@ class TriPlaneGenerator(nn.Module):
         self._styles: Dict[int, tuple] = {}      # id(layer) -> (styles, dcoef) of the pass in flight
         self._absmax = None                      # (slot buffers, layer names) of the last pass: f16_range_report()
         self._rgb_part = None                    # partial toRGB sums of the conv just run (fused toRGB, ops.modconv)
+        self._planes_absmax = None               # [64] slots with max |planes| of the pass in flight (16-bit decoder)
         self._scalars: Dict[int, tuple] = {}     # id(param) -> (version, data_ptr, python float)
         self._const_nhwc: Optional[tuple] = None
         self.timing: Optional[Dict[str, list]] = None   # bench.py: {'raymarch': [(ev0, ev1, units)], 'modconv': [...]}
@@ -380,7 +381,10 @@ class TriPlaneGenerator(nn.Module):
             wt, _ = self._prepared(tr.weight)
             y = ops.modconv(x, wt, tr.weight.shape[0], ops.CONV1X1, styles=styles, bias=tr.bias, act="linear",
                             gain=1.0, clamp=conv_clamp, batch=batch, x_absmax=am1)
-            img = ops.skip_upsample_add(img, y, plane_major=last)
+            # the block that writes the tri-planes also publishes max |planes|: the bound the ray marcher's 16-bit
+            # decoder scales its operands by (ops.raymarch planes_absmax)
+            self._planes_absmax = ops.absmax_slots(1, x.device)[0] if last else None
+            img = ops.skip_upsample_add(img, y, plane_major=last, out_absmax=self._planes_absmax)
         if tape is not None:
             rec["rgb"] = dict(torgb=tr, x=x, styles=styles, row=row, small=small_rgb, clamp=conv_clamp,
                               y=y if conv_clamp is not None else None, y_pre=y_pre)
@@ -458,7 +462,8 @@ class TriPlaneGenerator(nn.Module):
                     dec_w0=net["0"].weight, dec_b0=net["0"].bias, dec_w1=net["2"].weight, dec_b1=net["2"].bias,
                     res=cfg.neural_rendering_resolution, ray_start=cfg.ray_start, ray_end=cfg.ray_end,
                     box_warp=cfg.box_warp, decoder_lr_mul=cfg.decoder_lr_mul,
-                    plane_axes=0 if cfg.plane_axes == "eg3d_original" else 1, white_back=cfg.white_back)
+                    plane_axes=0 if cfg.plane_axes == "eg3d_original" else 1, white_back=cfg.white_back,
+                    decoder_precision=cfg.decoder_precision)
 
     def _uniforms(self, b: int, dev, u_strat, u_imp):
         cfg = self.cfg
@@ -469,7 +474,7 @@ class TriPlaneGenerator(nn.Module):
             u_imp = torch.rand(b * r, cfg.depth_resolution_importance, device=dev)
         return u_strat.reshape(b, r, -1).contiguous(), u_imp.contiguous()
 
-    def render(self, planes: torch.Tensor, c: torch.Tensor, u_strat=None, u_imp=None):
+    def render(self, planes: torch.Tensor, c: torch.Tensor, u_strat=None, u_imp=None, planes_absmax=None):
         cfg = self.cfg
         b = planes.shape[0]
         r = cfg.neural_rendering_resolution ** 2
@@ -479,7 +484,7 @@ class TriPlaneGenerator(nn.Module):
         s_tot = cfg.depth_resolution + cfg.depth_resolution_importance
         nbytes = float(b) * r * (s_tot * 3 * 4 * 32 * 4 + 34 * 4 + s_tot * 4)
         return self._timed("raymarch", nbytes, ops.raymarch, planes, u_strat=u_strat, u_imp=u_imp,
-                           **self._render_args(c))
+                           planes_absmax=planes_absmax, **self._render_args(c))
 
     def superres(self, rgb_raw: torch.Tensor, feat_img: torch.Tensor, ws: torch.Tensor, tape=None) -> torch.Tensor:
         cfg = self.cfg
@@ -522,7 +527,8 @@ class TriPlaneGenerator(nn.Module):
         sr_tape = [] if tape is not None else None
         planes = self.backbone_planes(ws, bb_tape)
         u_strat, u_imp = self._uniforms(b, ws.device, u_strat, u_imp)
-        feat, depth, wsum, tmm = self.render(planes, c, u_strat, u_imp)
+        pam = getattr(self, "_planes_absmax", None)
+        feat, depth, wsum, tmm = self.render(planes, c, u_strat, u_imp, planes_absmax=pam)
         # MipRayMarcher2 clamps the expected depth to the GLOBAL min/max sample depth of the batch
         depth = torch.clamp(depth, tmm[..., 0].min(), tmm[..., 1].max())
         feat_img = feat.view(b, res, res, 32)                             # channels-last
@@ -530,7 +536,7 @@ class TriPlaneGenerator(nn.Module):
         img = self.superres(rgb_raw, feat_img, ws, sr_tape)
         if tape is not None:
             tape.update(backbone=bb_tape, sr=sr_tape, planes=planes, c=c, u_strat=u_strat, u_imp=u_imp,
-                        feat_img=feat_img, batch=b)
+                        feat_img=feat_img, batch=b, planes_absmax=pam)
         return img, rgb_raw, depth.view(b, 1, res, res), planes, feat_img
 
     def synthesis(self, ws: torch.Tensor, c: torch.Tensor, noise_mode: str = "const",

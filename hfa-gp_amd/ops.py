@@ -315,8 +315,10 @@ def upfir_epilogue(yt: torch.Tensor, dcoef: Optional[torch.Tensor], noise: Optio
     return y
 
 
-def skip_upsample_add(img: Optional[torch.Tensor], y: torch.Tensor, plane_major: bool = False) -> torch.Tensor:
-    """SynthesisBlock 'skip': upsample2d(img) + y (channels-last).  plane_major → [B,3,H,W,C/3]."""
+def skip_upsample_add(img: Optional[torch.Tensor], y: torch.Tensor, plane_major: bool = False,
+                      out_absmax: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """SynthesisBlock 'skip': upsample2d(img) + y (channels-last).  plane_major → [B,3,H,W,C/3].  out_absmax ([64],
+    `absmax_slots`): receives max |output| (the bound the ray marcher's 16-bit decoder scales by)."""
     _chk(y, "y")
     b, ho, wo, c = y.shape
     a = L.SkipArgs()
@@ -328,6 +330,7 @@ def skip_upsample_add(img: Optional[torch.Tensor], y: torch.Tensor, plane_major:
     out = torch.empty((b, 3, ho, wo, c // 3) if plane_major else (b, ho, wo, c), device=y.device,
                       dtype=torch.float32)
     a.y, a.img_out, a.B, a.C, a.plane_major = _ptr(y), _ptr(out), b, c, int(plane_major)
+    a.out_absmax = _ptr(out_absmax)
     L.check(L.lib().hfagp_skip_upsample_add(C.byref(a), _stream()), "skip_upsample_add")
     return out
 
@@ -355,8 +358,12 @@ def torgb_small(x: torch.Tensor, weight: torch.Tensor, styles: torch.Tensor, bia
 def raymarch(planes: torch.Tensor, cam2world: torch.Tensor, intrinsics: torch.Tensor, u_strat: torch.Tensor,
              u_imp: torch.Tensor, dec_w0: torch.Tensor, dec_b0: torch.Tensor, dec_w1: torch.Tensor,
              dec_b1: torch.Tensor, res: int, ray_start: float, ray_end: float, box_warp: float,
-             decoder_lr_mul: float = 1.0, plane_axes: int = 0, white_back: bool = False):
-    """planes [B,3,H,W,32] → feat [B,R,32], depth [B,R] (unclamped), wsum [B,R], tminmax [B,R,2]."""
+             decoder_lr_mul: float = 1.0, plane_axes: int = 0, white_back: bool = False,
+             decoder_precision: str = "f16x3", planes_absmax: Optional[torch.Tensor] = None):
+    """planes [B,3,H,W,32] → feat [B,R,32], depth [B,R] (unclamped), wsum [B,R], tminmax [B,R,2].
+    decoder_precision 'f16x3': the decoder MLP on the 16-bit matrix pipe with split fp16 operands (fp32-class); it needs
+    a bound on |planes| — `planes_absmax` ([64] slots as published by `skip_upsample_add(out_absmax=...)`), computed here
+    with one reduction over the planes when the caller has none.  'fp32': the exact fp32 matrix instructions."""
     _chk(planes, "planes")
     b, three, h, w, ch = planes.shape
     if three != 3 or ch != 32:
@@ -379,8 +386,20 @@ def raymarch(planes: torch.Tensor, cam2world: torch.Tensor, intrinsics: torch.Te
     a.B, a.H, a.W, a.res, a.Sc, a.Sf = b, h, w, res, sc, sf
     a.plane_axes, a.white_back = plane_axes, int(white_back)
     a.ray_start, a.ray_end, a.box_warp, a.decoder_lr_mul = ray_start, ray_end, box_warp, decoder_lr_mul
+    a.planes_absmax = _ptr(_decoder_bound(planes, decoder_precision, planes_absmax))
     L.check(L.lib().hfagp_raymarch_fwd(C.byref(a), _stream()), "raymarch_fwd")
     return feat, depth, wsum, tmm
+
+
+def _decoder_bound(planes: torch.Tensor, decoder_precision: str, planes_absmax: Optional[torch.Tensor]):
+    """The [64]-slot bound on |planes| of the 16-bit decoder (None for the exact fp32 decoder)."""
+    if decoder_precision == "fp32":
+        return None
+    if decoder_precision != "f16x3":
+        raise ValueError(f"decoder_precision must be 'fp32' or 'f16x3', got {decoder_precision!r}")
+    if planes_absmax is None:
+        planes_absmax = planes.abs().amax().expand(L.ABSMAX_SLOTS).contiguous()
+    return _chk(planes_absmax, "planes_absmax")
 
 
 # ----------------------------------------------------------------------------- standalone ops (NCHW)
@@ -616,7 +635,8 @@ def channel_sum(g: torch.Tensor, out: torch.Tensor, accumulate: bool = True) -> 
 def raymarch_bwd(g_feat: torch.Tensor, planes: torch.Tensor, cam2world, intrinsics, u_strat, u_imp, dec_w0, dec_b0,
                  dec_w1, dec_b1, res: int, ray_start: float, ray_end: float, box_warp: float,
                  decoder_lr_mul: float = 1.0, plane_axes: int = 0, white_back: bool = False,
-                 return_rec: bool = False, decoder_grads: bool = False):
+                 return_rec: bool = False, decoder_grads: bool = False, decoder_precision: str = "f16x3",
+                 planes_absmax: Optional[torch.Tensor] = None):
     """g_feat [B,R,32] → d planes [B,3,H,W,32] (fp32 atomics into a zero-initialised buffer)."""
     _chk(planes, "planes")
     _chk(g_feat, "g_feat")
@@ -633,6 +653,7 @@ def raymarch_bwd(g_feat: torch.Tensor, planes: torch.Tensor, cam2world, intrinsi
     f.B, f.H, f.W, f.res, f.Sc, f.Sf = b, h, w, res, sc, sf
     f.plane_axes, f.white_back = plane_axes, int(white_back)
     f.ray_start, f.ray_end, f.box_warp, f.decoder_lr_mul = ray_start, ray_end, box_warp, decoder_lr_mul
+    f.planes_absmax = _ptr(_decoder_bound(planes, decoder_precision, planes_absmax))
     a.g_feat, a.d_planes, a.rec = _ptr(g_feat), _ptr(d_planes), _ptr(rec)
     dec = None
     if decoder_grads:

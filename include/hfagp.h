@@ -72,6 +72,12 @@ typedef struct {
     int32_t white_back;
     double ray_start, ray_end;/* python floats of rendering_kwargs (kept double: linspace/delta rounding) */
     float box_warp, decoder_lr_mul;
+    /* optional: HFAGP_ABSMAX_SLOTS floats whose maximum bounds |planes| (published by the kernel that wrote the planes,
+     * hfagp_skip_upsample_add, or any upper bound).  With it the decoder MLP runs on the 16-bit matrix pipe with split
+     * operands (fp16 hi + lo parts, 3 MFMAs per product as HFAGP_PREC_F16X3: ~2^-22, fp32-class; gradients: bf16 parts),
+     * every operand scaled into fp16's range by an exact power of two derived from this bound and the weights.
+     * NULL: the decoder runs on the exact fp32 matrix instructions (5x the matrix-pipe time).                      */
+    const float* planes_absmax;
 } HfagpRaymarchArgs;
 
 int hfagp_raymarch_fwd(const HfagpRaymarchArgs* a, void* stream);
@@ -226,6 +232,7 @@ typedef struct {
     float*       img_out;
     int32_t B, H, W, C;       /* H, W = resolution of img_in */
     int32_t plane_major;
+    float*       out_absmax;  /* optional [HFAGP_ABSMAX_SLOTS]: receives max |img_out| (HfagpRaymarchArgs::planes_absmax) */
 } HfagpSkipArgs;
 
 int hfagp_skip_upsample_add(const HfagpSkipArgs* a, void* stream);

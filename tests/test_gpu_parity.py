@@ -361,7 +361,34 @@ def test_raymarch_vs_oracle(dev, preset):
     from hfa_gp_amd.config import PRESETS
     cfg = dataclasses.replace(PRESETS[preset](), neural_rendering_resolution=12, img_resolution=48)
     c = look_at_label(torch.tensor([1.2, 1.9]), torch.tensor([1.4, 1.75]))
-    _render_case(dev, cfg, c)
+    _render_case(dev, cfg, c)                                                            # decoder on split fp16 MFMAs (default)
+    _render_case(dev, dataclasses.replace(cfg, decoder_precision="fp32"), c)             # exact fp32 matrix instructions
+    # the 16-bit decoder below fp16's normal range: planes of 1e-6
+    _render_case(dev, cfg, c, planes_scale=1e-6)
+
+
+def test_decoder16_far_beyond_fp16_range(dev):
+    """Planes of 1e5 put the hidden units at ~1e6, far beyond fp16's 65504: the split-fp16 decoder scales every operand
+    by an exact power of two from the published bound, so nothing overflows.  In that regime the renderer itself is
+    ill-conditioned (saturated colours, densities of 1e5: the importance pdf is a spike and a rounding difference moves
+    samples across bins), so the comparison with the exact-fp32 decoder is statistical: finite everywhere, identical for
+    the typical ray, close for 99 % of them."""
+    import dataclasses
+    from hfa_gp_amd.config import tiny64
+    from hfa_gp_amd.generator import TriPlaneGenerator
+    cfg = dataclasses.replace(tiny64(), neural_rendering_resolution=12, img_resolution=48)
+    c = look_at_label(torch.tensor([1.2, 1.9]), torch.tensor([1.4, 1.75])).to(dev)
+    g = torch.Generator().manual_seed(1)
+    pl = (1e5 * torch.randn(2, 3, 24, 24, 32, generator=g)).to(dev)
+    us = torch.rand(2, 144, cfg.depth_resolution, generator=g).to(dev)
+    ui = torch.rand(2 * 144, cfg.depth_resolution_importance, generator=g).to(dev)
+    outs = {}
+    for prec in ("f16x3", "fp32"):
+        gen = perturb_state(TriPlaneGenerator(dataclasses.replace(cfg, decoder_precision=prec), seed=0)).to(dev)
+        outs[prec] = gen.render(pl, c, us, ui)[0]
+    assert torch.isfinite(outs["f16x3"]).all()
+    d = (outs["f16x3"] - outs["fp32"]).abs().flatten()
+    assert d.median().item() < 1e-6 and d.kthvalue(int(0.99 * d.numel())).values.item() < 5e-3, (d.median(), d.max())
 
 
 def test_raymarch_edge_cases(dev):
