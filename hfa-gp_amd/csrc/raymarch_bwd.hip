@@ -39,7 +39,9 @@ struct DecGrads { float *w0, *b0, *w1, *b1; };   // [64][32], [64], [33][64], [3
 // 4 with them (PG: 13 KB more per wave, one workgroup per CU).
 template <bool PG> struct BwdWaves { static constexpr int value = PG ? 4 : 6; };
 
-template <int S, bool PG, bool MIRROR>
+// DEC16: decoder forward (split fp16) and backward (split bf16) on the 16-bit matrix pipe (raymarch_common.h; needs
+// HfagpRaymarchArgs::planes_absmax): 48 MFMAs of ~17 cycles per tile instead of 128 fp32 ones of 32.
+template <int S, bool PG, bool MIRROR, bool DEC16>
 __global__ void __launch_bounds__(BwdWaves<PG>::value * 64, PG ? 1 : 2)
 raymarch_bwd_tiles_kernel(const RayParams p, float* __restrict__ d_planes, const DecGrads dg) {
     constexpr int NWB = BwdWaves<PG>::value, NTHB = NWB * 64;
@@ -62,9 +64,18 @@ raymarch_bwd_tiles_kernel(const RayParams p, float* __restrict__ d_planes, const
     if (wave == 0) {
         DecoderRegs dec;
         load_decoder(a, j, g, dec);
-        store_decoder_lds(dec, wfwd, lane);
+        if constexpr (DEC16) {
+            Dec16Regs d16;
+            make_dec16(dec, a.planes_absmax, lane, d16);
+            store_dec16_lds(d16, wfwd, lane);
+        } else {
+            store_decoder_lds(dec, wfwd, lane);
+        }
     }
-    {
+    if constexpr (DEC16) {
+        build_grad16_lds(a, w1t, w0t, lane, wave, NWB);
+        __syncthreads();
+    } else {
         const float g0 = a.decoder_lr_mul * 0.17677669529663687f, g1 = a.decoder_lr_mul * 0.125f;
         for (int i = threadIdx.x; i < 4 * 8 * 64; i += NTHB) {
             const int l = i & 63, st = (i >> 6) & 7, mt = i >> 9, jj = l & 15, gg = l >> 4;
@@ -120,7 +131,8 @@ raymarch_bwd_tiles_kernel(const RayParams p, float* __restrict__ d_planes, const
         }
         f32x4 hp[4], h[4], o[2];
         float sigma;
-        decoder_fwd_lds<true>(wfwd, lane, f, hp, h, sigma, o);
+        if constexpr (DEC16) decoder_fwd16_lds<true>(wfwd, lane, f, hp, h, sigma, o);
+        else decoder_fwd_lds<true>(wfwd, lane, f, hp, h, sigma, o);
 
         // dL/do (colour logits) in the C layout: lane (j, g), register r of tile ot -> channel 16ot + 4g + r
         //   colour = sigmoid(o) * 1.002 - 0.001,  dL/dcolour = omega * 2 dL/dfeat
@@ -137,8 +149,10 @@ raymarch_bwd_tiles_kernel(const RayParams p, float* __restrict__ d_planes, const
         }
         // dH^T = W1c^T . dO^T + wsig (x) dsigma:  A[i][k] = W1[1 + c(k)][16mt + i],  c(k) = 16ot + 4g + r
         f32x4 dH[4];
+        f32x4 dF[2];
+        if constexpr (DEC16) decoder_bwd16_lds(wfwd, w1t, w0t, lane, dO, rec.z, hp, dH, dF);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
+        for (int mt = 0; mt < (DEC16 ? 0 : 4); ++mt) {
             const float* ws_ = wfwd + (48 + mt * 4) * 64 + lane;
             dH[mt] = f32x4{ws_[0] * rec.z, ws_[64] * rec.z, ws_[128] * rec.z, ws_[192] * rec.z};
 #pragma unroll
@@ -152,17 +166,18 @@ raymarch_bwd_tiles_kernel(const RayParams p, float* __restrict__ d_planes, const
             for (int r = 0; r < 4; ++r) dH[mt][r] *= sigmoid_f(hp[mt][r]);      // softplus' = sigmoid
         }
         // dF^T = W0^T . dHpre^T:  A[i][k] = W0[16mt + 4g + r][16ft + i]
-        f32x4 dF[2];
 #pragma unroll
         for (int ft = 0; ft < 2; ++ft) {
-            dF[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (!DEC16) {
+                dF[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+                for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float wA = w0t[(ft * 16 + mt * 4 + r) * 64 + lane];
-                    dF[ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(wA, dH[mt][r], dF[ft], 0, 0, 0);
-                }
+                    for (int r = 0; r < 4; ++r) {
+                        const float wA = w0t[(ft * 16 + mt * 4 + r) * 64 + lane];
+                        dF[ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(wA, dH[mt][r], dF[ft], 0, 0, 0);
+                    }
+            }
             // lane (j, g), register r -> feature channel 16ft + 4g + r of sample j
             *reinterpret_cast<float4*>(&lds.df[j * 32 + 16 * ft + 4 * g]) =
                 make_float4(dF[ft][0], dF[ft][1], dF[ft][2], dF[ft][3]);
@@ -351,7 +366,7 @@ struct ColTileLds {
     __attribute__((aligned(16))) int4  upd[2 * 16];        // plane (x,z): [zrow][sample] = (row | -1, x0, bits(w0), bits(w1))
 };
 
-template <int S>
+template <int S, bool DEC16>
 __global__ void __launch_bounds__(kColWaves * 64, 1)
 raymarch_bwd_cols_kernel(const RayParams p, float* __restrict__ d_planes, const int nchunks, const int chunks_per_col) {
     constexpr int NT = S / 16, RPR = kColWaves / NT;       // tiles per ray, rays per round
@@ -373,9 +388,17 @@ raymarch_bwd_cols_kernel(const RayParams p, float* __restrict__ d_planes, const 
     if (wave == 0) {
         DecoderRegs dec;
         load_decoder(a, j, g, dec);
-        store_decoder_lds(dec, wfwd, lane);
+        if constexpr (DEC16) {
+            Dec16Regs d16;
+            make_dec16(dec, a.planes_absmax, lane, d16);
+            store_dec16_lds(d16, wfwd, lane);
+        } else {
+            store_decoder_lds(dec, wfwd, lane);
+        }
     }
-    {
+    if constexpr (DEC16) {
+        build_grad16_lds(a, w1t, w0t, lane, wave, kColWaves);
+    } else {
         const float g0 = a.decoder_lr_mul * 0.17677669529663687f, g1 = a.decoder_lr_mul * 0.125f;
         for (int i = threadIdx.x; i < 4 * 8 * 64; i += kColWaves * 64) {
             const int l = i & 63, st = (i >> 6) & 7, mt = i >> 9, jj = l & 15, gg = l >> 4;
@@ -420,7 +443,8 @@ raymarch_bwd_cols_kernel(const RayParams p, float* __restrict__ d_planes, const 
                 }
                 f32x4 hp[4], h[4], o[2];
                 float sigma;
-                decoder_fwd_lds<true>(wfwd, lane, f, hp, h, sigma, o);
+                if constexpr (DEC16) decoder_fwd16_lds<true>(wfwd, lane, f, hp, h, sigma, o);
+                else decoder_fwd_lds<true>(wfwd, lane, f, hp, h, sigma, o);
                 f32x4 dO[2];
 #pragma unroll
                 for (int ot = 0; ot < 2; ++ot) {
@@ -433,8 +457,10 @@ raymarch_bwd_cols_kernel(const RayParams p, float* __restrict__ d_planes, const 
                     }
                 }
                 f32x4 dH[4];
+                f32x4 dF2[2];
+                if constexpr (DEC16) decoder_bwd16_lds(wfwd, w1t, w0t, lane, dO, rec.z, hp, dH, dF2);
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
+                for (int mt = 0; mt < (DEC16 ? 0 : 4); ++mt) {
                     const float* ws_ = wfwd + (48 + mt * 4) * 64 + lane;
                     dH[mt] = f32x4{ws_[0] * rec.z, ws_[64] * rec.z, ws_[128] * rec.z, ws_[192] * rec.z};
 #pragma unroll
@@ -450,13 +476,17 @@ raymarch_bwd_cols_kernel(const RayParams p, float* __restrict__ d_planes, const 
 #pragma unroll
                 for (int ft = 0; ft < 2; ++ft) {
                     f32x4 dF = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if constexpr (DEC16) {
+                        dF = dF2[ft];
+                    } else {
 #pragma unroll
-                    for (int mt = 0; mt < 4; ++mt)
+                        for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float wA = w0t[(ft * 16 + mt * 4 + r) * 64 + lane];
-                            dF = __builtin_amdgcn_mfma_f32_16x16x4f32(wA, dH[mt][r], dF, 0, 0, 0);
-                        }
+                            for (int r = 0; r < 4; ++r) {
+                                const float wA = w0t[(ft * 16 + mt * 4 + r) * 64 + lane];
+                                dF = __builtin_amdgcn_mfma_f32_16x16x4f32(wA, dH[mt][r], dF, 0, 0, 0);
+                            }
+                    }
                     *reinterpret_cast<float4*>(&lds.df[j * 32 + 16 * ft + 4 * g]) = make_float4(dF[0], dF[1], dF[2], dF[3]);
                 }
                 if (g == 0) {
@@ -624,16 +654,23 @@ __global__ void __launch_bounds__(256) mirror_plane_kernel(float* __restrict__ d
     dst[c4] = src[c4];
 }
 
+template <int S, bool DEC16>
+static void launch_tiles2(bool pg, bool mirror, unsigned blocks, const RayParams& p, float* d_planes, const DecGrads& dg,
+                          hipStream_t s) {
+    if (pg) {
+        if (mirror) raymarch_bwd_tiles_kernel<S, true, true, DEC16><<<blocks, BwdWaves<true>::value * 64, 0, s>>>(p, d_planes, dg);
+        else raymarch_bwd_tiles_kernel<S, true, false, DEC16><<<blocks, BwdWaves<true>::value * 64, 0, s>>>(p, d_planes, dg);
+    } else {
+        if (mirror) raymarch_bwd_tiles_kernel<S, false, true, DEC16><<<blocks, BwdWaves<false>::value * 64, 0, s>>>(p, d_planes, dg);
+        else raymarch_bwd_tiles_kernel<S, false, false, DEC16><<<blocks, BwdWaves<false>::value * 64, 0, s>>>(p, d_planes, dg);
+    }
+}
+
 template <int S>
 static void launch_tiles(bool pg, bool mirror, unsigned blocks, const RayParams& p, float* d_planes, const DecGrads& dg,
                          hipStream_t s) {
-    if (pg) {
-        if (mirror) raymarch_bwd_tiles_kernel<S, true, true><<<blocks, BwdWaves<true>::value * 64, 0, s>>>(p, d_planes, dg);
-        else raymarch_bwd_tiles_kernel<S, true, false><<<blocks, BwdWaves<true>::value * 64, 0, s>>>(p, d_planes, dg);
-    } else {
-        if (mirror) raymarch_bwd_tiles_kernel<S, false, true><<<blocks, BwdWaves<false>::value * 64, 0, s>>>(p, d_planes, dg);
-        else raymarch_bwd_tiles_kernel<S, false, false><<<blocks, BwdWaves<false>::value * 64, 0, s>>>(p, d_planes, dg);
-    }
+    if (p.a.planes_absmax) launch_tiles2<S, true>(pg, mirror, blocks, p, d_planes, dg, s);
+    else launch_tiles2<S, false>(pg, mirror, blocks, p, d_planes, dg, s);
 }
 
 static size_t cols_lds_bytes() {
@@ -641,17 +678,24 @@ static size_t cols_lds_bytes() {
            (size_t)(4 * 8 * 64 + 2 * 16 * 64 + kDecLdsRows * 64) * sizeof(float) + kColWaves * sizeof(ColTileLds);
 }
 
-template <int S>
-static int launch_cols(unsigned blocks, size_t lds, const RayParams& p, float* d_planes, int nchunks, int chunks_per_col,
-                       hipStream_t s) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&raymarch_bwd_cols_kernel<S>),
+template <int S, bool DEC16>
+static int launch_cols2(unsigned blocks, size_t lds, const RayParams& p, float* d_planes, int nchunks, int chunks_per_col,
+                        hipStream_t s) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&raymarch_bwd_cols_kernel<S, DEC16>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
         set_error("raymarch_bwd: cannot raise dynamic LDS to %zu bytes: %s", lds, hipGetErrorString(e));
         return HFAGP_ELAUNCH;
     }
-    raymarch_bwd_cols_kernel<S><<<blocks, kColWaves * 64, lds, s>>>(p, d_planes, nchunks, chunks_per_col);
+    raymarch_bwd_cols_kernel<S, DEC16><<<blocks, kColWaves * 64, lds, s>>>(p, d_planes, nchunks, chunks_per_col);
     return HFAGP_OK;
+}
+
+template <int S>
+static int launch_cols(unsigned blocks, size_t lds, const RayParams& p, float* d_planes, int nchunks, int chunks_per_col,
+                       hipStream_t s) {
+    return p.a.planes_absmax ? launch_cols2<S, true>(blocks, lds, p, d_planes, nchunks, chunks_per_col, s)
+                             : launch_cols2<S, false>(blocks, lds, p, d_planes, nchunks, chunks_per_col, s);
 }
 
 }  // namespace hfagp

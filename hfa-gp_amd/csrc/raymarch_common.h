@@ -480,9 +480,167 @@ __device__ __forceinline__ void decoder_fwd16(const Dec16Regs& w, const float f[
     }
 }
 
+// ---- LDS images for the backward kernels (lane-linear rows of 64 dwords: every ds_read_b32 is conflict-free)
+// Dec16Regs image: rows 0-15 w0h[mt][q], 16-31 w0l, 32-47 w1h[ot][ks][q], 48-63 w1l, 64-79 b0c[mt][r], 80-95 wsig[mt][r],
+// 96-103 b1c[ot][r], 104 bsig, 105 sF, 106 sH, 107 u1, 108 u2
+constexpr int kDec16LdsRows = 109, kDec16Wsig = 80;
+__device__ __forceinline__ void store_dec16_lds(const Dec16Regs& w, float* imgf, int lane) {
+    unsigned* img = reinterpret_cast<unsigned*>(imgf);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            img[(mt * 4 + q) * 64 + lane] = w.w0h[mt][q];
+            img[(16 + mt * 4 + q) * 64 + lane] = w.w0l[mt][q];
+            imgf[(64 + mt * 4 + q) * 64 + lane] = w.b0c[mt][q];
+            imgf[(kDec16Wsig + mt * 4 + q) * 64 + lane] = w.wsig[mt][q];
+        }
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                img[(32 + (ot * 2 + ks) * 4 + q) * 64 + lane] = w.w1h[ot][ks][q];
+                img[(48 + (ot * 2 + ks) * 4 + q) * 64 + lane] = w.w1l[ot][ks][q];
+            }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) imgf[(96 + ot * 4 + r) * 64 + lane] = w.b1c[ot][r];
+    }
+    imgf[104 * 64 + lane] = w.bsig;
+    imgf[105 * 64 + lane] = w.sF;
+    imgf[106 * 64 + lane] = w.sH;
+    imgf[107 * 64 + lane] = w.u1;
+    imgf[108 * 64 + lane] = w.u2;
+}
+
+__device__ __forceinline__ u32x4r lds_row4(const float* imgf, int row0, int lane) {
+    const unsigned* img = reinterpret_cast<const unsigned*>(imgf) + lane;
+    return u32x4r{img[row0 * 64], img[(row0 + 1) * 64], img[(row0 + 2) * 64], img[(row0 + 3) * 64]};
+}
+
+template <bool KEEP_PRE>
+__device__ __forceinline__ void decoder_fwd16_lds(const float* imgf, int lane, const float f[8], f32x4 hp[4], f32x4 h[4],
+                                                  float& sigma, f32x4 o[2]) {
+    const float* W = imgf + lane;
+    const float sF = W[105 * 64], sH = W[106 * 64], u1 = W[107 * 64], u2 = W[108 * 64];
+    u32x4r fh, fl;
+    {
+        float fs[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) fs[t] = f[t] * sF;
+        split8_f16(fs, fh, fl);
+    }
+    float sg = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const f32x4 acc = mfma3_f16(lds_row4(imgf, mt * 4, lane), lds_row4(imgf, 16 + mt * 4, lane), fh, fl,
+                                    f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float pre = fmaf(acc[r], u1, W[(64 + mt * 4 + r) * 64]);
+            if (KEEP_PRE) hp[mt][r] = pre;
+            h[mt][r] = softplus_f(pre);
+            sg = fmaf(h[mt][r], W[(kDec16Wsig + mt * 4 + r) * 64], sg);
+        }
+    }
+    sg += __shfl_xor(sg, 16);
+    sg += __shfl_xor(sg, 32);
+    sigma = sg + W[104 * 64];
+    u32x4r hh[2], hl[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        float hs[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) hs[c] = h[2 * ks + (c >> 2)][c & 3] * sH;
+        split8_f16(hs, hh[ks], hl[ks]);
+    }
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot) {
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            acc = mfma3_f16(lds_row4(imgf, 32 + (ot * 2 + ks) * 4, lane), lds_row4(imgf, 48 + (ot * 2 + ks) * 4, lane),
+                            hh[ks], hl[ks], acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[ot][r] = fmaf(acc[r], u2, W[(96 + ot * 4 + r) * 64]);
+    }
+}
+
+// Gradient A operands (split bf16: a gradient needs fp32's exponent range; ~2^-16 per product is ample for a gradient):
+//   g1img rows mt*4+q (hi), 16+mt*4+q (lo):        A[16mt + j][k = (g, c)] = W1[1 + 16(c>>2) + 4g + (c&3)][16mt + j] * g1
+//   g0img rows (ft*2+ks)*4+q (hi), 16+... (lo):    A[16ft + j][k = (g, c)] = W0[16(2ks + (c>>2)) + 4g + (c&3)][16ft + j] * g0
+// built by whichever waves the block has (`wave` of `nwaves`)
+__device__ __forceinline__ void build_grad16_lds(const HfagpRaymarchArgs& a, float* g1img, float* g0img, int lane, int wave,
+                                                 int nwaves) {
+    const int j = lane & 15, g = lane >> 4;
+    const float g0 = a.decoder_lr_mul * 0.17677669529663687f, g1 = a.decoder_lr_mul * 0.125f;
+    unsigned* i1 = reinterpret_cast<unsigned*>(g1img);
+    unsigned* i0 = reinterpret_cast<unsigned*>(g0img);
+    for (int t = wave; t < 8; t += nwaves) {
+        float v[8];
+        u32x4r hi, lo;
+        if (t < 4) {
+            const int mt = t;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] = a.dec_w1[(1 + 16 * (c >> 2) + 4 * g + (c & 3)) * 64 + 16 * mt + j] * g1;
+            split8_bf16(v, hi, lo);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { i1[(mt * 4 + q) * 64 + lane] = hi[q]; i1[(16 + mt * 4 + q) * 64 + lane] = lo[q]; }
+        } else {
+            const int ft = (t - 4) >> 1, ks = (t - 4) & 1;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] = a.dec_w0[(16 * (2 * ks + (c >> 2)) + 4 * g + (c & 3)) * 32 + 16 * ft + j] * g0;
+            split8_bf16(v, hi, lo);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                i0[((ft * 2 + ks) * 4 + q) * 64 + lane] = hi[q];
+                i0[(16 + (ft * 2 + ks) * 4 + q) * 64 + lane] = lo[q];
+            }
+        }
+    }
+}
+
+// decoder backward on the 16-bit pipe: dH (pre-activation gradient, C layout of the hidden tiles) and dF (C layout of the
+// two feature tiles) from dO (colour-logit gradients), d sigma, the saved pre-activations
+__device__ __forceinline__ void decoder_bwd16_lds(const float* dimg, const float* g1img, const float* g0img, int lane,
+                                                  const f32x4 dO[2], float dsig, const f32x4 hp[4], f32x4 dH[4], f32x4 dF[2]) {
+    u32x4r oh, ol;
+    {
+        float v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = dO[c >> 2][c & 3];
+        split8_bf16(v, oh, ol);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const float* ws_ = dimg + (kDec16Wsig + mt * 4) * 64 + lane;
+        dH[mt] = f32x4{ws_[0] * dsig, ws_[64] * dsig, ws_[128] * dsig, ws_[192] * dsig};
+        dH[mt] = mfma3_bf16(lds_row4(g1img, mt * 4, lane), lds_row4(g1img, 16 + mt * 4, lane), oh, ol, dH[mt]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dH[mt][r] *= sigmoid_f(hp[mt][r]);      // softplus' = sigmoid
+    }
+    u32x4r dh[2], dl[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        float v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = dH[2 * ks + (c >> 2)][c & 3];
+        split8_bf16(v, dh[ks], dl[ks]);
+    }
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft) {
+        dF[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            dF[ft] = mfma3_bf16(lds_row4(g0img, (ft * 2 + ks) * 4, lane), lds_row4(g0img, 16 + (ft * 2 + ks) * 4, lane),
+                                dh[ks], dl[ks], dF[ft]);
+    }
+}
+
 // The same decoder with the A operands read from an LDS image [105][64] of DecoderRegs (lane-linear, so every
 // ds_read_b32 is conflict-free): used where the registers are needed for the backward products.
-constexpr int kDecLdsRows = 105;
+constexpr int kDecLdsRows = 109;          // (109: the 16-bit image, kDec16LdsRows, shares the buffer)
 __device__ __forceinline__ void store_decoder_lds(const DecoderRegs& w, float* img, int lane) {
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {

@@ -250,7 +250,10 @@ def test_full_size_backward_properties(dev, full_gen):
     assert torch.isfinite(full).all() and full.abs().max() > 0
     one = grad([1])
     sc = full[1].abs().max().item()
-    assert (full[1] - one[0]).abs().max().item() <= 2e-4 * sc              # per-sample independence (atomics reorder sums)
+    # per-sample independence: batch-dependent split-K, the batch-wide bound on |planes| (a power-of-two operand scale of
+    # the 16-bit decoder) and the atomics reorder fp32 sums; the full-size gradient itself moves by ~5e-4 under such
+    # perturbations (importance samples crossing a bin), see test_full_size_backward_vs_oracle_autograd
+    assert (full[1] - one[0]).abs().max().item() <= 5e-4 * sc
     again = grad([0, 1, 2])
     assert (again - full).abs().max().item() <= 1e-4 * full.abs().max().item()
     twice = grad([0, 1, 2], scale=2.0)
