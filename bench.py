@@ -46,7 +46,7 @@ MFMA_F16_PEAK_TFLOPS = 2500.0   # v_mfma_f32_32x32x16_f16 dense peak (same rate 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32,
                     help="frames per step per GPU (throughput: 8 -> 16 -> 32 frames per synthesis call render "
@@ -571,7 +571,10 @@ def main():
         gather_bytes = frames_per_launch * r * s_tot * 3 * 4 * 32 * 4
         dec_flops = frames_per_launch * r * s_tot * 2.0 * (32 * 64 + 64 * 33)
         rm_avg_ms = rm_ms / max(rm_n, 1)
-        floor_ms = (gather_bytes / (L2_PEAK_GBS * 1e9) + dec_flops / (MFMA_F32_PEAK_TFLOPS * 1e12)) * 1e3
+        # decoder MLP: split fp16 operands on the 16-bit pipe (3 MFMAs per product against 2.5 PF dense) or exact fp32 MFMA
+        dec16 = cfg.decoder_precision == "f16x3"
+        dec_peak = MFMA_F16_PEAK_TFLOPS / 3 if dec16 else MFMA_F32_PEAK_TFLOPS
+        floor_ms = (gather_bytes / (L2_PEAK_GBS * 1e9) + dec_flops / (dec_peak * 1e12)) * 1e3
         rm_traffic = profiled_traffic("raymarch_kernel")
         compulsory = frames_per_launch * (3 * cfg.plane_resolution ** 2 * 32 * 4 + r * (34 + s_tot) * 4)
         out = {
@@ -591,12 +594,13 @@ def main():
             # dominant kernel by time: the modulated-conv implicit GEMM
             "roofline": roof,
             # the kernel north_star names: see the comment above
-            "roofline_raymarch": {"bound": "l2+mfma", "kernel": "raymarch_kernel<3,3>",
+            "roofline_raymarch": {"bound": "l2+mfma", "kernel": "raymarch_kernel<3,3> (decoder: " + cfg.decoder_precision + ")",
                                   "achieved": frames_per_launch / (rm_avg_ms * 1e-3),
                                   "peak": frames_per_launch / (floor_ms * 1e-3), "unit": "frames/s (kernel alone)",
                                   "frac": floor_ms / rm_avg_ms,
                                   "floor_ms_per_launch": {"l2_gather": gather_bytes / (L2_PEAK_GBS * 1e9) * 1e3,
-                                                          "decoder_mfma_f32": dec_flops / (MFMA_F32_PEAK_TFLOPS * 1e12) * 1e3},
+                                                          ("decoder_mfma_f16x3" if dec16 else "decoder_mfma_f32"):
+                                                              dec_flops / (dec_peak * 1e12) * 1e3},
                                   "avg_launch_ms": rm_avg_ms, "launches": rm_n,
                                   "gather_rate_GBps_survey8d": rm_gbs,
                                   "gather_rate_over_hbm_peak_survey8d": rm_gbs / HBM_PEAK_GBS,

@@ -57,6 +57,7 @@ class ModconvArgs(C.Structure):
 
 
 ABSMAX_SLOTS = 64       # HFAGP_ABSMAX_SLOTS
+ABSMAX_FLOATS = 64 * 32  # HFAGP_ABSMAX_FLOATS: one 128-byte line per slot
 
 
 class UpfirEpilogueArgs(C.Structure):

@@ -117,7 +117,7 @@ __device__ __forceinline__ float style_range_guard(const float* styles, int cin,
     float m = styles ? 0.f : 1.f;
     if (styles)
         for (int i = lane; i < cin; i += 64) m = fmaxf(m, fabsf(styles[i]));
-    float mx = x_absmax ? x_absmax[lane] : 0.f;
+    float mx = x_absmax ? x_absmax[lane * HFAGP_ABSMAX_STRIDE] : 0.f;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         m = fmaxf(m, __shfl_xor(m, o));

@@ -385,7 +385,7 @@ struct Dec16Regs {
 
 // from the fp32 register image + the bound M on |planes| (max over the HFAGP_ABSMAX_SLOTS slots)
 __device__ __forceinline__ void make_dec16(const DecoderRegs& w, const float* planes_absmax, int lane, Dec16Regs& d) {
-    const float M = wave_max(planes_absmax[lane]);
+    const float M = wave_max(planes_absmax[lane * HFAGP_ABSMAX_STRIDE]);
     float m0 = 0.f, m1 = 0.f, rs = 0.f, hb = 0.f;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {

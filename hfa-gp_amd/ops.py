@@ -207,8 +207,8 @@ def fully_connected(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.
 
 # ----------------------------------------------------------------------------- modulated conv
 def absmax_slots(n: int, device) -> torch.Tensor:
-    """[n, 64] zeroed slot buffers for the fp16 range tracking of n tensors (row i: max |.| of tensor i = row.max())."""
-    return torch.zeros(n, L.ABSMAX_SLOTS, device=device, dtype=torch.float32)
+    """[n, 64 * 32] zeroed slot buffers (64 slots, one 128-byte line each) for the fp16 range tracking of n tensors (row i: max |.| of tensor i = row.max())."""
+    return torch.zeros(n, L.ABSMAX_FLOATS, device=device, dtype=torch.float32)
 
 
 def modconv(x: torch.Tensor, wt: torch.Tensor, cout: int, mode: int, styles: Optional[torch.Tensor] = None,
@@ -221,7 +221,7 @@ def modconv(x: torch.Tensor, wt: torch.Tensor, cout: int, mode: int, styles: Opt
     mode CONVT3X3_UP2: returns the RAW transposed-conv result [B, 2H+1, 2W+1, Cout].
     ``wt`` from :func:`weight_prep` (fp32, exact MFMA) or :func:`weight_prep_split` (bfloat16 parts: the
     split-bf16 MFMA path, BF16X3 for 2 parts, BF16X6 for 3; float16, 1 part: the single-pass fp16 path).
-    ``x_absmax`` / ``y_absmax`` ([64] fp32, `absmax_slots`): fp16 range tracking — max |x| of the input as published by its
+    ``x_absmax`` / ``y_absmax`` ([64 x 32] fp32, `absmax_slots`): fp16 range tracking — max |x| of the input as published by its
     producer (the fp16 kinds scale the operand by an exact power of two so nothing saturates) and the slot buffer that
     receives max |y| of a fused-epilogue output (include/hfagp.h).
     ``rgb_w`` [B, 3, Cout] (toRGB weight x its styles): fused toRGB — returns (y, rgb_part [parts, B, H, W, 4]) for
@@ -317,7 +317,7 @@ def upfir_epilogue(yt: torch.Tensor, dcoef: Optional[torch.Tensor], noise: Optio
 
 def skip_upsample_add(img: Optional[torch.Tensor], y: torch.Tensor, plane_major: bool = False,
                       out_absmax: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """SynthesisBlock 'skip': upsample2d(img) + y (channels-last).  plane_major → [B,3,H,W,C/3].  out_absmax ([64],
+    """SynthesisBlock 'skip': upsample2d(img) + y (channels-last).  plane_major → [B,3,H,W,C/3].  out_absmax ([64 x 32],
     `absmax_slots`): receives max |output| (the bound the ray marcher's 16-bit decoder scales by)."""
     _chk(y, "y")
     b, ho, wo, c = y.shape
@@ -362,7 +362,7 @@ def raymarch(planes: torch.Tensor, cam2world: torch.Tensor, intrinsics: torch.Te
              decoder_precision: str = "f16x3", planes_absmax: Optional[torch.Tensor] = None):
     """planes [B,3,H,W,32] → feat [B,R,32], depth [B,R] (unclamped), wsum [B,R], tminmax [B,R,2].
     decoder_precision 'f16x3': the decoder MLP on the 16-bit matrix pipe with split fp16 operands (fp32-class); it needs
-    a bound on |planes| — `planes_absmax` ([64] slots as published by `skip_upsample_add(out_absmax=...)`), computed here
+    a bound on |planes| — `planes_absmax` (64 slots as published by `skip_upsample_add(out_absmax=...)`), computed here
     with one reduction over the planes when the caller has none.  'fp32': the exact fp32 matrix instructions."""
     _chk(planes, "planes")
     b, three, h, w, ch = planes.shape
@@ -392,13 +392,13 @@ def raymarch(planes: torch.Tensor, cam2world: torch.Tensor, intrinsics: torch.Te
 
 
 def _decoder_bound(planes: torch.Tensor, decoder_precision: str, planes_absmax: Optional[torch.Tensor]):
-    """The [64]-slot bound on |planes| of the 16-bit decoder (None for the exact fp32 decoder)."""
+    """The 64-slot bound on |planes| of the 16-bit decoder (None for the exact fp32 decoder)."""
     if decoder_precision == "fp32":
         return None
     if decoder_precision != "f16x3":
         raise ValueError(f"decoder_precision must be 'fp32' or 'f16x3', got {decoder_precision!r}")
     if planes_absmax is None:
-        planes_absmax = planes.abs().amax().expand(L.ABSMAX_SLOTS).contiguous()
+        planes_absmax = planes.abs().amax().expand(L.ABSMAX_FLOATS).contiguous()
     return _chk(planes_absmax, "planes_absmax")
 
 

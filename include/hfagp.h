@@ -72,7 +72,7 @@ typedef struct {
     int32_t white_back;
     double ray_start, ray_end;/* python floats of rendering_kwargs (kept double: linspace/delta rounding) */
     float box_warp, decoder_lr_mul;
-    /* optional: HFAGP_ABSMAX_SLOTS floats whose maximum bounds |planes| (published by the kernel that wrote the planes,
+    /* optional: HFAGP_ABSMAX_FLOATS floats (64 slots, HFAGP_ABSMAX_STRIDE apart) whose maximum bounds |planes| (published by the kernel that wrote the planes,
      * hfagp_skip_upsample_add, or any upper bound).  With it the decoder MLP runs on the 16-bit matrix pipe with split
      * operands (fp16 hi + lo parts, 3 MFMAs per product as HFAGP_PREC_F16X3: ~2^-22, fp32-class; gradients: bf16 parts),
      * every operand scaled into fp16's range by an exact power of two derived from this bound and the weights.
@@ -186,12 +186,12 @@ typedef struct {
     int32_t precision;        /* HFAGP_PREC_*                                                 */
     /* fp16 range tracking (optional, both may be NULL).  A tensor without a clamp (EG3D's fp32 backbone,
      * conv_clamp = None) has no bound, and fp16 parts saturate at 65504 and lose bits below 2^-14: the producer of
-     * such a tensor publishes max |y| into y_absmax (HFAGP_ABSMAX_SLOTS floats, zeroed by the caller before the
+     * such a tensor publishes max |y| into y_absmax (HFAGP_ABSMAX_FLOATS floats = 64 slots, zeroed by the caller before the
      * launch; blocks write different slots, the maximum over the slots is the tensor's), and the fp16 kinds (F16X3,
      * F16) that consume it read x_absmax and scale the operand by the power of two that brings max |x| to 2^15 —
      * undone on the accumulators, so the result is that of un-scaled arithmetic and nothing saturates.            */
-    const float* x_absmax;    /* [HFAGP_ABSMAX_SLOTS] max |x| of the input tensor, or NULL (then |x| <= 65504 is the caller's promise) */
-    float*       y_absmax;    /* [HFAGP_ABSMAX_SLOTS] receives max |y| of the fused-epilogue output, or NULL */
+    const float* x_absmax;    /* [HFAGP_ABSMAX_FLOATS] max |x| of the input tensor, or NULL (then |x| <= 65504 is the caller's promise) */
+    float*       y_absmax;    /* [HFAGP_ABSMAX_FLOATS] receives max |y| of the fused-epilogue output, or NULL */
     /* fused toRGB of a block's last conv (optional, both or none; 16-bit precisions, modes 0 / 2 without split-K —
      * hfagp_modconv_workspace_bytes() == 0): while the output tile is still in registers the block also forms
      *   rgb[r] = sum_co y[co] * rgb_w[b][r][co]     (r < 3; rgb_w = toRGB weight * its styles, Cout entries per r)
@@ -203,6 +203,10 @@ typedef struct {
 /* number of partial-sum images a call with rgb_part writes: (Cout / 128) x 2 */
 int32_t hfagp_modconv_rgb_parts(const HfagpModconvArgs* a);
 #define HFAGP_ABSMAX_SLOTS 64
+/* an absmax buffer is HFAGP_ABSMAX_FLOATS floats: slot i lives at float index i * HFAGP_ABSMAX_STRIDE (one 128-byte
+ * line per slot, so the publishing waves' atomics spread over the L2 channels instead of queueing on two lines) */
+#define HFAGP_ABSMAX_STRIDE 32
+#define HFAGP_ABSMAX_FLOATS (HFAGP_ABSMAX_SLOTS * HFAGP_ABSMAX_STRIDE)
 
 size_t hfagp_modconv_workspace_bytes(const HfagpModconvArgs* a);
 int hfagp_modconv_fwd(const HfagpModconvArgs* a, void* stream);
@@ -218,7 +222,7 @@ typedef struct {
     int32_t B, H, W, C;       /* H, W = INPUT resolution of the up-conv */
     int32_t act;
     float noise_strength, alpha, gain, clamp;
-    float*       y_absmax;    /* optional [HFAGP_ABSMAX_SLOTS]: max |y| (see HfagpModconvArgs) */
+    float*       y_absmax;    /* optional [HFAGP_ABSMAX_FLOATS]: max |y| (see HfagpModconvArgs) */
 } HfagpUpfirEpilogueArgs;
 
 int hfagp_upfir_epilogue_fwd(const HfagpUpfirEpilogueArgs* a, void* stream);
@@ -232,7 +236,7 @@ typedef struct {
     float*       img_out;
     int32_t B, H, W, C;       /* H, W = resolution of img_in */
     int32_t plane_major;
-    float*       out_absmax;  /* optional [HFAGP_ABSMAX_SLOTS]: receives max |img_out| (HfagpRaymarchArgs::planes_absmax) */
+    float*       out_absmax;  /* optional [HFAGP_ABSMAX_FLOATS]: receives max |img_out| (HfagpRaymarchArgs::planes_absmax) */
 } HfagpSkipArgs;
 
 int hfagp_skip_upsample_add(const HfagpSkipArgs* a, void* stream);
