@@ -222,8 +222,18 @@ __global__ void __launch_bounds__(256) splitk_epilogue_kernel(const float* __res
                                                               float clamp, float* __restrict__ y_absmax) {
     const long long i4 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i4 * 4 >= slab) return;
+    // the slabs are summed in order (bitwise repeatable), but eight loads are in flight at a time: a plain loop waited for
+    // every L2 round trip in turn (14 us per call at ksplit 64, 18 calls per frame at B = 1)
     float4 s = reinterpret_cast<const float4*>(ws)[i4];
-    for (int k = 1; k < ksplit; ++k) {
+    int k = 1;
+    for (; k + 8 <= ksplit; k += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = reinterpret_cast<const float4*>(ws + (size_t)(k + q) * slab)[i4];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { s.x += v[q].x; s.y += v[q].y; s.z += v[q].z; s.w += v[q].w; }
+    }
+    for (; k < ksplit; ++k) {
         const float4 v = reinterpret_cast<const float4*>(ws + (size_t)k * slab)[i4];
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }

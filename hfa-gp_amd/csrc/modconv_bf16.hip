@@ -468,6 +468,9 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
                     if (p.fused) v = lrelu_gain_clamp(v * d + bs + nz[q], p.act, p.alpha, p.gain, p.clamp);
                     else if constexpr (F16) v *= sback;
                     vmax = fmaxf(vmax, fabsf(v));
+#ifdef HFAGP_ABL_NOSTORE    // (developer ablation: one store per 16 values)
+                    if (q == 0 && rw == 0)
+#endif
                     rowp[n * cstep] = v;
                     if constexpr (RGB) {
 #pragma unroll
@@ -726,6 +729,9 @@ __global__ void __launch_bounds__(NW * 64, 1) upconv_bf16_kernel(const ConvParam
                     for (int q = 0; q < 8; ++q) {
                         const int n = n0 + 8 * (q >> 2) + 4 * h + (q & 3);
                         if (n >= mw) continue;
+#ifdef HFAGP_ABL_NOSTORE
+                        if (q == 0 && rw == 0)
+#endif
                         rowp[2 * n * p.Cout] = F16 ? acc[f][tm][tn][8 * rw + q] * sback : acc[f][tm][tn][8 * rw + q];
                     }
                 }

@@ -3,7 +3,7 @@
 set -uo pipefail
 R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 tag="${1:-train}"; B="${2:-2}"; iters="${3:-10}"
-out="$R/gpurun_out/prof_$tag"; mkdir -p "$out"
+out="/tmp/prof_$tag"; rm -rf "$out"; mkdir -p "$out"      # raw traces stay on the box (gpurun copies back <= 64 MiB)
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o bench -- python "$R/tests/bench_train.py" "$B" "$iters" > "$out/trace.log" 2>&1
 python - "$out" "$iters" <<'PY'

@@ -4,7 +4,7 @@
 set -euo pipefail
 here="$(cd "$(dirname "${BASH_SOURCE[0]}")/../.." && pwd)"
 csrc="$here/hfa-gp_amd/csrc"
-variants=(base "old:-DHFAGP_LOADA_EARLY=0 -DHFAGP_B_EARLY=0" "aearly:-DHFAGP_LOADA_EARLY=1 -DHFAGP_B_EARLY=0" "bearly:-DHFAGP_LOADA_EARLY=0 -DHFAGP_B_EARLY=1"
+variants=(base "nostore:-DHFAGP_ABL_NOSTORE" "old:-DHFAGP_LOADA_EARLY=0 -DHFAGP_B_EARLY=0" "aearly:-DHFAGP_LOADA_EARLY=1 -DHFAGP_B_EARLY=0" "bearly:-DHFAGP_LOADA_EARLY=0 -DHFAGP_B_EARLY=1"
           "nob:-DHFAGP_ABL_NOB" "noa:-DHFAGP_ABL_NOA" "nostage:-DHFAGP_ABL_NOSTAGE"
           "mfmaonly:-DHFAGP_ABL_NOB -DHFAGP_ABL_NOA -DHFAGP_ABL_NOSTAGE -DHFAGP_ABL_NOBAR")
 [[ -n "${ABL_VARIANTS:-}" ]] && read -r -a variants <<< "$ABL_VARIANTS"
@@ -31,5 +31,6 @@ else
         done
         echo -n "$name: "; HFAGP_LIB_PATH="$lib" python "$here/tests/bench_conv.py" 8 512 128 128 1 0 100 f16x3 2>&1 | tail -1
         echo -n "$name: "; HFAGP_LIB_PATH="$lib" python "$here/tests/bench_conv.py" 8 64 512 512 1 0 300 f16x3 2>&1 | tail -1
+        echo -n "$name: "; HFAGP_LIB_PATH="$lib" python "$here/tests/bench_conv.py" 8 256 256 128 2 0 100 f16x3 2>&1 | tail -1
     done
 fi

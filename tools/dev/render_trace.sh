@@ -3,7 +3,7 @@
 set -uo pipefail
 R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}"
 tag="${1:-render}"; steps="${2:-20}"; shift 2 || true
-out="$R/gpurun_out/prof_$tag"; mkdir -p "$out"
+out="/tmp/prof_$tag"; rm -rf "$out"; mkdir -p "$out"      # raw traces stay on the box (gpurun copies back <= 64 MiB)
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o bench -- python "$R/bench.py" --steps "$steps" --warmup 3 --no-cpu-baseline --no-train --no-sweep --no-fp32-leg --no-f16-leg --audio-frames 0 "$@" > "$out/trace.log" 2>&1
 python - "$out" "$steps" <<'PY'
