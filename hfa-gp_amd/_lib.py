@@ -156,6 +156,9 @@ SYMBOLS = {
     "hfagp_pool_mse_fwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 4 + [C.c_void_p]),
     "hfagp_pool_mse_bwd": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 4 + [C.c_void_p]),
     "hfagp_upfirdn2d_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int32] * 12 + [C.c_float, C.c_void_p]),
+    "hfagp_upfirdn2d_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int32] * 12 + [C.c_float, C.c_void_p]),
+    "hfagp_bias_act_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_float,
+                                     C.c_float, C.c_void_p]),
     "hfagp_bias_act_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64,
                                      C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "hfagp_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p]),

@@ -415,7 +415,8 @@ __global__ void __launch_bounds__(256) torgb_finish_kernel(HfagpTorgbFinishArgs 
 // ---------------------------------------------------------------- generic upfirdn2d (NCHW, test surface)
 __global__ void __launch_bounds__(256) upfirdn2d_kernel(const float* __restrict__ x, const float* __restrict__ f,
                                                         float* __restrict__ y, int NC, int H, int W, int fh, int fw,
-                                                        int up, int down, int px0, int py0, int Ho, int Wo, float gain) {
+                                                        int up, int down, int px0, int py0, int Ho, int Wo, float gain,
+                                                        int noflip) {
     const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= (long long)NC * Ho * Wo) return;
     const int ox = (int)(tid % Wo), oy = (int)((tid / Wo) % Ho);
@@ -433,7 +434,8 @@ __global__ void __launch_bounds__(256) upfirdn2d_kernel(const float* __restrict_
             if (ux < 0 || ux % up != 0) continue;
             const int ix = ux / up;
             if (ix >= W) continue;
-            acc += f[(fh - 1 - p) * fw + (fw - 1 - q)] * src[(size_t)iy * W + ix];
+            // forward: true convolution (filter flipped, EG3D flip_filter=False); the adjoint correlates (noflip)
+            acc += (noflip ? f[p * fw + q] : f[(fh - 1 - p) * fw + (fw - 1 - q)]) * src[(size_t)iy * W + ix];
         }
     }
     y[tid] = acc * gain;
@@ -448,6 +450,21 @@ __global__ void __launch_bounds__(256) bias_act_kernel(const float* __restrict__
         float v = x[i];
         if (b) v += b[(i / inner) % C];
         y[i] = lrelu_gain_clamp(v, act, alpha, gain, clamp);
+    }
+}
+
+// adjoint of bias_act w.r.t. x (and, summed over everything but the channel, b): EG3D's bias_act backward works from the
+// OUTPUT y (sign(y) = sign(x + b) for leaky ReLU; the clamp passes gradient where |y| < clamp)
+__global__ void __launch_bounds__(256) bias_act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                           float* __restrict__ dx, long long n, int act, float alpha,
+                                                           float gain, float clamp) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float yv = y[i];
+        float g = dy[i] * gain;
+        if (act == HFAGP_ACT_LRELU && yv < 0.f) g *= alpha;
+        if (clamp >= 0.f && !(fabsf(yv) < clamp)) g = 0.f;
+        dx[i] = g;
     }
 }
 
@@ -595,8 +612,23 @@ int hfagp_upfirdn2d_fwd(const float* x, const float* f, float* y, int32_t N, int
     HFAGP_REQUIRE(Ho > 0 && Wo > 0, HFAGP_EBADARG, "upfirdn2d: empty output");
     const long long total = (long long)N * C * Ho * Wo;
     upfirdn2d_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
-        x, f, y, N * C, H, W, fh, fw, up, down, px0, py0, Ho, Wo, gain);
+        x, f, y, N * C, H, W, fh, fw, up, down, px0, py0, Ho, Wo, gain, 0);
     return check_launch("upfirdn2d");
+}
+
+int hfagp_upfirdn2d_bwd(const float* dy, const float* f, float* dx, int32_t N, int32_t C, int32_t H, int32_t W,
+                        int32_t fh, int32_t fw, int32_t up, int32_t down, int32_t px0, int32_t px1, int32_t py0,
+                        int32_t py1, float gain, void* stream) {
+    HFAGP_REQUIRE(dy && f && dx, HFAGP_EBADARG, "upfirdn2d_bwd: null pointer");
+    HFAGP_REQUIRE(up >= 1 && down >= 1 && fh >= 1 && fw >= 1, HFAGP_EBADARG, "upfirdn2d_bwd: bad up/down/filter");
+    const int Ho = (H * up + py0 + py1 - fh) / down + 1, Wo = (W * up + px0 + px1 - fw) / down + 1;
+    HFAGP_REQUIRE(Ho > 0 && Wo > 0, HFAGP_EBADARG, "upfirdn2d_bwd: empty forward output");
+    // EG3D's Upfirdn2dCuda.backward: the same operator with up and down exchanged, the filter NOT flipped and the padding
+    //   [fw - px0 - 1, W up - Wo down + px0 - up + 1, fh - py0 - 1, H up - Ho down + py0 - up + 1]; its output is [H][W]
+    const long long total = (long long)N * C * H * W;
+    upfirdn2d_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+        dy, f, dx, N * C, Ho, Wo, fh, fw, down, up, fw - px0 - 1, fh - py0 - 1, H, W, gain, 1);
+    return check_launch("upfirdn2d_bwd");
 }
 
 int hfagp_bias_act_fwd(const float* x, const float* b, float* y, int64_t n, int32_t C, int64_t inner, int32_t act,
@@ -608,6 +640,17 @@ int hfagp_bias_act_fwd(const float* x, const float* b, float* y, int64_t n, int3
     bias_act_kernel<<<(unsigned)(blocks > 8192 ? 8192 : blocks), 256, 0, (hipStream_t)stream>>>(
         x, b, y, n, C > 0 ? C : 1, inner > 0 ? inner : 1, act, alpha, gain, clamp);
     return check_launch("bias_act");
+}
+
+int hfagp_bias_act_bwd(const float* dy, const float* y, float* dx, int64_t n, int32_t act, float alpha, float gain,
+                       float clamp, void* stream) {
+    HFAGP_REQUIRE(act == HFAGP_ACT_LINEAR || act == HFAGP_ACT_LRELU, HFAGP_EUNSUPPORTED, "bias_act_bwd: act %d", act);
+    if (n == 0) return HFAGP_OK;
+    HFAGP_REQUIRE(dy && y && dx && n > 0, HFAGP_EBADARG, "bias_act_bwd: null pointer");
+    const long long blocks = (n + 255) / 256;
+    bias_act_bwd_kernel<<<(unsigned)(blocks > 8192 ? 8192 : blocks), 256, 0, (hipStream_t)stream>>>(dy, y, dx, n, act, alpha,
+                                                                                                 gain, clamp);
+    return check_launch("bias_act_bwd");
 }
 
 int hfagp_nchw_to_nhwc(const float* x, float* y, int32_t B, int32_t C, int32_t H, int32_t W, void* stream) {

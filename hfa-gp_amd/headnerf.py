@@ -56,6 +56,52 @@ def toogle_grad(model, flag=True):
         p.requires_grad = flag
 
 
+class _QrMonitor:
+    """Host-side watch on the conditioning of the latent basis for the fast QR (see `_LatentBasis._qr`).  Holds a pinned
+    buffer and a HIP event, so it is deliberately NOT copied or pickled with the module: a copy starts fresh."""
+
+    # orthogonality defect of the fast QR's first pass above which the instance switches to the library Householder QR
+    # for good: the re-orthogonalised result is O(eps)-orthonormal up to a defect of ~0.3 (cond(A) ~ 3000 in fp32), the
+    # monitor reads the status word of the PREVIOUS call (no host sync in the step), so the margin is wide
+    DEFECT_LIMIT = 1e-2
+
+    def __init__(self):
+        self.fallback = False
+        self.checked = False
+        self._pending = None          # (pinned host tensor, event) of the status word in flight
+        self._host = None
+
+    def __deepcopy__(self, memo):
+        return _QrMonitor()
+
+    def __reduce__(self):
+        return (_QrMonitor, ())
+
+    def bad(self, st) -> bool:
+        defect, broke = st
+        return broke != 0.0 or not (defect <= self.DEFECT_LIMIT)
+
+    def watch(self, status: torch.Tensor) -> None:
+        if self._pending is not None:         # the previous status word is still in flight
+            return
+        if self._host is None:
+            self._host = torch.empty(2, dtype=torch.float32, pin_memory=True)
+        self._host.copy_(status, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._pending = (self._host, ev)
+
+    def poll(self) -> None:
+        if self._pending is not None and self._pending[1].query():
+            host, _ = self._pending
+            self._pending = None
+            if self.bad(host.tolist()):
+                import warnings
+                warnings.warn("HeadNeRF latent basis became ill-conditioned for the Gram-matrix QR "
+                              f"(first-pass orthogonality defect {host[0].item():.2e}); switching to torch.linalg.qr")
+                self.fallback = True
+
+
 class _LatentBasis(nn.Module):
     """Shared implementation of the K-dimensional W+ subspace (rows A1-A3 of SURVEY.md §8a)."""
 
@@ -79,57 +125,37 @@ class _LatentBasis(nn.Module):
             return q
         return self._qr((bases + 1e-8).T)
 
-    # orthogonality defect of the fast QR's first pass above which the instance switches to the library Householder QR
-    # for good: the re-orthogonalised result is O(eps)-orthonormal up to a defect of ~0.3 (cond(A) ~ 3000 in fp32), the
-    # monitor reads the status word of the PREVIOUS call (no host sync in the step), so the margin is wide
-    QR_DEFECT_LIMIT = 1e-2
-
     def _qr(self, a: torch.Tensor) -> torch.Tensor:
         """Q of torch.linalg.qr(a, 'reduced') (headnerf.py:85-91).  On the GPU the [7168, K<=64] panel goes through the
-        Gram-matrix Householder kernel + one Cholesky re-orthogonalisation (ops.TallSkinnyQR: LAPACK's signs, ~0.15 ms
+        Gram-matrix Householder kernel + one Cholesky re-orthogonalisation (ops.TallSkinnyQR: LAPACK's signs, ~0.3 ms
         instead of ~1.4 ms of rocSOLVER launches; it works on A^T A, so it is only used for tall panels, m >= 8 K, and
         only while the conditioning monitor is green); elsewhere (CPU, K > 64, ill-conditioned basis such as a
         PTI-pivot initialisation with a large shared mean) through torch.linalg.qr.
-        Conditioning monitor: the first call on an instance checks the defect of pass 1 synchronously (one host sync,
-        once); later calls poll the status word of the previous call through a pinned host copy + event, so a basis
-        that degrades during training switches to the library path one step late at worst, without a sync per step."""
+        Conditioning monitor (`_QrMonitor`): the first call on an instance checks the defect of pass 1 synchronously
+        (one host sync, once); later calls poll the status word of the previous call through a pinned host copy + event,
+        so a basis that degrades during training switches to the library path one step late at worst, without a sync
+        per step."""
+        mon = self.__dict__.setdefault("_qr_monitor", _QrMonitor())
         fast = (a.is_cuda and a.dtype == torch.float32 and a.shape[1] <= 64 and a.shape[0] >= 8 * a.shape[1]
-                and not getattr(self, "_qr_fallback", False))
+                and not mon.fallback)
         if not fast:
             return torch.linalg.qr(a, mode="reduced")[0]
         from . import ops
-        self._qr_poll()
+        mon.poll()
         status = torch.empty(2, device=a.device, dtype=torch.float32)
         q = ops.TallSkinnyQR.apply(a, status)
-        if not getattr(self, "_qr_checked", False):
-            self._qr_checked = True
-            if self._qr_bad(status.tolist()):
-                self._qr_fallback = True
+        if not mon.checked:
+            mon.checked = True
+            if mon.bad(status.tolist()):
+                mon.fallback = True
                 return torch.linalg.qr(a, mode="reduced")[0]
             return q
-        if getattr(self, "_qr_watch", None) is None:            # (the previous status word is still in flight otherwise)
-            host = getattr(self, "_qr_host", None)
-            if host is None:
-                host = self._qr_host = torch.empty(2, dtype=torch.float32, pin_memory=True)
-            host.copy_(status, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-            self._qr_watch = (host, ev)
+        mon.watch(status)
         return q
 
-    def _qr_bad(self, st) -> bool:
-        defect, broke = st
-        return broke != 0.0 or not (defect <= self.QR_DEFECT_LIMIT)
-
-    def _qr_poll(self) -> None:
-        watch = getattr(self, "_qr_watch", None)
-        if watch is not None and watch[1].query():
-            self._qr_watch = None
-            if self._qr_bad(watch[0].tolist()):
-                import warnings
-                warnings.warn("HeadNeRF latent basis became ill-conditioned for the Gram-matrix QR "
-                              f"(first-pass orthogonality defect {watch[0][0].item():.2e}); switching to torch.linalg.qr")
-                self._qr_fallback = True
+    @property
+    def _qr_fallback(self) -> bool:
+        return self.__dict__.get("_qr_monitor") is not None and self.__dict__["_qr_monitor"].fallback
 
     def get_latent(self, weights: Optional[torch.Tensor], person_2: bool = False):
         bases, delta = self._select(person_2)

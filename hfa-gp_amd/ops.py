@@ -403,11 +403,7 @@ def _decoder_bound(planes: torch.Tensor, decoder_precision: str, planes_absmax: 
 
 
 # ----------------------------------------------------------------------------- standalone ops (NCHW)
-def upfirdn2d(x: torch.Tensor, f: torch.Tensor, up: int = 1, down: int = 1,
-              padding=(0, 0, 0, 0), gain: float = 1.0) -> torch.Tensor:
-    """EG3D upfirdn2d(x, f, up, down, padding=[px0,px1,py0,py1], gain) on NCHW fp32."""
-    _chk(x, "x")
-    _chk(f, "f")
+def _upfirdn2d_raw(x, f, up, down, padding, gain):
     n, c, h, w = x.shape
     fh, fw = f.shape
     px0, px1, py0, py1 = padding
@@ -419,16 +415,39 @@ def upfirdn2d(x: torch.Tensor, f: torch.Tensor, up: int = 1, down: int = 1,
     return y
 
 
+class _UpFirDn2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, f, up, down, padding, gain):
+        ctx.save_for_backward(f)
+        ctx.cfg = (x.shape, up, down, tuple(padding), gain)
+        return _upfirdn2d_raw(x, f, up, down, padding, gain)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (f,) = ctx.saved_tensors
+        (n, c, h, w), up, down, (px0, px1, py0, py1), gain = ctx.cfg
+        dy = _chk(dy.contiguous(), "dy")
+        dx = torch.empty(n, c, h, w, device=dy.device, dtype=torch.float32)
+        L.check(L.lib().hfagp_upfirdn2d_bwd(_ptr(dy), _ptr(f), _ptr(dx), n, c, h, w, f.shape[0], f.shape[1], up, down,
+                                            px0, px1, py0, py1, gain, _stream()), "upfirdn2d_bwd")
+        return dx, None, None, None, None, None
+
+
+def upfirdn2d(x: torch.Tensor, f: torch.Tensor, up: int = 1, down: int = 1,
+              padding=(0, 0, 0, 0), gain: float = 1.0) -> torch.Tensor:
+    """EG3D upfirdn2d(x, f, up, down, padding=[px0,px1,py0,py1], gain) on NCHW fp32; differentiable w.r.t. x."""
+    _chk(x, "x")
+    _chk(f, "f")
+    if x.requires_grad and torch.is_grad_enabled():
+        return _UpFirDn2d.apply(x, f, up, down, tuple(padding), gain)
+    return _upfirdn2d_raw(x, f, up, down, padding, gain)
+
+
 def upsample2d(x: torch.Tensor, f: torch.Tensor) -> torch.Tensor:
     return upfirdn2d(x, f, up=2, padding=(2, 1, 2, 1), gain=4.0)
 
 
-def bias_act(x: torch.Tensor, b: Optional[torch.Tensor] = None, dim: int = 1, act: str = "linear",
-             alpha: float = 0.2, gain: Optional[float] = None, clamp: Optional[float] = None) -> torch.Tensor:
-    """EG3D bias_act.bias_act(x, b, dim, act, alpha, gain, clamp)."""
-    _chk(x, "x")
-    if gain is None:
-        gain = math.sqrt(2.0) if act == "lrelu" else 1.0
+def _bias_act_raw(x, b, dim, act, alpha, gain, clamp):
     y = torch.empty_like(x)
     inner = 1
     for s in x.shape[dim + 1:]:
@@ -436,6 +455,37 @@ def bias_act(x: torch.Tensor, b: Optional[torch.Tensor] = None, dim: int = 1, ac
     L.check(L.lib().hfagp_bias_act_fwd(_ptr(x), _ptr(b), _ptr(y), x.numel(), x.shape[dim], inner, _ACT[act],
                                        alpha, gain, -1.0 if clamp is None else float(clamp), _stream()), "bias_act_fwd")
     return y
+
+
+class _BiasAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, b, dim, act, alpha, gain, clamp):
+        y = _bias_act_raw(x, b, dim, act, alpha, gain, clamp)
+        ctx.save_for_backward(y)
+        ctx.cfg = (dim, act, alpha, gain, clamp, b is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dim, act, alpha, gain, clamp, has_b = ctx.cfg
+        dy = _chk(dy.contiguous(), "dy")
+        dx = torch.empty_like(y)
+        L.check(L.lib().hfagp_bias_act_bwd(_ptr(dy), _ptr(y), _ptr(dx), y.numel(), _ACT[act], alpha, gain,
+                                           -1.0 if clamp is None else float(clamp), _stream()), "bias_act_bwd")
+        db = dx.sum([d for d in range(dx.dim()) if d != dim]) if has_b else None
+        return dx, db, None, None, None, None, None
+
+
+def bias_act(x: torch.Tensor, b: Optional[torch.Tensor] = None, dim: int = 1, act: str = "linear",
+             alpha: float = 0.2, gain: Optional[float] = None, clamp: Optional[float] = None) -> torch.Tensor:
+    """EG3D bias_act.bias_act(x, b, dim, act, alpha, gain, clamp); differentiable w.r.t. x and b."""
+    _chk(x, "x")
+    if gain is None:
+        gain = math.sqrt(2.0) if act == "lrelu" else 1.0
+    if torch.is_grad_enabled() and (x.requires_grad or (b is not None and b.requires_grad)):
+        return _BiasAct.apply(x, b, dim, act, alpha, gain, clamp)
+    return _bias_act_raw(x, b, dim, act, alpha, gain, clamp)
 
 
 def nchw_to_nhwc(x: torch.Tensor) -> torch.Tensor:

@@ -425,6 +425,15 @@ int hfagp_upfirdn2d_fwd(const float* x, const float* f, float* y,
 
 int hfagp_bias_act_fwd(const float* x, const float* b, float* y, int64_t n, int32_t C, int64_t inner,
                        int32_t act, float alpha, float gain, float clamp, void* stream);
+/* adjoints of the two operators above (EG3D's upfirdn2d / bias_act are differentiable):
+ *   hfagp_upfirdn2d_bwd: dx [N][C][H][W] from dy [N][C][Ho][Wo]; H, W, up, down, padding: those of the FORWARD call
+ *   hfagp_bias_act_bwd:  dx = dy * gain * (y < 0 ? alpha : 1) where |y| < clamp, else 0, from the forward OUTPUT y
+ *                        (d bias = sum of dx over everything but the channel: the caller's reduction)               */
+int hfagp_upfirdn2d_bwd(const float* dy, const float* f, float* dx, int32_t N, int32_t C, int32_t H, int32_t W,
+                        int32_t fh, int32_t fw, int32_t up, int32_t down, int32_t px0, int32_t px1, int32_t py0,
+                        int32_t py1, float gain, void* stream);
+int hfagp_bias_act_bwd(const float* dy, const float* y, float* dx, int64_t n, int32_t act, float alpha, float gain,
+                       float clamp, void* stream);
 
 /* layout helpers */
 int hfagp_nchw_to_nhwc(const float* x, float* y, int32_t B, int32_t C, int32_t H, int32_t W, void* stream);

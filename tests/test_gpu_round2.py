@@ -482,3 +482,37 @@ def test_fused_torgb_in_conv_epilogue(dev, prec, cout, h):
     assert not ops.fused_torgb_supported(xs, wb, cout, 1)
     with pytest.raises(RuntimeError, match="split-K"):
         ops.modconv(xs, wb, cout, ops.CONV3X3, rgb_w=(s_rgb[:1, None, :] * w_rgb[None]).contiguous(), styles=s[:1])
+
+
+@pytest.mark.parametrize("up,down,pad", [(1, 1, (1, 1, 1, 1)), (2, 1, (2, 1, 2, 1)), (1, 2, (1, 1, 1, 1)), (2, 1, (1, 2, 2, 0)), (1, 1, (0, 0, 0, 0))])
+def test_upfirdn2d_and_bias_act_backward(dev, up, down, pad):
+    """The EG3D operator API is differentiable: hfagp_upfirdn2d_bwd / hfagp_bias_act_bwd (through ops.upfirdn2d /
+    ops.bias_act) against autograd through the oracle's operators (themselves pinned to the reference's
+    `upfirdn2d_native` / `fused_leaky_relu`, tests/test_oracle_pins.py); an asymmetric filter exercises the flip."""
+    from hfa_gp_amd import ops
+    from oracle import eg3d_oracle as O
+    g = torch.Generator().manual_seed(up * 10 + down)
+    x = torch.randn(2, 3, 9, 7, generator=g)
+    f = torch.tensor([[1.0, 2.0, 0.5, 3.0], [0.2, 1.0, 4.0, 1.0], [2.0, 0.1, 1.0, 0.3], [0.7, 1.5, 0.4, 1.0]])
+    f = f / f.sum()
+    x_ref = x.clone().requires_grad_(True)
+    y_ref = O.upfirdn2d(x_ref, f, up=up, down=down, padding=pad, gain=float(up * up))
+    gy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(gy)
+    x_d = x.to(dev).requires_grad_(True)
+    y = ops.upfirdn2d(x_d, f.to(dev), up=up, down=down, padding=pad, gain=float(up * up))
+    close(y, y_ref, atol=1e-5)
+    y.backward(gy.to(dev))
+    close(x_d.grad, x_ref.grad, atol=1e-5)
+    # bias_act: leaky ReLU * sqrt(2) with a clamp that bites, bias along dim 1
+    b = torch.randn(3, generator=g)
+    xr, br = (3.0 * x).clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = O.bias_act(xr, br, act="lrelu", clamp=2.5)
+    gb = torch.randn(yr.shape, generator=g)
+    yr.backward(gb)
+    xd, bd = (3.0 * x).to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    yd = ops.bias_act(xd, bd, act="lrelu", clamp=2.5)
+    close(yd, yr, atol=1e-5)
+    yd.backward(gb.to(dev))
+    close(xd.grad, xr.grad, atol=1e-5)
+    close(bd.grad, br.grad, atol=1e-4)

@@ -2,7 +2,7 @@
 # Run ON THE GPU BOX: kernel trace of the fitting step with the generator being tuned (tests/bench_tune.py).
 set -uo pipefail
 R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}"
-out="$R/gpurun_out/prof_tune"; mkdir -p "$out"
+out="/tmp/prof_tune"; rm -rf "$out"; mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o bench -- python "$R/tests/bench_tune.py" > "$out/trace.log" 2>&1
 tail -2 "$out/trace.log"
