@@ -192,7 +192,8 @@ def train_legs(args, cfg_name, dev, rank, world, dist):
     from hfa_gp_amd.trainer import Trainer
     from tests.util import look_at_label
     out = {}
-    torch.backends.cudnn.benchmark = True        # MIOpen picks its fastest kernels for the RGB driver's (Encoder) convs
+    # (torch.backends.cudnn.benchmark = True makes the Encoder 0.7 ms per step faster — and MIOpen's exhaustive search took
+    #  3.5 minutes of a fresh box's first run: left off)
 
     def make(mode, lpips):
         fa = _FitArgs()
@@ -470,26 +471,35 @@ def main():
         p["frames_per_s_per_gpu"] = b / (p["median"] * 1e-3)
         return p
 
+    leg_s = {}                 # wall seconds per leg of this script (rank 0), for whoever budgets the run
+
+    def timed_leg(name, fn, *a):
+        t = time.perf_counter()
+        out_ = fn(*a)
+        torch.cuda.synchronize()
+        leg_s[name] = round(leg_s.get(name, 0.0) + time.perf_counter() - t, 2)
+        return out_
+
     prec = args.precision or cfg.conv_precision
     # the headline leg first, exactly as the contract words it (W warm-up steps, then K timed steps), WITHOUT the
     # per-kernel timing events (they cost host time per launch); a second pass of the same leg collects the events
     # the roofline objects are computed from
-    dt, own_dt, timing_head = render_leg(prec, events=False)
-    _, _, timing = render_leg(prec)
+    dt, own_dt, timing_head = timed_leg("render", render_leg, prec, None, False)
+    _, _, timing = timed_leg("render", render_leg, prec)
     timing["step"] = timing_head["step"]
     dt32 = timing32 = dtb3 = None
     if prec != "fp32" and not args.no_fp32_leg:
-        dt32, _, timing32 = render_leg("fp32")
+        dt32, _, timing32 = timed_leg("render_other_precisions", render_leg, "fp32")
         if prec != "bf16x3":
-            dtb3, _, _ = render_leg("bf16x3", events=False)
+            dtb3, _, _ = timed_leg("render_other_precisions", render_leg, "bf16x3", None, False)
     dt16sr = dt16 = timing16 = None
     if not args.no_f16_leg:
         # the reference's CUDA defaults: fp32-class backbone, fp16 super-resolution; then every conv in fp16
-        dt16sr, _, timing16 = render_leg(prec, "f16")
-        dt16, _, _ = render_leg("f16", events=False)
+        dt16sr, _, timing16 = timed_leg("render_other_precisions", render_leg, prec, "f16")
+        dt16, _, _ = timed_leg("render_other_precisions", render_leg, "f16", None, False)
     sweep = None
     if not args.no_sweep:
-        sweep = {str(b): sweep_leg(b, prec, steps=20 if b <= 16 else 10) for b in (1, 4, 8, 16, 32) if b != B}
+        sweep = {str(b): timed_leg("batch_sweep", sweep_leg, b, prec, 20 if b <= 16 else 10) for b in (1, 4, 8, 16, 32) if b != B}
     gen.conv_precision, gen.sr_conv_precision = prec, None
     overflow = gen.f16_range_report()
 
@@ -510,15 +520,15 @@ def main():
     train = train_B = fit = fit3 = audio = None
     if not args.no_train:
         torch.cuda.empty_cache()
-        train, train_B = train_legs(args, args.preset, dev, rank, world, dist)
+        train, train_B = timed_leg("train_steps", train_legs, args, args.preset, dev, rank, world, dist)
         if args.fit_frames > 0:
-            fit = fit_leg(args, args.preset, dev, rank, world, dist)
+            fit = timed_leg("fit_rgb", fit_leg, args, args.preset, dev, rank, world, dist)
             torch.cuda.empty_cache()
         if args.fit3dmm_frames_per_rank > 0:
-            fit3 = fit3dmm_leg(args, args.preset, dev, rank, world, dist)
+            fit3 = timed_leg("fit_3dmm_sharded", fit3dmm_leg, args, args.preset, dev, rank, world, dist)
     if args.audio_frames > 0:
         torch.cuda.empty_cache()
-        audio = audio_leg(args, args.preset, dev, rank, world, dist)
+        audio = timed_leg("audio_reenactment", audio_leg, args, args.preset, dev, rank, world, dist)
 
     def profiled_traffic(prefix):
         """HBM bytes per launch from the committed PMC passes (profiles/traffic.json), only if the batch matches."""
@@ -669,7 +679,10 @@ def main():
         if audio is not None:
             out["audio_reenactment"] = audio
         if state is not None:
+            t_cpu = time.perf_counter()
             out["cpu_baseline"] = cpu_baseline(cfg, state, args.cpu_runs, args.cpu_warmup, args.cpu_n1)
+            leg_s["cpu_baseline"] = round(time.perf_counter() - t_cpu, 2)
+        out["leg_seconds"] = leg_s
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
