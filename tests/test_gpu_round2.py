@@ -332,15 +332,19 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _nccl_worker(rank, world, port, out):
+def _nccl_worker(rank, world, port, out, backend="nccl"):
     import torch.distributed as dist
     from hfa_gp_amd.synthetic import make_frame_set
     from hfa_gp_amd.trainer import Trainer
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(rank)
-    dev = torch.device("cuda", rank)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    local = rank if backend == "nccl" else 0            # gloo: both ranks share cuda:0 (RCCL refuses that)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.manual_seed(10 + rank)                        # rank 0's parameters must win (broadcast)
         tr = Trainer(FitArgs(), dev, rank=rank, world_size=world, mode="3dmm", lpips="none")
@@ -352,6 +356,31 @@ def _nccl_worker(rank, world, port, out):
         out[rank] = {"grad": tr.gen.bases.grad.detach().cpu(), "start": tr.gen.bases.detach().cpu(), "img": img.cpu()}
     finally:
         dist.destroy_process_group()
+
+
+def test_two_ranks_sharing_the_gpu_over_gloo(dev):
+    """The N > 1 fitting path with TWO PROCESSES on the GPU (both on cuda:0, collective over gloo — what a 1-GPU box can
+    run; RCCL needs one device per rank): rank 0's parameters win the broadcast, the bucketed in-place all-reduce gives both
+    ranks the same gradient, and it is the mean of the two per-frame gradients (statistically: the renderer draws fresh
+    uniforms per call)."""
+    import torch.multiprocessing as mp
+    from hfa_gp_amd.synthetic import make_frame_set
+    from hfa_gp_amd.trainer import Trainer
+    world, port = 2, _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_nccl_worker, args=(world, port, out, "gloo"), nprocs=world, join=True)
+        r0, r1 = out[0], out[1]
+    assert torch.equal(r0["start"], r1["start"]) and torch.equal(r0["grad"], r1["grad"])
+    assert r0["grad"].abs().sum() > 0 and torch.isfinite(r0["img"]).all() and torch.isfinite(r1["img"]).all()
+    torch.manual_seed(10)
+    tr = Trainer(FitArgs(), dev, mode="3dmm", lpips="none")
+    assert torch.equal(tr.gen.bases.detach().cpu(), r0["start"])
+    tr.optimizer = torch.optim.SGD(tr.gen.parameters(), lr=0.0)
+    data = make_frame_set(tr.gen, 2, size=FitArgs.size, seed=42, params_len=76)
+    tr.gen_update(data["real"], data["label"].clone(), data["params"])
+    want = tr.gen.bases.grad.cpu()
+    assert (r0["grad"] - want).norm() <= 0.2 * want.norm()
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs (RCCL refuses two ranks on one device)")
