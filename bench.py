@@ -344,6 +344,7 @@ def audio_leg(args, cfg_name, dev, rank, world, dist):
     torch.manual_seed(2)
     tr = AudioTrainer(audio_features(n).numpy(), n, fa, dev, rank=rank, world_size=world, lpips="none")
     tr.gen.generator.sr_conv_precision = "f16"
+    tr.gen.generator.sr_storage = "f16"          # forward-only reenactment: fp16 tensors between the SR layers, as EG3D's
     lo, hi = shard_range(n, rank, world)
     labels = gaussian_labels(n, dev, seed=51)
     idx = torch.arange(lo, hi, device=dev)
@@ -422,11 +423,12 @@ def main():
     def step():
         return gen.synthesis(ws, c, noise_mode="const", u_strat=us, u_imp=ui)["image"]
 
-    def render_leg(precision, sr_precision=None, events=True):
+    def render_leg(precision, sr_precision=None, events=True, sr_storage="f32"):
         """W warm-up + K timed steps with the conv GEMMs in ``precision`` (super-resolution blocks: ``sr_precision``
         when given); (seconds max over ranks, this rank's seconds, event table)."""
         gen.conv_precision = precision
         gen.sr_conv_precision = sr_precision
+        gen.sr_storage = sr_storage
         for _ in range(args.warmup):
             step()
         torch.cuda.synchronize()
@@ -492,11 +494,14 @@ def main():
         dt32, _, timing32 = timed_leg("render_other_precisions", render_leg, "fp32")
         if prec != "bf16x3":
             dtb3, _, _ = timed_leg("render_other_precisions", render_leg, "bf16x3", None, False)
-    dt16sr = dt16 = timing16 = None
+    dt16sr = dt16 = dt16srh = timing16 = None
     if not args.no_f16_leg:
         # the reference's CUDA defaults: fp32-class backbone, fp16 super-resolution; then every conv in fp16
         dt16sr, _, timing16 = timed_leg("render_other_precisions", render_leg, prec, "f16")
         dt16, _, _ = timed_leg("render_other_precisions", render_leg, "f16", None, False)
+        # ... and with the super-resolution activations STORED in fp16 as well (EG3D's fp16 blocks; forward-only calls)
+        dt16srh, _, _ = timed_leg("render_other_precisions", render_leg, prec, "f16", False, "f16")
+        gen.sr_storage = "f32"
     sweep = None
     if not args.no_sweep:
         sweep = {str(b): timed_leg("batch_sweep", sweep_leg, b, prec, 20 if b <= 16 else 10) for b in (1, 4, 8, 16, 32) if b != B}
@@ -632,6 +637,7 @@ def main():
             # precision split) or of all convs (value_f16) rounded to fp16, one fp16 MFMA per product
             out["value_f16_sr"] = frames / dt16sr
             out["value_f16"] = frames / dt16
+            out["value_f16_sr_f16_storage"] = frames / dt16srh     # + activations between the SR layers kept in fp16
             ms, flops, n = agg("modconv_f16", timing16)
             tf = flops / (ms * 1e-3) / 1e12
             out["roofline_f16_sr"] = {"bound": "mfma", "kernel": "modconv_bf16_kernel<1> / upconv_bf16_kernel<1> "

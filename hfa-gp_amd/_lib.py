@@ -14,7 +14,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # (HFAGP_LIB_PATH: developer override, used by the ablation builds of tools/dev/ — the product loads the in-tree library)
 LIB_PATH = os.environ.get("HFAGP_LIB_PATH") or os.path.join(_HERE, "libhfagp_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 c_float_p = C.c_void_p  # device pointers travel as integers
 
@@ -53,6 +53,7 @@ class ModconvArgs(C.Structure):
         ("precision", C.c_int32),
         ("x_absmax", C.c_void_p), ("y_absmax", C.c_void_p),
         ("rgb_w", C.c_void_p), ("rgb_part", C.c_void_p),
+        ("x_f16", C.c_int32), ("y_f16", C.c_int32),
     ]
 
 
@@ -65,7 +66,7 @@ class UpfirEpilogueArgs(C.Structure):
         ("yt", C.c_void_p), ("dcoef", C.c_void_p), ("noise", C.c_void_p), ("bias", C.c_void_p), ("y", C.c_void_p),
         ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("act", C.c_int32),
         ("noise_strength", C.c_float), ("alpha", C.c_float), ("gain", C.c_float), ("clamp", C.c_float),
-        ("y_absmax", C.c_void_p),
+        ("y_absmax", C.c_void_p), ("io_f16", C.c_int32),
     ]
 
 

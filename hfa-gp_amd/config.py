@@ -58,6 +58,10 @@ class GeneratorConfig:
     # precision of the two super-resolution blocks when it differs from conv_precision: "f16" reproduces the
     # reference's CUDA defaults (fp32 backbone, fp16 super-resolution: sr_num_fp16_res = 4)
     sr_conv_precision: Optional[str] = None
+    # storage of the activations BETWEEN the super-resolution layers: "f32" (default) or "f16" — with sr_conv_precision
+    # "f16", forward-only calls keep them in fp16 as EG3D's fp16 blocks do (half the HBM traffic of these HBM-heavy
+    # layers; values are rounded to fp16 exactly where the reference's `x.to(torch.float16)` tensors are)
+    sr_storage: str = "f32"
     # arithmetic of the decoder MLP inside the ray marcher: "f16x3" = split fp16 operands on the 16-bit matrix pipe
     # (3 MFMAs per product, ~2^-22: fp32-class; operands scaled into fp16's range by exact powers of two from a bound on
     # |planes| that the plane-writing kernel publishes), "fp32" = the exact fp32 matrix instructions (5x the pipe time)
@@ -111,6 +115,7 @@ class GeneratorConfig:
         assert self.plane_channels == 32, "decoder / ray-march kernel are written for 32 features"
         assert self.plane_axes in ("eg3d_original", "eg3d_fixed")
         assert self.decoder_precision in ("fp32", "f16x3")
+        assert self.sr_storage in ("f32", "f16")
 
 
 def ffhq512_128() -> GeneratorConfig:

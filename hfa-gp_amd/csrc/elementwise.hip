@@ -128,6 +128,31 @@ __global__ void __launch_bounds__(256) weight_prep_kernel(const float* __restric
 // the image borders are handled by clamped addresses with zeroed tap weights (no branches in the loop).
 constexpr int kStrip = 8;
 
+typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+typedef float f2_t __attribute__((ext_vector_type(2)));
+// 4 channels of one pixel: fp32 (float4) or fp16 storage (8 bytes) — io_f16 of HfagpUpfirEpilogueArgs / HfagpModconvArgs
+template <bool H16>
+__device__ __forceinline__ float4 load4(const void* base, size_t idx4) {
+    if constexpr (H16) {
+        const uint2 u = reinterpret_cast<const uint2*>(base)[idx4];
+        const h2_t a = __builtin_bit_cast(h2_t, u.x), b = __builtin_bit_cast(h2_t, u.y);
+        return make_float4((float)a[0], (float)a[1], (float)b[0], (float)b[1]);
+    } else {
+        return reinterpret_cast<const float4*>(base)[idx4];
+    }
+}
+template <bool H16>
+__device__ __forceinline__ void store4(void* base, size_t idx4, float4 v) {
+    if constexpr (H16) {
+        const f2_t lo = {v.x, v.y}, hi = {v.z, v.w};
+        reinterpret_cast<uint2*>(base)[idx4] = make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(lo, h2_t)),
+                                                          __builtin_bit_cast(unsigned, __builtin_convertvector(hi, h2_t)));
+    } else {
+        reinterpret_cast<float4*>(base)[idx4] = v;
+    }
+}
+
+template <bool H16>
 __global__ void __launch_bounds__(256) upfir_epilogue_kernel(HfagpUpfirEpilogueArgs a) {
     const int C4 = a.C >> 2;
     const int Wo = 2 * a.W, Ho = 2 * a.H, Wi = 2 * a.W + 1, Hi = 2 * a.H + 1;
@@ -141,7 +166,7 @@ __global__ void __launch_bounds__(256) upfir_epilogue_kernel(HfagpUpfirEpilogueA
     const int st = (int)((tid / ((long long)C4 * Wp)) % strips);
     const int b = (int)(tid / ((long long)C4 * Wp * strips));
     const int Y0 = st * kStrip;
-    const float4* src = reinterpret_cast<const float4*>(a.yt) + (size_t)b * Hi * Wi * C4 + c4;
+    const size_t src0 = (size_t)b * Hi * Wi * C4 + c4;           // in units of 4 channels
     const float f0 = 0.25f, f1 = 0.75f;
 
     // input columns X-1 .. X+3: clamped offset + validity
@@ -157,10 +182,10 @@ __global__ void __launch_bounds__(256) upfir_epilogue_kernel(HfagpUpfirEpilogueA
 
     auto hrow = [&](int yin, float4& ha, float4& hb) {
         const float m = (yin >= 0 && yin < Hi) ? 1.f : 0.f;
-        const float4* row = src + (size_t)min(max(yin, 0), Hi - 1) * Wi * C4;
+        const size_t row = src0 + (size_t)min(max(yin, 0), Hi - 1) * Wi * C4;
         float4 v[5];
 #pragma unroll
-        for (int q = 0; q < 5; ++q) v[q] = row[xo[q]];
+        for (int q = 0; q < 5; ++q) v[q] = load4<H16>(a.yt, row + xo[q]);
         ha.x = m * (wa[0] * v[0].x + wa[1] * v[1].x + wa[2] * v[2].x + wa[3] * v[3].x);
         ha.y = m * (wa[0] * v[0].y + wa[1] * v[1].y + wa[2] * v[2].y + wa[3] * v[3].y);
         ha.z = m * (wa[0] * v[0].z + wa[1] * v[1].z + wa[2] * v[2].z + wa[3] * v[3].z);
@@ -177,7 +202,7 @@ __global__ void __launch_bounds__(256) upfir_epilogue_kernel(HfagpUpfirEpilogueA
 
     float4 a0, a1, a2, b0, b1, b2;
     hrow(Y0 - 1, a0, b0); hrow(Y0, a1, b1); hrow(Y0 + 1, a2, b2);
-    float4* dst = reinterpret_cast<float4*>(a.y) + (size_t)b * Ho * Wo * C4 + c4;
+    const size_t dst0 = (size_t)b * Ho * Wo * C4 + c4;
     float vmax = 0.f;                                        // max |y| of this thread's stores (a.y_absmax)
     auto finish = [&](float4 o, float nz) -> float4 {
         o.x = lrelu_gain_clamp(o.x * d.x + nz + bs.x, a.act, a.alpha, a.gain, a.clamp);
@@ -207,8 +232,8 @@ __global__ void __launch_bounds__(256) upfir_epilogue_kernel(HfagpUpfirEpilogueA
             nza = a.noise[(size_t)Y * Wo + X] * a.noise_strength;
             nzb = a.noise[(size_t)Y * Wo + X + 1] * a.noise_strength;
         }
-        dst[((size_t)Y * Wo + X) * C4] = finish(oa, nza);
-        dst[((size_t)Y * Wo + X + 1) * C4] = finish(ob, nzb);
+        store4<H16>(a.y, dst0 + ((size_t)Y * Wo + X) * C4, finish(oa, nza));
+        store4<H16>(a.y, dst0 + ((size_t)Y * Wo + X + 1) * C4, finish(ob, nzb));
         a0 = a1; a1 = a2; a2 = a3;
         b0 = b1; b1 = b2; b2 = b3;
     }
@@ -560,7 +585,8 @@ int hfagp_upfir_epilogue_fwd(const HfagpUpfirEpilogueArgs* a, void* stream) {
                   "upfir_epilogue: C=%d must be a multiple of 4", a->C);
     const int strips = (2 * a->H + kStrip - 1) / kStrip;
     const long long total = (long long)a->B * strips * a->W * (a->C / 4);
-    upfir_epilogue_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(*a);
+    if (a->io_f16) upfir_epilogue_kernel<true><<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(*a);
+    else upfir_epilogue_kernel<false><<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(*a);
     return check_launch("upfir_epilogue");
 }
 

@@ -295,6 +295,8 @@ int hfagp_modconv_fwd(const HfagpModconvArgs* a, void* stream) {
     } else {
         p.out = a->y;
     }
+    HFAGP_REQUIRE(!(a->x_f16 || a->y_f16) || a->precision == HFAGP_PREC_F16, HFAGP_EUNSUPPORTED,
+                  "modconv: fp16 storage (x_f16 / y_f16) goes with precision HFAGP_PREC_F16");
     if (a->precision != HFAGP_PREC_F32) {
         rc = launch_modconv_bf16(a, pl, s);
         if (rc != HFAGP_OK) return rc;

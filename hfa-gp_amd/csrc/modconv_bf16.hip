@@ -132,10 +132,15 @@ __device__ __forceinline__ float style_range_guard(const float* styles, int cin,
     return ldexpf(1.f, -e);
 }
 
-template <int KD, int TM, int NTAPS>
+// IO: fp16 STORAGE of the activations (hfagp.h x_f16 / y_f16; KD = 1 only): bit 0 = x is fp16 (staging copies the halves
+// and applies the style with packed fp16 multiplies), bit 1 = y is written as fp16
+template <int KD, int TM, int NTAPS, int IO = 0>
 __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p, const int phase0) {
     constexpr int NP = kind_parts(KD);
     constexpr bool F16 = kind_f16(KD);
+    constexpr bool XH = (IO & 1) != 0, YH = (IO & 2) != 0;
+    constexpr int XB = XH ? 2 : 4;                       // bytes per input element
+    static_assert(IO == 0 || KD == 1, "fp16 storage goes with the single-pass fp16 arithmetic");
 #ifndef HFAGP_WAVES_N
 #define HFAGP_WAVES_N 2
 #endif
@@ -183,7 +188,7 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
     constexpr int A_PER_T = ((PH + 2) * (PW + 2) * 4 + 255) / 256;
     static_assert(A_PER_T == 3, "the staging schedule below is written for three slots per thread");
     float4 ra[A_PER_T];
-    const char* xb = reinterpret_cast<const char*>(p.x + ph.in_off + (long long)b * p.x_batch_stride);
+    const char* xb = reinterpret_cast<const char*>(p.x) + (ph.in_off + (long long)b * p.x_batch_stride) * XB;
     for (int i = tid; i < p.Cin; i += 256) Ss[i] = p.styles ? p.styles[(size_t)b * p.Cin + i] : 1.f;
     float sback = 1.f, sdown = 1.f;                      // 2^e, 2^-e of the fp16 range guard (1 for the bf16 kinds)
     if constexpr (F16) sdown = style_range_guard(p.styles ? p.styles + (size_t)b * p.Cin : nullptr, p.Cin, lane, &sback, p.x_absmax);
@@ -197,14 +202,22 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
         lds_a[k] = ((pix / p.pw) * LPWB + pix % p.pw) * APITCH + 8 * q;
         const int iy = m0 + p.dymin + pix / p.pw, ix = n0 + p.dxmin + pix % p.pw;
         const bool inside = iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
-        aoff[k] = inside ? (unsigned)((iy * p.in_w + ix) * p.Cin + 4 * q) * 4u : 0u;     // bytes, < 2^32 per image
+        aoff[k] = inside ? (unsigned)((iy * p.in_w + ix) * p.Cin + 4 * q) * (unsigned)XB : 0u;   // bytes, < 2^32 per image
         amask[k] = inside ? sdown : 0.f;          // zero padding and the fp16 range guard in one factor
         soff[k] = 4 * q;
     }
     auto load_a = [&](int chunk) __attribute__((always_inline)) {
-        const char* xc = xb + (long long)chunk * (CKB * 4);
+        const char* xc = xb + (long long)chunk * (CKB * XB);
 #pragma unroll
-        for (int k = 0; k < A_PER_T; ++k) ra[k] = *reinterpret_cast<const float4*>(xc + aoff[k]);
+        for (int k = 0; k < A_PER_T; ++k) {
+            if constexpr (XH) {
+                const uint2 u = *reinterpret_cast<const uint2*>(xc + aoff[k]);
+                ra[k].x = __builtin_bit_cast(float, u.x);
+                ra[k].y = __builtin_bit_cast(float, u.y);
+            } else {
+                ra[k] = *reinterpret_cast<const float4*>(xc + aoff[k]);
+            }
+        }
     };
     // slot K of the staged patch of `chunk`: scale by the style, split, write the parts to LDS buffer BUF
     auto store_a = [&](int chunk, auto buf_tag, auto k_tag) __attribute__((always_inline)) {
@@ -213,6 +226,15 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
             const float m = amask[k];
             const float4 sv = *reinterpret_cast<const float4*>(Ss + chunk * CKB + soff[k]);
             uint2 parts[NP];
+            if constexpr (XH) {
+                // fp16 storage: the halves are the operand already; the style (|s| <= 1 after the range guard, |x| <= the
+                // layer's clamp) goes on with two packed fp16 multiplies, as EG3D's fp16 blocks do
+                const f32x2 s01 = {sv.x * m, sv.y * m}, s23 = {sv.z * m, sv.w * m};
+                const f16x2 x01 = __builtin_bit_cast(f16x2, __builtin_bit_cast(unsigned, ra[k].x));
+                const f16x2 x23 = __builtin_bit_cast(f16x2, __builtin_bit_cast(unsigned, ra[k].y));
+                parts[0] = make_uint2(__builtin_bit_cast(unsigned, x01 * __builtin_convertvector(s01, f16x2)),
+                                      __builtin_bit_cast(unsigned, x23 * __builtin_convertvector(s23, f16x2)));
+            } else
             split4<KD>(make_float4(ra[k].x * (sv.x * m), ra[k].y * (sv.y * m), ra[k].z * (sv.z * m),
                                    ra[k].w * (sv.w * m)), parts);
 #pragma unroll
@@ -419,7 +441,7 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
     // ---- epilogue.  C/D layout of 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5): the 16 registers of
     // a tile are 2 patch rows (r>>3) x columns 8*((r>>2)&1) + 4h + (r&3).  One 64-bit row pointer per (tile, patch
     // row); everything else is a 32-bit offset (the per-element 64-bit index products were ~8k VALU cycles per wave).
-    float* out = p.out + (size_t)(ks * p.nslab + ph.slab) * p.slab;
+    float* out = p.out + (size_t)(ks * p.nslab + ph.slab) * p.slab;       // (YH: no split-K, p.out = y as fp16)
     const int cstep = ph.sx * p.Cout;                                     // elements between neighbouring columns
     float vmax = 0.f;                                                     // max |y| of this lane's stores (y_absmax)
     // fused toRGB (hfagp.h rgb_w / rgb_part): rgbp[position][r] collects y[co] * rgb_w[r][co] over this lane's channels
@@ -452,7 +474,9 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
                 const int m = m0 + 2 * (wm * TMW + tm) + rw;
                 if (m >= ph.mh) continue;
                 const int oy = ph.sy * m + ph.oy0;
-                float* rowp = out + (((size_t)b * p.Ho + oy) * p.Wo + ph.ox0) * p.Cout + co;
+                const size_t rowoff = (((size_t)b * p.Ho + oy) * p.Wo + ph.ox0) * p.Cout + co;
+                float* rowp = out + rowoff;
+                _Float16* rowh = reinterpret_cast<_Float16*>(p.out) + rowoff;
                 const float* nrow = (p.fused && p.noise) ? p.noise + (size_t)oy * p.Wo + ph.ox0 : nullptr;
                 float nz[8];
 #pragma unroll
@@ -471,7 +495,10 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
 #ifdef HFAGP_ABL_NOSTORE    // (developer ablation: one store per 16 values)
                     if (q == 0 && rw == 0)
 #endif
-                    rowp[n * cstep] = v;
+                    {
+                        if constexpr (YH) rowh[n * cstep] = (_Float16)v;
+                        else rowp[n * cstep] = v;
+                    }
                     if constexpr (RGB) {
 #pragma unroll
                         for (int r = 0; r < 3; ++r)
@@ -526,10 +553,13 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
 // channels per block and two waves per SIMD (256 registers each) — the patch is staged once for twice the MFMA
 // work and the second wave of a SIMD covers the barrier / staging bubbles of the first; used when the layer
 // still fills the chip with the larger tile (make_plan).
-template <int KD, int NW>
+template <int KD, int NW, int IO = 0>
 __global__ void __launch_bounds__(NW * 64, 1) upconv_bf16_kernel(const ConvParams p) {
     constexpr int NP = kind_parts(KD);
     constexpr bool F16 = kind_f16(KD);
+    constexpr bool XH = (IO & 1) != 0, YH = (IO & 2) != 0;       // fp16 storage of x / y_t (see modconv_bf16_kernel)
+    constexpr int XB = XH ? 2 : 4;
+    static_assert(IO == 0 || KD == 1, "fp16 storage goes with the single-pass fp16 arithmetic");
     constexpr int NTH = NW * 64;
     constexpr int TM = 2, TN = 1, WN = NW / 2, BM = 128, BNU = WN * TN * 32, PH = BM / PW, NITEM = 9, RB = NP == 1 ? 6 : 3;
     constexpr int LPWB = RowPitch<NP>::value;
@@ -564,7 +594,7 @@ __global__ void __launch_bounds__(NW * 64, 1) upconv_bf16_kernel(const ConvParam
     constexpr int A_PER_T = ((PH + 2) * (PW + 2) * 4 + NTH - 1) / NTH;
     static_assert(A_PER_T == 2 || A_PER_T == 3, "staging schedule: two or three slots per thread");
     float4 ra[A_PER_T];
-    const char* xb = reinterpret_cast<const char*>(p.x + (long long)b * p.x_batch_stride);
+    const char* xb = reinterpret_cast<const char*>(p.x) + (long long)b * p.x_batch_stride * XB;
     for (int i = tid; i < p.Cin; i += NTH) Ss[i] = p.styles ? p.styles[(size_t)b * p.Cin + i] : 1.f;
     float sback = 1.f, sdown = 1.f;
     if constexpr (F16) sdown = style_range_guard(p.styles ? p.styles + (size_t)b * p.Cin : nullptr, p.Cin, lane, &sback, p.x_absmax);
@@ -578,14 +608,22 @@ __global__ void __launch_bounds__(NW * 64, 1) upconv_bf16_kernel(const ConvParam
         lds_a[k] = ((pix / p.pw) * LPWB + pix % p.pw) * APITCH + 8 * q;
         const int iy = m0 - 1 + pix / p.pw, ix = n0 - 1 + pix % p.pw;
         const bool inside = iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
-        aoff[k] = inside ? (unsigned)((iy * p.in_w + ix) * p.Cin + 4 * q) * 4u : 0u;
+        aoff[k] = inside ? (unsigned)((iy * p.in_w + ix) * p.Cin + 4 * q) * (unsigned)XB : 0u;
         amask[k] = inside ? sdown : 0.f;          // zero padding and the fp16 range guard in one factor
         soff[k] = 4 * q;
     }
     auto load_a = [&](int chunk) __attribute__((always_inline)) {
-        const char* xc = xb + (long long)chunk * (CKB * 4);
+        const char* xc = xb + (long long)chunk * (CKB * XB);
 #pragma unroll
-        for (int k = 0; k < A_PER_T; ++k) ra[k] = *reinterpret_cast<const float4*>(xc + aoff[k]);
+        for (int k = 0; k < A_PER_T; ++k) {
+            if constexpr (XH) {
+                const uint2 u = *reinterpret_cast<const uint2*>(xc + aoff[k]);
+                ra[k].x = __builtin_bit_cast(float, u.x);
+                ra[k].y = __builtin_bit_cast(float, u.y);
+            } else {
+                ra[k] = *reinterpret_cast<const float4*>(xc + aoff[k]);
+            }
+        }
     };
     auto store_a = [&](int chunk, auto buf_tag, auto k_tag) __attribute__((always_inline)) {
         constexpr int BUF = decltype(buf_tag)::value, k = decltype(k_tag)::value;
@@ -593,6 +631,13 @@ __global__ void __launch_bounds__(NW * 64, 1) upconv_bf16_kernel(const ConvParam
             const float m = amask[k];
             const float4 sv = *reinterpret_cast<const float4*>(Ss + chunk * CKB + soff[k]);
             uint2 parts[NP];
+            if constexpr (XH) {
+                const f32x2 s01 = {sv.x * m, sv.y * m}, s23 = {sv.z * m, sv.w * m};
+                const f16x2 x01 = __builtin_bit_cast(f16x2, __builtin_bit_cast(unsigned, ra[k].x));
+                const f16x2 x23 = __builtin_bit_cast(f16x2, __builtin_bit_cast(unsigned, ra[k].y));
+                parts[0] = make_uint2(__builtin_bit_cast(unsigned, x01 * __builtin_convertvector(s01, f16x2)),
+                                      __builtin_bit_cast(unsigned, x23 * __builtin_convertvector(s23, f16x2)));
+            } else
             split4<KD>(make_float4(ra[k].x * (sv.x * m), ra[k].y * (sv.y * m), ra[k].z * (sv.z * m),
                                    ra[k].w * (sv.w * m)), parts);
 #pragma unroll
@@ -724,7 +769,9 @@ __global__ void __launch_bounds__(NW * 64, 1) upconv_bf16_kernel(const ConvParam
                 for (int rw = 0; rw < 2; ++rw) {
                     const int m = m0 + 2 * (wm * TM + tm) + rw;
                     if (m >= mh) continue;
-                    float* rowp = out + (((size_t)b * p.Ho + 2 * m + (f >> 1)) * p.Wo + (f & 1)) * p.Cout + co;
+                    const size_t rowoff = (((size_t)b * p.Ho + 2 * m + (f >> 1)) * p.Wo + (f & 1)) * p.Cout + co;
+                    float* rowp = out + rowoff;
+                    _Float16* rowh = reinterpret_cast<_Float16*>(p.out) + rowoff;
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
                         const int n = n0 + 8 * (q >> 2) + 4 * h + (q & 3);
@@ -732,7 +779,11 @@ __global__ void __launch_bounds__(NW * 64, 1) upconv_bf16_kernel(const ConvParam
 #ifdef HFAGP_ABL_NOSTORE
                         if (q == 0 && rw == 0)
 #endif
-                        rowp[2 * n * p.Cout] = F16 ? acc[f][tm][tn][8 * rw + q] * sback : acc[f][tm][tn][8 * rw + q];
+                        {
+                            const float v = F16 ? acc[f][tm][tn][8 * rw + q] * sback : acc[f][tm][tn][8 * rw + q];
+                            if constexpr (YH) rowh[2 * n * p.Cout] = (_Float16)v;
+                            else rowp[2 * n * p.Cout] = v;
+                        }
                     }
                 }
         }
@@ -754,6 +805,17 @@ static void launch_group(const Plan& pl, int phase0, int nphase, int ntaps, int 
         case 4: modconv_bf16_kernel<KD, 2, 4><<<grid, 256, lds, s>>>(pl.p, phase0); break;
         case 2: modconv_bf16_kernel<KD, 2, 2><<<grid, 256, lds, s>>>(pl.p, phase0); break;
         default: modconv_bf16_kernel<KD, 2, 1><<<grid, 256, lds, s>>>(pl.p, phase0); break;
+    }
+}
+
+// fp16-storage variants (KD = 1 only): io = x_f16 | y_f16 << 1
+static void launch_up_io(const Plan& pl, int cin, int io, hipStream_t s) {
+    const size_t lds = bf16_lds_bytes<1, 2>(cin);
+    const bool w8 = pl.up_waves == 8;
+    if (io == 2) {
+        if (w8) upconv_bf16_kernel<1, 8, 2><<<pl.grid, 512, lds, s>>>(pl.p); else upconv_bf16_kernel<1, 4, 2><<<pl.grid, 256, lds, s>>>(pl.p);
+    } else {
+        if (w8) upconv_bf16_kernel<1, 8, 3><<<pl.grid, 512, lds, s>>>(pl.p); else upconv_bf16_kernel<1, 4, 3><<<pl.grid, 256, lds, s>>>(pl.p);
     }
 }
 
@@ -788,6 +850,24 @@ int launch_modconv_bf16(const HfagpModconvArgs* a, Plan& pl, hipStream_t s) {
     HFAGP_REQUIRE(a->Cin <= 512, HFAGP_EUNSUPPORTED, "modconv (16-bit MFMA): Cin=%d > 512 (style image in LDS)", a->Cin);
     const int kd = kind_of(a->precision);
     HFAGP_REQUIRE(kd != 0, HFAGP_EBADARG, "modconv: unknown precision %d", a->precision);
+    const int io = (a->x_f16 ? 1 : 0) | (a->y_f16 ? 2 : 0);
+    if (io) {
+        const ConvParams& q = pl.p;
+        HFAGP_REQUIRE(kd == 1 && q.ksplit * q.nslab == 1 && a->Cout % BNB == 0 &&
+                          ((a->mode == HFAGP_CONV3X3 && io == 3) || (a->mode == HFAGP_CONVT3X3_UP2 && (io & 2))),
+                      HFAGP_EUNSUPPORTED, "modconv: fp16 storage needs precision F16, no split-K, Cout %% 128 == 0 and mode 0 "
+                                          "(x and y fp16) or mode 1 (y fp16); got precision %d mode %d x_f16 %d y_f16 %d ksplit %d",
+                      a->precision, a->mode, a->x_f16, a->y_f16, q.ksplit);
+        if (a->mode == HFAGP_CONVT3X3_UP2) {
+            HFAGP_REQUIRE(pl.merged_up, HFAGP_EUNSUPPORTED, "modconv: fp16 storage of the up-conv needs the merged four-phase "
+                                                            "kernel (grids >= 32x32 at Cin <= 512)");
+            launch_up_io(pl, a->Cin, io, s);
+            return check_launch("modconv_fwd (fp16 storage, merged up-conv)");
+        }
+        const dim3 grid(pl.grid.x, 1, 1);
+        modconv_bf16_kernel<1, 2, 9, 3><<<grid, 256, bf16_lds_bytes<1, 2>(a->Cin), s>>>(pl.p, 0);
+        return check_launch("modconv_fwd (fp16 storage)");
+    }
     // the kernel is specialised on the tap count: one launch per run of phases with the same number of taps
     // (3x3: one; stride-2 transposed conv and its adjoint: 4 | 2, 2 | 1)
     const ConvParams& p = pl.p;

@@ -22,6 +22,7 @@ struct ConvParams {
     const float* noise; const float* bias;
     const float* x_absmax; float* y_absmax;    // fp16 range tracking (hfagp.h), may be null
     const float* rgb_w; float* rgb_part;       // fused toRGB (hfagp.h), may be null
+    int x_f16, y_f16;                          // fp16 storage of x / y (hfagp.h)
     float* out;                  // y, or the split-K workspace
     long long x_batch_stride;
     long long slab;              // elements per split-K slab (B*Ho*Wo*Cout)
@@ -61,6 +62,7 @@ static inline int make_plan(const HfagpModconvArgs* a, Plan& pl, int ck) {
     p.x = a->x; p.wt = a->wt; p.styles = a->styles; p.dcoef = a->dcoef; p.noise = a->noise; p.bias = a->bias;
     p.x_absmax = a->x_absmax; p.y_absmax = a->y_absmax;
     p.rgb_w = a->rgb_w; p.rgb_part = a->rgb_part;
+    p.x_f16 = a->x_f16; p.y_f16 = a->y_f16;
     p.x_batch_stride = a->x_batch_stride;
     p.B = a->B; p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.Cout = a->Cout;
     p.act = a->act; p.noise_strength = a->noise_strength; p.alpha = a->alpha; p.gain = a->gain; p.clamp = a->clamp;

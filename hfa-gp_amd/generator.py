@@ -146,6 +146,7 @@ class TriPlaneGenerator(nn.Module):
         self._sr_conv_precision: Optional[str] = None
         self.conv_precision = cfg.conv_precision
         self.sr_conv_precision = cfg.sr_conv_precision
+        self.sr_storage = cfg.sr_storage
         self._styles: Dict[int, tuple] = {}      # id(layer) -> (styles, dcoef) of the pass in flight
         self._absmax = None                      # (slot buffers, layer names) of the last pass: f16_range_report()
         self._rgb_part = None                    # partial toRGB sums of the conv just run (fused toRGB, ops.modconv)
@@ -298,9 +299,10 @@ class TriPlaneGenerator(nn.Module):
 
     # ----------------------------------------------------------------- layers
     def _layer(self, x, layer: _SynthesisLayer, w, row, batch, noise_mode, conv_clamp, tape, x_absmax=None,
-               y_absmax=None, rgb=None):
+               y_absmax=None, rgb=None, half=False):
         """x_absmax / y_absmax: fp16 range tracking of an UNCLAMPED activation chain (ops.modconv): the slot buffer with
-        max |x| of the input as published by its producer, and the one this layer publishes max |out| into."""
+        max |x| of the input as published by its producer, and the one this layer publishes max |out| into.
+        half: write the output (and the raw up-conv intermediate) as float16 (`sr_storage = "f16"`, no tape)."""
         cfg = self.cfg
         wt, wsq = self._prepared(layer.weight)
         pre = self._styles.pop(id(layer), None) if self._styles else None      # computed up front (_precompute_styles)
@@ -322,7 +324,7 @@ class TriPlaneGenerator(nn.Module):
                "modconv_f16" if wt.dtype == torch.float16 and wt.shape[0] == 1 else "modconv_split")
         if layer.up == 2:
             yt = self._timed(key, flops, ops.modconv, x, wt, cout, ops.CONVT3X3_UP2, styles=k_styles, batch=batch,
-                             x_absmax=x_absmax)
+                             x_absmax=x_absmax, y_f16=half)
             out = ops.upfir_epilogue(yt, k_dcoef, noise, ns, layer.bias, "lrelu", cfg.lrelu_alpha, gain, conv_clamp,
                                      y_absmax=y_absmax)
         else:
@@ -334,7 +336,7 @@ class TriPlaneGenerator(nn.Module):
             out = self._timed(key, flops, ops.modconv, x, wt, cout, ops.CONV3X3, styles=k_styles, dcoef=k_dcoef,
                               noise=noise, noise_strength=ns, bias=layer.bias, act="lrelu", alpha=cfg.lrelu_alpha,
                               gain=gain, clamp=conv_clamp, batch=batch, x_absmax=x_absmax, y_absmax=y_absmax,
-                              rgb_w=rgb_w)
+                              rgb_w=rgb_w, y_f16=half)
             if rgb_w is not None:
                 out, self._rgb_part = out
         rec = None
@@ -345,7 +347,7 @@ class TriPlaneGenerator(nn.Module):
         return out, rec
 
     def _block(self, x, img, blk: _SynthesisBlock, ws, rows, batch, noise_mode, conv_clamp, small_rgb, last, tape,
-               absmax=None):
+               absmax=None, half=False):
         """rows = the ws row of (conv0,) conv1, torgb.  absmax = (slots of the block input | None, slots for conv0's
         output, slots for conv1's output) when the chain is unclamped (fp16 range tracking), else None."""
         rec = dict(conv0=None, first=blk.in_channels == 0, img_in=img, const=getattr(blk, "const", None))
@@ -364,9 +366,9 @@ class TriPlaneGenerator(nn.Module):
                                           noise_mode, conv_clamp, tape, None, am1, rgb)
         else:
             x, rec["conv0"] = self._layer(x, blk.conv0, ws[:, rows[0]], rows[0], batch, noise_mode, conv_clamp, tape,
-                                          am_in, am0)
+                                          am_in, am0, None, half)
             x, rec["conv1"] = self._layer(x, blk.conv1, ws[:, rows[1]], rows[1], batch, noise_mode, conv_clamp, tape,
-                                          am0, am1, rgb)
+                                          am0, am1, rgb, half)
         y = y_pre = None
         if small_rgb:
             if tape is not None and conv_clamp is not None:
@@ -375,8 +377,8 @@ class TriPlaneGenerator(nn.Module):
                 img = ops.torgb_finish(self._rgb_part, tr.bias, img, conv_clamp, y_pre)
                 self._rgb_part = None
             else:
-                img = ops.torgb_small(x, tr.weight.detach().reshape(tr.weight.shape[0], cin), styles, tr.bias, img,
-                                      conv_clamp, y_pre)
+                img = ops.torgb_small(x.float() if half else x, tr.weight.detach().reshape(tr.weight.shape[0], cin),
+                                      styles, tr.bias, img, conv_clamp, y_pre)
         else:
             wt, _ = self._prepared(tr.weight)
             y = ops.modconv(x, wt, tr.weight.shape[0], ops.CONV1X1, styles=styles, bias=tr.bias, act="linear",
@@ -492,11 +494,27 @@ class TriPlaneGenerator(nn.Module):
         last = cfg.num_ws - 1
         sr = self.superresolution
         self._precompute_styles(ws, [(sr.block0, [last] * 3), (sr.block1, [last] * 3)])
+        half = self._sr_half(b, feat_img.shape[1], tape)
         x, rgb = self._block(feat_img, rgb_raw, sr.block0, ws, [last] * 3, b, cfg.sr_noise_mode, cfg.sr_conv_clamp,
-                             True, False, tape)
+                             True, False, tape, None, half)
         x, rgb = self._block(x, rgb, sr.block1, ws, [last] * 3, b, cfg.sr_noise_mode, cfg.sr_conv_clamp, True, False,
-                             tape)
+                             tape, None, half)
         return rgb
+
+    def _sr_half(self, batch: int, res: int, tape) -> bool:
+        """fp16 STORAGE of the super-resolution activations (cfg.sr_storage = "f16"): EG3D's own arrangement for these two
+        blocks (sr_num_fp16_res = 4: fp16 tensors between the layers, clamp 256).  Taken only where the arithmetic is
+        the single-pass fp16 one (sr_conv_precision "f16"), nothing is recorded for a backward pass, and every conv of
+        the two blocks is one the kernels can run that way (ops.f16_storage_supported)."""
+        cfg = self.cfg
+        if self.sr_storage != "f16" or self._sr_conv_precision != "f16" or tape is not None:
+            return False
+        if cfg.sr_conv_clamp is None:
+            return False                  # fp16 storage relies on the clamp (|x| <= 256) for its range
+        c0, c1 = cfg.sr_channels
+        ok = ops.f16_storage_supported
+        return (ok(res, res, cfg.plane_channels, c0, batch) and ok(2 * res, 2 * res, c0, c0, batch) and
+                ok(2 * res, 2 * res, c0, c1, batch) and ok(4 * res, 4 * res, c1, c1, batch))
 
     def _check_inputs(self, ws, c, noise_mode):
         cfg = self.cfg

@@ -216,7 +216,7 @@ def modconv(x: torch.Tensor, wt: torch.Tensor, cout: int, mode: int, styles: Opt
             noise_strength: float = 0.0, bias: Optional[torch.Tensor] = None, act: str = "linear",
             alpha: float = 0.2, gain: float = 1.0, clamp: Optional[float] = None, batch: Optional[int] = None,
             ksplit: int = 0, x_absmax: Optional[torch.Tensor] = None,
-            y_absmax: Optional[torch.Tensor] = None, rgb_w: Optional[torch.Tensor] = None):
+            y_absmax: Optional[torch.Tensor] = None, rgb_w: Optional[torch.Tensor] = None, y_f16: bool = False):
     """x [B|1, H, W, Cin] channels-last.  mode CONV3X3 / CONV1X1: fused epilogue, returns [B,H,W,Cout];
     mode CONVT3X3_UP2: returns the RAW transposed-conv result [B, 2H+1, 2W+1, Cout].
     ``wt`` from :func:`weight_prep` (fp32, exact MFMA) or :func:`weight_prep_split` (bfloat16 parts: the
@@ -225,8 +225,17 @@ def modconv(x: torch.Tensor, wt: torch.Tensor, cout: int, mode: int, styles: Opt
     producer (the fp16 kinds scale the operand by an exact power of two so nothing saturates) and the slot buffer that
     receives max |y| of a fused-epilogue output (include/hfagp.h).
     ``rgb_w`` [B, 3, Cout] (toRGB weight x its styles): fused toRGB — returns (y, rgb_part [parts, B, H, W, 4]) for
-    `torgb_finish`; only where `fused_torgb_supported` says so."""
-    _chk(x, "x")
+    `torgb_finish`; only where `fused_torgb_supported` says so.
+    fp16 STORAGE (single-pass fp16 weights only, `f16_storage_supported`): a float16 ``x`` is read as stored and
+    ``y_f16`` writes the result as float16 (EG3D's fp16 super-resolution blocks keep their activations in fp16)."""
+    x_f16 = x.dtype == torch.float16
+    if x_f16 or y_f16:
+        if not (wt.dtype == torch.float16 and wt.dim() == 5 and wt.shape[0] == 1):
+            raise RuntimeError("modconv: fp16 storage (float16 x / y_f16) goes with the single-pass fp16 weight image")
+        if not (x.is_cuda and x.is_contiguous()):
+            raise RuntimeError("x: expected a contiguous CUDA/ROCm tensor")
+    if not x_f16:
+        _chk(x, "x")
     if mode == CONVS2_BWD:                      # x = four parity images [2,2,B,H+1,W+1,Cin]
         _, _, xb, h, w, cin = x.shape
         h, w = h - 1, w - 1
@@ -238,7 +247,7 @@ def modconv(x: torch.Tensor, wt: torch.Tensor, cout: int, mode: int, styles: Opt
         nparts = (2, 3) if wt.dtype == torch.bfloat16 else (1, 2)
         if not (wt.is_cuda and wt.is_contiguous() and wt.dim() == 5 and wt.shape[0] in nparts):
             raise RuntimeError("modconv: 16-bit weight images must come from weight_prep_prec")
-        a.x, a.wt = _ptr(x), wt.data_ptr()
+        a.x, a.wt = x.data_ptr(), wt.data_ptr()
         if wt.dtype == torch.float16:
             a.precision = PREC_F16 if wt.shape[0] == 1 else PREC_F16X3
         else:
@@ -253,11 +262,13 @@ def modconv(x: torch.Tensor, wt: torch.Tensor, cout: int, mode: int, styles: Opt
     a.noise_strength, a.alpha, a.gain = noise_strength, alpha, gain
     a.clamp = -1.0 if clamp is None else float(clamp)
     a.x_absmax, a.y_absmax = _ptr(x_absmax), _ptr(y_absmax)
+    a.x_f16, a.y_f16 = int(x_f16), int(y_f16)
+    ydt = torch.float16 if y_f16 else torch.float32
     if mode == CONVT3X3_UP2:
-        y = torch.empty(b, 2 * h + 1, 2 * w + 1, cout, device=x.device, dtype=torch.float32)
+        y = torch.empty(b, 2 * h + 1, 2 * w + 1, cout, device=x.device, dtype=ydt)
     else:
-        y = torch.empty(b, h, w, cout, device=x.device, dtype=torch.float32)
-    a.y = _ptr(y)
+        y = torch.empty(b, h, w, cout, device=x.device, dtype=ydt)
+    a.y = y.data_ptr()
     nbytes = L.lib().hfagp_modconv_workspace_bytes(C.byref(a))
     ws = None
     if nbytes:
@@ -269,6 +280,15 @@ def modconv(x: torch.Tensor, wt: torch.Tensor, cout: int, mode: int, styles: Opt
         a.rgb_w, a.rgb_part = _ptr(_chk(rgb_w, "rgb_w")), _ptr(part)
     L.check(L.lib().hfagp_modconv_fwd(C.byref(a), _stream()), "modconv_fwd")
     return y if rgb_w is None else (y, part)
+
+
+def f16_storage_supported(h: int, w: int, cin: int, cout: int, batch: int) -> bool:
+    """Whether a 3x3 / up-sampling modconv on an h x w input grid can keep its activations in fp16 (`modconv` y_f16,
+    float16 x): 128-channel output tiles and a launch the library does not split along K (its rule: at least 2 x 256
+    blocks of 8 x 16 positions x 128 channels, or fewer than four 16-channel K chunks)."""
+    if cin % 16 != 0 or cout % 128 != 0:
+        return False
+    return cin < 64 or batch * ((h + 7) // 8) * ((w + 15) // 16) * (cout // 128) >= 512
 
 
 def fused_torgb_supported(x: torch.Tensor, wt: torch.Tensor, cout: int, batch: int) -> bool:
@@ -300,13 +320,20 @@ def upfir_epilogue(yt: torch.Tensor, dcoef: Optional[torch.Tensor], noise: Optio
                    noise_strength: float, bias: Optional[torch.Tensor], act: str = "lrelu", alpha: float = 0.2,
                    gain: float = math.sqrt(2.0), clamp: Optional[float] = None,
                    y_absmax: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """yt [B, 2H+1, 2W+1, C] raw transposed conv → FIR(pad 1, gain 4) → demod/noise/bias/act → [B,2H,2W,C]."""
-    _chk(yt, "yt")
+    """yt [B, 2H+1, 2W+1, C] raw transposed conv → FIR(pad 1, gain 4) → demod/noise/bias/act → [B,2H,2W,C].
+    A float16 ``yt`` (fp16 storage, `modconv` y_f16) gives a float16 result; the arithmetic is fp32 either way."""
+    half = yt.dtype == torch.float16
+    if half:
+        if not (yt.is_cuda and yt.is_contiguous()):
+            raise RuntimeError("yt: expected a contiguous CUDA/ROCm tensor")
+    else:
+        _chk(yt, "yt")
     b, hi, wi, c = yt.shape
     h, w = (hi - 1) // 2, (wi - 1) // 2
-    y = torch.empty(b, 2 * h, 2 * w, c, device=yt.device, dtype=torch.float32)
+    y = torch.empty(b, 2 * h, 2 * w, c, device=yt.device, dtype=yt.dtype)
     a = L.UpfirEpilogueArgs()
-    a.yt, a.dcoef, a.noise, a.bias, a.y = _ptr(yt), _ptr(dcoef), _ptr(noise), _ptr(bias), _ptr(y)
+    a.yt, a.dcoef, a.noise, a.bias, a.y = yt.data_ptr(), _ptr(dcoef), _ptr(noise), _ptr(bias), y.data_ptr()
+    a.io_f16 = int(half)
     a.B, a.H, a.W, a.C, a.act = b, h, w, c, _ACT[act]
     a.noise_strength, a.alpha, a.gain = noise_strength, alpha, gain
     a.clamp = -1.0 if clamp is None else float(clamp)

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define HFAGP_ABI_VERSION 5
+#define HFAGP_ABI_VERSION 6
 
 enum { HFAGP_OK = 0, HFAGP_EBADARG = -1, HFAGP_EUNSUPPORTED = -2, HFAGP_ELAUNCH = -3 };
 
@@ -199,6 +199,11 @@ typedef struct {
      * bias, the clamp and the up-sampled previous image.  Saves the separate toRGB pass over the activation.    */
     const float* rgb_w;       /* [B][3][Cout] or NULL */
     float*       rgb_part;    /* [hfagp_modconv_rgb_parts()][B][H][W][4] floats (3 used), written, or NULL */
+    /* fp16 STORAGE of the activations (EG3D's fp16 blocks keep them in fp16: super-resolution, sr_num_fp16_res = 4):
+     * x_f16 = 1: x holds IEEE fp16 values (same shape; pass the pointer as x), y_f16 = 1: y is written as fp16.
+     * Only with precision HFAGP_PREC_F16, modes 0 and 1, no split-K (hfagp_modconv_workspace_bytes() == 0); the styles
+     * are applied with packed fp16 multiplies and staging is a copy instead of a conversion.                        */
+    int32_t x_f16, y_f16;
 } HfagpModconvArgs;
 /* number of partial-sum images a call with rgb_part writes: (Cout / 128) x 2 */
 int32_t hfagp_modconv_rgb_parts(const HfagpModconvArgs* a);
@@ -214,15 +219,16 @@ int hfagp_modconv_fwd(const HfagpModconvArgs* a, void* stream);
 /* FIR (4x4 [1,3,3,1]^2/64, pad [1,1,1,1], gain 4) over the raw transposed-conv
  * output + demod + noise + bias + act.  yt [B][2H+1][2W+1][C] -> y [B][2H][2W][C] */
 typedef struct {
-    const float* yt;
+    const void*  yt;          /* fp32, or fp16 when io_f16 */
     const float* dcoef;       /* [B][C] or NULL */
     const float* noise;       /* [2H][2W] or NULL */
     const float* bias;        /* [C] or NULL */
-    float*       y;
+    void*        y;           /* fp32, or fp16 when io_f16 */
     int32_t B, H, W, C;       /* H, W = INPUT resolution of the up-conv */
     int32_t act;
     float noise_strength, alpha, gain, clamp;
     float*       y_absmax;    /* optional [HFAGP_ABSMAX_FLOATS]: max |y| (see HfagpModconvArgs) */
+    int32_t      io_f16;      /* 1: yt and y are IEEE fp16 tensors (same shapes; HfagpModconvArgs::x_f16 / y_f16), math stays fp32 */
 } HfagpUpfirEpilogueArgs;
 
 int hfagp_upfir_epilogue_fwd(const HfagpUpfirEpilogueArgs* a, void* stream);

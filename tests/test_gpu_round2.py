@@ -545,3 +545,103 @@ def test_upfirdn2d_and_bias_act_backward(dev, up, down, pad):
     yd.backward(gb.to(dev))
     close(xd.grad, xr.grad, atol=1e-5)
     close(bd.grad, br.grad, atol=1e-4)
+
+
+# ----------------------------------------------------------------------------- fp16 storage of the SR activations
+@pytest.mark.parametrize("h,cin,cout", [(136, 64, 128), (96, 128, 256)])
+def test_conv3x3_with_fp16_storage(dev, h, cin, cout):
+    """modconv with a float16 x and y_f16 (HfagpModconvArgs.x_f16 / y_f16): against the SAME single-pass fp16 arithmetic
+    on fp32-stored tensors.  The operands differ only in where the style is applied (packed fp16 multiply on the stored
+    halves vs fp32 multiply then one rounding): one extra fp16 rounding per operand; the output is rounded to fp16.  The
+    fused toRGB sums are formed from the fp32 accumulators in both variants."""
+    from hfa_gp_amd import ops
+    g = torch.Generator().manual_seed(h)
+    b = 4
+    x = (torch.randn(b, h, h, cin, generator=g) * 3.0).to(dev)
+    w = torch.randn(cout, cin, 3, 3, generator=g).to(dev)
+    s = (torch.randn(b, cin, generator=g) + 1.0).to(dev)
+    dcoef = (torch.rand(b, cout, generator=g) * 0.05 + 0.02).to(dev)
+    bias = torch.randn(cout, generator=g).to(dev)
+    rgb_w = (torch.randn(b, 3, cout, generator=g) / math.sqrt(cout)).to(dev)
+    wb = ops.weight_prep_prec(w, "f16")
+    assert ops.f16_storage_supported(h, h, cin, cout, b)
+    xh = x.half()
+    kw = dict(styles=s, dcoef=dcoef, bias=bias, act="lrelu", gain=math.sqrt(2), clamp=256.0)
+    y_ref, part_ref = ops.modconv(xh.float(), wb, cout, ops.CONV3X3, rgb_w=rgb_w, **kw)
+    y, part = ops.modconv(xh, wb, cout, ops.CONV3X3, rgb_w=rgb_w, y_f16=True, **kw)
+    assert y.dtype == torch.float16 and y.shape == y_ref.shape
+    scale = y_ref.abs().max().item()
+    err = (y.float() - y_ref).abs().max().item()
+    rms = (y.float() - y_ref).pow(2).mean().sqrt().item() / y_ref.pow(2).mean().sqrt().item()
+    print(f"fp16 storage conv3x3: max err {err:.3e} of {scale:.3e}, relative rms {rms:.3e}")
+    assert err <= 2e-3 * scale and rms <= 6e-4, (err, scale, rms)
+    perr = (part.sum(0) - part_ref.sum(0)).abs().max().item() / part_ref.sum(0).abs().max().item()
+    assert perr <= 2e-3, perr
+    # refused where it cannot be honoured: split weights, and launches the library would split along K
+    with pytest.raises(RuntimeError, match="fp16 storage"):
+        ops.modconv(xh, ops.weight_prep_prec(w, "f16x3"), cout, ops.CONV3X3, **kw)
+    assert not ops.f16_storage_supported(8, 8, cin, cout, 1)
+    with pytest.raises(RuntimeError, match="fp16 storage"):
+        ops.modconv(xh[:1, :8, :8].contiguous(), wb, cout, ops.CONV3X3, styles=s[:1], y_f16=True)
+
+
+@pytest.mark.parametrize("x_half,h,cin,cout,b", [(False, 128, 32, 256, 1), (True, 64, 256, 128, 16), (True, 72, 64, 128, 12)])
+def test_upconv_and_fir_epilogue_with_fp16_storage(dev, x_half, h, cin, cout, b):
+    """The up-sampling layer with fp16 storage: raw transposed conv written as float16 (from an fp32 or a float16 input),
+    then hfagp_upfir_epilogue_fwd with io_f16 reading and writing halves — against the fp32-stored run of the same
+    single-pass fp16 arithmetic."""
+    from hfa_gp_amd import ops
+    g = torch.Generator().manual_seed(h + cin)
+    x = (torch.randn(b, h, h, cin, generator=g) * 2.0).to(dev)
+    w = torch.randn(cout, cin, 3, 3, generator=g).to(dev)
+    s = (torch.randn(b, cin, generator=g) + 1.0).to(dev)
+    dcoef = (torch.rand(b, cout, generator=g) * 0.05 + 0.02).to(dev)
+    bias = torch.randn(cout, generator=g).to(dev)
+    wb = ops.weight_prep_prec(w, "f16")
+    assert ops.f16_storage_supported(h, h, cin, cout, b)
+    xin = x.half() if x_half else x
+    yt_ref = ops.modconv(xin.float(), wb, cout, ops.CONVT3X3_UP2, styles=s)
+    yt = ops.modconv(xin, wb, cout, ops.CONVT3X3_UP2, styles=s, y_f16=True)
+    assert yt.dtype == torch.float16 and yt.shape == (b, 2 * h + 1, 2 * h + 1, cout)
+    scale = yt_ref.abs().max().item()
+    assert scale < 6e4                                    # (the test's own precondition: representable in fp16)
+    err = (yt.float() - yt_ref).abs().max().item()
+    assert err <= 2e-3 * scale, (err, scale)
+    am = ops.absmax_slots(1, dev)[0]
+    out_ref = ops.upfir_epilogue(yt.float(), dcoef, None, 0.0, bias, "lrelu", 0.2, math.sqrt(2), 256.0)
+    out = ops.upfir_epilogue(yt, dcoef, None, 0.0, bias, "lrelu", 0.2, math.sqrt(2), 256.0, y_absmax=am)
+    assert out.dtype == torch.float16 and out.shape == (b, 2 * h, 2 * h, cout)
+    # same inputs, same fp32 arithmetic: the result is the fp32 one rounded to fp16, exactly
+    assert torch.equal(out, out_ref.half())
+    assert abs(am.max().item() - out_ref.abs().max().item()) <= 1e-6 * out_ref.abs().max().item()
+
+
+def test_generator_sr_storage_f16(dev, full_gen):
+    """cfg.sr_storage = "f16" on the full-size generator: forward-only calls keep the super-resolution activations in
+    fp16 (EG3D's fp16 blocks); the image stays within the fp16 blocks' own error of the default path, calls that record a
+    backward pass keep fp32 storage (and so do not change), and the f32-storage f16-arithmetic image is the closer one."""
+    cfg, gen, _ = full_gen
+    ws, c, us, ui = (t.to(dev) for t in make_inputs(cfg, 2, seed=5))
+    u = (us, ui)
+    old = (gen.sr_conv_precision, gen.sr_storage)
+    try:
+        with torch.no_grad():
+            img_def = gen.synthesis(ws, c, u_strat=u[0], u_imp=u[1])["image"]
+            gen.sr_conv_precision = "f16"
+            img_f16 = gen.synthesis(ws, c, u_strat=u[0], u_imp=u[1])["image"]
+            gen.sr_storage = "f16"
+            assert gen._sr_half(2, gen.cfg.neural_rendering_resolution, None)
+            assert gen._sr_half(1, gen.cfg.neural_rendering_resolution, None)
+            img_h = gen.synthesis(ws, c, u_strat=u[0], u_imp=u[1])["image"]
+        scale = img_def.abs().max().item()
+        e_arith = (img_f16 - img_def).abs().max().item() / scale
+        e_store = (img_h - img_def).abs().max().item() / scale
+        e_rms = (img_h - img_def).pow(2).mean().sqrt().item() / img_def.pow(2).mean().sqrt().item()
+        print(f"SR fp16: arithmetic only {e_arith:.3e}, with fp16 storage {e_store:.3e} (relative rms {e_rms:.3e})")
+        assert e_store <= 1e-2 and e_rms <= 2e-3, (e_arith, e_store, e_rms)
+        # a call that needs gradients keeps fp32 storage: identical to the f32-storage image
+        wsg = ws.clone().requires_grad_(True)
+        img_g = gen.synthesis(wsg, c, u_strat=u[0], u_imp=u[1])["image"]
+        assert torch.equal(img_g.detach(), img_f16)
+    finally:
+        gen.sr_conv_precision, gen.sr_storage = old
