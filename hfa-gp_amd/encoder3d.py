@@ -21,6 +21,10 @@ SQRT2 = math.sqrt(2.0)
 
 
 def fused_leaky_relu(x: torch.Tensor, bias: torch.Tensor, negative_slope: float = 0.2, scale: float = SQRT2):
+    if x.is_cuda and x.dtype == torch.float32 and x.dim() >= 2 and bias.numel() == x.shape[1]:
+        # one HIP pass forward (hfagp_bias_act_fwd) and one backward (hfagp_bias_act_bwd) instead of add / leaky_relu / mul
+        from . import ops
+        return ops.bias_act(x.contiguous(), bias.reshape(-1), dim=1, act="lrelu", alpha=negative_slope, gain=scale)
     return F.leaky_relu(x + bias, negative_slope) * scale
 
 
@@ -36,6 +40,11 @@ def upfirdn2d(x: torch.Tensor, kernel: torch.Tensor, up: int = 1, down: int = 1,
     flipped kernel, keep every `down`-th sample.  NCHW, pure PyTorch (CPU or ROCm)."""
     n, c, h, w = x.shape
     p0, p1 = pad
+    if x.is_cuda and x.dtype == torch.float32:
+        # the HIP FIR (hfagp_upfirdn2d_fwd / _bwd; pinned to the reference's upfirdn2d_native by tests/golden) instead of
+        # zero-insert + pad + crop + a one-channel F.conv2d over n*c images (which MIOpen serves with its naive kernel)
+        from . import ops
+        return ops.upfirdn2d(x.contiguous(), kernel.contiguous(), up=up, down=down, padding=(p0, p1, p0, p1), gain=1.0)
     if up > 1:
         z = x.new_zeros(n, c, h, up, w, up)
         z[:, :, :, 0, :, 0] = x

@@ -645,3 +645,33 @@ def test_generator_sr_storage_f16(dev, full_gen):
         assert torch.equal(img_g.detach(), img_f16)
     finally:
         gen.sr_conv_precision, gen.sr_storage = old
+
+
+def test_encoder_on_gpu_matches_its_cpu_path(dev):
+    """The RGB driver network on the GPU (FIR blur and fused leaky-ReLU through hfagp_upfirdn2d_* / hfagp_bias_act_*, the
+    convolutions on MIOpen) against the same module on the CPU (pure PyTorch, the path the reference-generated golden vectors
+    pin in tests/test_host_golden.py): outputs and every parameter gradient."""
+    import copy
+    from hfa_gp_amd.encoder3d import Encoder
+    torch.manual_seed(3)
+    enc = Encoder(64, 512, 50)
+    x = torch.randn(2, 3, 64, 64)
+    gy = torch.randn(2, 50)
+    y_ref = enc(x)
+    (y_ref * gy).sum().backward()
+    ref = {n: p.grad.clone() for n, p in enc.named_parameters()}
+    enc_g = copy.deepcopy(enc).to(dev)
+    for p in enc_g.parameters():
+        p.grad = None
+    xg = x.to(dev).requires_grad_(True)
+    y = enc_g(xg)
+    (y * gy.to(dev)).sum().backward()
+    close(y.cpu(), y_ref.detach(), 2e-4 * y_ref.abs().max().item())
+    worst = 0.0
+    for n, p in enc_g.named_parameters():
+        if ref[n].abs().max().item() == 0.0:
+            continue
+        worst = max(worst, (p.grad.cpu() - ref[n]).abs().max().item() / ref[n].abs().max().item())
+    print(f"encoder gradients GPU vs CPU: worst relative max error {worst:.2e}")
+    assert worst <= 2e-3, worst
+    assert torch.isfinite(xg.grad).all()
