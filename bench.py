@@ -573,7 +573,7 @@ def main():
             roof = {"bound": "mfma", "kernel": f"modconv_bf16_kernel<{kd}> / upconv_bf16_kernel<{kd}> ({SPLIT_MFMAS[prec]} x "
                                                f"v_mfma_f32_32x32x16_{SPLIT_ELEM[prec]} per fp32 product)",
                     "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
-                    "traffic": profiled_traffic(f"modconv_bf16_kernel<{kd}, 2, 9>"), "avg_launch_ms": ms / max(n, 1),
+                    "traffic": profiled_traffic(f"modconv_bf16_kernel<{kd}, 2, 9"), "avg_launch_ms": ms / max(n, 1),
                     "launches": n, "mfma_16bit_tflops": tf * SPLIT_MFMAS[prec]}
         # ray march: the planes of a frame (25 MB) are cache resident, so the SURVEY 8d "algorithmic bytes" are a GATHER
         # rate served by L2 / Infinity Cache, not HBM traffic.  The kernel's physical floor is the L2 gather

@@ -70,6 +70,15 @@ class UpfirEpilogueArgs(C.Structure):
     ]
 
 
+class TorgbSkipArgs(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("wt", C.c_void_p), ("styles", C.c_void_p), ("bias", C.c_void_p),
+        ("img_in", C.c_void_p), ("img_out", C.c_void_p), ("x_absmax", C.c_void_p), ("out_absmax", C.c_void_p),
+        ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32),
+        ("precision", C.c_int32), ("plane_major", C.c_int32),
+    ]
+
+
 class SkipArgs(C.Structure):
     _fields_ = [
         ("img_in", C.c_void_p), ("y", C.c_void_p), ("img_out", C.c_void_p),
@@ -139,6 +148,7 @@ SYMBOLS = {
     "hfagp_modconv_fwd": (C.c_int, [C.POINTER(ModconvArgs), C.c_void_p]),
     "hfagp_upfir_epilogue_fwd": (C.c_int, [C.POINTER(UpfirEpilogueArgs), C.c_void_p]),
     "hfagp_skip_upsample_add": (C.c_int, [C.POINTER(SkipArgs), C.c_void_p]),
+    "hfagp_torgb_skip_fwd": (C.c_int, [C.POINTER(TorgbSkipArgs), C.c_void_p]),
     "hfagp_torgb_fwd": (C.c_int, [C.POINTER(TorgbArgs), C.c_void_p]),
     "hfagp_torgb_finish_fwd": (C.c_int, [C.POINTER(TorgbFinishArgs), C.c_void_p]),
     "hfagp_modconv_rgb_parts": (C.c_int32, [C.POINTER(ModconvArgs)]),

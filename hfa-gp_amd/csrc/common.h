@@ -38,6 +38,13 @@ __device__ __forceinline__ float lrelu_gain_clamp(float v, int act, float alpha,
     return v;
 }
 
+// the two taps (indices into the half-resolution image, weights) of upsample2d (FIR [1,3,3,1], up 2, pad (2,1), gain 4) at
+// output coordinate Y; a tap outside the image contributes nothing
+__device__ __forceinline__ void up2_taps(int Y, int& i0, int& i1, float& w0, float& w1) {
+    if (Y & 1) { i0 = (Y - 1) >> 1; i1 = i0 + 1; w0 = 0.75f; w1 = 0.25f; }
+    else       { i1 = Y >> 1; i0 = i1 - 1; w0 = 0.25f; w1 = 0.75f; }
+}
+
 // fp16 range tracking (include/hfagp.h, HfagpModconvArgs::y_absmax): wave maximum of |v| -> ONE atomic per wave into
 // one of HFAGP_ABSMAX_SLOTS slots (non-negative floats order like their bit patterns; spreading the blocks over the
 // slots keeps same-address atomics from serialising in L2).

@@ -244,10 +244,6 @@ __global__ void __launch_bounds__(256) upfir_epilogue_kernel(HfagpUpfirEpilogueA
 // upsample2d = zero-insert x2, pad [2,1,2,1], FIR [1,3,3,1]^2/64, gain 4  ==  per axis
 //   out[2i]   = .25*in[i-1] + .75*in[i]
 //   out[2i+1] = .75*in[i]   + .25*in[i+1]          (out-of-range taps are zero)
-__device__ __forceinline__ void up2_taps(int Y, int& i0, int& i1, float& w0, float& w1) {
-    if (Y & 1) { i0 = (Y - 1) >> 1; i1 = i0 + 1; w0 = 0.75f; w1 = 0.25f; }
-    else       { i1 = Y >> 1; i0 = i1 - 1; w0 = 0.25f; w1 = 0.75f; }
-}
 
 __global__ void __launch_bounds__(256) skip_kernel(HfagpSkipArgs a) {
     const int C4 = a.C >> 2;
@@ -274,7 +270,7 @@ __global__ void __launch_bounds__(256) skip_kernel(HfagpSkipArgs a) {
                 if (ys[p] >= 0 && ys[p] < a.H && xs[q] >= 0 && xs[q] < a.W) {
                     const float4 v = src[((size_t)ys[p] * a.W + xs[q]) * C4];
                     const float wgt = wy[p] * wx[q];
-                    o.x += wgt * v.x; o.y += wgt * v.y; o.z += wgt * v.z; o.w += wgt * v.w;
+                    o.x = fmaf(wgt, v.x, o.x); o.y = fmaf(wgt, v.y, o.y); o.z = fmaf(wgt, v.z, o.z); o.w = fmaf(wgt, v.w, o.w);
                 }
     }
     if (a.plane_major) {

@@ -381,12 +381,17 @@ class TriPlaneGenerator(nn.Module):
                                       styles, tr.bias, img, conv_clamp, y_pre)
         else:
             wt, _ = self._prepared(tr.weight)
-            y = ops.modconv(x, wt, tr.weight.shape[0], ops.CONV1X1, styles=styles, bias=tr.bias, act="linear",
-                            gain=1.0, clamp=conv_clamp, batch=batch, x_absmax=am1)
             # the block that writes the tri-planes also publishes max |planes|: the bound the ray marcher's 16-bit
             # decoder scales its operands by (ops.raymarch planes_absmax)
             self._planes_absmax = ops.absmax_slots(1, x.device)[0] if last else None
-            img = ops.skip_upsample_add(img, y, plane_major=last, out_absmax=self._planes_absmax)
+            if conv_clamp is None and x.shape[0] == batch and ops.torgb_skip_supported(x, wt, tr.weight.shape[0]):
+                # toRGB and the skip connection in one streaming pass (the toRGB output is never stored)
+                img = ops.torgb_skip(x, wt, tr.weight.shape[0], styles, tr.bias, img, plane_major=last, x_absmax=am1,
+                                     out_absmax=self._planes_absmax)
+            else:
+                y = ops.modconv(x, wt, tr.weight.shape[0], ops.CONV1X1, styles=styles, bias=tr.bias, act="linear",
+                                gain=1.0, clamp=conv_clamp, batch=batch, x_absmax=am1)
+                img = ops.skip_upsample_add(img, y, plane_major=last, out_absmax=self._planes_absmax)
         if tape is not None:
             rec["rgb"] = dict(torgb=tr, x=x, styles=styles, row=row, small=small_rgb, clamp=conv_clamp,
                               y=y if conv_clamp is not None else None, y_pre=y_pre)

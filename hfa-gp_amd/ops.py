@@ -362,6 +362,42 @@ def skip_upsample_add(img: Optional[torch.Tensor], y: torch.Tensor, plane_major:
     return out
 
 
+def torgb_skip_supported(x: torch.Tensor, wt: torch.Tensor, cout: int) -> bool:
+    """Whether `torgb_skip` (hfagp_torgb_skip_fwd, the streaming toRGB + skip kernel) takes this layer: a 16-bit weight
+    image, Cout a multiple of 32 (<= 128), Cin a multiple of 16 (<= 512), rows of a multiple of 32 positions."""
+    _, h, w, cin = x.shape
+    return (wt.dtype in (torch.float16, torch.bfloat16) and cout % 32 == 0 and cout <= 128 and cin % 16 == 0 and
+            cin <= 512 and w % 32 == 0 and (h * w) % 128 == 0)
+
+
+def torgb_skip(x: torch.Tensor, wt: torch.Tensor, cout: int, styles: torch.Tensor, bias: torch.Tensor,
+               img: Optional[torch.Tensor], plane_major: bool = False, x_absmax: Optional[torch.Tensor] = None,
+               out_absmax: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """SynthesisBlock 'skip' branch in one pass: upsample2d(img) + toRGB(x) (1x1 modulated conv, linear, bias), x and img
+    channels-last; returns [B,H,W,Cout] or, plane_major, [B,3,H,W,Cout/3].  ``wt``: `weight_prep_prec` image of the toRGB
+    weight.  Same bits as `modconv(CONV1X1)` + `skip_upsample_add` (when that conv is not split along K)."""
+    _chk(x, "x")
+    b, h, w, cin = x.shape
+    if not (wt.is_cuda and wt.is_contiguous() and wt.dim() == 5 and wt.dtype in (torch.float16, torch.bfloat16)):
+        raise RuntimeError("torgb_skip: the weight image must come from weight_prep_prec (16-bit kinds)")
+    a = L.TorgbSkipArgs()
+    if wt.dtype == torch.float16:
+        a.precision = PREC_F16 if wt.shape[0] == 1 else PREC_F16X3
+    else:
+        a.precision = PREC_BF16X3 if wt.shape[0] == 2 else PREC_BF16X6
+    out = torch.empty((b, 3, h, w, cout // 3) if plane_major else (b, h, w, cout), device=x.device, dtype=torch.float32)
+    a.x, a.wt, a.styles, a.bias = _ptr(x), wt.data_ptr(), _ptr(_chk(styles, "styles")), _ptr(_chk(bias, "bias"))
+    if img is not None:
+        _chk(img, "img")
+        if img.shape != (b, h // 2, w // 2, cout):
+            raise RuntimeError(f"torgb_skip: img {tuple(img.shape)} is not the half-resolution image of {(b, h, w, cout)}")
+        a.img_in = _ptr(img)
+    a.img_out, a.x_absmax, a.out_absmax = _ptr(out), _ptr(x_absmax), _ptr(out_absmax)
+    a.B, a.H, a.W, a.Cin, a.Cout, a.plane_major = b, h, w, cin, cout, int(plane_major)
+    L.check(L.lib().hfagp_torgb_skip_fwd(C.byref(a), _stream()), "torgb_skip_fwd")
+    return out
+
+
 def torgb_small(x: torch.Tensor, weight: torch.Tensor, styles: torch.Tensor, bias: torch.Tensor,
                 rgb_in: Optional[torch.Tensor], clamp: Optional[float], y_pre: Optional[torch.Tensor] = None) -> torch.Tensor:
     """ToRGBLayer with ≤4 output channels + skip add; x channels-last, rgb NCHW.  `y_pre` (optional,

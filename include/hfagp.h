@@ -247,6 +247,29 @@ typedef struct {
 
 int hfagp_skip_upsample_add(const HfagpSkipArgs* a, void* stream);
 
+/* toRGB of a backbone block with its skip connection in ONE streaming pass (EG3D SynthesisBlock.forward, architecture
+ * 'skip': `img = upsample2d(img); y = self.torgb(x, ws); img = img.add_(y)`), for the 96-channel tri-plane image:
+ *   img_out[b][p][co] = sum_i x[b][p][i] styles[b][i] w[co][i] + bias[co] + upsample2d(img_in)[b][p][co]
+ * on the 16-bit matrix pipe with split operands (precision = HFAGP_PREC_F16X3 / BF16X3 / BF16X6 / F16, as hfagp_modconv_fwd),
+ * every wave streaming 32 positions x Cin channels straight from HBM into MFMA operands; the toRGB output never
+ * goes through memory.  Cout a multiple of 32 (<= 128), Cin a multiple of 16 (<= 512), W a multiple of 32, H*W of 128;
+ * other shapes: hfagp_modconv_fwd (HFAGP_CONV1X1) + hfagp_skip_upsample_add.                                         */
+typedef struct {
+    const float* x;           /* [B][H][W][Cin] channels-last */
+    const void*  wt;          /* hfagp_weight_prep_prec image of the [Cout][Cin][1][1] weight (taps = 1) */
+    const float* styles;      /* [B][Cin] (already * 1/sqrt(Cin)) */
+    const float* bias;        /* [Cout] */
+    const float* img_in;      /* [B][H/2][W/2][Cout] channels-last, or NULL (first block: img_out = toRGB) */
+    float*       img_out;     /* [B][H][W][Cout], or [B][3][H][W][Cout/3] when plane_major (needs Cout = 96) */
+    const float* x_absmax;    /* optional [HFAGP_ABSMAX_FLOATS]: max |x| as published by x's producer (fp16 kinds) */
+    float*       out_absmax;  /* optional [HFAGP_ABSMAX_FLOATS]: receives max |img_out| */
+    int32_t B, H, W, Cin, Cout;
+    int32_t precision;        /* HFAGP_PREC_* of the weight image (not F32) */
+    int32_t plane_major;
+} HfagpTorgbSkipArgs;
+
+int hfagp_torgb_skip_fwd(const HfagpTorgbSkipArgs* a, void* stream);
+
 /* toRGB with few output channels (super-resolution, img_channels = 3):
  * rgb_out[b][c][y][x] (NCHW) = sum_i x[b][y][x][i]*styles[b][i]*w[c][i] + bias[c]
  *                              (clamped) + upsample2d(rgb_in)[b][c][y][x]           */

@@ -82,7 +82,7 @@ def main():
              "--no-train; bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (KiB -> bytes); averages over all launches of "
              "the kernel in one synthesis"}
     for k, v in traffic.items():
-        if k.startswith(("modconv_kernel<2, 2, 2, 2>", "modconv_bf16_kernel<2, 2, 9>", "modconv_bf16_kernel<4, 2, 9>", "upconv_bf16_kernel",
+        if k.startswith(("modconv_kernel<2, 2, 2, 2>", "modconv_bf16_kernel<2, 2, 9", "modconv_bf16_kernel<4, 2, 9", "upconv_bf16_kernel",
                          "raymarch_kernel")):
             out_t[k] = {"fetch_raw": v.get("FETCH_SIZE"), "write": v.get("WRITE_SIZE"),
                         "hbm_bytes": 2 * v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)}
