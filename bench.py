@@ -287,7 +287,16 @@ def fit3dmm_leg(args, cfg_name, dev, rank, world, dist):
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
-    losses = fit_frames(tr, full["real"], full["label"], full["params"], epochs=1, batch=args.train_batch)
+    marks = {}
+
+    def on_step(i, _out):
+        if i in (half, last):
+            marks[i] = torch.cuda.Event(enable_timing=True)
+            marks[i].record()
+    from hfa_gp_amd.trainer import epoch_batches
+    nsteps = sum(1 for _ in epoch_batches(n, rank, world, args.train_batch))
+    half, last = nsteps // 2, nsteps - 1
+    losses = fit_frames(tr, full["real"], full["label"], full["params"], epochs=1, batch=args.train_batch, on_step=on_step)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -297,7 +306,10 @@ def fit3dmm_leg(args, cfg_name, dev, rank, world, dist):
     return {"workload": f"train_3dmm-style fit, {n} synthetic frames = {args.fit3dmm_frames_per_rank} per rank in contiguous "
                         f"blocks (rank r owns [{args.fit3dmm_frames_per_rank} r, {args.fit3dmm_frames_per_rank} (r+1))), "
                         f"Weights_3DMM -> basis -> generator, L2, Adam 3e-4, batch {args.train_batch}/rank, one pass",
-            "steps": len(l), "ms_per_step": dt / max(len(l), 1) * 1e3, "frames_per_s": n / dt,
+            "steps": len(l), "ms_per_step": dt / max(len(l), 1) * 1e3,
+            "ms_per_step_second_half": (marks[half].elapsed_time(marks[last]) / max(last - half, 1)
+                                        if half in marks and last in marks and last > half else None),
+            "frames_per_s": n / dt,
             "loss_first_tenth": float(l[:k].mean()), "loss_last_tenth": float(l[-k:].mean())}
 
 
@@ -318,16 +330,27 @@ def fit_leg(args, cfg_name, dev, rank, world, dist):
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
-    losses = fit_frames(tr, data["real"], data["label"], epochs=1, batch=args.train_batch)
+    marks = {}          # HIP events on the launch stream at the middle and the end of the pass: the steady-state step time
+
+    def on_step(i, _out):
+        if i in (half, last):
+            marks[i] = torch.cuda.Event(enable_timing=True)
+            marks[i].record()
+    from hfa_gp_amd.trainer import epoch_batches
+    nsteps = sum(1 for _ in epoch_batches(args.fit_frames, rank, world, args.train_batch))
+    half, last = nsteps // 2, nsteps - 1
+    losses = fit_frames(tr, data["real"], data["label"], epochs=1, batch=args.train_batch, on_step=on_step)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
     l = torch.stack(losses).float().cpu()
     k = max(1, len(l) // 10)
+    steady = marks[half].elapsed_time(marks[last]) / max(last - half, 1) if half in marks and last in marks and last > half else None
     return {"workload": f"train_rgb-style fit, {args.fit_frames} synthetic frames (targets rendered from a hidden basis, "
                         f"256^2), Encoder -> basis -> generator, L2, Adam 3e-4, batch {args.train_batch}/rank, one pass",
-            "steps": len(l), "ms_per_step": dt / max(len(l), 1) * 1e3, "frames_per_s": args.fit_frames / dt,
+            "steps": len(l), "ms_per_step": dt / max(len(l), 1) * 1e3, "ms_per_step_second_half": steady,
+            "frames_per_s": args.fit_frames / dt,
             "loss_first_tenth": float(l[:k].mean()), "loss_last_tenth": float(l[-k:].mean())}
 
 
