@@ -578,6 +578,8 @@ def main():
 
         def f32_roofline(table):
             ms, flops, n = agg("modconv", table)
+            ms_u, flops_u, n_u = agg("modconv_up", table)
+            ms, flops, n = ms + ms_u, flops + flops_u, n + n_u
             tf = flops / (ms * 1e-3) / 1e12
             return {"bound": "mfma", "kernel": "modconv_kernel (v_mfma_f32_32x32x2_f32, exact fp32)",
                     "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
@@ -589,15 +591,25 @@ def main():
         else:
             # split-operand path: ALGORITHMIC flops (2*M*N*K of the fp32 conv) against the 16-bit dense MFMA peak (2.5 PF
             # for f16 and bf16 alike) divided by the MFMAs each algorithmic product costs (3 or 6)
+            # The DOMINANT kernel is the 9-tap instance (the nine 3x3 layers of a synthesis: half of the step); the merged
+            # up-sampling conv (eight layers) and both together are reported beside it.
             ms, flops, n = agg("modconv_split")
+            ms_up, flops_up, n_up = agg("modconv_split_up")
             tf = flops / (ms * 1e-3) / 1e12
             peak = MFMA_BF16_PEAK_TFLOPS / SPLIT_MFMAS[prec]
             kd = {"f16x3": 4, "bf16x3": 2, "bf16x6": 3}[prec]
-            roof = {"bound": "mfma", "kernel": f"modconv_bf16_kernel<{kd}> / upconv_bf16_kernel<{kd}> ({SPLIT_MFMAS[prec]} x "
+            roof = {"bound": "mfma", "kernel": f"modconv_bf16_kernel<{kd}, 2, 9> ({SPLIT_MFMAS[prec]} x "
                                                f"v_mfma_f32_32x32x16_{SPLIT_ELEM[prec]} per fp32 product)",
                     "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
                     "traffic": profiled_traffic(f"modconv_bf16_kernel<{kd}, 2, 9"), "avg_launch_ms": ms / max(n, 1),
                     "launches": n, "mfma_16bit_tflops": tf * SPLIT_MFMAS[prec]}
+            if n_up:
+                tf_up = flops_up / (ms_up * 1e-3) / 1e12
+                tf_all = (flops + flops_up) / ((ms + ms_up) * 1e-3) / 1e12
+                roof["up_conv"] = {"kernel": f"upconv_bf16_kernel<{kd}> (stride-2 transposed 3x3, four phases merged; flops counted "
+                                             "at INPUT resolution)", "achieved": tf_up, "frac": tf_up / peak,
+                                   "avg_launch_ms": ms_up / n_up, "launches": n_up}
+                roof["all_conv_gemms"] = {"achieved": tf_all, "frac": tf_all / peak}
         # ray march: the planes of a frame (25 MB) are cache resident, so the SURVEY 8d "algorithmic bytes" are a GATHER
         # rate served by L2 / Infinity Cache, not HBM traffic.  The kernel's physical floor is the L2 gather
         # (gather bytes / 34.5 TB/s) plus the decoder MLP on the fp32 matrix pipe (13.1 GF per frame / 157.3 TF); `frac`
@@ -662,6 +674,8 @@ def main():
             out["value_f16"] = frames / dt16
             out["value_f16_sr_f16_storage"] = frames / dt16srh     # + activations between the SR layers kept in fp16
             ms, flops, n = agg("modconv_f16", timing16)
+            ms_u, flops_u, n_u = agg("modconv_f16_up", timing16)
+            ms, flops, n = ms + ms_u, flops + flops_u, n + n_u
             tf = flops / (ms * 1e-3) / 1e12
             out["roofline_f16_sr"] = {"bound": "mfma", "kernel": "modconv_bf16_kernel<1> / upconv_bf16_kernel<1> "
                                                                  "(1 x v_mfma_f32_32x32x16_f16 per product)",

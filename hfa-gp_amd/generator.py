@@ -323,7 +323,7 @@ class TriPlaneGenerator(nn.Module):
         key = ("modconv" if wt.dtype == torch.float32 else
                "modconv_f16" if wt.dtype == torch.float16 and wt.shape[0] == 1 else "modconv_split")
         if layer.up == 2:
-            yt = self._timed(key, flops, ops.modconv, x, wt, cout, ops.CONVT3X3_UP2, styles=k_styles, batch=batch,
+            yt = self._timed(key + "_up", flops, ops.modconv, x, wt, cout, ops.CONVT3X3_UP2, styles=k_styles, batch=batch,
                              x_absmax=x_absmax, y_f16=half)
             out = ops.upfir_epilogue(yt, k_dcoef, noise, ns, layer.bias, "lrelu", cfg.lrelu_alpha, gain, conv_clamp,
                                      y_absmax=y_absmax)
