@@ -149,6 +149,8 @@ SYMBOLS = {
     "hfagp_upfir_epilogue_fwd": (C.c_int, [C.POINTER(UpfirEpilogueArgs), C.c_void_p]),
     "hfagp_skip_upsample_add": (C.c_int, [C.POINTER(SkipArgs), C.c_void_p]),
     "hfagp_torgb_skip_fwd": (C.c_int, [C.POINTER(TorgbSkipArgs), C.c_void_p]),
+    "hfagp_blur_down_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "hfagp_blur_down_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "hfagp_torgb_fwd": (C.c_int, [C.POINTER(TorgbArgs), C.c_void_p]),
     "hfagp_torgb_finish_fwd": (C.c_int, [C.POINTER(TorgbFinishArgs), C.c_void_p]),
     "hfagp_modconv_rgb_parts": (C.c_int32, [C.POINTER(ModconvArgs)]),

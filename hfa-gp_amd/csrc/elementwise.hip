@@ -286,6 +286,69 @@ __global__ void __launch_bounds__(256) skip_kernel(HfagpSkipArgs a) {
                        blockIdx.x * 4 + (threadIdx.x >> 6));
 }
 
+// ---------------------------------------------------------------- Blur(pad 1) + stride-2 sampling, channels-last
+// (front of the 1x1 skip conv of the RGB driver's ResBlock) and its adjoint; thread = (pixel, 4 channels)
+__global__ void __launch_bounds__(256) blur_down_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H,
+                                                        int W, int C4) {
+    const int Ho = H >> 1, Wo = W >> 1;
+    const long long total = (long long)B * Ho * Wo * C4;
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= total) return;
+    const int c4 = (int)(tid % C4);
+    const int j = (int)((tid / C4) % Wo);
+    const int i = (int)((tid / ((long long)C4 * Wo)) % Ho);
+    const int b = (int)(tid / ((long long)C4 * Wo * Ho));
+    const float f[4] = {0.125f, 0.375f, 0.375f, 0.125f};
+    const float4* src = reinterpret_cast<const float4*>(x) + (size_t)b * H * W * C4 + c4;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int yy = 2 * i + a - 1;
+        if (yy < 0 || yy >= H) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int xx = 2 * j + q - 1;
+            if (xx < 0 || xx >= W) continue;
+            const float4 v = src[((size_t)yy * W + xx) * C4];
+            const float wgt = f[a] * f[q];
+            o.x = fmaf(wgt, v.x, o.x); o.y = fmaf(wgt, v.y, o.y); o.z = fmaf(wgt, v.z, o.z); o.w = fmaf(wgt, v.w, o.w);
+        }
+    }
+    reinterpret_cast<float4*>(y)[tid] = o;
+}
+
+// gx[y][x] = sum over (i, a): 2i + a - 1 = y, (j, q): 2j + q - 1 = x of f[a] f[q] gy[i][j]  (two candidates per axis)
+__global__ void __launch_bounds__(256) blur_down_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx, int B,
+                                                            int H, int W, int C4) {
+    const int Ho = H >> 1, Wo = W >> 1;
+    const long long total = (long long)B * H * W * C4;
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= total) return;
+    const int c4 = (int)(tid % C4);
+    const int X = (int)((tid / C4) % W);
+    const int Y = (int)((tid / ((long long)C4 * W)) % H);
+    const int b = (int)(tid / ((long long)C4 * W * H));
+    const float f[4] = {0.125f, 0.375f, 0.375f, 0.125f};
+    // a = Y + 1 - 2i in [0, 4): i = (Y + 1 - a) / 2 for the two a of the right parity
+    const int a0 = (Y + 1) & 1, q0 = (X + 1) & 1;
+    const float4* src = reinterpret_cast<const float4*>(gy) + (size_t)b * Ho * Wo * C4 + c4;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int a = a0 + 2 * u, i = (Y + 1 - a) >> 1;
+        if (Y + 1 - a < 0 || i >= Ho) continue;
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const int q = q0 + 2 * v, j = (X + 1 - q) >> 1;
+            if (X + 1 - q < 0 || j >= Wo) continue;
+            const float4 g = src[((size_t)i * Wo + j) * C4];
+            const float wgt = f[a] * f[q];
+            o.x = fmaf(wgt, g.x, o.x); o.y = fmaf(wgt, g.y, o.y); o.z = fmaf(wgt, g.z, o.z); o.w = fmaf(wgt, g.w, o.w);
+        }
+    }
+    reinterpret_cast<float4*>(gx)[tid] = o;
+}
+
 // ---------------------------------------------------------------- toRGB (few output channels) + skip
 // 8 lanes per pixel, each lane strides the input channels in float4 steps, so a wave
 // reads 8 full 128-byte-aligned runs per load instruction.
@@ -623,6 +686,24 @@ int hfagp_torgb_finish_fwd(const HfagpTorgbFinishArgs* a, void* stream) {
     const long long total = (long long)a->B * a->H * a->W;
     torgb_finish_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(*a);
     return check_launch("torgb_finish");
+}
+
+int hfagp_blur_down_fwd(const float* x, float* y, int32_t B, int32_t H, int32_t W, int32_t C, void* stream) {
+    HFAGP_REQUIRE(x && y, HFAGP_EBADARG, "blur_down: null pointer");
+    HFAGP_REQUIRE(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C % 4 == 0, HFAGP_EUNSUPPORTED,
+                  "blur_down: H=%d, W=%d must be even and C=%d a multiple of 4", H, W, C);
+    const long long total = (long long)B * (H / 2) * (W / 2) * (C / 4);
+    blur_down_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, y, B, H, W, C / 4);
+    return check_launch("blur_down_fwd");
+}
+
+int hfagp_blur_down_bwd(const float* gy, float* gx, int32_t B, int32_t H, int32_t W, int32_t C, void* stream) {
+    HFAGP_REQUIRE(gy && gx, HFAGP_EBADARG, "blur_down_bwd: null pointer");
+    HFAGP_REQUIRE(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C % 4 == 0, HFAGP_EUNSUPPORTED,
+                  "blur_down_bwd: H=%d, W=%d must be even and C=%d a multiple of 4", H, W, C);
+    const long long total = (long long)B * H * W * (C / 4);
+    blur_down_bwd_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(gy, gx, B, H, W, C / 4);
+    return check_launch("blur_down_bwd");
 }
 
 int hfagp_upfirdn2d_fwd(const float* x, const float* f, float* y, int32_t N, int32_t C, int32_t H, int32_t W,

@@ -2,8 +2,9 @@
 /root/reference/code/networks/encoder3d.py:86-298 (`Encoder`, `EncoderApp`, `ResBlock`, `ConvLayer`,
 `EqualConv2d`, `EqualLinear`, `Blur`, `FusedLeakyReLU`).
 
-SURVEY.md §8a row D1: this net is small next to the generator and is deliberately left on
-PyTorch-ROCm (MIOpen convolutions); it is not a HIP-kernel target.  What matters for drop-in use is
+SURVEY.md §8a row D1 leaves this net on PyTorch-ROCm; the module definitions below are that (and the CPU path the golden
+vectors pin).  On CUDA/ROCm tensors `EncoderApp.forward` hands the conv trunk to `encoder_hip.py`, which runs it on the
+generator's HIP conv kernels (the down-sampling layer is the adjoint of the generator's up-sampling layer).  What matters for drop-in use is
 that module/parameter NAMES match the reference so that HFA-GP checkpoints load
 (`encoder.net_app.convs.N...`, `encoder.fc.N.{weight,bias}`) and that outputs match the golden
 vectors captured from the reference (tests/test_host_golden.py).
@@ -167,6 +168,11 @@ class EncoderApp(nn.Module):
         self.convs = nn.ModuleList(convs)
 
     def forward(self, x):
+        if x.is_cuda:
+            # CUDA/ROCm tensors: the trunk runs on the HIP conv kernels (encoder_hip.py) where its shapes allow
+            from . import encoder_hip
+            if encoder_hip.supported(self, x):
+                return encoder_hip.forward_app(self, x)
         for m in self.convs:
             x = m(x)
         return x.squeeze(-1).squeeze(-1)

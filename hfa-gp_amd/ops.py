@@ -540,6 +540,17 @@ class _BiasAct(torch.autograd.Function):
         return dx, db, None, None, None, None, None
 
 
+def bias_act_bwd(dy: torch.Tensor, y: torch.Tensor, act: str, alpha: float, gain: float,
+                 clamp: Optional[float]) -> torch.Tensor:
+    """Gradient of bias_act w.r.t. its pre-activation input from the OUTPUT y (EG3D's bias_act backward): dy * gain *
+    lrelu'(y) * [|y| < clamp]; any layout (elementwise)."""
+    _chk(dy, "dy"), _chk(y, "y")
+    dx = torch.empty_like(y)
+    L.check(L.lib().hfagp_bias_act_bwd(_ptr(dy), _ptr(y), _ptr(dx), y.numel(), _ACT[act], alpha, gain,
+                                       -1.0 if clamp is None else float(clamp), _stream()), "bias_act_bwd")
+    return dx
+
+
 def bias_act(x: torch.Tensor, b: Optional[torch.Tensor] = None, dim: int = 1, act: str = "linear",
              alpha: float = 0.2, gain: Optional[float] = None, clamp: Optional[float] = None) -> torch.Tensor:
     """EG3D bias_act.bias_act(x, b, dim, act, alpha, gain, clamp); differentiable w.r.t. x and b."""
@@ -549,6 +560,31 @@ def bias_act(x: torch.Tensor, b: Optional[torch.Tensor] = None, dim: int = 1, ac
     if torch.is_grad_enabled() and (x.requires_grad or (b is not None and b.requires_grad)):
         return _BiasAct.apply(x, b, dim, act, alpha, gain, clamp)
     return _bias_act_raw(x, b, dim, act, alpha, gain, clamp)
+
+
+class _BlurDown(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        b, h, w, c = x.shape
+        ctx.shape = (b, h, w, c)
+        y = torch.empty(b, h // 2, w // 2, c, device=x.device, dtype=torch.float32)
+        L.check(L.lib().hfagp_blur_down_fwd(_ptr(x), _ptr(y), b, h, w, c, _stream()), "blur_down_fwd")
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        b, h, w, c = ctx.shape
+        gy = _chk(gy.contiguous(), "gy")
+        gx = torch.empty(b, h, w, c, device=gy.device, dtype=torch.float32)
+        L.check(L.lib().hfagp_blur_down_bwd(_ptr(gy), _ptr(gx), b, h, w, c, _stream()), "blur_down_bwd")
+        return gx
+
+
+def blur_down(x: torch.Tensor) -> torch.Tensor:
+    """Blur(pad (1,1), FIR [1,3,3,1]) + stride-2 sampling of a channels-last tensor [B,H,W,C] -> [B,H/2,W/2,C]
+    (the front of the RGB driver's 1x1 skip conv, encoder3d.py ConvLayer(downsample=True)); differentiable."""
+    _chk(x, "x")
+    return _BlurDown.apply(x)
 
 
 def nchw_to_nhwc(x: torch.Tensor) -> torch.Tensor:

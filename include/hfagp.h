@@ -464,6 +464,13 @@ int hfagp_upfirdn2d_bwd(const float* dy, const float* f, float* dx, int32_t N, i
 int hfagp_bias_act_bwd(const float* dy, const float* y, float* dx, int64_t n, int32_t act, float alpha, float gain,
                        float clamp, void* stream);
 
+/* Blur(pad (1,1)) of the FIR [1,3,3,1] x [1,3,3,1] / 64 followed by stride-2 sampling, channels-last — the front of the 1x1
+ * skip convolution of the RGB driver's ResBlock (/root/reference/code/networks/encoder3d.py:215, ConvLayer(..., 1,
+ * downsample=True)): y[b][i][j][c] = sum_ab f[a] f[b] x[b][2i + a - 1][2j + b - 1][c], zero outside; H, W even, C % 4 == 0.
+ * hfagp_blur_down_bwd is its adjoint (gx [B][H][W][C] from gy [B][H/2][W/2][C]).                                     */
+int hfagp_blur_down_fwd(const float* x, float* y, int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
+int hfagp_blur_down_bwd(const float* gy, float* gx, int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
+
 /* layout helpers */
 int hfagp_nchw_to_nhwc(const float* x, float* y, int32_t B, int32_t C, int32_t H, int32_t W, void* stream);
 int hfagp_nhwc_to_nchw(const float* x, float* y, int32_t B, int32_t C, int32_t H, int32_t W, void* stream);

@@ -648,8 +648,9 @@ def test_generator_sr_storage_f16(dev, full_gen):
 
 
 def test_encoder_on_gpu_matches_its_cpu_path(dev):
-    """The RGB driver network on the GPU (FIR blur and fused leaky-ReLU through hfagp_upfirdn2d_* / hfagp_bias_act_*, the
-    convolutions on MIOpen) against the same module on the CPU (pure PyTorch, the path the reference-generated golden vectors
+    """The RGB driver network on the GPU (its conv trunk on the generator's HIP conv kernels, encoder_hip.py; with an image
+    that requires grad: FIR blur and fused leaky-ReLU through hfagp_upfirdn2d_* / hfagp_bias_act_*, the convolutions on
+    MIOpen) against the same module on the CPU (pure PyTorch, the path the reference-generated golden vectors
     pin in tests/test_host_golden.py): outputs and every parameter gradient."""
     import copy
     from hfa_gp_amd.encoder3d import Encoder
@@ -660,21 +661,27 @@ def test_encoder_on_gpu_matches_its_cpu_path(dev):
     y_ref = enc(x)
     (y_ref * gy).sum().backward()
     ref = {n: p.grad.clone() for n, p in enc.named_parameters()}
+    from hfa_gp_amd import encoder_hip
     enc_g = copy.deepcopy(enc).to(dev)
-    for p in enc_g.parameters():
-        p.grad = None
-    xg = x.to(dev).requires_grad_(True)
-    y = enc_g(xg)
-    (y * gy.to(dev)).sum().backward()
-    close(y.cpu(), y_ref.detach(), 2e-4 * y_ref.abs().max().item())
-    worst = 0.0
-    for n, p in enc_g.named_parameters():
-        if ref[n].abs().max().item() == 0.0:
-            continue
-        worst = max(worst, (p.grad.cpu() - ref[n]).abs().max().item() / ref[n].abs().max().item())
-    print(f"encoder gradients GPU vs CPU: worst relative max error {worst:.2e}")
-    assert worst <= 2e-3, worst
-    assert torch.isfinite(xg.grad).all()
+    # (a) the HIP trunk (encoder_hip.py: every conv GEMM, data and weight gradient on the generator's kernels);
+    # (b) an image that itself requires grad takes the plain torch path (MIOpen convs + HIP blur / activation)
+    for hip_trunk in (True, False):
+        for p in enc_g.parameters():
+            p.grad = None
+        xg = x.to(dev).requires_grad_(not hip_trunk)
+        assert encoder_hip.supported(enc_g.net_app, xg) == hip_trunk
+        y = enc_g(xg)
+        (y * gy.to(dev)).sum().backward()
+        close(y.cpu(), y_ref.detach(), 2e-4 * y_ref.abs().max().item())
+        worst = 0.0
+        for n, p in enc_g.named_parameters():
+            if ref[n].abs().max().item() == 0.0:
+                continue
+            worst = max(worst, (p.grad.cpu() - ref[n]).abs().max().item() / ref[n].abs().max().item())
+        print(f"encoder gradients GPU ({'HIP trunk' if hip_trunk else 'torch trunk'}) vs CPU: worst relative max error {worst:.2e}")
+        assert worst <= 2e-3, worst
+        if not hip_trunk:
+            assert torch.isfinite(xg.grad).all()
 
 
 @pytest.mark.parametrize("prec", ["f16x3", "bf16x3", "f16", "bf16x6"])
@@ -711,3 +718,70 @@ def test_streaming_torgb_skip_matches_conv1x1_plus_skip(dev, prec, h, w, cin, pl
     assert not ops.torgb_skip_supported(xs, wb, cout)
     with pytest.raises(RuntimeError, match="torgb_skip"):
         ops.torgb_skip(xs, wb, cout, s, bias, None)
+
+
+@pytest.mark.parametrize("h,c", [(16, 64), (64, 8), (6, 128)])
+def test_blur_down_and_its_adjoint(dev, h, c):
+    """hfagp_blur_down_fwd / _bwd (Blur(pad 1) + stride-2 sampling, channels-last: the front of the RGB driver's 1x1 skip
+    conv) against the reference composition upfirdn2d(pad (1, 1))[::2, ::2] and its autograd (the FIR itself is pinned to
+    the reference's upfirdn2d_native by tests/golden)."""
+    from hfa_gp_amd import ops
+    from hfa_gp_amd.encoder3d import make_kernel
+    g = torch.Generator().manual_seed(h + c)
+    x = torch.randn(2, c, h, h + 2, generator=g)
+    k = make_kernel([1, 3, 3, 1])
+    xr = x.clone().requires_grad_(True)
+    xp = F.pad(xr, [1, 1, 1, 1])
+    y_ref = F.conv2d(xp.reshape(-1, 1, h + 2, h + 4), torch.flip(k, [0, 1]).view(1, 1, 4, 4)).view(2, c, h - 1, h + 1)[:, :, ::2, ::2]
+    gy = torch.randn(y_ref.shape, generator=g)
+    (y_ref * gy).sum().backward()
+    xg = x.permute(0, 2, 3, 1).contiguous().to(dev).requires_grad_(True)
+    y = ops.blur_down(xg)
+    (y * gy.permute(0, 2, 3, 1).to(dev)).sum().backward()
+    close(y.permute(0, 3, 1, 2), y_ref, 1e-6)
+    close(xg.grad.permute(0, 3, 1, 2), xr.grad, 1e-6)
+
+
+@pytest.mark.parametrize("cin,cout,h", [(128, 256, 16), (64, 128, 32), (512, 512, 8)])
+def test_encoder_conv_layers_on_hip_kernels(dev, cin, cout, h):
+    """The two conv layers of the RGB driver's ResBlock as autograd Functions over the generator's kernels
+    (encoder_hip._Conv3x3Act: HFAGP_CONV3X3 / _BWD / conv_wgrad; encoder_hip._BlurConvDown: hfagp_upfir_bwd + HFAGP_CONVS2_BWD
+    forward, HFAGP_CONVT3X3_UP2 + FIR epilogue for the data gradient, conv_wgrad in its up-sampling mode with x and g
+    exchanged for the weights) against F.conv2d and torch autograd — outputs, d x, d w, d bias; no flips anywhere."""
+    from hfa_gp_amd import encoder_hip as E
+    from hfa_gp_amd.encoder3d import make_kernel
+    g = torch.Generator().manual_seed(cin + h)
+    x = torch.randn(2, cin, h, h, generator=g).to(dev)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(9 * cin)).to(dev)
+    b = torch.randn(cout, generator=g).to(dev)
+    k = make_kernel([1, 3, 3, 1]).to(dev)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous()
+    nchw = lambda t: t.permute(0, 3, 1, 2)
+
+    def rel(a, ref):
+        return ((a - ref).abs().max() / ref.abs().max()).item()
+
+    # ---- stride 1 + bias + leaky ReLU
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y_ref = F.leaky_relu(F.conv2d(xr, wr, padding=1) + br.view(1, -1, 1, 1), 0.2) * math.sqrt(2)
+    gy = torch.randn(y_ref.shape, generator=torch.Generator().manual_seed(1)).to(dev)
+    (y_ref * gy).sum().backward()
+    xh, wh, bh = nhwc(x).requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y = E._Conv3x3Act.apply(xh, wh, bh)
+    (y * nhwc(gy)).sum().backward()
+    errs = dict(y=rel(nchw(y), y_ref), dx=rel(nchw(xh.grad), xr.grad), dw=rel(wh.grad, wr.grad), db=rel(bh.grad, br.grad))
+    print("conv3x3 + act:", {n: f"{v:.1e}" for n, v in errs.items()})
+    assert errs["y"] <= 2e-6 and errs["dx"] <= 2e-5 and errs["dw"] <= 5e-5 and errs["db"] <= 1e-5, errs
+    # ---- Blur(pad 2) + stride 2 (the caller passes w with the 1/4 of the FIR gain folded in)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    xp = F.pad(xr, [2, 2, 2, 2])
+    xb = F.conv2d(xp.reshape(-1, 1, h + 4, h + 4), torch.flip(k, [0, 1]).view(1, 1, 4, 4)).view(2, cin, h + 1, h + 1)
+    y_ref = F.conv2d(xb, wr, stride=2)
+    gy = torch.randn(y_ref.shape, generator=torch.Generator().manual_seed(2)).to(dev)
+    (y_ref * gy).sum().backward()
+    xh, wh = nhwc(x).requires_grad_(True), w.clone().requires_grad_(True)
+    y = E._BlurConvDown.apply(xh, wh * 0.25)
+    (y * nhwc(gy)).sum().backward()
+    errs = dict(y=rel(nchw(y), y_ref), dx=rel(nchw(xh.grad), xr.grad), dw=rel(wh.grad, wr.grad))
+    print("blur + conv3x3 stride 2:", {n: f"{v:.1e}" for n, v in errs.items()})
+    assert errs["y"] <= 2e-6 and errs["dx"] <= 2e-5 and errs["dw"] <= 5e-5, errs
