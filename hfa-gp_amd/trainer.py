@@ -42,6 +42,19 @@ def pooled_l2(face_pool: nn.Module, real_image: torch.Tensor, generated: torch.T
     return F.mse_loss(real_image, pooled, reduction="mean"), pooled
 
 
+def _adam(params, **kw) -> torch.optim.Adam:
+    """torch.optim.Adam as the reference builds it (trainer_rgb.py:58); on CUDA/ROCm parameters the FUSED implementation
+    (one multi-tensor kernel per step instead of ~16: the update of the 22.7 M-parameter driver net and, once tuned, the
+    30.7 M generator parameters is HBM-bound).  Same state_dict layout, same update rule."""
+    params = list(params)
+    if params and all(p.is_cuda and p.dtype == torch.float32 for p in params):
+        try:
+            return torch.optim.Adam(params, fused=True, **kw)
+        except (RuntimeError, TypeError):
+            pass
+    return torch.optim.Adam(params, **kw)
+
+
 def requires_grad(net: nn.Module, flag: bool = True) -> None:
     for p in net.parameters():
         p.requires_grad = flag
@@ -309,7 +322,7 @@ class Trainer(nn.Module):
         # Adam over ALL parameters, THEN freeze the generator — same order as trainer_rgb.py:58-60 /
         # trainer_3dmm.py:33-35, so that tune_generator() starts updating the generator without rebuilding the optimiser.
         self.optim_key = "g_optim" if mode == "rgb" else "w_optim"
-        setattr(self, self.optim_key, torch.optim.Adam(self.gen.parameters(), lr=args.lr))
+        setattr(self, self.optim_key, _adam(self.gen.parameters(), lr=args.lr))
         requires_grad(self.gen.generator, False)
         if lpips is None:
             # the reference objective is ALWAYS l2 + LPIPS(alex) (trainer_rgb.py:62,86-91); its weights cannot be
@@ -566,10 +579,10 @@ class AudioTrainer(nn.Module):
         self.gen = gen.to(device)
         self.AudNet = AudioNet(args.dim_aud, args.win_size).to(device)
         self.AudAttNet = AudioAttNet().to(device)       # default dim_aud = 32 while features are 64-d: reference quirk 7
-        self.optimizer_Aud = torch.optim.Adam(params=list(self.AudNet.parameters()), lr=args.lr, betas=(0.9, 0.999))
+        self.optimizer_Aud = _adam(list(self.AudNet.parameters()), lr=args.lr, betas=(0.9, 0.999))
         self.optimizer_AudAtt = torch.optim.Adam(params=list(self.AudAttNet.parameters()), lr=args.lr,
                                                  betas=(0.9, 0.999))
-        self.w_optim = torch.optim.Adam(self.gen.parameters(), lr=args.lr)
+        self.w_optim = _adam(self.gen.parameters(), lr=args.lr)
         requires_grad(self.gen.generator, False)
         if lpips is None:
             warnings.warn("AudioTrainer: no LPIPS module given — optimising the L2 term only (the reference trains on "
