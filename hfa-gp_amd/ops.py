@@ -364,10 +364,13 @@ def skip_upsample_add(img: Optional[torch.Tensor], y: torch.Tensor, plane_major:
 
 def torgb_skip_supported(x: torch.Tensor, wt: torch.Tensor, cout: int) -> bool:
     """Whether `torgb_skip` (hfagp_torgb_skip_fwd, the streaming toRGB + skip kernel) takes this layer: a 16-bit weight
-    image, Cout a multiple of 32 (<= 128), Cin a multiple of 16 (<= 512), rows of a multiple of 32 positions."""
-    _, h, w, cin = x.shape
+    image, Cout a multiple of 32 (<= 128), Cin a multiple of 16 (<= 512), rows of a multiple of 32 positions, and enough
+    positions to fill the chip."""
+    b, h, w, cin = x.shape
+    # (below 512 wave tiles of 32 positions the K loop's HBM latency is not covered by other waves — at one frame the
+    # 32^2 and 64^2 blocks take 46 / 42 us here against 24 / 27 us for the split-K conv + reducer + skip kernels)
     return (wt.dtype in (torch.float16, torch.bfloat16) and cout % 32 == 0 and cout <= 128 and cin % 16 == 0 and
-            cin <= 512 and w % 32 == 0 and (h * w) % 128 == 0)
+            cin <= 512 and w % 32 == 0 and (h * w) % 128 == 0 and b * h * w >= 512 * 32)
 
 
 def torgb_skip(x: torch.Tensor, wt: torch.Tensor, cout: int, styles: torch.Tensor, bias: torch.Tensor,
