@@ -286,6 +286,8 @@ int hfagp_modconv_fwd(const HfagpModconvArgs* a, void* stream) {
                   HFAGP_EUNSUPPORTED, "modconv: the fused toRGB needs a 16-bit precision, mode 0 / 2, Cout %% 128 == 0 and no "
                                       "split-K (workspace_bytes() == 0); got precision %d mode %d Cout %d ksplit %d",
                   a->precision, a->mode, a->Cout, p.ksplit);
+    HFAGP_REQUIRE(a->y || (a->rgb_part && !a->y_absmax), HFAGP_EBADARG,
+                  "modconv: y may only be NULL with the fused toRGB (rgb_w / rgb_part) and without y_absmax");
     hipStream_t s = (hipStream_t)stream;
     const int nslabs = p.ksplit * p.nslab;
     if (nslabs > 1) {

@@ -393,7 +393,7 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
 #ifdef HFAGP_ABL_NOSTORE    // (developer ablation: one store per 16 values)
                     if (q == 0 && rw == 0)
 #endif
-                    {
+                    if (p.out) {                 // (NULL: the caller only wants the fused toRGB sums — last SR layer, forward only)
                         if constexpr (YH) rowh[n * cstep] = (_Float16)v;
                         else rowp[n * cstep] = v;
                     }

@@ -172,7 +172,8 @@ static inline int make_plan(const HfagpModconvArgs* a, Plan& pl, int ck) {
 }
 
 static inline int validate(const HfagpModconvArgs* a, int ck) {
-    HFAGP_REQUIRE(a && a->x && a->wt && a->y, HFAGP_EBADARG, "modconv: null pointer");
+    // (y may be NULL when the fused toRGB sums are the only output wanted: hfagp.h, rgb_part)
+    HFAGP_REQUIRE(a && a->x && a->wt && (a->y || a->rgb_part), HFAGP_EBADARG, "modconv: null pointer");
     HFAGP_REQUIRE(a->B > 0 && a->H > 0 && a->W > 0 && a->Cin > 0 && a->Cout > 0, HFAGP_EBADARG, "modconv: bad dims");
     HFAGP_REQUIRE(a->Cin % ck == 0, HFAGP_EUNSUPPORTED, "modconv: Cin=%d must be a multiple of %d", a->Cin, ck);
     HFAGP_REQUIRE(a->Cout % 4 == 0, HFAGP_EUNSUPPORTED, "modconv: Cout=%d must be a multiple of 4", a->Cout);

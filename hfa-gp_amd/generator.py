@@ -299,7 +299,7 @@ class TriPlaneGenerator(nn.Module):
 
     # ----------------------------------------------------------------- layers
     def _layer(self, x, layer: _SynthesisLayer, w, row, batch, noise_mode, conv_clamp, tape, x_absmax=None,
-               y_absmax=None, rgb=None, half=False):
+               y_absmax=None, rgb=None, half=False, keep_out=True):
         """x_absmax / y_absmax: fp16 range tracking of an UNCLAMPED activation chain (ops.modconv): the slot buffer with
         max |x| of the input as published by its producer, and the one this layer publishes max |out| into.
         half: write the output (and the raw up-conv intermediate) as float16 (`sr_storage = "f16"`, no tape)."""
@@ -336,7 +336,8 @@ class TriPlaneGenerator(nn.Module):
             out = self._timed(key, flops, ops.modconv, x, wt, cout, ops.CONV3X3, styles=k_styles, dcoef=k_dcoef,
                               noise=noise, noise_strength=ns, bias=layer.bias, act="lrelu", alpha=cfg.lrelu_alpha,
                               gain=gain, clamp=conv_clamp, batch=batch, x_absmax=x_absmax, y_absmax=y_absmax,
-                              rgb_w=rgb_w, y_f16=half)
+                              rgb_w=rgb_w, y_f16=half,
+                              store_y=keep_out or rgb_w is None or tape is not None or y_absmax is not None)
             if rgb_w is not None:
                 out, self._rgb_part = out
         rec = None
@@ -347,8 +348,11 @@ class TriPlaneGenerator(nn.Module):
         return out, rec
 
     def _block(self, x, img, blk: _SynthesisBlock, ws, rows, batch, noise_mode, conv_clamp, small_rgb, last, tape,
-               absmax=None, half=False):
-        """rows = the ws row of (conv0,) conv1, torgb.  absmax = (slots of the block input | None, slots for conv0's
+               absmax=None, half=False, keep_out=True):
+        """keep_out=False: nobody reads this block's feature output x (the last super-resolution block): when its toRGB
+        rides in conv1's epilogue and nothing is recorded for a backward pass, conv1 does not store its activation (x is
+        then returned as None).
+        rows = the ws row of (conv0,) conv1, torgb.  absmax = (slots of the block input | None, slots for conv0's
         output, slots for conv1's output) when the chain is unclamped (fp16 range tracking), else None."""
         rec = dict(conv0=None, first=blk.in_channels == 0, img_in=img, const=getattr(blk, "const", None))
         am_in, am0, am1 = absmax if absmax is not None else (None, None, None)
@@ -368,7 +372,7 @@ class TriPlaneGenerator(nn.Module):
             x, rec["conv0"] = self._layer(x, blk.conv0, ws[:, rows[0]], rows[0], batch, noise_mode, conv_clamp, tape,
                                           am_in, am0, None, half)
             x, rec["conv1"] = self._layer(x, blk.conv1, ws[:, rows[1]], rows[1], batch, noise_mode, conv_clamp, tape,
-                                          am0, am1, rgb, half)
+                                          am0, am1, rgb, half, keep_out)
         y = y_pre = None
         if small_rgb:
             if tape is not None and conv_clamp is not None:
@@ -503,7 +507,7 @@ class TriPlaneGenerator(nn.Module):
         x, rgb = self._block(feat_img, rgb_raw, sr.block0, ws, [last] * 3, b, cfg.sr_noise_mode, cfg.sr_conv_clamp,
                              True, False, tape, None, half)
         x, rgb = self._block(x, rgb, sr.block1, ws, [last] * 3, b, cfg.sr_noise_mode, cfg.sr_conv_clamp, True, False,
-                             tape, None, half)
+                             tape, None, half, keep_out=False)
         return rgb
 
     def _sr_half(self, batch: int, res: int, tape) -> bool:

@@ -216,7 +216,8 @@ def modconv(x: torch.Tensor, wt: torch.Tensor, cout: int, mode: int, styles: Opt
             noise_strength: float = 0.0, bias: Optional[torch.Tensor] = None, act: str = "linear",
             alpha: float = 0.2, gain: float = 1.0, clamp: Optional[float] = None, batch: Optional[int] = None,
             ksplit: int = 0, x_absmax: Optional[torch.Tensor] = None,
-            y_absmax: Optional[torch.Tensor] = None, rgb_w: Optional[torch.Tensor] = None, y_f16: bool = False):
+            y_absmax: Optional[torch.Tensor] = None, rgb_w: Optional[torch.Tensor] = None, y_f16: bool = False,
+            store_y: bool = True):
     """x [B|1, H, W, Cin] channels-last.  mode CONV3X3 / CONV1X1: fused epilogue, returns [B,H,W,Cout];
     mode CONVT3X3_UP2: returns the RAW transposed-conv result [B, 2H+1, 2W+1, Cout].
     ``wt`` from :func:`weight_prep` (fp32, exact MFMA) or :func:`weight_prep_split` (bfloat16 parts: the
@@ -225,7 +226,8 @@ def modconv(x: torch.Tensor, wt: torch.Tensor, cout: int, mode: int, styles: Opt
     producer (the fp16 kinds scale the operand by an exact power of two so nothing saturates) and the slot buffer that
     receives max |y| of a fused-epilogue output (include/hfagp.h).
     ``rgb_w`` [B, 3, Cout] (toRGB weight x its styles): fused toRGB — returns (y, rgb_part [parts, B, H, W, 4]) for
-    `torgb_finish`; only where `fused_torgb_supported` says so.
+    `torgb_finish`; only where `fused_torgb_supported` says so.  ``store_y=False`` (with rgb_w): y is not written and None
+    is returned in its place (last super-resolution layer of a forward-only call).
     fp16 STORAGE (single-pass fp16 weights only, `f16_storage_supported`): a float16 ``x`` is read as stored and
     ``y_f16`` writes the result as float16 (EG3D's fp16 super-resolution blocks keep their activations in fp16)."""
     x_f16 = x.dtype == torch.float16
@@ -264,11 +266,16 @@ def modconv(x: torch.Tensor, wt: torch.Tensor, cout: int, mode: int, styles: Opt
     a.x_absmax, a.y_absmax = _ptr(x_absmax), _ptr(y_absmax)
     a.x_f16, a.y_f16 = int(x_f16), int(y_f16)
     ydt = torch.float16 if y_f16 else torch.float32
-    if mode == CONVT3X3_UP2:
+    if not store_y:
+        # only the fused toRGB sums are wanted (`rgb_w`): the activation is not written at all
+        if rgb_w is None or y_absmax is not None:
+            raise RuntimeError("modconv: store_y=False needs rgb_w (the fused toRGB is then the only output) and no y_absmax")
+        y = None
+    elif mode == CONVT3X3_UP2:
         y = torch.empty(b, 2 * h + 1, 2 * w + 1, cout, device=x.device, dtype=ydt)
     else:
         y = torch.empty(b, h, w, cout, device=x.device, dtype=ydt)
-    a.y = y.data_ptr()
+    a.y = y.data_ptr() if y is not None else None
     nbytes = L.lib().hfagp_modconv_workspace_bytes(C.byref(a))
     ws = None
     if nbytes:

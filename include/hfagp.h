@@ -197,6 +197,8 @@ typedef struct {
      *   rgb[r] = sum_co y[co] * rgb_w[b][r][co]     (r < 3; rgb_w = toRGB weight * its styles, Cout entries per r)
      * over ITS output channels and writes the partial sums to rgb_part; hfagp_torgb_finish_fwd adds the parts, the
      * bias, the clamp and the up-sampled previous image.  Saves the separate toRGB pass over the activation.    */
+    /* (with rgb_part, y may be NULL: the activation itself is not stored — the last super-resolution layer of a
+     *  forward-only call, whose output feeds nothing but this toRGB)                                                */
     const float* rgb_w;       /* [B][3][Cout] or NULL */
     float*       rgb_part;    /* [hfagp_modconv_rgb_parts()][B][H][W][4] floats (3 used), written, or NULL */
     /* fp16 STORAGE of the activations (EG3D's fp16 blocks keep them in fp16: super-resolution, sr_num_fp16_res = 4):

@@ -500,6 +500,12 @@ def test_fused_torgb_in_conv_epilogue(dev, prec, cout, h):
     rgb_ref = ops.torgb_small(y_ref, w_rgb, s_rgb, b_rgb, prev, 2.0, pre_ref)
     y, part = ops.modconv(x, wb, cout, ops.CONV3X3, rgb_w=(s_rgb[:, None, :] * w_rgb[None]).contiguous(), **kw)
     assert torch.equal(y, y_ref) and part.shape == (2 * cout // 128, b, h, h, 4)
+    # the activation itself need not be stored (y = NULL: last super-resolution layer of a forward-only call)
+    y_none, part_only = ops.modconv(x, wb, cout, ops.CONV3X3, rgb_w=(s_rgb[:, None, :] * w_rgb[None]).contiguous(),
+                                    store_y=False, **kw)
+    assert y_none is None and torch.equal(part_only, part)
+    with pytest.raises(RuntimeError, match="store_y"):
+        ops.modconv(x, wb, cout, ops.CONV3X3, store_y=False, **kw)
     pre = torch.empty(b, 3, h, h, device=dev)
     rgb = ops.torgb_finish(part, b_rgb, prev, 2.0, pre)
     scale = pre_ref.abs().max().item()
