@@ -133,6 +133,13 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
                 parts[0] = make_uint2(__builtin_bit_cast(unsigned, x01 * __builtin_convertvector(s01, f16x2)),
                                       __builtin_bit_cast(unsigned, x23 * __builtin_convertvector(s23, f16x2)));
             } else
+#ifdef HFAGP_ABL_PRESPLIT   // (developer ablation: what would activations stored as (hi, lo) halves save? timing only)
+            if constexpr (NP == 2) {
+                parts[0] = make_uint2(__builtin_bit_cast(unsigned, ra[k].x), __builtin_bit_cast(unsigned, ra[k].y));
+                parts[1] = make_uint2(__builtin_bit_cast(unsigned, ra[k].z), __builtin_bit_cast(unsigned, ra[k].w));
+                (void)m; (void)sv;
+            } else
+#endif
             split4<KD>(make_float4(ra[k].x * (sv.x * m), ra[k].y * (sv.y * m), ra[k].z * (sv.z * m),
                                    ra[k].w * (sv.w * m)), parts);
 #pragma unroll
@@ -536,6 +543,13 @@ __global__ void __launch_bounds__(NW * 64, 1) upconv_bf16_kernel(const ConvParam
                 parts[0] = make_uint2(__builtin_bit_cast(unsigned, x01 * __builtin_convertvector(s01, f16x2)),
                                       __builtin_bit_cast(unsigned, x23 * __builtin_convertvector(s23, f16x2)));
             } else
+#ifdef HFAGP_ABL_PRESPLIT   // (developer ablation: what would activations stored as (hi, lo) halves save? timing only)
+            if constexpr (NP == 2) {
+                parts[0] = make_uint2(__builtin_bit_cast(unsigned, ra[k].x), __builtin_bit_cast(unsigned, ra[k].y));
+                parts[1] = make_uint2(__builtin_bit_cast(unsigned, ra[k].z), __builtin_bit_cast(unsigned, ra[k].w));
+                (void)m; (void)sv;
+            } else
+#endif
             split4<KD>(make_float4(ra[k].x * (sv.x * m), ra[k].y * (sv.y * m), ra[k].z * (sv.z * m),
                                    ra[k].w * (sv.w * m)), parts);
 #pragma unroll

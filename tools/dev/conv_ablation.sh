@@ -6,7 +6,7 @@ here="$(cd "$(dirname "${BASH_SOURCE[0]}")/../.." && pwd)"
 csrc="$here/hfa-gp_amd/csrc"
 variants=(base "nostore:-DHFAGP_ABL_NOSTORE" "old:-DHFAGP_LOADA_EARLY=0 -DHFAGP_B_EARLY=0" "aearly:-DHFAGP_LOADA_EARLY=1 -DHFAGP_B_EARLY=0" "bearly:-DHFAGP_LOADA_EARLY=0 -DHFAGP_B_EARLY=1"
           "nob:-DHFAGP_ABL_NOB" "noa:-DHFAGP_ABL_NOA" "nostage:-DHFAGP_ABL_NOSTAGE"
-          "mfmaonly:-DHFAGP_ABL_NOB -DHFAGP_ABL_NOA -DHFAGP_ABL_NOSTAGE -DHFAGP_ABL_NOBAR")
+          "mfmaonly:-DHFAGP_ABL_NOB -DHFAGP_ABL_NOA -DHFAGP_ABL_NOSTAGE -DHFAGP_ABL_NOBAR" "presplit:-DHFAGP_ABL_PRESPLIT")
 [[ -n "${ABL_VARIANTS:-}" ]] && read -r -a variants <<< "$ABL_VARIANTS"
 if [[ "${1:-build}" == "build" ]]; then
     bash "$csrc/build.sh" >/dev/null
@@ -18,7 +18,7 @@ if [[ "${1:-build}" == "build" ]]; then
     wait
     for v in "${variants[@]}"; do
         name="${v%%:*}"; [[ "$name" == base ]] && continue
-        objs=(); for s in elementwise modconv raymarch backward raymarch_bwd wgrad wgrad_bf16 qr loss; do objs+=("$csrc/$s.o"); done
+        objs=(); for s in elementwise modconv torgb_skip raymarch backward raymarch_bwd wgrad wgrad_bf16 qr loss; do objs+=("$csrc/$s.o"); done
         /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC "${objs[@]}" "/tmp/mcb_$name.o" -o "$here/hfa-gp_amd/libhfagp_abl_$name.so"
     done
     ls -la "$here"/hfa-gp_amd/libhfagp_abl_*.so
