@@ -418,6 +418,12 @@ def main():
                          f"(developer check of the N > 1 path on one GPU: --backend gloo --share-device)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # The contract is ONE JSON line on stdout.  Native libraries write banners straight to file descriptor 1 (gloo: "[Gloo]
+    # Rank 0 is connected to ..."; RCCL / MIOpen warnings), so everything between here and the final print goes to stderr:
+    # fd 1 is pointed at fd 2 and restored for the one line rank 0 prints.
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -726,7 +732,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg, state, args.cpu_runs, args.cpu_warmup, args.cpu_n1)
             leg_s["cpu_baseline"] = round(time.perf_counter() - t_cpu, 2)
         out["leg_seconds"] = leg_s
+        sys.stdout.flush()
+        os.dup2(stdout_fd, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if dist is not None:
         dist.destroy_process_group()
 
