@@ -199,7 +199,9 @@ def train_legs(args, cfg_name, dev, rank, world, dist):
         fa = _FitArgs()
         fa.generator_preset = cfg_name
         torch.manual_seed(0)
-        return fa, Trainer(fa, dev, rank=rank, world_size=world, mode=mode, lpips=lpips)
+        tr_ = Trainer(fa, dev, rank=rank, world_size=world, mode=mode, lpips=lpips)
+        tr_.force_collective = os.environ.get("HFAGP_BENCH_FORCE_DIST") == "1"
+        return fa, tr_
 
     def inputs(fa, B, g):
         real = (0.5 * torch.randn(B, 3, fa.size, fa.size, generator=g)).clamp(-1, 1).to(dev)
@@ -280,6 +282,7 @@ def fit3dmm_leg(args, cfg_name, dev, rank, world, dist):
     n = args.fit3dmm_frames_per_rank * world
     torch.manual_seed(3)
     tr = Trainer(fa, dev, rank=rank, world_size=world, mode="3dmm", lpips="none")
+    tr.force_collective = os.environ.get("HFAGP_BENCH_FORCE_DIST") == "1"
     # every rank renders only its own shard of the targets (the data set is synthetic: same seed -> same frames)
     lo, hi = shard_range(n, rank, world)
     full = make_frame_set(tr.gen, n, size=fa.size, seed=44, params_len=fa.params_len, only=(lo, hi))
@@ -425,9 +428,12 @@ def main():
     stdout_fd = os.dup(1)
     os.dup2(2, 1)
     dist = None
-    if world > 1:
+    # (HFAGP_BENCH_FORCE_DIST=1, developer: a ONE-rank process group, so that a 1-GPU box runs every collective call of the
+    # N > 1 code path — RCCL init with device_id, barriers, the MAX reduction of the timing, the trainers' all-reduces)
+    if world > 1 or os.environ.get("HFAGP_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:

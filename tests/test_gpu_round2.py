@@ -428,8 +428,11 @@ def test_plain_c_host_launches_kernels(dev, tmp_path):
     assert run.returncode == 0 and "c_abi_kernel OK" in run.stdout, run.stdout + run.stderr
 
 
-def test_bucketed_allreduce_sink_matches_plain_autograd_on_gpu(dev):
-    """The multi-GPU gradient path on one GPU (1-rank gloo group): with the generator being tuned, `SynthesisFn.backward`
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_bucketed_allreduce_sink_matches_plain_autograd_on_gpu(dev, backend):
+    """The multi-GPU gradient path on one GPU (1-rank process group; "nccl" = RCCL exactly as the 8-GPU run initialises and
+    calls it — device_id, in-place ReduceOp.AVG, asynchronous bucket collectives on RCCL's stream ordered against the launch
+    stream, the parameter broadcast): with the generator being tuned, `SynthesisFn.backward`
     hands its parameter gradients to the trainer's bucketed all-reduce block by block (they are ADDED into the flat
     buffer, autograd gets None) and the buckets' collectives start in readiness order — super-resolution first, the affine
     layers and the basis / driver last.  The resulting .grad of every parameter must equal the plain autograd path."""
@@ -437,7 +440,11 @@ def test_bucketed_allreduce_sink_matches_plain_autograd_on_gpu(dev):
     from hfa_gp_amd.synthetic import make_frame_set
     from hfa_gp_amd.trainer import FlatGrads, Trainer
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(_free_port())
-    dist.init_process_group("gloo", rank=0, world_size=1)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=0, world_size=1)
     try:
         grads = {}
         for overlapped in (False, True):
