@@ -14,7 +14,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # (HFAGP_LIB_PATH: developer override, used by the ablation builds of tools/dev/ — the product loads the in-tree library)
 LIB_PATH = os.environ.get("HFAGP_LIB_PATH") or os.path.join(_HERE, "libhfagp_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 c_float_p = C.c_void_p  # device pointers travel as integers
 
@@ -29,7 +29,7 @@ class RaymarchArgs(C.Structure):
         ("Sc", C.c_int32), ("Sf", C.c_int32), ("plane_axes", C.c_int32), ("white_back", C.c_int32),
         ("ray_start", C.c_double), ("ray_end", C.c_double),
         ("box_warp", C.c_float), ("decoder_lr_mul", C.c_float),
-        ("planes_absmax", C.c_void_p),
+        ("planes_absmax", C.c_void_p), ("state", C.c_void_p),
     ]
 
 

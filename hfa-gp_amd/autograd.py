@@ -231,6 +231,7 @@ class SynthesisFn(torch.autograd.Function):
         res = cfg.neural_rendering_resolution
         rb = ops.raymarch_bwd(g_feat.view(b, res * res, 32), tape["planes"], u_strat=tape["u_strat"],
                               u_imp=tape["u_imp"], decoder_grads=ctx.pg, planes_absmax=tape.get("planes_absmax"),
+                              state=tape.get("ray_state"),
                               **gen._render_args(tape["c"]))
         if ctx.pg:
             d_planes, dec = rb

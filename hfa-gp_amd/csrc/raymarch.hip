@@ -46,8 +46,12 @@ struct WaveLds {
 // DEC16: the decoder MLP on the 16-bit matrix pipe with split fp16 operands (raymarch_common.h decoder_fwd16; needs
 // HfagpRaymarchArgs::planes_absmax) instead of the exact fp32 matrix instructions — which were 0.9 of the 2.0 ms of an
 // 8-frame launch.
-template <int NC, int NF, bool GRADS, bool DEC16>
+// FROM_STATE (GRADS only): the per-sample colours, densities, depths and sort order of every ray are READ from
+// HfagpRaymarchArgs::state, where the forward call of the same step left them (13.4 KB per ray), instead of being recomputed
+// — no gather, no decoder: the compositing adjoint alone.
+template <int NC, int NF, bool GRADS, bool DEC16, bool FROM_STATE = false>
 __global__ void __launch_bounds__(256, 2) raymarch_kernel(const RayParams p) {
+    static_assert(!FROM_STATE || GRADS, "the saved state is consumed by the backward pass");
     using L = WaveLds<NC, NF>;
     constexpr int SC = L::SC, SF = L::SF, S = L::S;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -58,133 +62,159 @@ __global__ void __launch_bounds__(256, 2) raymarch_kernel(const RayParams p) {
     const int R = a.res * a.res;
 
     typename std::conditional<DEC16, Dec16Regs, DecoderRegs>::type dec;
-    if constexpr (DEC16) {
+    if constexpr (FROM_STATE) {
+        (void)dec; (void)j; (void)g;
+    } else if constexpr (DEC16) {
         DecoderRegs dec32;
         load_decoder(a, j, g, dec32);
         make_dec16(dec32, a.planes_absmax, lane, dec);
     } else {
         load_decoder(a, j, g, dec);
     }
+    constexpr int kStateFloats = S * 35;        // per ray: col [S][32] | ts [S] | ss [S] | sid [S]
 
     const RaySchedule sch = ray_schedule(p.total_rays, wave);
     for (int seq = __builtin_amdgcn_readfirstlane((int)sch.begin); seq < (int)sch.end; seq += sch.stride) {
         int b, pi, pj;                                         // wave-uniform -> scalar registers
         ray_of(seq, a.res, b, pi, pj);
         const int ray = __builtin_amdgcn_readfirstlane(b * R + pi * a.res + pj);   // index into the [B][R] tensors
-        float o3[3], d3[3];
-        ray_setup(a, b, pi, pj, o3, d3);
+        if constexpr (FROM_STATE) {
+            const float* st = a.state + (size_t)ray * kStateFloats;
+#pragma unroll 4
+            for (int i = lane; i < S * 32; i += 64) lds.col[(i >> 5) * CS + (i & 31)] = st[i];
+            for (int i = lane; i < S; i += 64) {
+                lds.ts[i] = st[S * 32 + i];
+                lds.ss[i] = st[S * 33 + i];
+                lds.sid[i] = __float_as_int(st[S * 34 + i]);
+            }
+        } else {
+            float o3[3], d3[3];
+            ray_setup(a, b, pi, pj, o3, d3);
 
-        // ---- stratified depths: torch.linspace(start, end, SC)[s] + u * delta
-        if (lane < SC) {
-            const float fs = (float)a.ray_start, fe = (float)a.ray_end;
-            const float lin = lane < SC / 2 ? __fadd_rn(fs, __fmul_rn(p.lin_step, (float)lane))
-                                            : __fsub_rn(fe, __fmul_rn(p.lin_step, (float)(SC - 1 - lane)));
-            const float u = a.u_strat[(size_t)ray * SC + lane];
-            lds.t[lane] = __fadd_rn(lin, __fmul_rn(u, p.delta));
-        }
-        WAVE_SYNC();
+            // ---- stratified depths: torch.linspace(start, end, SC)[s] + u * delta
+            if (lane < SC) {
+                const float fs = (float)a.ray_start, fe = (float)a.ray_end;
+                const float lin = lane < SC / 2 ? __fadd_rn(fs, __fmul_rn(p.lin_step, (float)lane))
+                                                : __fsub_rn(fe, __fmul_rn(p.lin_step, (float)(SC - 1 - lane)));
+                const float u = a.u_strat[(size_t)ray * SC + lane];
+                lds.t[lane] = __fadd_rn(lin, __fmul_rn(u, p.delta));
+            }
+            WAVE_SYNC();
 
-        // ---- gather + decoder for one 16-sample tile starting at sample id `s0`
-        auto eval_tile = [&](int s0) {
-            const int s = s0 + j;
-            float f[8];
+            // ---- gather + decoder for one 16-sample tile starting at sample id `s0`
+            auto eval_tile = [&](int s0) {
+                const int s = s0 + j;
+                float f[8];
+                {
+                    // The gather runs in a quad layout — lanes 4q..4q+3 read the four 32-B channel groups of the SAME
+                    // texel line of sample q — so that a load instruction touches 16 lines with 4 adjacent lanes
+                    // each, not 64 lines with one lane each (4x fewer tag look-ups in the texture addresser: 2.6 ->
+                    // 2.0 ms per 8 frames; 8 lanes per line with two samples per lane measured 2.3 ms).  The
+                    // interpolated features then move to the MFMA layout (lane 16g + j <- lane 4j + g).
+                    PlaneTaps taps[3];
+                    sample_taps(p, o3, d3, lds.t[s0 + (lane >> 2)], taps);
+                    gather8(a, b, lane & 3, taps, f);
+                    const int src = 4 * j + g;
+    #pragma unroll
+                    for (int c = 0; c < 8; ++c) f[c] = __shfl(f[c], src);
+                }
+                f32x4 h[4], o[2];
+                float sigma;
+                if constexpr (DEC16) decoder_fwd16<false>(dec, f, h, h, sigma, o);
+                else decoder_fwd<false>(dec, f, h, h, sigma, o);
+                if (g == 0) lds.sig[s] = sigma;
+    #pragma unroll
+                for (int ot = 0; ot < 2; ++ot) {
+                    float4 cv;
+                    cv.x = sigmoid_f(o[ot][0]) * 1.002f - 0.001f;
+                    cv.y = sigmoid_f(o[ot][1]) * 1.002f - 0.001f;
+                    cv.z = sigmoid_f(o[ot][2]) * 1.002f - 0.001f;
+                    cv.w = sigmoid_f(o[ot][3]) * 1.002f - 0.001f;
+                    *reinterpret_cast<float4*>(&lds.col[s * CS + 16 * ot + 4 * g]) = cv;
+                }
+            };
+
+            // ---- coarse pass
+    #pragma unroll 1
+            for (int tile = 0; tile < NC; ++tile) eval_tile(16 * tile);
+            WAVE_SYNC();
+
+            // ---- coarse compositing weights (MipRayMarcher2) -> importance depths (sample_pdf)
             {
-                // The gather runs in a quad layout — lanes 4q..4q+3 read the four 32-B channel groups of the SAME
-                // texel line of sample q — so that a load instruction touches 16 lines with 4 adjacent lanes
-                // each, not 64 lines with one lane each (4x fewer tag look-ups in the texture addresser: 2.6 ->
-                // 2.0 ms per 8 frames; 8 lanes per line with two samples per lane measured 2.3 ms).  The
-                // interpolated features then move to the MFMA layout (lane 16g + j <- lane 4j + g).
-                PlaneTaps taps[3];
-                sample_taps(p, o3, d3, lds.t[s0 + (lane >> 2)], taps);
-                gather8(a, b, lane & 3, taps, f);
-                const int src = 4 * j + g;
-#pragma unroll
-                for (int c = 0; c < 8; ++c) f[c] = __shfl(f[c], src);
+                float w = 0.f, sh = 1.f;
+                const bool mid = lane < SC - 1;
+                if (mid) {
+                    const float t0 = lds.t[lane], t1 = lds.t[lane + 1];
+                    const float dm = softplus_f((lds.sig[lane] + lds.sig[lane + 1]) * 0.5f - 1.f);
+                    const float alpha = 1.f - exp_f(-(dm * (t1 - t0)));
+                    sh = 1.f - alpha + 1e-10f;
+                    w = alpha;
+                    lds.tmid[lane] = 0.5f * (t0 + t1);
+                }
+                const float incl = wave_scan_mul(sh, lane);
+                float T = __shfl_up(incl, 1);
+                if (lane == 0) T = 1.f;
+                w = mid ? w * T : -INFINITY;                   // lanes >= SC-1 act as the -inf padding
+                float wp = __shfl_up(w, 1);
+                if (lane == 0) wp = -INFINITY;
+                const float m = fmaxf(wp, w);                  // max_pool1d(k=2, s=1, pad=1): SC values
+                const float mn = __shfl_down(m, 1);
+                const float sm = (m + mn) * 0.5f + 0.01f;      // avg_pool1d(k=2, s=1) + 0.01: lanes 0..SC-2
+                const bool inpdf = lane >= 1 && lane <= SC - 3; // weights[:, 1:-1]
+                const float pw = inpdf ? sm + 1e-5f : 0.f;
+                const float tot = wave_sum(pw);
+                const float pdf = inpdf ? pw / tot : 0.f;
+                const float c = wave_scan_add(pdf, lane);
+                if (lane <= SC - 3) lds.cdf[lane] = lane == 0 ? 0.f : c;   // SC-2 entries
             }
-            f32x4 h[4], o[2];
-            float sigma;
-            if constexpr (DEC16) decoder_fwd16<false>(dec, f, h, h, sigma, o);
-            else decoder_fwd<false>(dec, f, h, h, sigma, o);
-            if (g == 0) lds.sig[s] = sigma;
-#pragma unroll
-            for (int ot = 0; ot < 2; ++ot) {
-                float4 cv;
-                cv.x = sigmoid_f(o[ot][0]) * 1.002f - 0.001f;
-                cv.y = sigmoid_f(o[ot][1]) * 1.002f - 0.001f;
-                cv.z = sigmoid_f(o[ot][2]) * 1.002f - 0.001f;
-                cv.w = sigmoid_f(o[ot][3]) * 1.002f - 0.001f;
-                *reinterpret_cast<float4*>(&lds.col[s * CS + 16 * ot + 4 * g]) = cv;
+            WAVE_SYNC();
+            if (lane < SF) {
+                const float u = a.u_imp[(size_t)ray * SF + lane];
+                int inds = 0;
+                for (int k = 0; k < SC - 2; ++k) inds += lds.cdf[k] <= u ? 1 : 0;   // searchsorted(right=True)
+                const int below = max(inds - 1, 0), above = min(inds, SC - 3);
+                const float c0 = lds.cdf[below], c1 = lds.cdf[above];
+                const float b0 = lds.tmid[below], b1 = lds.tmid[above];
+                float den = c1 - c0;
+                if (den < 1e-5f) den = 1.f;
+                lds.t[SC + lane] = b0 + (u - c0) / den * (b1 - b0);
             }
-        };
+            WAVE_SYNC();
 
-        // ---- coarse pass
-#pragma unroll 1
-        for (int tile = 0; tile < NC; ++tile) eval_tile(16 * tile);
-        WAVE_SYNC();
+            // ---- fine pass
+    #pragma unroll 1
+            for (int tile = 0; tile < NF; ++tile) eval_tile(SC + 16 * tile);
+            WAVE_SYNC();
 
-        // ---- coarse compositing weights (MipRayMarcher2) -> importance depths (sample_pdf)
-        {
-            float w = 0.f, sh = 1.f;
-            const bool mid = lane < SC - 1;
-            if (mid) {
-                const float t0 = lds.t[lane], t1 = lds.t[lane + 1];
-                const float dm = softplus_f((lds.sig[lane] + lds.sig[lane + 1]) * 0.5f - 1.f);
-                const float alpha = 1.f - exp_f(-(dm * (t1 - t0)));
-                sh = 1.f - alpha + 1e-10f;
-                w = alpha;
-                lds.tmid[lane] = 0.5f * (t0 + t1);
+            // ---- merge: rank of every sample in the union (coarse is already ascending)
+            {
+                const bool hc = lane < SC, hf = lane < SF;
+                const float tc = hc ? lds.t[lane] : 0.f;
+                const float tf = hf ? lds.t[SC + lane] : 0.f;
+                int rc = lane, rf = 0;
+                for (int k = 0; k < SF; ++k) {
+                    const float x = lds.t[SC + k];
+                    rc += x < tc ? 1 : 0;
+                    rf += (x < tf || (x == tf && k < lane)) ? 1 : 0;
+                }
+                for (int k = 0; k < SC; ++k) rf += lds.t[k] <= tf ? 1 : 0;
+                if (hc) { lds.ts[rc] = tc; lds.ss[rc] = lds.sig[lane]; lds.sid[rc] = lane; }
+                if (hf) { lds.ts[rf] = tf; lds.ss[rf] = lds.sig[SC + lane]; lds.sid[rf] = SC + lane; }
             }
-            const float incl = wave_scan_mul(sh, lane);
-            float T = __shfl_up(incl, 1);
-            if (lane == 0) T = 1.f;
-            w = mid ? w * T : -INFINITY;                   // lanes >= SC-1 act as the -inf padding
-            float wp = __shfl_up(w, 1);
-            if (lane == 0) wp = -INFINITY;
-            const float m = fmaxf(wp, w);                  // max_pool1d(k=2, s=1, pad=1): SC values
-            const float mn = __shfl_down(m, 1);
-            const float sm = (m + mn) * 0.5f + 0.01f;      // avg_pool1d(k=2, s=1) + 0.01: lanes 0..SC-2
-            const bool inpdf = lane >= 1 && lane <= SC - 3; // weights[:, 1:-1]
-            const float pw = inpdf ? sm + 1e-5f : 0.f;
-            const float tot = wave_sum(pw);
-            const float pdf = inpdf ? pw / tot : 0.f;
-            const float c = wave_scan_add(pdf, lane);
-            if (lane <= SC - 3) lds.cdf[lane] = lane == 0 ? 0.f : c;   // SC-2 entries
         }
         WAVE_SYNC();
-        if (lane < SF) {
-            const float u = a.u_imp[(size_t)ray * SF + lane];
-            int inds = 0;
-            for (int k = 0; k < SC - 2; ++k) inds += lds.cdf[k] <= u ? 1 : 0;   // searchsorted(right=True)
-            const int below = max(inds - 1, 0), above = min(inds, SC - 3);
-            const float c0 = lds.cdf[below], c1 = lds.cdf[above];
-            const float b0 = lds.tmid[below], b1 = lds.tmid[above];
-            float den = c1 - c0;
-            if (den < 1e-5f) den = 1.f;
-            lds.t[SC + lane] = b0 + (u - c0) / den * (b1 - b0);
-        }
-        WAVE_SYNC();
-
-        // ---- fine pass
-#pragma unroll 1
-        for (int tile = 0; tile < NF; ++tile) eval_tile(SC + 16 * tile);
-        WAVE_SYNC();
-
-        // ---- merge: rank of every sample in the union (coarse is already ascending)
-        {
-            const bool hc = lane < SC, hf = lane < SF;
-            const float tc = hc ? lds.t[lane] : 0.f;
-            const float tf = hf ? lds.t[SC + lane] : 0.f;
-            int rc = lane, rf = 0;
-            for (int k = 0; k < SF; ++k) {
-                const float x = lds.t[SC + k];
-                rc += x < tc ? 1 : 0;
-                rf += (x < tf || (x == tf && k < lane)) ? 1 : 0;
+        if constexpr (!GRADS) {
+            if (a.state) {                          // forward of a step that will be differentiated: leave the state behind
+                float* st = a.state + (size_t)ray * kStateFloats;
+#pragma unroll 4
+                for (int i = lane; i < S * 32; i += 64) st[i] = lds.col[(i >> 5) * CS + (i & 31)];
+                for (int i = lane; i < S; i += 64) {
+                    st[S * 32 + i] = lds.ts[i];
+                    st[S * 33 + i] = lds.ss[i];
+                    st[S * 34 + i] = __int_as_float(lds.sid[i]);
+                }
             }
-            for (int k = 0; k < SC; ++k) rf += lds.t[k] <= tf ? 1 : 0;
-            if (hc) { lds.ts[rc] = tc; lds.ss[rc] = lds.sig[lane]; lds.sid[rc] = lane; }
-            if (hf) { lds.ts[rf] = tf; lds.ss[rf] = lds.sig[SC + lane]; lds.sid[rf] = SC + lane; }
         }
-        WAVE_SYNC();
 
         // ---- backward only: P_j = sum_c 2 dL/dfeat[c] * colour_j[c]
         float gsum2 = 0.f;
@@ -305,32 +335,34 @@ __global__ void __launch_bounds__(256, 2) raymarch_kernel(const RayParams p) {
     }
 }
 
-template <int NC, int NF, bool GRADS, bool DEC16>
+template <int NC, int NF, bool GRADS, bool DEC16, bool FROM_STATE = false>
 static int launch(const RayParams& p, hipStream_t s) {
     const size_t lds = 4 * sizeof(WaveLds<NC, NF>);
     int blocks = (p.total_rays + 3) / 4;
     const int cap = kNumCU * 2 * 4;          // 2 resident workgroups per CU, a few rounds each
     if (blocks > cap) blocks = cap;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&raymarch_kernel<NC, NF, GRADS, DEC16>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&raymarch_kernel<NC, NF, GRADS, DEC16, FROM_STATE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             set_error("raymarch: cannot raise dynamic LDS to %zu bytes: %s", lds, hipGetErrorString(e));
             return HFAGP_ELAUNCH;
         }
     }
-    raymarch_kernel<NC, NF, GRADS, DEC16><<<blocks, 256, lds, s>>>(p);
+    raymarch_kernel<NC, NF, GRADS, DEC16, FROM_STATE><<<blocks, 256, lds, s>>>(p);
     return check_launch(GRADS ? "raymarch_bwd/samples" : "raymarch_fwd");
 }
 
-template <bool GRADS, bool DEC16>
+template <bool GRADS, bool DEC16, bool FROM_STATE = false>
 static int launch_n(const RayParams& p, hipStream_t s) {
     const int n = p.a.Sc / 16;
-    return n == 3 ? launch<3, 3, GRADS, DEC16>(p, s) : n == 2 ? launch<2, 2, GRADS, DEC16>(p, s) : launch<1, 1, GRADS, DEC16>(p, s);
+    return n == 3 ? launch<3, 3, GRADS, DEC16, FROM_STATE>(p, s) : n == 2 ? launch<2, 2, GRADS, DEC16, FROM_STATE>(p, s)
+                                                                          : launch<1, 1, GRADS, DEC16, FROM_STATE>(p, s);
 }
 
 int launch_raymarch(const RayParams& p, bool grads, hipStream_t s) {
     const bool dec16 = p.a.planes_absmax != nullptr;
+    if (grads && p.a.state) return launch_n<true, false, true>(p, s);        // (no decoder in this variant)
     if (grads) return dec16 ? launch_n<true, true>(p, s) : launch_n<true, false>(p, s);
     return dec16 ? launch_n<false, true>(p, s) : launch_n<false, false>(p, s);
 }

@@ -485,7 +485,8 @@ class TriPlaneGenerator(nn.Module):
             u_imp = torch.rand(b * r, cfg.depth_resolution_importance, device=dev)
         return u_strat.reshape(b, r, -1).contiguous(), u_imp.contiguous()
 
-    def render(self, planes: torch.Tensor, c: torch.Tensor, u_strat=None, u_imp=None, planes_absmax=None):
+    def render(self, planes: torch.Tensor, c: torch.Tensor, u_strat=None, u_imp=None, planes_absmax=None, state=None):
+        """state (ops.raymarch_state): filled with the per-sample results the backward pass of this step will need."""
         cfg = self.cfg
         b = planes.shape[0]
         r = cfg.neural_rendering_resolution ** 2
@@ -495,7 +496,7 @@ class TriPlaneGenerator(nn.Module):
         s_tot = cfg.depth_resolution + cfg.depth_resolution_importance
         nbytes = float(b) * r * (s_tot * 3 * 4 * 32 * 4 + 34 * 4 + s_tot * 4)
         return self._timed("raymarch", nbytes, ops.raymarch, planes, u_strat=u_strat, u_imp=u_imp,
-                           planes_absmax=planes_absmax, **self._render_args(c))
+                           planes_absmax=planes_absmax, state=state, **self._render_args(c))
 
     def superres(self, rgb_raw: torch.Tensor, feat_img: torch.Tensor, ws: torch.Tensor, tape=None) -> torch.Tensor:
         cfg = self.cfg
@@ -555,7 +556,12 @@ class TriPlaneGenerator(nn.Module):
         planes = self.backbone_planes(ws, bb_tape)
         u_strat, u_imp = self._uniforms(b, ws.device, u_strat, u_imp)
         pam = getattr(self, "_planes_absmax", None)
-        feat, depth, wsum, tmm = self.render(planes, c, u_strat, u_imp, planes_absmax=pam)
+        # a step that will be differentiated keeps the ray marcher's per-sample results (220 MB per frame at 128^2 rays x 96
+        # samples; skipped above 8 GB): the compositing adjoint then reads them instead of marching every ray again
+        ray_state = None
+        if tape is not None and b * res * res * (cfg.depth_resolution + cfg.depth_resolution_importance) * 140 <= (8 << 30):
+            ray_state = ops.raymarch_state(b, res, cfg.depth_resolution, cfg.depth_resolution_importance, ws.device)
+        feat, depth, wsum, tmm = self.render(planes, c, u_strat, u_imp, planes_absmax=pam, state=ray_state)
         # MipRayMarcher2 clamps the expected depth to the GLOBAL min/max sample depth of the batch
         depth = torch.clamp(depth, tmm[..., 0].min(), tmm[..., 1].max())
         feat_img = feat.view(b, res, res, 32)                             # channels-last
@@ -563,7 +569,7 @@ class TriPlaneGenerator(nn.Module):
         img = self.superres(rgb_raw, feat_img, ws, sr_tape)
         if tape is not None:
             tape.update(backbone=bb_tape, sr=sr_tape, planes=planes, c=c, u_strat=u_strat, u_imp=u_imp,
-                        feat_img=feat_img, batch=b, planes_absmax=pam)
+                        feat_img=feat_img, batch=b, planes_absmax=pam, ray_state=ray_state)
         return img, rgb_raw, depth.view(b, 1, res, res), planes, feat_img
 
     def synthesis(self, ws: torch.Tensor, c: torch.Tensor, noise_mode: str = "const",

@@ -432,8 +432,11 @@ def raymarch(planes: torch.Tensor, cam2world: torch.Tensor, intrinsics: torch.Te
              u_imp: torch.Tensor, dec_w0: torch.Tensor, dec_b0: torch.Tensor, dec_w1: torch.Tensor,
              dec_b1: torch.Tensor, res: int, ray_start: float, ray_end: float, box_warp: float,
              decoder_lr_mul: float = 1.0, plane_axes: int = 0, white_back: bool = False,
-             decoder_precision: str = "f16x3", planes_absmax: Optional[torch.Tensor] = None):
+             decoder_precision: str = "f16x3", planes_absmax: Optional[torch.Tensor] = None,
+             state: Optional[torch.Tensor] = None):
     """planes [B,3,H,W,32] → feat [B,R,32], depth [B,R] (unclamped), wsum [B,R], tminmax [B,R,2].
+    ``state`` (`raymarch_state`): receives the per-sample colours / densities / depths / sort order of every ray, so that
+    `raymarch_bwd` of the same step need not gather and decode every sample again for the compositing adjoint.
     decoder_precision 'f16x3': the decoder MLP on the 16-bit matrix pipe with split fp16 operands (fp32-class); it needs
     a bound on |planes| — `planes_absmax` (64 slots as published by `skip_upsample_add(out_absmax=...)`), computed here
     with one reduction over the planes when the caller has none.  'fp32': the exact fp32 matrix instructions."""
@@ -460,8 +463,17 @@ def raymarch(planes: torch.Tensor, cam2world: torch.Tensor, intrinsics: torch.Te
     a.plane_axes, a.white_back = plane_axes, int(white_back)
     a.ray_start, a.ray_end, a.box_warp, a.decoder_lr_mul = ray_start, ray_end, box_warp, decoder_lr_mul
     a.planes_absmax = _ptr(_decoder_bound(planes, decoder_precision, planes_absmax))
+    if state is not None:
+        if state.shape != (b, r, (sc + sf) * 35):
+            raise RuntimeError(f"raymarch: state must be [B, R, {(sc + sf) * 35}] (raymarch_state), got {tuple(state.shape)}")
+        a.state = _ptr(_chk(state, "state"))
     L.check(L.lib().hfagp_raymarch_fwd(C.byref(a), _stream()), "raymarch_fwd")
     return feat, depth, wsum, tmm
+
+
+def raymarch_state(b: int, res: int, sc: int, sf: int, device) -> torch.Tensor:
+    """Buffer for `raymarch(..., state=)` / `raymarch_bwd(..., state=)`: [B, R, 35 (Sc + Sf)] floats = 13.4 KB per ray at 48 + 48."""
+    return torch.empty(b, res * res, (sc + sf) * 35, device=device, dtype=torch.float32)
 
 
 def _decoder_bound(planes: torch.Tensor, decoder_precision: str, planes_absmax: Optional[torch.Tensor]):
@@ -795,8 +807,9 @@ def raymarch_bwd(g_feat: torch.Tensor, planes: torch.Tensor, cam2world, intrinsi
                  dec_w1, dec_b1, res: int, ray_start: float, ray_end: float, box_warp: float,
                  decoder_lr_mul: float = 1.0, plane_axes: int = 0, white_back: bool = False,
                  return_rec: bool = False, decoder_grads: bool = False, decoder_precision: str = "f16x3",
-                 planes_absmax: Optional[torch.Tensor] = None):
-    """g_feat [B,R,32] → d planes [B,3,H,W,32] (fp32 atomics into a zero-initialised buffer)."""
+                 planes_absmax: Optional[torch.Tensor] = None, state: Optional[torch.Tensor] = None):
+    """g_feat [B,R,32] → d planes [B,3,H,W,32] (fp32 atomics into a zero-initialised buffer).  ``state``: what the forward
+    call of this step left behind (`raymarch(..., state=)`): the compositing adjoint reads it instead of recomputing."""
     _chk(planes, "planes")
     _chk(g_feat, "g_feat")
     b, _, h, w, _ = planes.shape
@@ -813,6 +826,10 @@ def raymarch_bwd(g_feat: torch.Tensor, planes: torch.Tensor, cam2world, intrinsi
     f.plane_axes, f.white_back = plane_axes, int(white_back)
     f.ray_start, f.ray_end, f.box_warp, f.decoder_lr_mul = ray_start, ray_end, box_warp, decoder_lr_mul
     f.planes_absmax = _ptr(_decoder_bound(planes, decoder_precision, planes_absmax))
+    if state is not None:
+        if state.shape != (b, r, (sc + sf) * 35):
+            raise RuntimeError(f"raymarch_bwd: state must be [B, R, {(sc + sf) * 35}], got {tuple(state.shape)}")
+        f.state = _ptr(_chk(state, "state"))
     a.g_feat, a.d_planes, a.rec = _ptr(g_feat), _ptr(d_planes), _ptr(rec)
     dec = None
     if decoder_grads:

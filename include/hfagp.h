@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define HFAGP_ABI_VERSION 6
+#define HFAGP_ABI_VERSION 7
 
 enum { HFAGP_OK = 0, HFAGP_EBADARG = -1, HFAGP_EUNSUPPORTED = -2, HFAGP_ELAUNCH = -3 };
 
@@ -51,6 +51,8 @@ const char* hfagp_last_error(void);
  * One launch: ray generation -> stratified depths -> tri-plane bilinear gather
  * -> decoder MLP -> coarse compositing -> importance re-sampling -> second
  * gather+MLP -> depth merge -> final compositing.                              */
+#define HFAGP_RAYMARCH_STATE_FLOATS_PER_SAMPLE 35   /* HfagpRaymarchArgs::state: 32 colours, depth, density, sort index */
+
 typedef struct {
     const float* planes;      /* [B][3][H][W][32] fp32                                        */
     const float* cam2world;   /* [B][16] row-major 4x4 (label[:, :16])                        */
@@ -78,6 +80,11 @@ typedef struct {
      * every operand scaled into fp16's range by an exact power of two derived from this bound and the weights.
      * NULL: the decoder runs on the exact fp32 matrix instructions (5x the matrix-pipe time).                      */
     const float* planes_absmax;
+    /* optional [B][R][(Sc + Sf) * HFAGP_RAYMARCH_STATE_FLOATS_PER_SAMPLE] floats: in hfagp_raymarch_fwd the per-sample colours,
+     * densities, depths and sort order of every ray are LEFT here (13.4 KB per ray at 48+48 samples); hfagp_raymarch_bwd
+     * given the same buffer (fwd.state) reads them instead of gathering and decoding every sample again for the
+     * compositing adjoint.  NULL: nothing is saved / everything is recomputed.                                       */
+    float*       state;
 } HfagpRaymarchArgs;
 
 int hfagp_raymarch_fwd(const HfagpRaymarchArgs* a, void* stream);

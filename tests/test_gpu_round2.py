@@ -799,3 +799,37 @@ def test_encoder_conv_layers_on_hip_kernels(dev, cin, cout, h):
     errs = dict(y=rel(nchw(y), y_ref), dx=rel(nchw(xh.grad), xr.grad), dw=rel(wh.grad, wr.grad))
     print("blur + conv3x3 stride 2:", {n: f"{v:.1e}" for n, v in errs.items()})
     assert errs["y"] <= 2e-6 and errs["dx"] <= 2e-5 and errs["dw"] <= 5e-5, errs
+
+
+@pytest.mark.parametrize("preset,res,hw", [("ffhq512_128", 24, 64), ("small128", 16, 32), ("tiny64", 8, 16)])
+def test_raymarch_backward_from_saved_state(dev, preset, res, hw):
+    """HfagpRaymarchArgs::state: the forward call leaves the per-sample colours / densities / depths / sort order of every ray
+    behind, and hfagp_raymarch_bwd given that buffer runs the compositing adjoint from it instead of gathering and decoding
+    every sample again.  The per-sample records it produces must be the SAME BITS as the recomputing variant's (same
+    arithmetic on the same values); d planes then differs only by the atomics' summation order."""
+    import dataclasses
+    from hfa_gp_amd import ops
+    from hfa_gp_amd.config import PRESETS
+    from hfa_gp_amd.generator import TriPlaneGenerator
+    cfg = dataclasses.replace(PRESETS[preset](), neural_rendering_resolution=res, img_resolution=4 * res)
+    gen = perturb_state(TriPlaneGenerator(cfg, seed=0)).to(dev)
+    c = look_at_label(torch.tensor([1.3, 1.8]), torch.tensor([1.5, 1.7])).to(dev)
+    g = torch.Generator().manual_seed(res)
+    b, r = 2, res * res
+    sc, sf = cfg.depth_resolution, cfg.depth_resolution_importance
+    planes = torch.randn(b, 3, hw, hw, 32, generator=g).to(dev)
+    u_s, u_i = gen._uniforms(b, dev, torch.rand(b, r, sc, 1, generator=g).to(dev), torch.rand(b * r, sf, generator=g).to(dev))
+    g_feat = torch.randn(b, r, 32, generator=g).to(dev)
+    kw = dict(u_strat=u_s, u_imp=u_i, **gen._render_args(c))
+    state = ops.raymarch_state(b, res, sc, sf, dev)
+    state.fill_(float("nan"))
+    f0 = ops.raymarch(planes, **kw)
+    f1 = ops.raymarch(planes, state=state, **kw)
+    assert all(torch.equal(x, y) for x, y in zip(f0, f1)) and torch.isfinite(state[..., : (sc + sf) * 34]).all()
+    d_ref, rec_ref = ops.raymarch_bwd(g_feat, planes, return_rec=True, **kw)
+    d_st, rec_st = ops.raymarch_bwd(g_feat, planes, return_rec=True, state=state, **kw)
+    assert torch.equal(rec_st[..., :3], rec_ref[..., :3])
+    scale = d_ref.abs().max().item()
+    assert (d_st - d_ref).abs().max().item() <= 2e-6 * scale
+    with pytest.raises(RuntimeError, match="state"):
+        ops.raymarch_bwd(g_feat, planes, state=state[:, :1], **kw)
