@@ -41,13 +41,21 @@ template <bool PG> struct BwdWaves { static constexpr int value = PG ? 4 : 6; };
 
 // DEC16: decoder forward (split fp16) and backward (split bf16) on the 16-bit matrix pipe (raymarch_common.h; needs
 // HfagpRaymarchArgs::planes_absmax): 48 MFMAs of ~17 cycles per tile instead of 128 fp32 ones of 32.
-template <int S, bool PG, bool MIRROR, bool DEC16>
-__global__ void __launch_bounds__(BwdWaves<PG>::value * 64, PG ? 1 : 2)
+// SCATTER = false (PG only): the decoder-parameter gradients alone — d planes comes from raymarch_bwd_cols_kernel (the
+// generator-tuned step on mirrored square planes: the column kernel's LDS line cache scatters in 1.6 ms what this kernel's
+// global atomics take 3.2 ms for; what is left here is gather + decoder forward / backward + the weight-gradient MFMAs).
+// (the decoder-gradient-only variant with 8 waves per CU — the LDS would allow it without the scatter tables — measured
+// 2.2 ms against 1.9 ms: 256 registers per wave instead of 512 spill)
+template <bool PG, bool SCATTER> struct TileWaves { static constexpr int value = BwdWaves<PG>::value; };
+
+template <int S, bool PG, bool MIRROR, bool DEC16, bool SCATTER = true>
+__global__ void __launch_bounds__((TileWaves<PG, SCATTER>::value * 64), (PG ? 1 : 2))
 raymarch_bwd_tiles_kernel(const RayParams p, float* __restrict__ d_planes, const DecGrads dg) {
-    constexpr int NWB = BwdWaves<PG>::value, NTHB = NWB * 64;
-    __shared__ TileLds lds_all[NWB];
+    static_assert(SCATTER || PG, "without the scatter only the decoder gradients are left");
+    constexpr int NWB = TileWaves<PG, SCATTER>::value, NTHB = NWB * 64;
+    __shared__ TileLds lds_all[SCATTER ? NWB : 1];
     // (sized 1 float instead of one GradLds when the decoder gradients are off: 13 KB less -> 3 workgroups per CU)
-    __shared__ __attribute__((aligned(16))) float glds_raw[PG ? 4 * sizeof(GradLds) / sizeof(float) : 1];
+    __shared__ __attribute__((aligned(16))) float glds_raw[PG ? NWB * sizeof(GradLds) / sizeof(float) : 1];
     // A operands of the two backward products, lane-linear ([step][lane]: conflict-free ds_read_b32), shared by
     // the 4 waves:  w1t[mt][ot*4+r][lane] = W1[1 + 16ot + 4g + r][16mt + j] * g1
     //               w0t[ft][mt*4+r][lane] = W0[16mt + 4g + r][16ft + j] * g0
@@ -55,7 +63,7 @@ raymarch_bwd_tiles_kernel(const RayParams p, float* __restrict__ d_planes, const
     __shared__ float w0t[2 * 16 * 64];
     __shared__ float wfwd[kDecLdsRows * 64];       // forward A operands (DecoderRegs image)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    TileLds& lds = lds_all[wave];
+    TileLds& lds = lds_all[SCATTER ? wave : 0];     // never dereferenced unless SCATTER
     const HfagpRaymarchArgs& a = p.a;
     const int j = lane & 15, g = lane >> 4;
     const int R = a.res * a.res;
@@ -179,8 +187,9 @@ raymarch_bwd_tiles_kernel(const RayParams p, float* __restrict__ d_planes, const
                     }
             }
             // lane (j, g), register r -> feature channel 16ft + 4g + r of sample j
-            *reinterpret_cast<float4*>(&lds.df[j * 32 + 16 * ft + 4 * g]) =
-                make_float4(dF[ft][0], dF[ft][1], dF[ft][2], dF[ft][3]);
+            if constexpr (SCATTER)
+                *reinterpret_cast<float4*>(&lds.df[j * 32 + 16 * ft + 4 * g]) =
+                    make_float4(dF[ft][0], dF[ft][1], dF[ft][2], dF[ft][3]);
         }
         if constexpr (PG) {
             // operand images for the weight-gradient products + running bias / sigma-row sums
@@ -230,6 +239,7 @@ raymarch_bwd_tiles_kernel(const RayParams p, float* __restrict__ d_planes, const
                         aw0[kt][ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[kt], bf[ft], aw0[kt][ft], 0, 0, 0);
             }
         }
+        if constexpr (SCATTER) {
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)                 // lane (j, g = pl) publishes plane pl's taps of sample j
             if (g == pl) {                             // tap-major [plane*4 + tap][sample]: the scatter reads 16 samples as b128
@@ -289,6 +299,7 @@ raymarch_bwd_tiles_kernel(const RayParams p, float* __restrict__ d_planes, const
 #endif
             }
         }
+        }   // SCATTER
         WAVE_SYNC();
     }
     if constexpr (PG) {
@@ -666,6 +677,15 @@ static void launch_tiles2(bool pg, bool mirror, unsigned blocks, const RayParams
     }
 }
 
+// decoder-parameter gradients only (d planes is the column kernel's job)
+template <int S>
+static void launch_decoder_grads(unsigned blocks, const RayParams& p, float* d_planes, const DecGrads& dg, hipStream_t s) {
+    if (p.a.planes_absmax)
+        raymarch_bwd_tiles_kernel<S, true, true, true, false><<<blocks, TileWaves<true, false>::value * 64, 0, s>>>(p, d_planes, dg);
+    else
+        raymarch_bwd_tiles_kernel<S, true, true, false, false><<<blocks, TileWaves<true, false>::value * 64, 0, s>>>(p, d_planes, dg);
+}
+
 template <int S>
 static void launch_tiles(bool pg, bool mirror, unsigned blocks, const RayParams& p, float* d_planes, const DecGrads& dg,
                          hipStream_t s) {
@@ -718,7 +738,9 @@ extern "C" int hfagp_raymarch_bwd(const HfagpRaymarchBwdArgs* a, void* stream) {
     const bool pg = a->d_dec_w0 != nullptr;
     const int nwb = pg ? BwdWaves<true>::value : BwdWaves<false>::value;
     long long blocks = (ntiles + nwb - 1) / nwb;
-    const long long cap = (long long)kNumCU * 2 * 8;
+    // (decoder gradients: one resident workgroup per CU and ~4.3 k end-of-kernel atomics per wave on the same buffers —
+    // the grid is the chip; the ray schedule strides over the rest)
+    const long long cap = pg ? (long long)kNumCU : (long long)kNumCU * 2 * 8;
     if (blocks > cap) blocks = cap;
     HFAGP_REQUIRE(!pg || (a->d_dec_b0 && a->d_dec_w1 && a->d_dec_b1), HFAGP_EBADARG,
                   "raymarch_bwd: decoder gradients need all four buffers");
@@ -726,7 +748,7 @@ extern "C" int hfagp_raymarch_bwd(const HfagpRaymarchBwdArgs* a, void* stream) {
     const bool mirror = a->fwd.plane_axes == 0 && a->fwd.H == a->fwd.W;
     // frozen generator + mirrored square planes up to 256^2: the column variant (LDS line cache for plane (x,z))
     static const bool no_cols = getenv("HFAGP_DEV_NO_COLS") != nullptr;      // developer switch: A/B timing
-    if (!pg && mirror && a->fwd.H <= kColMaxRows && !no_cols) {
+    if (mirror && a->fwd.H <= kColMaxRows && !no_cols) {
         const int chunks_per_col = (a->fwd.res + kColRays - 1) / kColRays;
         const int nchunks = a->fwd.B * a->fwd.res * chunks_per_col;
         const size_t lds = cols_lds_bytes();
@@ -736,6 +758,14 @@ extern "C" int hfagp_raymarch_bwd(const HfagpRaymarchBwdArgs* a, void* stream) {
         else if (S == 64) rcl = launch_cols<64>(cblocks, lds, p, a->d_planes, nchunks, chunks_per_col, s);
         else rcl = launch_cols<32>(cblocks, lds, p, a->d_planes, nchunks, chunks_per_col, s);
         if (rcl != HFAGP_OK) return rcl;
+        if (pg) {                   // generator being tuned: the decoder-parameter gradients in a pass of their own
+            // one resident workgroup per CU (109 KB of LDS); every wave ends with ~4.3 k atomics on the SAME gradient
+            // buffers, so the grid is the chip, not a multiple of it (x16: 1.90 ms, x1: 1.09 ms per B = 2 call)
+            const unsigned gblocks = (unsigned)std::min<long long>((ntiles + 3) / 4, (long long)kNumCU);
+            if (S == 96) launch_decoder_grads<96>(gblocks, p, a->d_planes, dg, s);
+            else if (S == 64) launch_decoder_grads<64>(gblocks, p, a->d_planes, dg, s);
+            else launch_decoder_grads<32>(gblocks, p, a->d_planes, dg, s);
+        }
     } else if (S == 96) launch_tiles<96>(pg, mirror, (unsigned)blocks, p, a->d_planes, dg, s);
     else if (S == 64) launch_tiles<64>(pg, mirror, (unsigned)blocks, p, a->d_planes, dg, s);
     else launch_tiles<32>(pg, mirror, (unsigned)blocks, p, a->d_planes, dg, s);
