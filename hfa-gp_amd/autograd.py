@@ -57,9 +57,11 @@ class _Backward:
                 sink(prm, self.grads.pop(key))
                 self.released.add(key)
 
-    def affine_grads(self, affine, dstot: torch.Tensor, row: int):
-        dA = torch.zeros_like(affine.weight)
-        db = torch.zeros_like(affine.bias)
+    def affine_grads(self, affine, dstot: torch.Tensor, row: int, dA: Optional[torch.Tensor] = None,
+                     db: Optional[torch.Tensor] = None):
+        """dA / db: zero-initialised views of one flat buffer (flush_styles: one fill for all layers instead of two each)."""
+        dA = torch.zeros_like(affine.weight) if dA is None else dA
+        db = torch.zeros_like(affine.bias) if db is None else db
         ops.affine_grad(dstot, self.ws[:, row], dA, db)
         self._acc(affine.weight, dA)
         self._acc(affine.bias, db)
@@ -170,8 +172,14 @@ class _Backward:
     def flush_styles(self):
         dstots = ops.style_bwd_batch([it for it, _ in self.pending], self.d_ws)
         if self.pg:
-            for (it, affine), dstot in zip(self.pending, dstots):
-                self.affine_grads(affine, dstot, it[6])
+            sizes = [(affine.weight.numel(), affine.bias.numel()) for _, affine in self.pending]
+            flat = torch.zeros(sum(a + b for a, b in sizes), device=self.d_ws.device, dtype=torch.float32)
+            off = 0
+            for ((it, affine), dstot), (na, nb) in zip(zip(self.pending, dstots), sizes):
+                dA = flat[off: off + na].view_as(affine.weight)
+                db = flat[off + na: off + na + nb].view_as(affine.bias)
+                off += na + nb
+                self.affine_grads(affine, dstot, it[6], dA, db)
         self.pending = []
 
 
