@@ -660,7 +660,8 @@ def test_generator_sr_storage_f16(dev, full_gen):
         gen.sr_conv_precision, gen.sr_storage = old
 
 
-def test_encoder_on_gpu_matches_its_cpu_path(dev):
+@pytest.mark.parametrize("size", [64, 256])
+def test_encoder_on_gpu_matches_its_cpu_path(dev, size):
     """The RGB driver network on the GPU (its conv trunk on the generator's HIP conv kernels, encoder_hip.py; with an image
     that requires grad: FIR blur and fused leaky-ReLU through hfagp_upfirdn2d_* / hfagp_bias_act_*, the convolutions on
     MIOpen) against the same module on the CPU (pure PyTorch, the path the reference-generated golden vectors
@@ -668,8 +669,8 @@ def test_encoder_on_gpu_matches_its_cpu_path(dev):
     import copy
     from hfa_gp_amd.encoder3d import Encoder
     torch.manual_seed(3)
-    enc = Encoder(64, 512, 50)
-    x = torch.randn(2, 3, 64, 64)
+    enc = Encoder(size, 512, 50)            # 256: BASELINE config 3's driver (64- and 128-channel layers included)
+    x = torch.randn(2, 3, size, size)
     gy = torch.randn(2, 50)
     y_ref = enc(x)
     (y_ref * gy).sum().backward()
