@@ -111,7 +111,7 @@ def cpu_baseline(cfg, state, runs: int, warmup: int, n1: bool):
     after `warmup`; stage split backbone / ray-march / super-resolution."""
     import torch
     from oracle import eg3d_oracle as O
-    from tests.util import make_inputs
+    from hfa_gp_amd.synthetic import make_inputs
     ws, c, us, ui = make_inputs(cfg, 1, seed=10)
     res = cfg.neural_rendering_resolution
 
@@ -202,7 +202,7 @@ def train_legs(args, cfg_name, dev, rank, world, dist):
     3DMM-driven (config 4); ONE in-place all-reduce of the flat shared-gradient buffer per step when world > 1."""
     import torch
     from hfa_gp_amd.trainer import Trainer
-    from tests.util import look_at_label
+    from hfa_gp_amd.synthetic import look_at_label
     out = {}
     # (torch.backends.cudnn.benchmark = True makes the Encoder 0.7 ms per step faster — and MIOpen's exhaustive search took
     #  3.5 minutes of a fresh box's first run: left off)
@@ -461,7 +461,7 @@ def main():
 
     from hfa_gp_amd.config import PRESETS
     from hfa_gp_amd.generator import TriPlaneGenerator
-    from tests.util import make_inputs, state_cpu
+    from hfa_gp_amd.synthetic import make_inputs, state_cpu
 
     cfg = PRESETS[args.preset]()
     gen = TriPlaneGenerator(cfg, seed=0).requires_grad_(False)

@@ -97,7 +97,7 @@ __global__ void __launch_bounds__(256) pointwise_bwd_kernel(const HfagpPointwise
                     if (a.clamp >= 0.f && fabsf(xv[k]) >= a.clamp) g = 0.f;
                     g *= a.gain;
                     pre = xv[k] / a.gain;
-                    if (a.act_p == HFAGP_ACT_LRELU && xv[k] < 0.f) { g *= a.alpha; pre /= a.alpha; }
+                    if (a.act_p == HFAGP_ACT_LRELU && !(xv[k] > 0.f)) { g *= a.alpha; pre /= a.alpha; }   // (alpha at 0, as ATen / EG3D)
                     acc[3][k] += g * (pre - bv[k] - nz) / dv[k];
                     if (a.param_grads) { acc[4][k] += g; acc[5][k] += g * nraw; }
                     g *= dv[k];

@@ -546,7 +546,7 @@ __global__ void __launch_bounds__(256) bias_act_bwd_kernel(const float* __restri
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const float yv = y[i];
         float g = dy[i] * gain;
-        if (act == HFAGP_ACT_LRELU && yv < 0.f) g *= alpha;
+        if (act == HFAGP_ACT_LRELU && !(yv > 0.f)) g *= alpha;     // slope alpha AT 0 too: ATen's leaky_relu_backward, EG3D's bias_act
         if (clamp >= 0.f && !(fabsf(yv) < clamp)) g = 0.f;
         dx[i] = g;
     }

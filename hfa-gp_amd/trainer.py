@@ -152,12 +152,18 @@ class FlatGrads:
 class BucketedAllReduce:
     """Overlaps the all-reduce of `FlatGrads` buckets with the rest of the backward pass (when the
     generator is tuned the shared gradients are 123 MB — bandwidth-bound on xGMI — and should travel while the
-    backward pass is still running).  A bucket's collective is started (async, on RCCL's own stream, ordered after the
-    launch stream) as soon as the LAST of its parameters has its final gradient:
+    backward pass is still running).  A bucket becomes READY when the last of its parameters has its final gradient:
       * generator parameters: `SynthesisFn.backward` hands them to `generator._grad_sink` block by block
         (autograd.py `release_ready`), in the order super-resolution -> decoder -> backbone 256 ... 4 -> affine layers;
-      * everything else (basis, driver net): `register_post_accumulate_grad_hook`.
-    `finish()` starts whatever is left (parameters that got no gradient this step), waits, and averages."""
+      * everything else (basis, driver net): `register_post_accumulate_grad_hook`;
+      * parameters the caller declares ABSENT for this step (`begin_step(absent=...)`: the other identity's basis, nets
+        that are not on this step's path) count as ready from the start.
+    Collectives are STARTED IN BUCKET INDEX ORDER ONLY — bucket b goes out (async, on RCCL's own stream, ordered after
+    the launch stream) once it is ready AND buckets 0 .. b-1 are out — so every rank issues the same collective
+    sequence whatever order its own backward pass finished things in, including a rank whose batch is empty (ragged
+    shard tail: it runs no backward pass and `finish()` starts all buckets, in index order).  The flat buffer is laid out
+    in readiness order (`_readiness_order`), so in-order launching costs no overlap.
+    `finish()` starts whatever is left, waits, and averages."""
 
     def __init__(self, flat: FlatGrads, world_size: int, group=None):
         import torch.distributed as dist
@@ -172,12 +178,30 @@ class BucketedAllReduce:
             self.bucket_of[id(p)] = b
             self.size[b] += 1
             off += p.numel()
+        self.active = False
+        self.last_order: List[int] = []
         self.reset()
 
     def reset(self):
+        """Forget the state of an interrupted step: outstanding collectives are waited for (their buffers are about to be
+        zeroed), the counters start over."""
+        for w in getattr(self, "works", []):
+            if w is not None:
+                w.wait()
         self.left = list(self.size)
         self.works = [None] * len(self.size)
+        self.seen = set()
+        self.next = 0                  # the next bucket to go out: buckets < next are in flight or done
         self.order = []                # buckets in the order their collectives were started (tests / diagnostics)
+
+    def begin_step(self, absent: Iterable[torch.Tensor] = ()):
+        """Start of a step (after `FlatGrads.zero()`): fresh counters; `absent` parameters receive no gradient in this
+        step and must not hold their bucket back."""
+        self.reset()
+        self.active = True
+        for p in absent:
+            self._count(p)
+        self._advance()
 
     def _launch(self, b: int):
         import torch.distributed as dist
@@ -186,31 +210,54 @@ class BucketedAllReduce:
         self.works[b] = dist.all_reduce(self.flat.flat[lo:hi], op=op, group=self.group, async_op=True)
         self.order.append(b)
 
-    def on_grad(self, p: torch.Tensor):
+    def _advance(self):
+        while self.next < len(self.size) and self.left[self.next] == 0:
+            self._launch(self.next)
+            self.next += 1
+
+    def _count(self, p: torch.Tensor) -> Optional[int]:
         b = self.bucket_of.get(id(p))
-        if b is None or self.works[b] is not None:
-            return
+        if b is None or id(p) in self.seen:
+            return b
+        self.seen.add(id(p))
         self.left[b] -= 1
-        if self.left[b] == 0:
-            self._launch(b)
+        return b
+
+    def on_grad(self, p: torch.Tensor):
+        if not self.active:
+            return                     # a backward pass outside gen_update (autograd.grad, a sample): nothing to overlap
+        b = self.bucket_of.get(id(p))
+        if b is None:
+            return
+        if self.works[b] is not None:
+            raise RuntimeError("BucketedAllReduce: a gradient arrived for a parameter whose bucket is already being "
+                               "all-reduced (the parameter was declared absent, or its gradient is produced twice in one "
+                               "step — e.g. two synthesis calls in one graph); sum the losses into ONE backward pass and "
+                               "do not list used parameters as absent")
+        self._count(p)
+        self._advance()
 
     def sink(self, p: torch.Tensor, g: torch.Tensor):
         """generator._grad_sink: accumulate into the flat slice, then count the parameter as ready."""
+        b = self.bucket_of.get(id(p))
+        if self.active and b is not None and self.works[b] is not None:
+            self.on_grad(p)            # raises: the slice is being reduced, it must not be written
         p.grad.add_(g.view_as(p.grad))
         self.on_grad(p)
 
     def finish(self):
+        self.launched_early = self.next        # buckets that went out from inside the backward pass (diagnostics / tests)
         for b in range(len(self.size)):
-            if self.works[b] is None:
-                self._launch(b)
+            self.left[b] = 0
+        self._advance()
         for w in self.works:
             w.wait()
         if self.avg is None:
             self.flat.flat.div_(self.world)
         n = self.flat.numel
-        order = self.order
-        self.reset()
-        self.last_order = order
+        self.last_order = self.order
+        self.works = [None] * len(self.size)
+        self.active = False
         return n
 
 
@@ -238,6 +285,9 @@ def epoch_batches(n_frames: int, rank: int, world_size: int, batch: int):
         yield idx, counts[rank] * world_size / max(sum(counts), 1)
 
 
+_BASIS_NAMES = ("bases", "delta", "bases_2", "delta_2")
+
+
 def _readiness_order(*modules: nn.Module) -> List[torch.Tensor]:
     """Trainable parameters of `modules` ordered by when the backward pass finishes their gradients (see
     Trainer.shared_parameters)."""
@@ -255,28 +305,27 @@ def _readiness_order(*modules: nn.Module) -> List[torch.Tensor]:
             other = [n for n in named if n not in set(sr) | set(dec) | set(bb)]
             cfg = getattr(gen, "cfg", None)
 
-            def unused(n):        # never on the synthesis path: no gradient ever arrives, so they must not hold a bucket back
-                if n.startswith("backbone.mapping."):
-                    return True
-                if n.endswith(".noise_strength") and cfg is not None:
-                    mode = cfg.sr_noise_mode if n.startswith("superresolution.") else cfg.backbone_noise_mode
-                    return mode == "none"
-                return False
+            idle_ids = {id(p) for p in _generator_idle_parameters(gen)}   # no gradient ever arrives: they must not hold a bucket back
             for n in sr + dec + bb + other:
                 p = named[n]
                 if p.requires_grad and id(p) not in seen:
                     seen.add(id(p))
-                    (idle if unused(n) else affine if ".affine." in n else first).append(p)
-        for p in m.parameters():
-            if p.requires_grad and id(p) not in seen:
-                seen.add(id(p))
-                rest.append(p)
+                    (idle if id(p) in idle_ids else affine if ".affine." in n else first).append(p)
+        # everything that is not the generator: the backward pass reaches the latent basis first (QR adjoint, right after
+        # d ws), then walks the driver net from its LAST layer to its first — reverse registration order
+        own = [(n, p) for n, p in m.named_parameters() if p.requires_grad and id(p) not in seen]
+        basis = [(n, p) for n, p in own if n.split(".")[-1] in _BASIS_NAMES]
+        driver = [(n, p) for n, p in own if n.split(".")[-1] not in _BASIS_NAMES]
+        for n, p in basis + driver[::-1]:
+            seen.add(id(p))
+            rest.append(p)
     return first + affine + rest + idle
 
 
 def _install_grad_hooks(trainer, modules) -> None:
-    """Route final gradients to the trainer's CURRENT BucketedAllReduce (looked up at call time: the bucketer is rebuilt
-    when the set of trainable parameters changes).  Installed once per parameter / generator."""
+    """Route final gradients of the non-generator parameters to the trainer's CURRENT BucketedAllReduce (looked up at call
+    time: the bucketer is rebuilt when the set of trainable parameters changes).  Installed once per parameter; the hook
+    does nothing outside a step (`BucketedAllReduce.active`)."""
     def current():
         return getattr(trainer, "_bucketer", None)
     for m in modules:
@@ -290,15 +339,64 @@ def _install_grad_hooks(trainer, modules) -> None:
                 if b is not None:
                     b.on_grad(param)
             p.register_post_accumulate_grad_hook(hook)
-        gen = getattr(m, "generator", None)
-        if gen is not None and getattr(gen, "_grad_sink", None) is None:
-            def sink(param, grad, _cur=current):
-                b = _cur()
-                if b is not None:
-                    b.sink(param, grad)
-                else:
-                    param.grad.add_(grad.view_as(param.grad))
-            gen._grad_sink = sink
+
+
+class _StepScope:
+    """The part of a step during which gradients flow into the bucketer: `begin_step`, the generator's gradient sink
+    installed (generator parameters are then released block by block from inside `SynthesisFn.backward`), and on the
+    way out — also when forward or backward raised — the sink removed and the bucketer left inactive, so that a later
+    backward pass outside `gen_update` (autograd.grad, a second trainer sharing the generator) sees plain autograd."""
+
+    def __init__(self, bucketer: Optional[BucketedAllReduce], generators, absent):
+        self.b, self.gens, self.absent = bucketer, [g for g in generators if g is not None], absent
+
+    def __enter__(self):
+        if self.b is not None:
+            self.b.begin_step(self.absent)
+            for g in self.gens:
+                g._grad_sink = self.b.sink
+        return self.b
+
+    def __exit__(self, exc_type, exc, tb):
+        if self.b is not None:
+            for g in self.gens:
+                g._grad_sink = None
+            if exc_type is not None:
+                self.b.active = False
+        return False
+
+
+def _generator_idle_parameters(gen) -> List[torch.Tensor]:
+    """Trainable generator parameters that are never on the synthesis path (mapping network; noise strengths when the
+    noise mode is 'none'): they receive no gradient, ever."""
+    out = []
+    cfg = getattr(gen, "cfg", None)
+    for n, p in gen.named_parameters():
+        if not p.requires_grad:
+            continue
+        if n.startswith("backbone.mapping."):
+            out.append(p)
+        elif n.endswith(".noise_strength") and cfg is not None:
+            mode = cfg.sr_noise_mode if n.startswith("superresolution.") else cfg.backbone_noise_mode
+            if mode == "none":
+                out.append(p)
+    return out
+
+
+def step_skipping(optimizers, absent: Iterable[torch.Tensor]) -> None:
+    """`optimizer.step()` with the reference's `zero_grad()` semantics (set_to_none: trainer_rgb.py:75) on a PERSISTENT
+    gradient buffer: parameters that received no gradient this step (`absent`) must not take an Adam step — no moment
+    decay, no step-count advance — although their `.grad` slice exists and is zero.  Their `.grad` is hidden for the
+    duration of the step and restored (still the FlatGrads slice) afterwards."""
+    hidden = [(p, p.grad) for p in absent if p.grad is not None]
+    for p, _ in hidden:
+        p.grad = None
+    try:
+        for opt in optimizers:
+            opt.step()
+    finally:
+        for p, g in hidden:
+            p.grad = g
 
 
 class Trainer(nn.Module):
@@ -369,7 +467,7 @@ class Trainer(nn.Module):
         changes, e.g. after `tune_generator`, or when something replaced a .grad tensor)."""
         shared = self.shared_parameters()
         if self._flat is None or not self._flat.owns(shared):
-            self._flat = FlatGrads(shared)
+            self._flat = FlatGrads(shared, getattr(self, "bucket_bytes", 32 << 20))
             self._bucketer = None
         return self._flat
 
@@ -382,6 +480,22 @@ class Trainer(nn.Module):
             self._bucketer = BucketedAllReduce(flat, self.world_size)
             _install_grad_hooks(self, [self.gen])
         return self._bucketer
+
+    def absent_parameters(self, person_2: bool = False) -> List[torch.Tensor]:
+        """Trainable parameters that receive NO gradient in a step for identity `person_2` on every rank: the other
+        identity's basis / mean (headnerf.py:60-69,86-90), the Encoder's pose head (its output is not in the loss,
+        trainer_rgb.py:77-91), generator parameters off the synthesis path.  The reference's `zero_grad()` leaves their
+        `.grad` None, so Adam skips them (`step_skipping`); the bucketer counts them as ready (`begin_step`)."""
+        used = {id(t) for t in self.gen._select(person_2)}
+        out = []
+        for n, p in self.gen.named_parameters():
+            if not p.requires_grad or n.startswith("generator."):
+                continue
+            if n in _BASIS_NAMES and id(p) not in used:
+                out.append(p)
+            elif n.startswith("encoder.pose."):
+                out.append(p)
+        return out + _generator_idle_parameters(self.gen.generator)
 
     # ------------------------------------------------------------------ reference API
     def l2_loss(self, real_images, generated_images):
@@ -412,38 +526,42 @@ class Trainer(nn.Module):
             params, person_2 = None, params
         self.gen.train()
         flat = self.flat_grads()
-        flat.zero()
         bucketer = self._overlap(flat)
+        if bucketer is not None:
+            bucketer.reset()           # (waits for collectives an interrupted step left behind before their buffer is zeroed)
+        flat.zero()
+        absent = self.absent_parameters(person_2)
         t0 = self._mark()
         empty = real_image.shape[0] == 0
-        if empty:
-            l2 = lp = torch.zeros((), device=self.device)
-            generated = real_image
-            t1 = t2 = self._mark()
-        else:
-            if self.mode == "rgb":
-                weights = self.gen.get_weights(real_image)
-                if isinstance(weights, tuple):
-                    weights = weights[0]
-                latent = self.gen.get_latent(weights, person_2)
-                generated = self.gen.get_image(latent, label)
+        with _StepScope(bucketer, [self.gen.generator], absent):
+            if empty:
+                l2 = lp = torch.zeros((), device=self.device)
+                generated = real_image
+                t1 = t2 = self._mark()
             else:
-                generated = self.gen(params, label, person_2)
-            l2, generated = pooled_l2(self.face_pool, real_image, generated, self.lpips_loss is not None)
-            if self.lpips_loss is not None:
-                lp = torch.squeeze(self.lpips_loss(real_image, generated)).mean()
-            else:
-                lp = torch.zeros((), device=l2.device)
-            t1 = self._mark()
-            g_loss = l2 + lp
-            if loss_weight != 1.0:
-                g_loss = g_loss * loss_weight
-            g_loss.backward()
-            t2 = self._mark()
-        if bucketer is not None:
-            bucketer.finish()          # (most buckets are already in flight: started from inside the backward pass)
+                if self.mode == "rgb":
+                    weights = self.gen.get_weights(real_image)
+                    if isinstance(weights, tuple):
+                        weights = weights[0]
+                    latent = self.gen.get_latent(weights, person_2)
+                    generated = self.gen.get_image(latent, label)
+                else:
+                    generated = self.gen(params, label, person_2)
+                l2, generated = pooled_l2(self.face_pool, real_image, generated, self.lpips_loss is not None)
+                if self.lpips_loss is not None:
+                    lp = torch.squeeze(self.lpips_loss(real_image, generated)).mean()
+                else:
+                    lp = torch.zeros((), device=l2.device)
+                t1 = self._mark()
+                g_loss = l2 + lp
+                if loss_weight != 1.0:
+                    g_loss = g_loss * loss_weight
+                g_loss.backward()
+                t2 = self._mark()
+            if bucketer is not None:
+                bucketer.finish()      # (most buckets are already in flight: started from inside the backward pass)
         t3 = self._mark()
-        self.optimizer.step()
+        step_skipping([self.optimizer], absent)
         t4 = self._mark()
         self._span("fwd", t0, t1), self._span("bwd", t1, t2), self._span("allreduce", t2, t3), self._span("optim", t3, t4)
         if self.mode == "3dmm":
@@ -612,7 +730,7 @@ class AudioTrainer(nn.Module):
     def flat_grads(self) -> FlatGrads:
         shared = self.shared_parameters()
         if self._flat is None or not self._flat.owns(shared):
-            self._flat = FlatGrads(shared)
+            self._flat = FlatGrads(shared, getattr(self, "bucket_bytes", 32 << 20))
             self._bucketer = None
         return self._flat
 
@@ -643,20 +761,25 @@ class AudioTrainer(nn.Module):
     def gen_update(self, real_image, label, params, global_step: int, img_i: int, person_2: bool = False):
         self.gen.train(), self.AudNet.train(), self.AudAttNet.train()
         flat = self.flat_grads()
-        flat.zero()
         bucketer = self._overlap(flat)
-        generated = self.gen(self._drive(global_step, img_i, self.i_train), label, person_2)
-        l2_3dmm = torch.zeros(1, device=self.device)
-        l2, generated = pooled_l2(self.face_pool, real_image, generated, self.lpips_loss is not None)
-        lp = (torch.squeeze(self.lpips_loss(real_image, generated)).mean() if self.lpips_loss is not None
-              else torch.zeros((), device=l2.device))
-        (l2_3dmm + l2 + lp).backward()
         if bucketer is not None:
-            bucketer.finish()
-        self.w_optim.step()
-        self.optimizer_Aud.step()
-        if global_step >= self.args.nosmo_iters:
-            self.optimizer_AudAtt.step()
+            bucketer.reset()
+        flat.zero()
+        smooth = global_step >= self.args.nosmo_iters
+        absent = _generator_idle_parameters(self.gen.generator)
+        if not smooth:                     # the attention net is not on the path yet (trainer_audio.py:88-94)
+            absent = absent + [p for p in self.AudAttNet.parameters() if p.requires_grad]
+        with _StepScope(bucketer, [self.gen.generator], absent):
+            generated = self.gen(self._drive(global_step, img_i, self.i_train), label, person_2)
+            l2_3dmm = torch.zeros(1, device=self.device)
+            l2, generated = pooled_l2(self.face_pool, real_image, generated, self.lpips_loss is not None)
+            lp = (torch.squeeze(self.lpips_loss(real_image, generated)).mean() if self.lpips_loss is not None
+                  else torch.zeros((), device=l2.device))
+            (l2_3dmm + l2 + lp).backward()
+            if bucketer is not None:
+                bucketer.finish()
+        opts = [self.w_optim, self.optimizer_Aud] + ([self.optimizer_AudAtt] if smooth else [])
+        step_skipping(opts, absent)
         return l2_3dmm, l2.detach(), lp.detach(), generated.detach()
 
     def sample(self, real_image, label, params, global_step: int, img_i: int, person_2: bool = False):

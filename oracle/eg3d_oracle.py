@@ -335,9 +335,12 @@ def sample_importance(z: Tensor, weights: Tensor, u_imp: Tensor) -> Tensor:
 
 
 def importance_renderer(P: Dict[str, Tensor], cfg, planes: Tensor, origins: Tensor, dirs: Tensor,
-                        u_strat: Tensor, u_imp: Tensor):
+                        u_strat: Tensor, u_imp: Tensor, fine_depths: Optional[Tensor] = None):
     """ImportanceRenderer.forward (§3.4 step 4). planes [B,3,32,H,W];
-    u_strat [B,R,S,1]; u_imp [B*R,Sf] → feat [B,R,32], depth [B,R,1], wsum [B,R,1]."""
+    u_strat [B,R,S,1]; u_imp [B*R,Sf] → feat [B,R,32], depth [B,R,1], wsum [B,R,1].
+    ``fine_depths`` [B,R,Sf,1] (tests only): importance depths given from outside instead of drawn from the coarse
+    pass — both sides of a comparison then sample the volume at the SAME points, which separates arithmetic error
+    from the sensitivity of the inverse-CDF sampling to last-bit differences of the coarse weights."""
     axes = plane_axes(cfg.plane_axes)
     b, r, _ = origins.shape
     s = cfg.depth_resolution
@@ -353,7 +356,7 @@ def importance_renderer(P: Dict[str, Tensor], cfg, planes: Tensor, origins: Tens
     c_c, s_c = run(d_c)
     if cfg.depth_resolution_importance > 0:
         _, _, w = ray_march(c_c, s_c, d_c, cfg.white_back)
-        d_f = sample_importance(d_c, w, u_imp)
+        d_f = sample_importance(d_c, w, u_imp) if fine_depths is None else fine_depths.detach()
         c_f, s_f = run(d_f)
         d_all = torch.cat([d_c, d_f], -2)
         c_all = torch.cat([c_c, c_f], -2)
@@ -372,7 +375,7 @@ def importance_renderer(P: Dict[str, Tensor], cfg, planes: Tensor, origins: Tens
 # §3.4  TriPlaneGenerator.synthesis
 # --------------------------------------------------------------------------
 def synthesis(P: Dict[str, Tensor], cfg, ws: Tensor, c: Tensor, u_strat: Tensor, u_imp: Tensor,
-              fused: bool = True, return_planes: bool = False) -> Dict[str, Tensor]:
+              fused: bool = True, return_planes: bool = False, fine_depths: Optional[Tensor] = None) -> Dict[str, Tensor]:
     b = ws.shape[0]
     c2w = c[:, :16].reshape(-1, 4, 4)
     intr = c[:, 16:25].reshape(-1, 3, 3)
@@ -380,7 +383,7 @@ def synthesis(P: Dict[str, Tensor], cfg, ws: Tensor, c: Tensor, u_strat: Tensor,
     origins, dirs = ray_sampler(c2w, intr, res)
     planes = backbone_synthesis(P, cfg, ws, fused)
     planes5 = planes.reshape(b, 3, cfg.plane_channels, planes.shape[-2], planes.shape[-1])
-    feat, depth, _ = importance_renderer(P, cfg, planes5, origins, dirs, u_strat, u_imp)
+    feat, depth, _ = importance_renderer(P, cfg, planes5, origins, dirs, u_strat, u_imp, fine_depths)
     feat_img = feat.permute(0, 2, 1).reshape(b, feat.shape[-1], res, res).contiguous()
     depth_img = depth.permute(0, 2, 1).reshape(b, 1, res, res)
     rgb_raw = feat_img[:, :3]

@@ -434,8 +434,8 @@ def test_bucketed_allreduce_sink_matches_plain_autograd_on_gpu(dev, backend):
     calls it — device_id, in-place ReduceOp.AVG, asynchronous bucket collectives on RCCL's stream ordered against the launch
     stream, the parameter broadcast): with the generator being tuned, `SynthesisFn.backward`
     hands its parameter gradients to the trainer's bucketed all-reduce block by block (they are ADDED into the flat
-    buffer, autograd gets None) and the buckets' collectives start in readiness order — super-resolution first, the affine
-    layers and the basis / driver last.  The resulting .grad of every parameter must equal the plain autograd path."""
+    buffer, autograd gets None) and the buckets' collectives start in bucket INDEX order (= readiness order by layout:
+    super-resolution first, the affine layers and the basis / driver last), all of them from inside the backward pass.  The resulting .grad of every parameter must equal the plain autograd path."""
     import torch.distributed as dist
     from hfa_gp_amd.synthetic import make_frame_set
     from hfa_gp_amd.trainer import FlatGrads, Trainer
@@ -467,7 +467,10 @@ def test_bucketed_allreduce_sink_matches_plain_autograd_on_gpu(dev, backend):
             grads[overlapped] = {n: p.grad.detach().clone() for n, p in tr.gen.named_parameters() if p.grad is not None}
             if overlapped:
                 order = tr._bucketer.last_order
-                assert len(order) == len(tr._flat.buckets) > 4 and order[0] == 0, order
+                assert len(order) == len(tr._flat.buckets) > 4 and order == list(range(len(order))), order
+                # index order costs no overlap: the buffer is laid out in readiness order and absent parameters are
+                # counted at the start of the step, so every bucket left from INSIDE the backward pass
+                assert tr._bucketer.launched_early == len(order), (tr._bucketer.launched_early, len(order))
                 names = {id(p): n for n, p in tr.gen.named_parameters()}
                 first = names[id(tr._flat.params[0])]
                 assert first.startswith("generator.superresolution.block1."), first

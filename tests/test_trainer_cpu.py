@@ -470,3 +470,111 @@ def test_audio_trainer_two_ranks():
         mp.spawn(_audio_worker, args=(world, port, out), nprocs=world, join=True)
         for k in ("bases", "aud", "att_grad"):
             assert torch.equal(out[0][k], out[1][k]), k
+
+
+# ----------------------------------------------------------------------------- bucket order is rank-independent
+class RgbArgs(Args):
+    person_2 = True
+    same_bases = False
+    init = False
+    out_pose = True
+
+
+def make_rgb_trainer(seed=0, world_size=1, rank=0, bucket_bytes=256 << 10):
+    torch.manual_seed(seed)
+    gen = headnerf.HeadNeRF_final(RgbArgs(), RgbArgs.size, "cpu", 512, RgbArgs.latent_dim_shape)
+    OracleGenerator.adopt(gen.generator)
+    tr = Trainer(RgbArgs(), "cpu", rank=rank, world_size=world_size, mode="rgb", gen=gen, lpips="none")
+    tr.bucket_bytes = bucket_bytes
+    return tr
+
+
+def _rgb_ragged_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    try:
+        tr = make_rgb_trainer(seed=10 + rank, world_size=world, rank=rank)
+        tr.optimizer = torch.optim.SGD(tr.gen.parameters(), lr=0.05)
+        reals, labels, _ = _frame_set(3)
+        orders = []
+        fit_frames(tr, reals, labels, epochs=1, batch=1, on_step=lambda i, o: orders.append(list(tr._bucketer.last_order)))
+        tr.tune_generator()                                   # more buckets, generator gradients through the sink
+        fit_frames(tr, reals, labels, epochs=1, batch=1, on_step=lambda i, o: orders.append(list(tr._bucketer.last_order)))
+        out[rank] = {"orders": orders, "bases": tr.gen.bases.detach().clone(),
+                     "enc": tr.gen.encoder.fc[0].weight.detach().clone(),
+                     "gw": tr.gen.generator.backbone.synthesis.b8.conv1.weight.detach().clone(),
+                     "nb": len(tr._flat.buckets)}
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bucket_launch_order_is_rank_independent_with_empty_batches():
+    """3 frames / 2 ranks / batch 1 in RGB mode with buckets small enough for many of them: at step 1 rank 1 has an EMPTY
+    batch (no backward pass) while rank 0 finishes gradients in backward order.  Both must issue the SAME collective
+    sequence (index order) — with readiness-order launching gloo aborts with a size mismatch here — and end
+    with identical parameters, also once the generator is tuned."""
+    world, port = 2, _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_rgb_ragged_worker, args=(world, port, out), nprocs=world, join=True)
+        r0, r1 = out[0], out[1]
+    assert r0["nb"] > 3
+    assert r0["orders"] == r1["orders"]
+    for order in r0["orders"]:
+        assert order == list(range(len(order)))
+    assert len({len(o) for o in r0["orders"][2:]}) == 1 and len(r0["orders"][2]) == r0["nb"]
+    for k in ("bases", "enc", "gw"):
+        assert torch.equal(r0[k], r1[k]), k
+
+
+def test_bucketer_overlap_state_and_absent_parameters():
+    """One-rank gloo group: (i) buckets leave in index order while the backward pass is still running (the flat buffer is in
+    readiness order, so bucket 0 is NOT last); (ii) an exception between forward and backward leaves no stale counters;
+    (iii) outside gen_update the generator has no gradient sink; (iv) parameters without a gradient this step (the other
+    identity's basis, the pose head) take no Adam step — the reference's zero_grad(set_to_none) semantics."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(_free_port())
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        tr = make_rgb_trainer(seed=3, world_size=1)
+        tr.force_collective = True
+        tr.tune_generator()
+        real, label, _ = frame(7)
+        orig = tr.gen.generator.synthesis
+
+        b2_before = tr.gen.bases_2.detach().clone()
+        pose_before = [p.detach().clone() for p in tr.gen.encoder.pose.parameters()]
+        tr.gen_update(real, label.clone(), False)
+        bk = tr._bucketer
+        assert bk.last_order == list(range(len(tr._flat.buckets))) and not bk.active
+        assert bk.launched_early == len(tr._flat.buckets)                   # (i) all of them left during the backward pass
+        assert getattr(tr.gen.generator, "_grad_sink", None) is None
+        assert torch.equal(tr.gen.bases_2, b2_before)                       # absent: no Adam step at all
+        assert all(torch.equal(a, b) for a, b in zip(pose_before, tr.gen.encoder.pose.parameters()))
+        st = tr.optimizer.state
+        assert tr.gen.bases in st and tr.gen.bases_2 not in st
+        assert tr._flat.owns(tr.shared_parameters())                        # the hidden .grad slices are back
+        # the other identity: now bases / delta are absent and bases_2 / delta_2 move
+        b1_before = tr.gen.bases.detach().clone()
+        tr.gen_update(real, label.clone(), True)
+        assert torch.equal(tr.gen.bases, b1_before) and not torch.equal(tr.gen.bases_2, b2_before)
+
+        # (ii) a step that dies after the forward pass
+        def boom(*a, **k):
+            raise RuntimeError("boom")
+        tr.gen.generator.synthesis = boom
+        with pytest.raises(RuntimeError, match="boom"):
+            tr.gen_update(real, label.clone(), False)
+        tr.gen.generator.synthesis = orig
+        assert not bk.active and getattr(tr.gen.generator, "_grad_sink", None) is None
+        tr.gen_update(real, label.clone(), False)
+        assert tr._bucketer.last_order == list(range(len(tr._flat.buckets)))
+        # (iii) plain autograd outside a step reaches the generator parameters
+        w = tr.gen.get_weights(real)[0]
+        img = tr.gen.get_image(tr.gen.get_latent(w, False), label.clone())
+        gw = torch.autograd.grad(img.square().mean(), tr.gen.generator.backbone.synthesis.b8.conv1.weight)[0]
+        assert gw.abs().max() > 0
+    finally:
+        dist.destroy_process_group()
