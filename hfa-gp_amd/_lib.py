@@ -14,7 +14,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # (HFAGP_LIB_PATH: developer override, used by the ablation builds of tools/dev/ — the product loads the in-tree library)
 LIB_PATH = os.environ.get("HFAGP_LIB_PATH") or os.path.join(_HERE, "libhfagp_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 c_float_p = C.c_void_p  # device pointers travel as integers
 
@@ -147,6 +147,8 @@ SYMBOLS = {
     "hfagp_modconv_workspace_bytes": (C.c_size_t, [C.POINTER(ModconvArgs)]),
     "hfagp_modconv_fwd": (C.c_int, [C.POINTER(ModconvArgs), C.c_void_p]),
     "hfagp_upfir_epilogue_fwd": (C.c_int, [C.POINTER(UpfirEpilogueArgs), C.c_void_p]),
+    "hfagp_upconv_fir_scratch_bytes": (C.c_size_t, [C.POINTER(ModconvArgs)]),
+    "hfagp_upconv_fir_fwd": (C.c_int, [C.POINTER(ModconvArgs), C.c_void_p, C.c_void_p]),
     "hfagp_skip_upsample_add": (C.c_int, [C.POINTER(SkipArgs), C.c_void_p]),
     "hfagp_torgb_skip_fwd": (C.c_int, [C.POINTER(TorgbSkipArgs), C.c_void_p]),
     "hfagp_blur_down_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),

@@ -18,17 +18,9 @@
 //   ring that stays 3 (F16: 6) taps ahead of the MFMAs.  The patch of the next chunk is converted under the last
 //   taps of the current one into the other LDS buffer: one barrier per chunk.
 #include <type_traits>
-#include "modconv_plan.h"
-#include "split_mfma.h"
+#include "conv16_common.h"
 
 namespace hfagp {
-
-constexpr int APITCH = 48;       // LDS bytes per patch position and part: 16 bf16 + 16 B pad (3 x 16-B slots, odd)
-// LDS row pitch of the patch in positions.  32 (a multiple of 16) makes every 16-lane group of a ds_read_b128
-// cover 16 consecutive columns -> 16 distinct 16-B slots, no bank conflicts (the groups are {0-3,12-15,20-27},...);
-// the 3-part image would not fit twice per CU at that pitch and keeps the dense one (1 extra LDS cycle per group).
-template <int NP> struct RowPitch { static constexpr int value = NP <= 2 ? 32 : PW + 2; };
-constexpr int BNB = 128;         // output channels per block
 
 // IO: fp16 STORAGE of the activations (hfagp.h x_f16 / y_f16; KD = 1 only): bit 0 = x is fp16 (staging copies the halves
 // and applies the style with packed fp16 multiplies), bit 1 = y is written as fp16

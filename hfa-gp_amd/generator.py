@@ -16,6 +16,7 @@ device generator, or passed in as ``u_strat`` / ``u_imp`` for reproducible parit
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, Optional
 
 import torch
@@ -147,6 +148,11 @@ class TriPlaneGenerator(nn.Module):
         self.conv_precision = cfg.conv_precision
         self.sr_conv_precision = cfg.sr_conv_precision
         self.sr_storage = cfg.sr_storage
+        # up-sampling layers in ONE pass (FIR fused into the transposed conv, csrc/upconv_fir.hip): built, bit-for-bit-class
+        # parity with the two-kernel form (tests/test_gpu_round3.py), but measured SLOWER on the MI355X at every layer of this
+        # preset (profiles/r03_upfir/): the FIR arithmetic and the strip exports serialise with the GEMM inside the block's
+        # waves, whereas the stand-alone FIR kernel is a pure HBM stream.  Off unless asked for.
+        self.fuse_up_fir = os.environ.get("HFAGP_FUSE_UP_FIR", "0") == "1"
         self._styles: Dict[int, tuple] = {}      # id(layer) -> (styles, dcoef) of the pass in flight
         self._absmax = None                      # (slot buffers, layer names) of the last pass: f16_range_report()
         self._rgb_part = None                    # partial toRGB sums of the conv just run (fused toRGB, ops.modconv)
@@ -322,7 +328,12 @@ class TriPlaneGenerator(nn.Module):
         # which kernel bench.py times
         key = ("modconv" if wt.dtype == torch.float32 else
                "modconv_f16" if wt.dtype == torch.float16 and wt.shape[0] == 1 else "modconv_split")
-        if layer.up == 2:
+        if layer.up == 2 and self.fuse_up_fir and ops.upconv_fir_supported(x, wt, cout, batch):
+            # the whole up-sampling layer in one pass: the raw transposed-conv result stays on the chip (csrc/upconv_fir.hip)
+            out = self._timed(key + "_upfir", flops, ops.upconv_fir, x, wt, cout, k_styles, k_dcoef, noise, ns, layer.bias,
+                              "lrelu", cfg.lrelu_alpha, gain, conv_clamp, batch=batch, x_absmax=x_absmax,
+                              y_absmax=y_absmax, y_f16=half)
+        elif layer.up == 2:
             yt = self._timed(key + "_up", flops, ops.modconv, x, wt, cout, ops.CONVT3X3_UP2, styles=k_styles, batch=batch,
                              x_absmax=x_absmax, y_f16=half)
             out = ops.upfir_epilogue(yt, k_dcoef, noise, ns, layer.bias, "lrelu", cfg.lrelu_alpha, gain, conv_clamp,

@@ -323,6 +323,74 @@ def torgb_finish(part: torch.Tensor, bias: torch.Tensor, rgb_in: Optional[torch.
     return out
 
 
+def _up_layer_args(x, wt, cout, styles, dcoef, noise, noise_strength, bias, act, alpha, gain, clamp, batch, x_absmax,
+                   y_absmax, y_f16):
+    x_f16 = x.dtype == torch.float16
+    xb, h, w, cin = x.shape
+    b = batch if batch is not None else xb
+    a = L.ModconvArgs()
+    a.x, a.wt = x.data_ptr(), wt.data_ptr()
+    if wt.dtype == torch.float16:
+        a.precision = PREC_F16 if wt.shape[0] == 1 else PREC_F16X3
+    elif wt.dtype == torch.bfloat16:
+        a.precision = PREC_BF16X3 if wt.shape[0] == 2 else PREC_BF16X6
+    else:
+        a.precision = PREC_F32
+    a.styles, a.dcoef, a.noise, a.bias = _ptr(styles), _ptr(dcoef), _ptr(noise), _ptr(bias)
+    a.x_batch_stride = 0 if (xb == 1 and b > 1) else h * w * cin
+    a.B, a.H, a.W, a.Cin, a.Cout = b, h, w, cin, cout
+    a.mode, a.act, a.ksplit = CONVT3X3_UP2, _ACT[act], 0
+    a.noise_strength, a.alpha, a.gain = noise_strength, alpha, gain
+    a.clamp = -1.0 if clamp is None else float(clamp)
+    a.x_absmax, a.y_absmax = _ptr(x_absmax), _ptr(y_absmax)
+    a.x_f16, a.y_f16 = int(x_f16), int(y_f16)
+    return a, b, h, w
+
+
+_FIR_SCRATCH = {}        # device -> scratch tensor of upconv_fir (grown on demand; one launch stream per device)
+
+
+def upconv_fir_supported(x: torch.Tensor, wt: torch.Tensor, cout: int, batch: Optional[int] = None) -> bool:
+    """Whether `upconv_fir` takes this up-sampling layer (16-bit weight image with one or two parts, Cin % 16 == 0,
+    Cout % 128 == 0 and a launch that fills the chip): the library's own rule, hfagp_upconv_fir_scratch_bytes() > 0."""
+    if wt.dtype == torch.float32 or not x.is_cuda:
+        return False
+    if (x.dtype == torch.float16) and not (wt.dtype == torch.float16 and wt.shape[0] == 1):
+        return False
+    a, *_ = _up_layer_args(x, wt, cout, None, None, None, 0.0, None, "linear", 0.2, 1.0, None, batch, None, None, False)
+    return L.lib().hfagp_upconv_fir_scratch_bytes(C.byref(a)) > 0
+
+
+def upconv_fir(x: torch.Tensor, wt: torch.Tensor, cout: int, styles: Optional[torch.Tensor], dcoef: Optional[torch.Tensor],
+               noise: Optional[torch.Tensor], noise_strength: float, bias: Optional[torch.Tensor], act: str = "lrelu",
+               alpha: float = 0.2, gain: float = math.sqrt(2.0), clamp: Optional[float] = None, batch: Optional[int] = None,
+               x_absmax: Optional[torch.Tensor] = None, y_absmax: Optional[torch.Tensor] = None,
+               y_f16: bool = False) -> torch.Tensor:
+    """The up-sampling layer of a synthesis block in one pass: x [B|1, H, W, Cin] -> [B, 2H, 2W, Cout] =
+    bias_act(FIR(conv_transpose2d(x * styles, W, stride 2)) * dcoef + noise) (EG3D conv2d_resample(up=2) + bias_act), the raw
+    transposed-conv result never leaving the chip (`modconv(mode=CONVT3X3_UP2)` + `upfir_epilogue` move it through HBM in
+    fp32).  Only where `upconv_fir_supported` says so."""
+    if x.dtype != torch.float16:
+        _chk(x, "x")
+    elif not (x.is_cuda and x.is_contiguous()):
+        raise RuntimeError("x: expected a contiguous CUDA/ROCm tensor")
+    if wt.dtype == torch.float32 or not (wt.is_cuda and wt.is_contiguous() and wt.dim() == 5):
+        raise RuntimeError("upconv_fir: needs a 16-bit weight image from weight_prep_prec")
+    a, b, h, w = _up_layer_args(x, wt, cout, styles, dcoef, noise, noise_strength, bias, act, alpha, gain, clamp, batch,
+                                x_absmax, y_absmax, y_f16)
+    nbytes = L.lib().hfagp_upconv_fir_scratch_bytes(C.byref(a))
+    if nbytes == 0:
+        raise RuntimeError("upconv_fir: this layer shape / precision / batch is not supported (upconv_fir_supported)")
+    key = (x.device, torch.cuda.current_stream(x.device).cuda_stream)
+    scratch = _FIR_SCRATCH.get(key)
+    if scratch is None or scratch.numel() * 4 < nbytes:
+        scratch = _FIR_SCRATCH[key] = torch.empty((nbytes + 3) // 4, device=x.device, dtype=torch.float32)
+    y = torch.empty(b, 2 * h, 2 * w, cout, device=x.device, dtype=torch.float16 if y_f16 else torch.float32)
+    a.y = y.data_ptr()
+    L.check(L.lib().hfagp_upconv_fir_fwd(C.byref(a), _ptr(scratch), _stream()), "upconv_fir_fwd")
+    return y
+
+
 def upfir_epilogue(yt: torch.Tensor, dcoef: Optional[torch.Tensor], noise: Optional[torch.Tensor],
                    noise_strength: float, bias: Optional[torch.Tensor], act: str = "lrelu", alpha: float = 0.2,
                    gain: float = math.sqrt(2.0), clamp: Optional[float] = None,

@@ -224,16 +224,14 @@ class BucketedAllReduce:
         return b
 
     def on_grad(self, p: torch.Tensor):
+        """Post-accumulate notification (autograd hook).  PyTorch also fires it for a parameter whose gradient a custom
+        Function returned as None — every generator parameter that went through the sink is notified a second time WITHOUT a
+        write — so a notification for a parameter that is already counted is ignored; real writes into a bucket in flight are
+        caught where they happen (`sink`)."""
         if not self.active:
             return                     # a backward pass outside gen_update (autograd.grad, a sample): nothing to overlap
-        b = self.bucket_of.get(id(p))
-        if b is None:
+        if self.bucket_of.get(id(p)) is None or id(p) in self.seen:
             return
-        if self.works[b] is not None:
-            raise RuntimeError("BucketedAllReduce: a gradient arrived for a parameter whose bucket is already being "
-                               "all-reduced (the parameter was declared absent, or its gradient is produced twice in one "
-                               "step — e.g. two synthesis calls in one graph); sum the losses into ONE backward pass and "
-                               "do not list used parameters as absent")
         self._count(p)
         self._advance()
 
@@ -241,7 +239,10 @@ class BucketedAllReduce:
         """generator._grad_sink: accumulate into the flat slice, then count the parameter as ready."""
         b = self.bucket_of.get(id(p))
         if self.active and b is not None and self.works[b] is not None:
-            self.on_grad(p)            # raises: the slice is being reduced, it must not be written
+            raise RuntimeError("BucketedAllReduce: a generator gradient arrived for a parameter whose bucket is already being "
+                               "all-reduced (the parameter was declared absent, or its gradient is produced twice in one "
+                               "step — e.g. two synthesis calls in one graph); sum the losses into ONE backward pass and "
+                               "do not list used parameters as absent")
         p.grad.add_(g.view_as(p.grad))
         self.on_grad(p)
 

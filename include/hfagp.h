@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define HFAGP_ABI_VERSION 7
+#define HFAGP_ABI_VERSION 8
 
 enum { HFAGP_OK = 0, HFAGP_EBADARG = -1, HFAGP_EUNSUPPORTED = -2, HFAGP_ELAUNCH = -3 };
 
@@ -241,6 +241,21 @@ typedef struct {
 } HfagpUpfirEpilogueArgs;
 
 int hfagp_upfir_epilogue_fwd(const HfagpUpfirEpilogueArgs* a, void* stream);
+
+/* The whole up-sampling layer in ONE pass over its output (EG3D conv2d_resample(up = 2) + bias_act; replaces
+ * hfagp_modconv_fwd(mode HFAGP_CONVT3X3_UP2) + hfagp_upfir_epilogue_fwd):
+ *   y [B][2H][2W][Cout] = act(FIR(conv_transpose2d(x * styles, W, stride 2)) * dcoef + noise + bias) * gain, clamp
+ * The raw transposed-conv result never goes to HBM: a block owns a strip of 32 y_t columns, walks down a segment of
+ * tiles and filters each y_t tile in LDS; the three output columns at every strip boundary and the three output rows at
+ * every segment boundary are finished by a second, small kernel from raw strips in `scratch`.
+ * `a` as for hfagp_modconv_fwd with mode = HFAGP_CONVT3X3_UP2, except that y is the FINAL tensor, dcoef / noise / bias / act /
+ * alpha / gain / clamp / y_absmax apply (as in HfagpUpfirEpilogueArgs), workspace and ksplit are ignored and there is no
+ * fused toRGB.  Precisions BF16X3, F16X3, F16 (x_f16 / y_f16 storage allowed with F16); Cin % 16 == 0, Cin <= 512,
+ * Cout % 128 == 0; the launch must fill the chip (B * ceil((W+1)/16) * Cout/128 * segments >= 512 blocks).
+ * hfagp_upconv_fir_scratch_bytes(): bytes of `scratch` the call needs, or 0 when the shape is not supported — the caller
+ * then uses the two-call form.                                                                                      */
+size_t hfagp_upconv_fir_scratch_bytes(const HfagpModconvArgs* a);
+int hfagp_upconv_fir_fwd(const HfagpModconvArgs* a, void* scratch, void* stream);
 
 /* skip connection: img_out = upsample2d(img_in) + y  (both channels-last, C channels;
  * img_in may be NULL -> img_out = y).  Optional plane-major output for the last block:

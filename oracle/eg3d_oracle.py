@@ -61,7 +61,7 @@ def upfirdn2d(x: Tensor, f: Tensor, up: int = 1, down: int = 1,
         x = z.reshape(n, c, h * up, w * up)
     x = F.pad(x, [max(px0, 0), max(px1, 0), max(py0, 0), max(py1, 0)])
     x = x[:, :, max(-py0, 0): x.shape[2] - max(-py1, 0), max(-px0, 0): x.shape[3] - max(-px1, 0)]
-    k = (f * gain).flip([0, 1])[None, None].repeat(c, 1, 1, 1)
+    k = (f * gain).to(x.dtype).flip([0, 1])[None, None].repeat(c, 1, 1, 1)
     x = F.conv2d(x, k, groups=c)
     return x[:, :, ::down, ::down]
 
@@ -219,7 +219,7 @@ def ray_sampler(c2w: Tensor, intr: Tensor, res: int) -> Tuple[Tensor, Tensor]:
     fx, fy = intr[:, 0, 0], intr[:, 1, 1]
     cx, cy = intr[:, 0, 2], intr[:, 1, 2]
     sk = intr[:, 0, 1]
-    ar = torch.arange(res, dtype=torch.float32)
+    ar = torch.arange(res, dtype=c2w.dtype)      # (fp32 in EG3D; the tests also run this oracle in fp64 as ground truth)
     uv = torch.stack(torch.meshgrid(ar, ar, indexing="ij")) * (1.0 / res) + (0.5 / res)
     uv = uv.flip(0).reshape(2, -1).transpose(1, 0)[None].repeat(n, 1, 1)
     xc, yc = uv[:, :, 0], uv[:, :, 1]
@@ -249,9 +249,9 @@ def sample_from_planes(axes: Tensor, planes: Tensor, coords: Tensor, box_warp: f
     m = coords.shape[1]
     coords = (2.0 / box_warp) * coords
     cexp = coords[:, None].expand(-1, npl, -1, -1).reshape(n * npl, m, 3)
-    inv = torch.linalg.inv(axes)[None].expand(n, -1, -1, -1).reshape(n * npl, 3, 3)
+    inv = torch.linalg.inv(axes).to(coords.dtype)[None].expand(n, -1, -1, -1).reshape(n * npl, 3, 3)
     proj = torch.bmm(cexp, inv)[..., :2]
-    out = F.grid_sample(planes.reshape(n * npl, c, h, w), proj[:, None].float(), mode="bilinear",
+    out = F.grid_sample(planes.reshape(n * npl, c, h, w), proj[:, None].to(planes.dtype), mode="bilinear",
                         padding_mode="zeros", align_corners=False)
     return out.permute(0, 3, 2, 1).reshape(n, npl, m, c)
 
@@ -326,7 +326,7 @@ def sample_importance(z: Tensor, weights: Tensor, u_imp: Tensor) -> Tensor:
         b, r, s, _ = z.shape
         z = z.reshape(b * r, s)
         w = weights.reshape(b * r, -1)
-        w = F.max_pool1d(w[:, None].float(), 2, 1, padding=1)
+        w = F.max_pool1d(w[:, None].to(torch.promote_types(w.dtype, torch.float32)), 2, 1, padding=1)   # EG3D: .float()
         w = F.avg_pool1d(w, 2, 1).squeeze(1)
         w = w + 0.01
         z_mid = 0.5 * (z[:, :-1] + z[:, 1:])

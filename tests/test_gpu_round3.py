@@ -181,16 +181,21 @@ def _fine_depths_of(grad_fn, cfg, b):
     return by_index[..., sc:].reshape(b, r, sf, 1).cpu()
 
 
-def test_full_size_parameter_gradients_and_resampling_split(dev):
+def test_full_size_parameter_gradients_three_way(dev):
     """BASELINE config 3 after `tune_generator()` at its own size (the reference's mode for iterations 50 000 -> 800 000,
     trainer_rgb.py:69-71): dL/d(every generator parameter) and dL/d ws of the 512^2 / 128^2-ray / 48+48-sample generator
     against autograd through the CPU oracle, default f16x3 arithmetic (bwd-data and 3x3 weight-gradient GEMMs on split
     bf16: `wgrad_bf16_kernel` at 512 x 512 channels @ 64^2 and 128 x 128 @ 512^2, ksplit 128).
 
-    Two oracle runs: (A) the oracle draws its own importance depths — the plain comparison; (B) the oracle samples at the
-    importance depths the HIP forward used (`fine_depths`).  EG3D detaches those depths, so they are constants of the
-    gradient, but a last-bit difference in the coarse weights moves them, and with them every fine sample's tap weights.
-    If the gap of (A) is that sensitivity and not arithmetic, (B) must be several times tighter — asserted."""
+    What the residual IS ("nothing separates arithmetic error from resampling sensitivity").
+    Three oracle runs:
+      (A) fp32, the oracle draws its own importance depths        — the plain comparison;
+      (B) fp32, sampling at the importance depths the HIP forward used (`fine_depths`; EG3D detaches them, so they are
+          constants of the gradient, but last-bit differences in the coarse weights move them);
+      (T) fp64, same depths as (B)                                 — ground truth for the arithmetic.
+    Measured on the MI355X box (round 3): d ws rel-L2 HIP-vs-A 9.3e-4, HIP-vs-B 7.7e-4: resampling explains only a fifth
+    of the gap.  The rest is fp32 arithmetic ON BOTH SIDES, which (T) settles: asserted below is that the HIP gradients
+    are as close to the fp64 truth as the fp32 oracle's own gradients are (within 2x), parameter by parameter."""
     from hfa_gp_amd.config import ffhq512_128
     from hfa_gp_amd.generator import TriPlaneGenerator
     from oracle import eg3d_oracle as O
@@ -208,44 +213,122 @@ def test_full_size_parameter_gradients_and_resampling_split(dev):
     out = gen.synthesis(ws_d, c.to(dev), noise_mode="const", u_strat=us.to(dev), u_imp=ui.to(dev))
     fine = _fine_depths_of(out["image"].grad_fn, cfg, 1)
     ((out["image"] * G.to(dev)).sum() + (out["image_raw"] * G_raw.to(dev)).sum()).backward()
-    got_ws = ws_d.grad.cpu()
-    got = {n: p.grad.detach().cpu() if p.grad is not None else None for n, p in gen.named_parameters()}
+    got = {n: p.grad.detach().cpu() for n, p in gen.named_parameters() if p.grad is not None}
+    got["ws"] = ws_d.grad.cpu()
+    img_hip = out["image"].detach().cpu()
 
-    def oracle_grads(fine_depths):
-        P = {k: v.clone() for k, v in P0.items()}
+    def oracle_grads(fine_depths, dt):
+        P = {k: (v.to(dt) if v.is_floating_point() else v.clone()) for k, v in P0.items()}
         for n in names:
-            P[n].requires_grad_(True)
-        w = ws.clone().requires_grad_(True)
-        ref = O.synthesis(P, cfg, w, c, us, ui, fine_depths=fine_depths)
-        ((ref["image"] * G).sum() + (ref["image_raw"] * G_raw).sum()).backward()
-        return ref["image"].detach(), w.grad, {n: P[n].grad for n in names}
+            P[n] = P[n].clone().requires_grad_(True)
+        w = ws.to(dt).clone().requires_grad_(True)
+        fd = None if fine_depths is None else fine_depths.to(dt)
+        ref = O.synthesis(P, cfg, w, c.to(dt), us.to(dt), ui.to(dt), fine_depths=fd)
+        ((ref["image"] * G.to(dt)).sum() + (ref["image_raw"] * G_raw.to(dt)).sum()).backward()
+        grads = {n: P[n].grad for n in names if P[n].grad is not None}
+        grads["ws"] = w.grad
+        return ref["image"].detach(), grads
 
-    report = {}
-    for tag, fd in (("own_depths", None), ("hip_depths", fine)):
-        img, gws, gp = oracle_grads(fd)
-        close(out["image"], img, atol=1e-4)
-        rel = {"ws": ((got_ws - gws).norm() / gws.norm()).item()}
-        mx = {"ws": ((got_ws - gws).abs().max() / gws.abs().max()).item()}
-        for n in names:
-            if gp[n] is None:
-                assert got[n] is None or float(got[n].abs().max()) == 0.0, n
-                continue
-            assert got[n] is not None and got[n].shape == gp[n].shape, n
-            den = gp[n].norm().item()
-            rel[n] = ((got[n] - gp[n]).norm().item() / den) if den > 0 else 0.0
-            mx[n] = ((got[n] - gp[n]).abs().max().item() / max(gp[n].abs().max().item(), 1e-30))
-        report[tag] = (rel, mx)
-        worst = sorted(((v, k) for k, v in rel.items()), reverse=True)[:5]
-        print(f"full-size gradients vs oracle [{tag}]: d ws rel-L2 {rel['ws']:.2e} max {mx['ws']:.2e}; "
-              f"worst parameters (rel L2): {[(k, f'{v:.1e}') for v, k in worst]}")
-    rel_a, mx_a = report["own_depths"]
-    rel_b, mx_b = report["hip_depths"]
+    def rel(x, y):                               # ||x - y|| / ||y|| per tensor, in fp64
+        out = {}
+        for n, ref in y.items():
+            den = ref.double().norm().item()
+            out[n] = ((x[n].double() - ref.double()).norm().item() / den) if den > 0 else 0.0
+        return out
+
+    img_a, g_a = oracle_grads(None, torch.float32)
+    img_b, g_b = oracle_grads(fine, torch.float32)
+    img_t, g_t = oracle_grads(fine, torch.float64)
+    assert set(got) == set(g_a) == set(g_t), set(got) ^ set(g_t)          # the same parameters are on the path on both sides
+    close(img_hip, img_a, atol=1e-4)
+    close(img_hip, img_t.float(), atol=1e-4)
+    hip_a, hip_b, hip_t, orc_t = rel(got, g_a), rel(got, g_b), rel(got, g_t), rel(g_b, g_t)
     scalars = {n for n in names if P0[n].numel() == 1}
-    # (A) the plain comparison: every tensor-valued parameter within 2e-3 in the L2 norm (d ws: the round-2 bar), a scalar
-    # (noise_strength: ONE number = a sum over a whole activation with near-total cancellation) within 5e-2
-    bad = [(n, v) for n, v in rel_a.items() if v > (5e-2 if n in scalars else 2e-3)]
+
+    def worst(r, only=None):
+        return max((v, k) for k, v in r.items() if (only is None or k in only))
+    tensors = set(hip_t) - scalars
+    print(f"full-size gradients, rel-L2.  d ws: HIP-vs-A {hip_a['ws']:.2e}  HIP-vs-B {hip_b['ws']:.2e}  HIP-vs-T(fp64) "
+          f"{hip_t['ws']:.2e}  oracle32-vs-T {orc_t['ws']:.2e}")
+    print(f"  worst tensor parameter: HIP-vs-A {worst(hip_a, tensors)}  HIP-vs-T {worst(hip_t, tensors)}  "
+          f"oracle32-vs-T {worst(orc_t, tensors)}")
+    print(f"  worst scalar (noise_strength): HIP-vs-A {worst(hip_a, scalars)}  HIP-vs-T {worst(hip_t, scalars)}  "
+          f"oracle32-vs-T {worst(orc_t, scalars)}")
+    # (A) the plain comparison against the fp32 oracle: every tensor-valued parameter and d ws within 2e-3 in the L2 norm;
+    # a scalar (noise_strength = ONE number, a sum over a whole activation with near-total cancellation) within 5e-2
+    bad = [(n, v) for n, v in hip_a.items() if v > (5e-2 if n in scalars else 2e-3)]
     assert not bad, bad[:8]
-    # (B) same sample points on both sides: what is left is arithmetic (split-bf16 gradient GEMMs, fp32 summation order)
-    bad = [(n, v) for n, v in rel_b.items() if v > (5e-2 if n in scalars else 1e-3)]
+    # (T) against the fp64 truth at identical sample points the HIP path is fp32-class: no worse than twice the fp32
+    # oracle's own distance from the truth (floor 3e-4 / 1e-2 for tensors whose fp32-oracle error happens to be tiny)
+    bad = [(n, hip_t[n], orc_t[n]) for n in hip_t
+           if hip_t[n] > max(2.0 * orc_t[n], 1e-2 if n in scalars else 3e-4)]
     assert not bad, bad[:8]
-    assert rel_b["ws"] < 0.5 * rel_a["ws"], (rel_a["ws"], rel_b["ws"])
+
+
+# ----------------------------------------------------------------------------- fused up-sampling layer (csrc/upconv_fir.hip)
+@pytest.mark.parametrize("b,h,w,cin,cout,prec,nseg", [
+    (2, 24, 40, 32, 128, "f16x3", None),      # 3 strips, default segmentation
+    (3, 37, 21, 32, 128, "f16x3", 2),         # ragged: 2W = 42 output columns, 5 tile rows in 2 segments
+    (2, 16, 16, 64, 128, "bf16x3", 1),        # the second strip holds only y_t column 32; one segment (window all the way down)
+    (2, 19, 33, 64, 256, "f16x3", 3),         # two 128-channel tiles, 3 segments of one tile each (no window)
+    (1, 40, 24, 32, 128, "f16", 2),
+    (4, 64, 64, 128, 128, "f16x3", None),
+])
+def test_upconv_fir_matches_two_kernel_form(dev, monkeypatch, b, h, w, cin, cout, prec, nseg):
+    """hfagp_upconv_fir_fwd (transposed conv + FIR + demod / noise / bias / leaky ReLU / clamp in one pass, strips finished by
+    the fix-up kernel) against the two-kernel form it replaces and against the oracle's conv2d_resample path: every output
+    pixel, including the strip / segment boundary columns and rows, image borders, ragged extents, the published max |y|."""
+    import math
+    from hfa_gp_amd import ops
+    from oracle import eg3d_oracle as O
+    monkeypatch.setenv("HFAGP_DEV_FIR_MIN_BLOCKS", "1")
+    if nseg is not None:
+        monkeypatch.setenv("HFAGP_DEV_FIR_NSEG", str(nseg))
+    g = torch.Generator().manual_seed(b * 1000 + h * 10 + w)
+    x = torch.randn(b, cin, h, w, generator=g)
+    wgt = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    s = torch.randn(b, cin, generator=g) + 1.0
+    dco = torch.rand(b, cout, generator=g) + 0.5
+    bias = torch.randn(cout, generator=g)
+    noise = torch.randn(2 * h, 2 * w, generator=g)
+    ns, clamp = 0.3, 2.5
+    xd, sd, dd, bd, nd = ops.nchw_to_nhwc(x.to(dev)), s.to(dev), dco.to(dev), bias.to(dev), noise.to(dev)
+    wt = ops.weight_prep_prec(wgt.to(dev), prec)
+    assert ops.upconv_fir_supported(xd, wt, cout)
+    am1, am2 = ops.absmax_slots(1, dev)[0], ops.absmax_slots(1, dev)[0]
+    y = ops.upconv_fir(xd, wt, cout, sd, dd, nd, ns, bd, "lrelu", 0.2, math.sqrt(2.0), clamp, y_absmax=am1)
+    yt = ops.modconv(xd, wt, cout, ops.CONVT3X3_UP2, styles=sd)
+    want = ops.upfir_epilogue(yt, dd, nd, ns, bd, "lrelu", 0.2, math.sqrt(2.0), clamp, y_absmax=am2)
+    assert y.shape == want.shape == (b, 2 * h, 2 * w, cout)
+    err = (y - want).abs()
+    assert err.max().item() <= 2e-6 * max(1.0, want.abs().max().item()), (err.max().item(), err.argmax().item())
+    assert abs(am1.max().item() - am2.max().item()) <= 2e-6 * am2.max().item()
+    # and against the oracle's own up-sampling layer (fp32 conv_transpose2d + upfirdn2d)
+    ref = O._conv_up2(x * s[:, :, None, None], wgt, O.fir_kernel()) * dco[:, :, None, None] + noise * ns
+    ref = O.bias_act(ref, bias, act="lrelu", clamp=clamp)
+    tol = {"f16x3": 2e-5, "bf16x3": 2e-4, "f16": 2e-2}[prec]
+    assert (ops.nhwc_to_nchw(y).cpu() - ref).abs().max().item() <= tol
+
+
+def test_upconv_fir_fp16_storage(dev, monkeypatch):
+    """fp16 STORAGE of x and y around the fused up-sampling layer (EG3D's fp16 super-resolution blocks): y_t stays fp32 on the
+    chip, so the result is at least as close to the fp32 layer as the two-kernel fp16-storage form (which rounds y_t to fp16)."""
+    import math
+    from hfa_gp_amd import ops
+    monkeypatch.setenv("HFAGP_DEV_FIR_MIN_BLOCKS", "1")
+    g = torch.Generator().manual_seed(77)
+    b, h, w, cin, cout = 2, 32, 48, 32, 128
+    x = torch.randn(b, h, w, cin, generator=g).to(dev)
+    wgt = (torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)).to(dev)
+    s = (torch.rand(b, cin, generator=g) + 0.5).to(dev)
+    dco = (torch.rand(b, cout, generator=g) + 0.5).to(dev)
+    bias = torch.randn(cout, generator=g).to(dev)
+    wt = ops.weight_prep_prec(wgt, "f16")
+    exact = ops.upconv_fir(x, ops.weight_prep_prec(wgt, "f16x3"), cout, s, dco, None, 0.0, bias, clamp=256.0)
+    y = ops.upconv_fir(x.half(), wt, cout, s, dco, None, 0.0, bias, clamp=256.0, y_f16=True)
+    assert y.dtype == torch.float16
+    yt = ops.modconv(x.half(), wt, cout, ops.CONVT3X3_UP2, styles=s, y_f16=True)
+    two = ops.upfir_epilogue(yt, dco, None, 0.0, bias, clamp=256.0)
+    e_fused = (y.float() - exact).abs().max().item()
+    e_two = (two.float() - exact).abs().max().item()
+    assert e_fused <= 2e-2 and e_fused <= 1.5 * e_two + 1e-3, (e_fused, e_two)
