@@ -64,13 +64,17 @@ def parse():
                          "0 = skip)")
     ap.add_argument("--audio-frames", type=int, default=256,
                     help="frames of the batched audio-driven reenactment leg (BASELINE config 5; 0 = skip)")
-    ap.add_argument("--lpips", action="store_true",
-                    help="also time the fitting step with the LPIPS(alex) term (random weights: cost only)")
+    ap.add_argument("--no-lpips", dest="lpips", action="store_false",
+                    help="skip the fitting-step leg with the LPIPS(alex) term (seeded random weights: the COST of the reference "
+                         "objective l2 + lpips, trainer_rgb.py:86-91 — on by default)")
+    ap.add_argument("--dist-timeout", type=int, default=300,
+                    help="seconds a collective may wait for a peer before the job fails with a message (N > 1)")
     ap.add_argument("--no-sweep", action="store_true",
                     help="skip the batch-size sweeps (render B = 1, 4, 16; fitting step B = 1, 4; SURVEY.md section 8d)")
-    ap.add_argument("--cpu-runs", type=int, default=3, help="timed oracle runs (BASELINE.md section 3 plans 5)")
-    ap.add_argument("--cpu-warmup", type=int, default=1, help="oracle warm-up runs (BASELINE.md section 3 plans 2)")
-    ap.add_argument("--cpu-n1", action="store_true", help="also time the oracle with ONE thread (minutes)")
+    ap.add_argument("--cpu-runs", type=int, default=5, help="timed oracle runs (BASELINE.md section 3: 5)")
+    ap.add_argument("--cpu-warmup", type=int, default=2, help="oracle warm-up runs (BASELINE.md section 3: 2)")
+    ap.add_argument("--no-cpu-n1", dest="cpu_n1", action="store_false",
+                    help="skip the ONE-thread run of the oracle (BASELINE.md section 3: n = 1; ~5 s)")
     ap.add_argument("--precision", default=None, choices=["fp32", "f16x3", "bf16x3", "bf16x6"],
                     help="conv GEMM arithmetic of the headline leg (default: the preset's conv_precision)")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the second render leg on the exact fp32 kernel")
@@ -106,6 +110,24 @@ def cpu_model() -> str:
     return "unknown"
 
 
+def cpu_topology() -> dict:
+    """sockets / physical cores / logical CPUs of this host from /proc/cpuinfo (the GPU box: 2 x 64 cores, 256 threads)."""
+    phys, cores_per, logical = set(), 0, 0
+    try:
+        pid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("processor"):
+                logical += 1
+            elif line.startswith("physical id"):
+                pid = line.split(":", 1)[1].strip()
+                phys.add(pid)
+            elif line.startswith("cpu cores"):
+                cores_per = int(line.split(":", 1)[1])
+    except (OSError, ValueError):
+        pass
+    return {"sockets": len(phys) or 1, "cores_per_socket": cores_per, "logical_cpus": logical}
+
+
 def cpu_baseline(cfg, state, runs: int, warmup: int, n1: bool):
     """Oracle (kind 'port') timed on this box's host cores: B=1 synthesis of the same workload; median of `runs`
     after `warmup`; stage split backbone / ray-march / super-resolution."""
@@ -133,20 +155,29 @@ def cpu_baseline(cfg, state, runs: int, warmup: int, n1: bool):
             for _ in range(nwarm):
                 one()
             rows = [one() for _ in range(nruns)]
-        tot = sorted(sum(r) for r in rows)
+        totals = [sum(r) for r in rows]
+        tot = sorted(totals)
         med = tot[len(tot) // 2]
         stages = [sorted(r[i] for r in rows)[len(rows) // 2] for i in range(3)]
-        return med, stages
+        return med, stages, totals
 
+    topo = cpu_topology()
+    # n = all PHYSICAL cores of the box (torch's default pool is that already on the GPU box: 2 x 64)
+    phys = topo["sockets"] * topo["cores_per_socket"]
+    if phys > 0:
+        torch.set_num_threads(phys)
     threads = torch.get_num_threads()
-    med, stages = timed(runs, warmup)
+    med, stages, totals = timed(runs, warmup)
     out = {"value": 1.0 / med, "unit": "frames/s", "cores": threads, "kind": "port", "cpu_model": cpu_model(),
+           "topology": topo,
            "sample": f"median of {runs} x synthesis(B=1) of the {cfg.name} workload with the fp32 PyTorch-CPU oracle "
-                     f"after {warmup} warm-up, {threads} threads, {med:.2f} s/frame",
-           "stage_s": {"backbone": stages[0], "raymarch": stages[1], "superres": stages[2]}}
+                     f"after {warmup} warm-up (BASELINE.md section 3 protocol: 5 / 2), {threads} threads = "
+                     f"{topo['sockets']} sockets x {topo['cores_per_socket']} cores, {med:.2f} s/frame",
+           "runs_s": [round(t, 3) for t in totals],      # every timed run: the ATen CPU ops of this path vary 5 - 7.5 s/frame
+           "stage_s": {"backbone": stages[0], "raymarch": stages[1], "superres": stages[2]}}   # run to run on this box
     if n1:
         torch.set_num_threads(1)
-        med1, st1 = timed(1, 0)
+        med1, st1, _ = timed(1, 0)
         torch.set_num_threads(threads)
         out["n1"] = {"value": 1.0 / med1, "cores": 1, "s_per_frame": med1,
                      "stage_s": {"backbone": st1[0], "raymarch": st1[1], "superres": st1[2]}}
@@ -198,7 +229,7 @@ class _AudioArgs(_FitArgs):
 
 def train_legs(args, cfg_name, dev, rank, world, dist):
     """BASELINE configs 3 / 4 mechanics at full size: latent-basis fitting step, generator frozen, L2 loss at 256^2
-    (+ LPIPS with random weights under --lpips), Adam 3e-4; RGB-driven (Encoder in the step: config 3) and
+    (+ the same step with the LPIPS(alex) term, random weights: `train_step_ms_lpips`), Adam 3e-4; RGB-driven (Encoder in the step: config 3) and
     3DMM-driven (config 4); ONE in-place all-reduce of the flat shared-gradient buffer per step when world > 1."""
     import torch
     from hfa_gp_amd.trainer import Trainer
@@ -271,6 +302,7 @@ def train_legs(args, cfg_name, dev, rank, world, dist):
         torch.cuda.empty_cache()
     if args.lpips:
         from hfa_gp_amd.lpips_alex import LPIPSAlex
+        torch.manual_seed(1234)               # seeded random weights
         fa, tr = make("rgb", LPIPSAlex().to(dev))
         ms, phases = timed(tr, fa, args.train_steps, B)
         out["rgb_lpips"] = {"step_ms": ms, "phases_ms": phases,
@@ -451,12 +483,31 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(_free_port()))
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        if dist.get_world_size() != args.gpus:
-            raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus says {args.gpus}")
+        import datetime
+        # a rank that dies (or never starts) must end the job with a message, not hang its peers for the default 10 - 30 min
+        tmo = datetime.timedelta(seconds=args.dist_timeout)
+        try:
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=tmo)
+            else:
+                dist.init_process_group("gloo", rank=rank, world_size=world, timeout=tmo)
+            if dist.get_world_size() != args.gpus:
+                raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus says {args.gpus}")
+            # RCCL builds its rings at the FIRST collective: do it here, where a failure can be named, and check the answer
+            probe = torch.full((1,), float(rank + 1), device=dev)
+            dist.all_reduce(probe)
+            torch.cuda.synchronize()
+            if abs(float(probe) - world * (world + 1) / 2) > 1e-3:
+                raise RuntimeError(f"first all-reduce returned {float(probe)} instead of {world * (world + 1) / 2}")
+        except SystemExit:
+            raise
+        except Exception as e:  # noqa: BLE001
+            sys.stderr.write(f"[bench rank {rank}/{world} on cuda:{local_rank}] could not bring up the {args.backend} process "
+                             f"group within {args.dist_timeout} s: {type(e).__name__}: {e}\n"
+                             f"  (one process per GPU, rendezvous 127.0.0.1:{os.environ.get('MASTER_PORT')}; RCCL needs "
+                             f"HSA_ENABLE_IPC_MODE_LEGACY=0 on this host driver; every rank must see all {world} devices — do not "
+                             f"narrow HIP_VISIBLE_DEVICES per rank, the rank picks cuda:LOCAL_RANK itself)\n")
+            raise SystemExit(3)
     n_ranks = dist.get_world_size() if dist is not None else 1
 
     from hfa_gp_amd.config import PRESETS
@@ -694,6 +745,9 @@ def main():
                                    f"(48+48) samples, random-init weights, random latents+cameras",
                        "frames_per_step_per_gpu": B, "parallelism": f"frame-parallel x{n_ranks}"},
             "per_rank_frames_per_s": per_rank,
+            # (max - min) / median over the ranks: frame-parallel rendering has no collective in the timed region, so a spread
+            # beyond a few per cent means one GPU (clock, thermal state, a noisy neighbour on its NUMA node) holds the job back
+            "per_rank_spread": ((max(per_rank) - min(per_rank)) / sorted(per_rank)[len(per_rank) // 2]) if per_rank else 0.0,
             # dominant kernel by time: the modulated-conv implicit GEMM
             "roofline": roof,
             # the kernel north_star names: see the comment above

@@ -1,21 +1,30 @@
 #!/usr/bin/env bash
 # Build libhfagp_hip.so for gfx950 (cross-compiles without a GPU).
+# An object is rebuilt when the CONTENT of its source, of any header, of this script or of the flags changed (sha256 kept
+# next to the object) — not by mtime, so a checkout / copy cannot leave a stale object behind.  HFAGP_CLEAN=1 rebuilds all.
 set -euo pipefail
 here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 out="${here}/../libhfagp_hip.so"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function)
+common_hash="$(cat "${here}"/*.h "${here}/../../include/hfagp.h" "${here}/build.sh" | sha256sum | cut -d' ' -f1)"
 objs=()
+built=0
 for src in elementwise modconv modconv_bf16 upconv_fir torgb_skip raymarch backward raymarch_bwd wgrad wgrad_bf16 qr loss; do
     obj="${here}/${src}.o"
     extra=()
     # torgb_skip.hip: no SLP vectoriser (see the build note at the top of that file)
     [[ "$src" == torgb_skip ]] && extra=(-fno-slp-vectorize)
-    if [[ ! -f "$obj" || "${here}/${src}.hip" -nt "$obj" || "${here}/common.h" -nt "$obj" || "${here}/modconv_plan.h" -nt "$obj" || "${here}/split_mfma.h" -nt "$obj" || "${here}/conv16_common.h" -nt "$obj" || "${here}/raymarch_common.h" -nt "$obj" || "${here}/build.sh" -nt "$obj" || "${here}/../../include/hfagp.h" -nt "$obj" ]]; then
-        "$HIPCC" "${FLAGS[@]}" "${extra[@]}" ${HFAGP_EXTRA_FLAGS:-} -c "${here}/${src}.hip" -o "$obj" &
+    want="$( (echo "${common_hash} ${FLAGS[*]} ${extra[*]:-} ${HFAGP_EXTRA_FLAGS:-}"; cat "${here}/${src}.hip") | sha256sum | cut -d' ' -f1)"
+    have="$(cat "${obj}.sha256" 2>/dev/null || true)"
+    if [[ "${HFAGP_CLEAN:-0}" == 1 || ! -f "$obj" || "$want" != "$have" ]]; then
+        rm -f "${obj}.sha256"
+        ( "$HIPCC" "${FLAGS[@]}" "${extra[@]}" ${HFAGP_EXTRA_FLAGS:-} -c "${here}/${src}.hip" -o "$obj" && echo "$want" > "${obj}.sha256" ) &
+        built=$((built + 1))
     fi
     objs+=("$obj")
 done
 wait
+for obj in "${objs[@]}"; do [[ -f "${obj}.sha256" ]] || { echo "build.sh: ${obj} failed to compile" >&2; exit 1; }; done
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o "$out"
-echo "built $out"
+echo "built $out (${built} of ${#objs[@]} objects compiled)"

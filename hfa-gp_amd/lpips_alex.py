@@ -100,9 +100,28 @@ class LPIPSAlex(nn.Module):
     def _normalize(x, eps: float = 1e-10):
         return x / (torch.sqrt(torch.sum(x ** 2, dim=1, keepdim=True)) + eps)
 
+    accepts_unpooled = True       # forward(in0, in1) takes an in1 at 2x the resolution of in0 (see below)
+
+    def _features_of_unpooled(self, x: torch.Tensor):
+        """AlexNet features of AdaptiveAvgPool2d(H/2)(x) WITHOUT forming the pooled image: the 2 x 2 average folds into
+        the first conv (11 x 11, stride 4, pad 2 on the pooled image == 22 x 22, stride 8, pad 4 on x with every tap
+        duplicated 2 x 2 and divided by 4; the per-channel scaling layer commutes with the average).  The reference pools
+        first (trainer_rgb.py:84-87); here the L2 term keeps its fused pool + MSE pass and LPIPS reads the 512^2 image."""
+        c0 = self.net.slice1[0]
+        w = c0.weight.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3) * 0.25
+        y = F.relu(F.conv2d(self.scaling_layer(x), w, c0.bias, stride=8, padding=4))
+        outs = [y]
+        for s in (self.net.slice2, self.net.slice3, self.net.slice4, self.net.slice5):
+            y = s(y)
+            outs.append(y)
+        return outs
+
     def forward(self, in0: torch.Tensor, in1: torch.Tensor) -> torch.Tensor:
         f0 = self.net(self.scaling_layer(in0))
-        f1 = self.net(self.scaling_layer(in1))
+        if in1.shape[-1] == 2 * in0.shape[-1] and in1.shape[-2] == 2 * in0.shape[-2]:
+            f1 = self._features_of_unpooled(in1)
+        else:
+            f1 = self.net(self.scaling_layer(in1))
         val = 0
         for k in range(5):
             d = (self._normalize(f0[k]) - self._normalize(f1[k])) ** 2

@@ -548,9 +548,14 @@ class Trainer(nn.Module):
                     generated = self.gen.get_image(latent, label)
                 else:
                     generated = self.gen(params, label, person_2)
-                l2, generated = pooled_l2(self.face_pool, real_image, generated, self.lpips_loss is not None)
+                full = generated
+                # LPIPSAlex folds a 2 x 2 pool into its first conv: the L2 term then keeps the fused pool + MSE pass and no
+                # pooled image with a gradient is needed (lpips_alex.LPIPSAlex._features_of_unpooled)
+                fold = (self.lpips_loss is not None and getattr(self.lpips_loss, "accepts_unpooled", False)
+                        and full.shape[-1] == 2 * real_image.shape[-1] and full.shape[-2] == 2 * real_image.shape[-2])
+                l2, generated = pooled_l2(self.face_pool, real_image, generated, self.lpips_loss is not None and not fold)
                 if self.lpips_loss is not None:
-                    lp = torch.squeeze(self.lpips_loss(real_image, generated)).mean()
+                    lp = torch.squeeze(self.lpips_loss(real_image, full if fold else generated)).mean()
                 else:
                     lp = torch.zeros((), device=l2.device)
                 t1 = self._mark()

@@ -357,6 +357,13 @@ def test_lpips_alex_module_and_objective():
     assert torch.allclose(d, lp(b, a), atol=1e-6)
     lp2 = LPIPSAlex(state_dict=lp.state_dict())
     assert torch.equal(lp2(a, b), d)
+    # an in1 at twice the resolution: the 2 x 2 average pool of the reference (trainer_rgb.py:84) folded into the first conv
+    big = (torch.rand(2, 3, 128, 128) * 2 - 1).requires_grad_(True)
+    v_pool = lp(a, torch.nn.functional.adaptive_avg_pool2d(big, 64)).sum()
+    v_fold = lp(a, big).sum()
+    (g_pool,), (g_fold,) = torch.autograd.grad(v_pool, big), torch.autograd.grad(v_fold, big)
+    assert abs(float(v_pool) - float(v_fold)) <= 1e-5 * abs(float(v_pool))
+    assert (g_pool - g_fold).abs().max() <= 1e-4 * g_pool.abs().max()
     # as the second term of the step
     torch.manual_seed(4)
     gen = headnerf.HeadNeRF_3DMM(Args(), Args.size, "cpu", 512, Args.latent_dim_shape)
