@@ -449,6 +449,10 @@ def audio_leg(args, cfg_name, dev, rank, world, dist):
 
 def main():
     args = parse()
+    # The LPIPS leg is the only MIOpen user of this run (AlexNet convs on PyTorch-ROCm).  On a fresh box MIOpen's default
+    # find mode benchmarks every new conv shape on first use: 45 s of the 49 s that leg took.  FAST mode picks the kernel
+    # from the find-db / heuristics without timing candidates; nothing in the hot path goes through MIOpen.
+    os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher: start the N ranks ourselves, exactly as the driver does
         env = dict(os.environ)

@@ -349,6 +349,30 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
 #pragma unroll
         for (int i = 0; i < TMW * 16 * 3; ++i) rgbp[i] = 0.f;
     }
+#ifdef HFAGP_ABL_STORE4     // (developer ablation, TIMING ONLY — values land in the wrong places: the store pattern of a transposed
+    // accumulator layout, lane = position, 4 consecutive channels per 16-byte store; same bytes, a quarter of the instructions)
+    if (p.out && p.fused) {
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int tm = 0; tm < TMW; ++tm) {
+                const int m = m0 + 2 * (wm * TMW + tm) + (l31 >> 4), n = n0 + (l31 & 15);
+                if (m < ph.mh && n < ph.mw) {
+                    float* dst = out + (((size_t)b * p.Ho + m) * p.Wo + n) * p.Cout + co0 + (wn * TN + tn) * 32 + 4 * h;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float4 v;
+                        v.x = lrelu_gain_clamp(acc[tm][tn][4 * j + 0] * sback, p.act, p.alpha, p.gain, p.clamp);
+                        v.y = lrelu_gain_clamp(acc[tm][tn][4 * j + 1] * sback, p.act, p.alpha, p.gain, p.clamp);
+                        v.z = lrelu_gain_clamp(acc[tm][tn][4 * j + 2] * sback, p.act, p.alpha, p.gain, p.clamp);
+                        v.w = lrelu_gain_clamp(acc[tm][tn][4 * j + 3] * sback, p.act, p.alpha, p.gain, p.clamp);
+                        *reinterpret_cast<float4*>(dst + 8 * j) = v;
+                    }
+                }
+            }
+        return;
+    }
+#endif
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
         const int co = co0 + (wn * TN + tn) * 32 + l31;
@@ -661,6 +685,24 @@ __global__ void __launch_bounds__(NW * 64, 1) upconv_bf16_kernel(const ConvParam
     // ---- raw stores of the four phases: y_t[2m + (f>>1)][2n + (f&1)], extents (H+1-(f>>1)) x (W+1-(f&1));
     // one 64-bit row pointer per (phase, tile, patch row), 32-bit column offsets
     float* out = p.out + (size_t)ks * p.slab;
+#ifdef HFAGP_ABL_STORE4     // (developer ablation, TIMING ONLY: see modconv_bf16_kernel)
+    if constexpr (!YH) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const int m = m0 + 2 * (wm * TM + tm) + (l31 >> 4), n = n0 + (l31 & 15);
+                if (m < p.H + 1 - (f >> 1) && n < p.W + 1 - (f & 1)) {
+                    float* dst = out + (((size_t)b * p.Ho + 2 * m + (f >> 1)) * p.Wo + 2 * n + (f & 1)) * p.Cout + co0 + wn * 32 + 4 * h;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        *reinterpret_cast<float4*>(dst + 8 * j) = make_float4(acc[f][tm][0][4 * j], acc[f][tm][0][4 * j + 1],
+                                                                              acc[f][tm][0][4 * j + 2], acc[f][tm][0][4 * j + 3]);
+                }
+            }
+        return;
+    }
+#endif
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
         const int mh = p.H + 1 - (f >> 1), mw = p.W + 1 - (f & 1);
