@@ -1,8 +1,8 @@
 """Developer check: hipGraph capture of the whole synthesis (GPU box)."""
 import os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tests.util import make_inputs
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from hfa_gp_amd.synthetic import make_inputs
 from hfa_gp_amd.config import ffhq512_128
 from hfa_gp_amd.generator import TriPlaneGenerator
 

@@ -4,8 +4,8 @@ import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tests.util import make_inputs  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from hfa_gp_amd.synthetic import make_inputs  # noqa: E402
 from hfa_gp_amd.config import ffhq512_128  # noqa: E402
 from hfa_gp_amd.generator import TriPlaneGenerator  # noqa: E402
 

@@ -1,10 +1,10 @@
 """Developer timing of one fitting step (BASELINE config 3 mechanics) on the GPU box."""
 import os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from hfa_gp_amd import headnerf
 from hfa_gp_amd.trainer import Trainer
-from tests.util import look_at_label
+from hfa_gp_amd.synthetic import look_at_label
 
 
 class Args:

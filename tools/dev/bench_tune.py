@@ -1,10 +1,11 @@
 """Developer timing of one fitting step with the generator being tuned (GPU box)."""
 import os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tests.bench_train import Args
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from bench_train import Args
 from hfa_gp_amd.trainer import Trainer
-from tests.util import look_at_label
+from hfa_gp_amd.synthetic import look_at_label
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 4

@@ -1,7 +1,7 @@
 """Developer micro-benchmark of the weight-gradient GEMM (GPU box). usage: B H Cin Cout [up|bf16x3]"""
 import os, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from hfa_gp_amd import ops
 B, H, cin, cout = [int(v) for v in sys.argv[1:5]]
 up = len(sys.argv) > 5 and sys.argv[5] == "up"

@@ -27,10 +27,10 @@ else
         name="${v%%:*}"
         lib="$here/hfa-gp_amd/libhfagp_abl_$name.so"; [[ "$name" == base ]] && lib="$here/hfa-gp_amd/libhfagp_hip.so"
         for prec in f16x3 f16; do
-            echo -n "$name: "; HFAGP_LIB_PATH="$lib" python "$here/tests/bench_conv.py" 8 256 256 256 1 0 300 $prec 2>&1 | tail -1
+            echo -n "$name: "; HFAGP_LIB_PATH="$lib" python "$here/tools/dev/bench_conv.py" 8 256 256 256 1 0 300 $prec 2>&1 | tail -1
         done
-        echo -n "$name: "; HFAGP_LIB_PATH="$lib" python "$here/tests/bench_conv.py" 8 512 128 128 1 0 100 f16x3 2>&1 | tail -1
-        echo -n "$name: "; HFAGP_LIB_PATH="$lib" python "$here/tests/bench_conv.py" 8 64 512 512 1 0 300 f16x3 2>&1 | tail -1
-        echo -n "$name: "; HFAGP_LIB_PATH="$lib" python "$here/tests/bench_conv.py" 8 256 256 128 2 0 100 f16x3 2>&1 | tail -1
+        echo -n "$name: "; HFAGP_LIB_PATH="$lib" python "$here/tools/dev/bench_conv.py" 8 512 128 128 1 0 100 f16x3 2>&1 | tail -1
+        echo -n "$name: "; HFAGP_LIB_PATH="$lib" python "$here/tools/dev/bench_conv.py" 8 64 512 512 1 0 300 f16x3 2>&1 | tail -1
+        echo -n "$name: "; HFAGP_LIB_PATH="$lib" python "$here/tools/dev/bench_conv.py" 8 256 256 128 2 0 100 f16x3 2>&1 | tail -1
     done
 fi

@@ -1,11 +1,11 @@
 #!/usr/bin/env bash
-# Developer (GPU box): per-kernel ms per STEADY-STATE fitting step (the last 5 steps of tests/bench_train.py; MIOpen's
+# Developer (GPU box): per-kernel ms per STEADY-STATE fitting step (the last 5 steps of tools/dev/bench_train.py; MIOpen's
 # find-mode launches of the first steps are left out).  usage: fit_steady_trace.sh B mode(3dmm|rgb)
 R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}"
 B="${1:-2}"; mode="${2:-rgb}"
 out=/tmp/prof_fit_steady; rm -rf "$out"; mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d "$out" -o t -- python "$R/tests/bench_train.py" "$B" 12 "$mode" > "$out/log.txt" 2>&1
+rocprofv3 --kernel-trace --output-format csv -d "$out" -o t -- python "$R/tools/dev/bench_train.py" "$B" 12 "$mode" > "$out/log.txt" 2>&1
 tail -1 "$out/log.txt"
 python - "$out" <<'PY'
 import csv, glob, sys, collections

@@ -3,10 +3,10 @@ intermediate the generator exposes compared with the first run (planes, feature 
 sporadic hardware / code-generation hazard (see csrc/torgb_skip.hip) shows up here as isolated differing elements."""
 import os, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from hfa_gp_amd.config import ffhq512_128
 from hfa_gp_amd.generator import TriPlaneGenerator
-from tests.util import make_inputs, perturb_state
+from hfa_gp_amd.synthetic import make_inputs, perturb_state
 
 
 def main():

@@ -1,7 +1,7 @@
 """Developer timing of the RGB driver (Encoder(256), PyTorch-ROCm / MIOpen) forward + backward at the fitting batch."""
 import os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from hfa_gp_amd.encoder3d import Encoder
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2

@@ -5,11 +5,11 @@ import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from hfa_gp_amd.config import ffhq512_128  # noqa: E402
 from hfa_gp_amd.generator import TriPlaneGenerator  # noqa: E402
 from oracle import eg3d_oracle as O  # noqa: E402
-from tests.util import make_inputs, perturb_state, state_cpu  # noqa: E402
+from hfa_gp_amd.synthetic import make_inputs, perturb_state, state_cpu  # noqa: E402
 
 
 def main():

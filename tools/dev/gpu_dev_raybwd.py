@@ -1,8 +1,8 @@
 """Developer debug: per-sample records of the ray-march backward vs oracle autograd (GPU box)."""
 import dataclasses, os, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tests.util import look_at_label, perturb_state, state_cpu
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from hfa_gp_amd.synthetic import look_at_label, perturb_state, state_cpu
 from hfa_gp_amd import ops
 from hfa_gp_amd.config import tiny64
 from hfa_gp_amd.generator import TriPlaneGenerator

@@ -6,8 +6,8 @@ import time
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tests.util import make_inputs, perturb_state, state_cpu  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from hfa_gp_amd.synthetic import make_inputs, perturb_state, state_cpu  # noqa: E402
 from hfa_gp_amd import ops  # noqa: E402
 from hfa_gp_amd.config import PRESETS  # noqa: E402
 from hfa_gp_amd.generator import TriPlaneGenerator  # noqa: E402

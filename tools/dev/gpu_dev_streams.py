@@ -2,8 +2,8 @@
 FIR kernels of one half under the MFMA-bound convs of the other)."""
 import os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tests.util import make_inputs
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from hfa_gp_amd.synthetic import make_inputs
 from hfa_gp_amd.config import ffhq512_128
 from hfa_gp_amd.generator import TriPlaneGenerator
 

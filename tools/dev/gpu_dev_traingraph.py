@@ -2,10 +2,11 @@
 usage: gpu_dev_traingraph.py [B] [iters]"""
 import os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tests.bench_train import Args
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from bench_train import Args
 from hfa_gp_amd.trainer import Trainer
-from tests.util import look_at_label
+from hfa_gp_amd.synthetic import look_at_label
 
 
 def main():

@@ -6,10 +6,11 @@ import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tests.bench_train import Args  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from bench_train import Args  # noqa: E402
 from hfa_gp_amd.trainer import Trainer  # noqa: E402
-from tests.util import look_at_label  # noqa: E402
+from hfa_gp_amd.synthetic import look_at_label  # noqa: E402
 
 
 def main():

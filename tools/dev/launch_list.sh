@@ -4,7 +4,7 @@ R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}"
 B="${1:-1}"
 out=/tmp/prof_launches; rm -rf "$out"; mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d "$out" -o t -- python "$R/tests/gpu_dev_streams.py" "$B" 1 > "$out/log.txt" 2>&1
+rocprofv3 --kernel-trace --output-format csv -d "$out" -o t -- python "$R/tools/dev/gpu_dev_streams.py" "$B" 1 > "$out/log.txt" 2>&1
 python - "$out" <<'PY'
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]

@@ -16,7 +16,7 @@ else
     for v in base store4 nostore; do
         lib="$here/hfa-gp_amd/libhfagp_abl_$v.so"; [[ "$v" == base ]] && lib="$here/hfa-gp_amd/libhfagp_hip.so"
         for cfg in "32 256 256 256 1" "32 256 128 128 1" "32 512 128 128 1" "32 128 256 256 1" "32 256 256 128 2" "32 128 256 128 2" "32 64 512 256 2"; do
-            echo -n "$v: "; HFAGP_LIB_PATH="$lib" python "$here/tests/bench_conv.py" $cfg 0 20 f16x3 2>&1 | tail -1 | cut -c1-110
+            echo -n "$v: "; HFAGP_LIB_PATH="$lib" python "$here/tools/dev/bench_conv.py" $cfg 0 20 f16x3 2>&1 | tail -1 | cut -c1-110
         done
     done
 fi

@@ -1,10 +1,10 @@
 #!/usr/bin/env bash
-# Run ON THE GPU BOX: kernel trace of the fitting step with the generator being tuned (tests/bench_tune.py).
+# Run ON THE GPU BOX: kernel trace of the fitting step with the generator being tuned (tools/dev/bench_tune.py).
 set -uo pipefail
 R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}"
 out="/tmp/prof_tune"; rm -rf "$out"; mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o bench -- python "$R/tests/bench_tune.py" > "$out/trace.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o bench -- python "$R/tools/dev/bench_tune.py" > "$out/trace.log" 2>&1
 tail -2 "$out/trace.log"
 python - "$out" <<'PY'
 import csv, glob, os, sys
