@@ -237,175 +237,6 @@ __global__ void __launch_bounds__(256, 1) wgrad_bf16_kernel(const Wg16Params p) 
         }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Two wave groups (round 3).  The kernel above keeps ONE wave per SIMD (9 x 16 accumulator registers + staging): a lone wave's
-// staging work — scale, split, transposing LDS writes, forming the shifted windows — sits in series with its own MFMAs (210 -
-// 220 TFLOP/s against 310 with the global loads compiled out).  Here a block is 8 waves = two groups of four that read the
-// SAME staged tile: group 0 owns the first half of the tap slots, group 1 the rest (9 taps: 4 + 5 -> 80 accumulator registers
-// instead of 144), so two waves share a SIMD and one's vector-ALU work runs under the other's MFMAs.  Staging is spread over
-// the 512 threads: one x unit each (480 units), and the 256 g units go to group 0, which has the fewer taps.
-template <int DYM, int DXM, bool SWAP>
-__global__ void __launch_bounds__(512, 1) wgrad_bf16_kernel2(const Wg16Params p) {
-    constexpr int NDX = popc3(DXM), NT = popc3(DYM) * NDX;
-    constexpr int NT0 = NT / 2;                                   // tap slots [0, NT0) -> group 0, [NT0, NT) -> group 1
-    constexpr int NTG = NT - NT0;                                 // accumulators per wave (the larger group)
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
-    const int wi = (wave >> 1) & 1, wj = wave & 1;
-    const int h = lane >> 5, l31 = lane & 31;
-    const int ci0 = blockIdx.x * CT, co0 = blockIdx.y * CT, ks = blockIdx.z;
-
-    f32x16 acc[NTG];
-#pragma unroll
-    for (int t = 0; t < NTG; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-
-    const int units = p.B * p.tiles_h * p.tiles_w;
-    const int u_begin = (int)(((long long)units * ks) / p.ksplit), u_end = (int)(((long long)units * (ks + 1)) / p.ksplit);
-
-    float4 rx[4], rg[4], sx, sg = make_float4(1.f, 1.f, 1.f, 1.f);
-    float mx[4], mg[4];
-    const int xu = min(tid, XR * 5 * 16 - 1);                     // x unit of this thread (threads past 479 repeat the last)
-    const int xq = xu & 15, xcg = (xu >> 4) % 5, xrow = (xu >> 4) / 5;
-    const bool has_g = tid < QH * 4 * 16;                         // g units: the 256 threads of group 0
-    const int gq = tid & 15, gcg = (tid >> 4) & 3, grow = (tid >> 6) & 3;
-    auto fetch = [&](int u) {
-        const int tw = u % p.tiles_w, th = (u / p.tiles_w) % p.tiles_h, b = u / (p.tiles_w * p.tiles_h);
-        const int m0 = th * QH, n0 = tw * QW;
-        const float* xb = p.a + (size_t)b * p.aH * p.aW * p.aC + ci0;
-        {
-            const int iy = m0 - 1 + xrow;
-            const bool rowok = iy >= 0 && iy < p.aH;
-            sx = (p.styles && !SWAP) ? *reinterpret_cast<const float4*>(p.styles + (size_t)b * p.aC + ci0 + 4 * xq)
-                                     : make_float4(1.f, 1.f, 1.f, 1.f);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int ix = n0 - 1 + 4 * xcg + c;
-                const bool ok = rowok && ix >= 0 && ix < p.aW;
-                mx[c] = ok ? 1.f : 0.f;
-                rx[c] = *reinterpret_cast<const float4*>(xb + (ok ? ((size_t)iy * p.aW + ix) * p.aC : 0) + 4 * xq);
-            }
-        }
-        if (has_g) {
-            const float* gb = p.b + (size_t)b * p.bH * p.bW * p.bC + co0;
-            const int iy = m0 + grow;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int ix = n0 + 4 * gcg + c;
-                const bool ok = iy < p.bH && ix < p.bW;
-                mg[c] = ok ? 1.f : 0.f;
-                rg[c] = *reinterpret_cast<const float4*>(gb + (ok ? ((size_t)iy * p.bW + ix) * p.bC : 0) + 4 * gq);
-            }
-            if constexpr (SWAP) sg = p.styles ? *reinterpret_cast<const float4*>(p.styles + (size_t)b * p.bC + co0 + 4 * gq)
-                                              : make_float4(1.f, 1.f, 1.f, 1.f);
-        }
-    };
-    auto commit = [&](int buf) __attribute__((always_inline)) {
-        char* base = lds + buf * BUF;
-        {
-            const float sv[4] = {sx.x, sx.y, sx.z, sx.w};
-            const float* f0 = &rx[0].x; const float* f1 = &rx[1].x; const float* f2 = &rx[2].x; const float* f3 = &rx[3].x;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {             // channel 4q + e: columns 4cg .. 4cg+3
-                uint2 hi, lo;
-                split_run(f0[e] * (sv[e] * mx[0]), f1[e] * (sv[e] * mx[1]), f2[e] * (sv[e] * mx[2]), f3[e] * (sv[e] * mx[3]), hi, lo);
-                char* dst = base + (16 * e + xq) * XPITCH + (xrow * XC + 4 * xcg) * 2;
-                *reinterpret_cast<uint2*>(dst) = hi;
-                *reinterpret_cast<uint2*>(dst + XPART) = lo;
-            }
-        }
-        if (has_g) {
-            const float* f0 = &rg[0].x; const float* f1 = &rg[1].x; const float* f2 = &rg[2].x; const float* f3 = &rg[3].x;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                uint2 hi, lo;
-                const float se = e == 0 ? sg.x : e == 1 ? sg.y : e == 2 ? sg.z : sg.w;
-                split_run(f0[e] * (se * mg[0]), f1[e] * (se * mg[1]), f2[e] * (se * mg[2]), f3[e] * (se * mg[3]), hi, lo);
-                char* dst = base + 2 * XPART + (16 * e + gq) * GPITCH + (grow * QW + 4 * gcg) * 2;
-                *reinterpret_cast<uint2*>(dst) = hi;
-                *reinterpret_cast<uint2*>(dst + GPART) = lo;
-            }
-        }
-    };
-
-    const int abase = (32 * wi + l31) * XPITCH + 8 * h * 2;
-    const int bbase = 2 * XPART + (32 * wj + l31) * GPITCH + 8 * h * 2;
-
-    // the MFMAs of one staged tile for the tap slots [S0, S1) of a group (compile-time, so every accumulator index is static)
-    auto tile = [&](const char* st, auto s0_tag, auto s1_tag) __attribute__((always_inline)) {
-        constexpr int S0 = decltype(s0_tag)::value, S1 = decltype(s1_tag)::value;
-        if constexpr (S1 > S0) {
-#pragma unroll
-            for (int kr = 0; kr < QH; ++kr) {                 // K step = tile row kr (16 positions)
-                const u32x4 bh = *reinterpret_cast<const u32x4*>(st + bbase + kr * QW * 2);
-                const u32x4 bl = *reinterpret_cast<const u32x4*>(st + bbase + GPART + kr * QW * 2);
-#pragma unroll
-                for (int dy = 0; dy < 3; ++dy) {
-                    if (!((DYM >> dy) & 1)) continue;
-                    const int trow = rank3(DYM, dy) * NDX;    // first tap slot of this patch row
-                    if (trow + NDX <= S0 || trow >= S1) continue;          // no slot of this row belongs to the group
-                    const char* ar = st + abase + (kr + dy) * XC * 2;
-                    const u32x4 h4 = *reinterpret_cast<const u32x4*>(ar);
-                    const unsigned h5 = *reinterpret_cast<const unsigned*>(ar + 16);
-                    const u32x4 l4 = *reinterpret_cast<const u32x4*>(ar + XPART);
-                    const unsigned l5 = *reinterpret_cast<const unsigned*>(ar + XPART + 16);
-                    const unsigned hw[5] = {h4[0], h4[1], h4[2], h4[3], h5};
-                    const unsigned lw[5] = {l4[0], l4[1], l4[2], l4[3], l5};
-                    u32x4 ah[3], al[3];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        ah[0][e] = hw[e]; al[0][e] = lw[e];
-                        ah[1][e] = __builtin_amdgcn_alignbit(hw[e + 1], hw[e], 16);
-                        al[1][e] = __builtin_amdgcn_alignbit(lw[e + 1], lw[e], 16);
-                        ah[2][e] = hw[e + 1]; al[2][e] = lw[e + 1];
-                    }
-#pragma unroll
-                    for (int pr = 0; pr < 3; ++pr)            // product-major: hi.hi, lo.hi, hi.lo
-#pragma unroll
-                        for (int dx = 0; dx < 3; ++dx) {
-                            if (!((DXM >> dx) & 1)) continue;
-                            const int slot = trow + rank3(DXM, dx);
-                            if (slot < S0 || slot >= S1) continue;
-                            const u32x4 av = pr == 1 ? al[dx] : ah[dx];
-                            const u32x4 bv = pr == 2 ? bl : bh;
-                            acc[slot - S0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv),
-                                                                                     acc[slot - S0], 0, 0, 0);
-                        }
-                }
-            }
-        }
-    };
-
-    int cur = 0;
-    if (u_begin < u_end) { fetch(u_begin); commit(0); }
-    __syncthreads();
-    for (int u = u_begin; u < u_end; ++u) {
-        const bool more = u + 1 < u_end;
-        if (more) fetch(u + 1);
-        const char* st = lds + cur * BUF;
-        if (grp == 0) tile(st, std::integral_constant<int, 0>{}, std::integral_constant<int, NT0>{});
-        else tile(st, std::integral_constant<int, NT0>{}, std::integral_constant<int, NT>{});
-        if (more) commit(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
-    }
-    float* slab = p.slabs + (size_t)ks * NT * p.Cin * p.Cout;
-    const int s0 = grp == 0 ? 0 : NT0, ns = grp == 0 ? NT0 : NT - NT0;
-#pragma unroll
-    for (int t = 0; t < NTG; ++t) {
-        if (t >= ns) continue;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
-            const int ca = ci0 + 4 * (rr & 15) + 2 * wi + (rr >> 4), cb = co0 + 4 * (l31 & 15) + 2 * wj + (l31 >> 4);
-            const int ci = SWAP ? cb : ca, co = SWAP ? ca : cb;
-            slab[((size_t)(s0 + t) * p.Cin + ci) * p.Cout + co] = acc[t][r];
-        }
-    }
-}
-
 template <int DYM, int DXM, bool SWAP>
 static int launch_wg16(const Wg16Params& p, dim3 grid, hipStream_t s) {
     const size_t lds = 2 * BUF;
@@ -415,19 +246,7 @@ static int launch_wg16(const Wg16Params& p, dim3 grid, hipStream_t s) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    // (HFAGP_DEV_WGRAD_V1=1, developer: the one-wave-per-SIMD kernel, for A/B timing)
-    static const bool v1 = getenv("HFAGP_DEV_WGRAD_V1") != nullptr;
-    if (v1) {
-        wgrad_bf16_kernel<DYM, DXM, SWAP><<<grid, 256, lds, s>>>(p);
-    } else {
-        static bool attr2_set = false;
-        if (!attr2_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_kernel2<DYM, DXM, SWAP>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr2_set = true;
-        }
-        wgrad_bf16_kernel2<DYM, DXM, SWAP><<<grid, 512, lds, s>>>(p);
-    }
+    wgrad_bf16_kernel<DYM, DXM, SWAP><<<grid, 256, lds, s>>>(p);
     return check_launch("conv_wgrad (split bf16)");
 }
 
