@@ -176,6 +176,7 @@ SYMBOLS = {
                                      C.c_float, C.c_void_p]),
     "hfagp_bias_act_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64,
                                      C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "hfagp_allreduce_f32": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int32, C.c_void_p]),
     "hfagp_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p]),
     "hfagp_nhwc_to_nchw": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p]),
 }

@@ -10,7 +10,7 @@ FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function)
 common_hash="$(cat "${here}"/*.h "${here}/../../include/hfagp.h" "${here}/build.sh" | sha256sum | cut -d' ' -f1)"
 objs=()
 built=0
-for src in elementwise modconv modconv_bf16 upconv_fir torgb_skip raymarch backward raymarch_bwd wgrad wgrad_bf16 qr loss; do
+for src in elementwise modconv modconv_bf16 upconv_fir torgb_skip raymarch backward raymarch_bwd wgrad wgrad_bf16 qr loss collective; do
     obj="${here}/${src}.o"
     extra=()
     # torgb_skip.hip: no SLP vectoriser (see the build note at the top of that file)

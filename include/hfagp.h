@@ -499,6 +499,15 @@ int hfagp_blur_down_bwd(const float* gy, float* gx, int32_t B, int32_t H, int32_
 int hfagp_nchw_to_nhwc(const float* x, float* y, int32_t B, int32_t C, int32_t H, int32_t W, void* stream);
 int hfagp_nhwc_to_nchw(const float* x, float* y, int32_t B, int32_t C, int32_t H, int32_t W, void* stream);
 
+/* ------------------------------------------------------------------ the path's one exchange step, for non-PyTorch hosts
+ * In-place all-reduce (sum, or mean when average != 0) of n floats at `buf` over the ranks of `comm`, an RCCL communicator
+ * (ncclComm_t) the HOST created, enqueued on `stream`: the per-step reduction of the shared gradient buffer
+ * [bases | delta | driver net | generator when tuned] that HFA-GP gets from DistributedDataParallel
+ * (/root/reference/code/train_rgb.py:53-57,196-202; trainer_3dmm.py:29).  PyTorch hosts use torch.distributed instead
+ * (hfa_gp_amd.trainer.FlatGrads / BucketedAllReduce).  The library does not link RCCL: ncclAllReduce is resolved from the
+ * running process (or librccl.so on the loader path) at the first call; HFAGP_EUNSUPPORTED when it cannot be found.     */
+int hfagp_allreduce_f32(void* buf, size_t n, void* comm, int32_t average, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -511,3 +511,38 @@ def test_forward_and_backward_repeat_bit_for_bit(dev):
     finally:
         ops.raymarch_bwd = real_bwd
         gen.requires_grad_(False)
+
+
+# ----------------------------------------------------------------------------- hfagp_allreduce_f32 (non-PyTorch hosts)
+def test_abi_allreduce_on_a_host_created_rccl_communicator(dev):
+    """The C ABI's collective: a communicator created through RCCL's OWN C API (ncclGetUniqueId / ncclCommInitRank, as a
+    non-PyTorch host would — here one rank, the GPU box has one device) and `hfagp_allreduce_f32` on it: sum and mean of a
+    device buffer in place on the caller's stream; a null communicator is an argument error, not a crash."""
+    import ctypes as C
+    import os
+    from hfa_gp_amd import _lib
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    rccl = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), mode=C.RTLD_GLOBAL)
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        x = torch.randn(1 << 20, device=dev)
+        want = x.clone()
+        stream = torch.cuda.current_stream().cuda_stream
+        lib = _lib.lib()
+        for avg in (0, 1):
+            _lib.check(lib.hfagp_allreduce_f32(x.data_ptr(), x.numel(), comm, avg, stream), "allreduce_f32")
+            torch.cuda.synchronize()
+            assert torch.equal(x, want)                           # one rank: sum == mean == the buffer itself
+        assert lib.hfagp_allreduce_f32(x.data_ptr(), 0, comm, 0, stream) == 0
+        assert lib.hfagp_allreduce_f32(x.data_ptr(), 16, None, 0, stream) != 0
+        assert b"null communicator" in lib.hfagp_last_error()
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)
