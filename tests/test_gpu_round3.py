@@ -427,25 +427,38 @@ def test_trained_weight_statistics_stress(dev, preset):
             elif name.endswith(".bias"):
                 p.copy_(torch.randn(p.shape, generator=g) * 0.5)
     P = state_cpu(gen)
-    gen = gen.to(dev)
+    exact = TriPlaneGenerator(dataclasses.replace(cfg, conv_precision="fp32", decoder_precision="fp32"), seed=5)
+    exact.load_state_dict(gen.state_dict())
+    gen, exact = gen.to(dev), exact.to(dev)
     ws, c, us, ui = make_inputs(cfg, 1, seed=21)
     t = torch.distributions.StudentT(3.0)
     torch.manual_seed(13)
     ws = t.sample(ws.shape)
     ref = O.synthesis(P, cfg, ws, c, us, ui, return_planes=True)
-    out = gen.synthesis(ws.to(dev), c.to(dev), noise_mode="const", u_strat=us.to(dev), u_imp=ui.to(dev), return_planes=True)
     pr = cfg.plane_resolution
-    planes = out["planes"].permute(0, 1, 4, 2, 3).reshape(1, 96, pr, pr).cpu()
-    pmax = float(ref["planes"].abs().max())
-    perr = float((planes - ref["planes"]).abs().max())
-    ierr = float((out["image"].cpu() - ref["image"]).abs().max())
-    imax = float(ref["image"].abs().max())
-    print(f"{preset} trained-like statistics: |ws| max {float(ws.abs().max()):.1f}, |planes| max {pmax:.3g} (err {perr:.2e}), "
-          f"|image| max {imax:.3g} (err {ierr:.2e}), f16 range report {gen.f16_range_report() if hasattr(gen, 'f16_range_report') else None}")
-    assert torch.isfinite(out["image"]).all()
-    assert perr <= 5e-5 * max(1.0, pmax), (perr, pmax)
-    close(out["image_raw"], ref["image_raw"], atol=1e-4)
-    assert ierr <= 1e-4 * max(1.0, imax), (ierr, imax)
+    pmax, imax = float(ref["planes"].abs().max()), float(ref["image"].abs().max())
+    err = {}
+    for tag, g_ in (("f16x3", gen), ("exact_fp32", exact)):
+        out = g_.synthesis(ws.to(dev), c.to(dev), noise_mode="const", u_strat=us.to(dev), u_imp=ui.to(dev), return_planes=True)
+        assert torch.isfinite(out["image"]).all()
+        planes = out["planes"].permute(0, 1, 4, 2, 3).reshape(1, 96, pr, pr).cpu()
+        err[tag] = {"planes": float((planes - ref["planes"]).abs().max()),
+                    "image_raw": float((out["image_raw"].cpu() - ref["image_raw"]).abs().max()),
+                    "image": float((out["image"].cpu() - ref["image"]).abs().max())}
+    print(f"{preset} trained-like statistics: |ws| max {float(ws.abs().max()):.1f}, |planes| max {pmax:.3g}, |image| max {imax:.3g}; "
+          f"max abs error vs the oracle {err}")
+    # the backbone: fp32-class relative to the magnitudes that result (planes reach the hundreds here)
+    assert err["f16x3"]["planes"] <= 5e-5 * max(1.0, pmax), (err, pmax)
+    # behind the renderer the bar is the EXACT-fp32 kernels' own distance from the oracle: with planes of this size the
+    # decoder saturates and the importance pdf is sharply peaked, so fp32 summation-order differences are amplified on both
+    # paths alike (measured at full size: 3.6e-4 on image_raw, 2.3e-3 on an image of magnitude 13) — the split-operand path
+    # must not be worse than twice that, and stays inside north_star's 1e-3 MSE by orders of magnitude
+    for k in ("image_raw", "image"):
+        floor = 1e-4 * max(1.0, imax if k == "image" else 1.0)
+        assert err["f16x3"][k] <= max(2.0 * err["exact_fp32"][k], floor), (k, err)
+    mse = float((gen.synthesis(ws.to(dev), c.to(dev), noise_mode="const", u_strat=us.to(dev), u_imp=ui.to(dev))["image"].cpu()
+                 - ref["image"]).pow(2).mean())
+    assert mse <= 1e-6 * max(1.0, imax) ** 2, mse
 
 
 # ----------------------------------------------------------------------------- run-to-run bit repeatability (the v_pk_fma_f32 hazard)
