@@ -718,6 +718,14 @@ def main():
                                              "at INPUT resolution)", "achieved": tf_up, "frac": tf_up / peak,
                                    "avg_launch_ms": ms_up / n_up, "launches": n_up}
                 roof["all_conv_gemms"] = {"achieved": tf_all, "frac": tf_all / peak}
+            # the up-sampling LAYER fused with its FIR + epilogue (csrc/upconv_fir.hip; taken for short-K layers: the first
+            # super-resolution layer): the whole layer is one launch (+ two strip fix-ups), so this is the layer's rate
+            ms_uf, flops_uf, n_uf = agg("modconv_split_upfir")
+            if n_uf:
+                roof["up_layer_fused"] = {"kernel": f"upconv_fir_kernel<{kd}> + upfir_strip_kernel (transposed conv + FIR + demod / "
+                                                    "noise / bias / act in one pass)", "achieved": flops_uf / (ms_uf * 1e-3) / 1e12,
+                                          "frac": flops_uf / (ms_uf * 1e-3) / 1e12 / peak, "avg_launch_ms": ms_uf / n_uf,
+                                          "launches": n_uf}
         # ray march: the planes of a frame (25 MB) are cache resident, so the SURVEY 8d "algorithmic bytes" are a GATHER
         # rate served by L2 / Infinity Cache, not HBM traffic.  The kernel's physical floor is the L2 gather
         # (gather bytes / 34.5 TB/s) plus the decoder MLP on the fp32 matrix pipe (13.1 GF per frame / 157.3 TF); `frac`

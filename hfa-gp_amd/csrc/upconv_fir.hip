@@ -31,6 +31,7 @@ struct FirFuse {
     float* colstrip;     // [B][tiles_w - 1][Hp][6][Cout]: y_t columns 32 j - 3 .. 32 j + 2 around strip boundary j
     float* rowstrip;     // [B][nseg - 1][6][Wp][Cout]:    y_t rows R - 3 .. R + 2 around segment boundary R = 16 * first tile
     int nseg, Hp, Wp;    // Hp = 16 tiles_h, Wp = 32 tiles_w
+    unsigned long long* dbg;   // developer (HFAGP_DEV_FIR_DBG): per-phase clock sums of block 0
 };
 
 // strip layouts (element offsets): a tile's export for one channel group is one contiguous run
@@ -121,6 +122,11 @@ __global__ void __launch_bounds__(512, 1) upconv_fir_kernel(const ConvParams p, 
     const int C0 = 32 * tw;
     float vmax = 0.f;
 
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;   // K loop | tile write + barrier | FIR | barrier 2 | tile prologue
+    auto tick = [&](int slot) __attribute__((always_inline)) {
+        if (ff.dbg) { const unsigned long long now = __builtin_readcyclecounter(); tacc[slot] += now - tprev; tprev = now; }
+    };
+    if (ff.dbg) tprev = __builtin_readcyclecounter();
 #pragma unroll 1
     for (int th = t_begin; th < t_end; ++th) {
         const int m0 = th * PH;
@@ -233,6 +239,7 @@ __global__ void __launch_bounds__(512, 1) upconv_fir_kernel(const ConvParams p, 
         };
         static_assert((2 * NITEM) % RB == 0 && RB <= NITEM, "ring slots must repeat every chunk pair");
         {
+            tick(4);
             __syncthreads();                                    // styles / zeroed windows in LDS; the FIR tile of the tile above is consumed
             load_a(c_begin);
             issue_b(c_begin, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
@@ -271,6 +278,7 @@ __global__ void __launch_bounds__(512, 1) upconv_fir_kernel(const ConvParams p, 
             NZ[tid] = nz;                   // (NZ is outside the staging buffers; read after the barriers below)
         }
         __syncthreads();                    // the K loop is done with the staging buffers: they become the FIR tile
+        tick(0);
 #pragma unroll 1
         for (int g = 0; g < ((HFAGP_FIR_ABL & 16) ? 0 : 4); ++g) {
             if (wn == g && !(HFAGP_FIR_ABL & 8)) {
@@ -288,44 +296,67 @@ __global__ void __launch_bounds__(512, 1) upconv_fir_kernel(const ConvParams p, 
             }
             const int co4 = co0 + g * 32 + 4 * q4;
             __syncthreads();
+            tick(1);
             const float4 d = *reinterpret_cast<const float4*>(DB + g * 32 + 4 * q4);
             const float4 bs = *reinterpret_cast<const float4*>(DB + 128 + g * 32 + 4 * q4);
             if (!(HFAGP_FIR_ABL & 4)) {
                 // source rows u = -3 .. 15 of this round: u < 0 -> window row u + 3 (the tile above), u >= 0 -> tile row u;
                 // y_t columns fcol - 1 .. fcol + 2 of the strip (strip 0: column -1 IS the zero padding; columns >= 32
-                // only feed outputs that belong to upfir_strip_kernel)
+                // only feed outputs that belong to upfir_strip_kernel).
+                // Arithmetic: the FIR taps [1 3 3 1] / 4 per axis are applied as (a + d) + 3 (b + c) with the 1 / 16 folded into
+                // the demodulation coefficient, and gain * lrelu(z) as max(g z, g alpha z) with the gain folded into the
+                // coefficient and the bias (g > 0, 0 <= alpha <= 1; linear: alpha = 1): 3 + 3 + 6 instructions per value instead
+                // of 4 + 4 + 10 — the epilogue runs in the same waves as the GEMM, every instruction of it is exposed.
                 const float* Wg = Wn + g * 3 * FT_PLANE;
-                const float f0 = 0.25f, f1 = 0.75f;
-                const float m0 = fcol >= 1 ? f0 : 0.f;
+                const float m0 = fcol >= 1 ? 1.f : 0.f;
                 const int c0 = max(fcol - 1, 0) * 32 + 4 * q4, c1 = fcol * 32 + 4 * q4, c2 = min(fcol + 1, 31) * 32 + 4 * q4,
                           c3 = min(fcol + 2, 31) * 32 + 4 * q4;
+                float4 raw;                                            // y_t[u][fcol] of the row hrow() read last
                 auto hrow = [&](int u) __attribute__((always_inline)) -> float4 {
                     const float* rowp = u < 0 ? Wg + (u + 3) * FT_PLANE : T + u * FT_PLANE;
                     const float4 v0 = *reinterpret_cast<const float4*>(rowp + c0), v1 = *reinterpret_cast<const float4*>(rowp + c1);
                     const float4 v2 = *reinterpret_cast<const float4*>(rowp + c2), v3 = *reinterpret_cast<const float4*>(rowp + c3);
+                    raw = v1;
                     float4 r;
-                    r.x = m0 * v0.x + f1 * v1.x + f1 * v2.x + f0 * v3.x;
-                    r.y = m0 * v0.y + f1 * v1.y + f1 * v2.y + f0 * v3.y;
-                    r.z = m0 * v0.z + f1 * v1.z + f1 * v2.z + f0 * v3.z;
-                    r.w = m0 * v0.w + f1 * v1.w + f1 * v2.w + f0 * v3.w;
+                    r.x = fmaf(3.f, v1.x + v2.x, fmaf(v0.x, m0, v3.x));
+                    r.y = fmaf(3.f, v1.y + v2.y, fmaf(v0.y, m0, v3.y));
+                    r.z = fmaf(3.f, v1.z + v2.z, fmaf(v0.z, m0, v3.z));
+                    r.w = fmaf(3.f, v1.w + v2.w, fmaf(v0.w, m0, v3.w));
                     return r;
+                };
+                const float gain = p.gain, alpha = p.act == HFAGP_ACT_LRELU ? p.alpha : 1.f;
+                const float cl = p.clamp >= 0.f ? p.clamp : 3.0e38f;
+                const float s16 = gain * 0.0625f;
+                const float4 dg = make_float4(d.x * s16, d.y * s16, d.z * s16, d.w * s16);
+                const float4 bg = make_float4(bs.x * gain, bs.y * gain, bs.z * gain, bs.w * gain);
+                auto fin = [&](float vsum, float dgc, float nb) __attribute__((always_inline)) -> float {
+                    const float z = fmaf(vsum, dgc, nb);
+                    const float o = fmaxf(z, z * alpha);
+                    return __builtin_amdgcn_fmed3f(o, -cl, cl);
                 };
                 const int ox = C0 + fcol;
                 const bool col_ok = (fcol >= 1 || tw == 0) && fcol <= 29 && ox < Wo2;
                 const int k0 = 8 * rh;                                 // this thread's output rows: k0 .. k0 + 7
+                // raw strips for upfir_strip_kernel: the three columns on either side of a strip boundary leave from the
+                // threads that have them in registers anyway (tile rows k0 .. k0 + 7 of column fcol)
+                const int ebnd = fcol < 3 ? tw : tw + 1;               // boundary j sits between strips j - 1 and j
+                const bool exp_col = (fcol < 3 || fcol >= 29) && ebnd >= 1 && ebnd <= p.tiles_w - 1 && !(HFAGP_FIR_ABL & 2);
+                float* ecol = exp_col ? ff.colstrip + colstrip_at(b, p.tiles_w - 1, ebnd, p.Cout, ff.Hp, R0 + k0,
+                                                                  fcol < 3 ? 3 + fcol : fcol - 29, co4) : nullptr;
                 float4 h0 = hrow(k0 - 3), h1 = hrow(k0 - 2), h2 = hrow(k0 - 1);
 #pragma unroll HFAGP_FIR_UNROLL
                 for (int kk = 0; kk < 8; ++kk) {
                     const int k = k0 + kk;
                     const float4 h3 = hrow(k);
+                    if (exp_col) *reinterpret_cast<float4*>(ecol + (size_t)kk * 3 * 32) = raw;
                     const int oy = R0 + k - 2;
                     if (col_ok && oy >= oy_min && oy < Ho2) {
-                        const float nz = NZ[k * 32 + fcol];
+                        const float nzg = NZ[k * 32 + fcol] * gain;
                         float4 o;
-                        o.x = lrelu_gain_clamp((f0 * h0.x + f1 * h1.x + f1 * h2.x + f0 * h3.x) * d.x + nz + bs.x, p.act, p.alpha, p.gain, p.clamp);
-                        o.y = lrelu_gain_clamp((f0 * h0.y + f1 * h1.y + f1 * h2.y + f0 * h3.y) * d.y + nz + bs.y, p.act, p.alpha, p.gain, p.clamp);
-                        o.z = lrelu_gain_clamp((f0 * h0.z + f1 * h1.z + f1 * h2.z + f0 * h3.z) * d.z + nz + bs.z, p.act, p.alpha, p.gain, p.clamp);
-                        o.w = lrelu_gain_clamp((f0 * h0.w + f1 * h1.w + f1 * h2.w + f0 * h3.w) * d.w + nz + bs.w, p.act, p.alpha, p.gain, p.clamp);
+                        o.x = fin(fmaf(3.f, h1.x + h2.x, h0.x + h3.x), dg.x, nzg + bg.x);
+                        o.y = fin(fmaf(3.f, h1.y + h2.y, h0.y + h3.y), dg.y, nzg + bg.y);
+                        o.z = fin(fmaf(3.f, h1.z + h2.z, h0.z + h3.z), dg.z, nzg + bg.z);
+                        o.w = fin(fmaf(3.f, h1.w + h2.w, h0.w + h3.w), dg.w, nzg + bg.w);
                         vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
                         const size_t e = (((size_t)b * Ho2 + oy) * Wo2 + ox) * p.Cout + co4;
                         if ((HFAGP_FIR_ABL & 1) && o.x != 12345.f) {
@@ -341,23 +372,7 @@ __global__ void __launch_bounds__(512, 1) upconv_fir_kernel(const ConvParams p, 
                 }
             }
             if (!(HFAGP_FIR_ABL & 2)) {
-                // ---- raw strips for upfir_strip_kernel: the three columns on either side of a strip boundary ...
-#pragma unroll
-                for (int it = 0; it < 2; ++it) {
-                    const int idx = tid + it * NTH;                    // [16 rows][6][8 quads]
-                    if (idx < 16 * 6 * 8) {
-                        const int q = idx & 7, k6 = (idx >> 3) % 6, row = idx / 48;
-                        const int col = k6 < 3 ? k6 : 26 + k6;
-                        const int bnd = k6 < 3 ? tw : tw + 1;          // boundary j sits between strips j-1 and j
-                        if (bnd >= 1 && bnd <= p.tiles_w - 1) {
-                            const int slot = k6 < 3 ? 3 + k6 : k6 - 3;
-                            *reinterpret_cast<float4*>(ff.colstrip + colstrip_at(b, p.tiles_w - 1, bnd, p.Cout, ff.Hp, R0 + row, slot,
-                                                                                 co0 + g * 32 + 4 * q)) =
-                                *reinterpret_cast<const float4*>(T + row * FT_PLANE + col * 32 + 4 * q);
-                        }
-                    }
-                }
-                // ... and the three rows on either side of a segment boundary
+                // ---- raw strips: the three rows on either side of a segment boundary (first / last tile of a segment only)
                 if (exp_top || exp_bot) {
 #pragma unroll
                     for (int it = 0; it < 2; ++it) {
@@ -375,7 +390,9 @@ __global__ void __launch_bounds__(512, 1) upconv_fir_kernel(const ConvParams p, 
                     }
                 }
             }
+            tick(2);
             __syncthreads();                // every thread is done with the tile and the window of group g
+            tick(3);
             if (wn == g && wm == 1 && !(HFAGP_FIR_ABL & 8)) {       // rows 13, 14, 15 of this tile -> window of the tile below
                 float* Wd = Wn + g * 3 * FT_PLANE;
 #pragma unroll
@@ -392,6 +409,10 @@ __global__ void __launch_bounds__(512, 1) upconv_fir_kernel(const ConvParams p, 
         }
     }
     if (p.y_absmax) publish_absmax(p.y_absmax, vmax, blockIdx.x * 8 + wave);
+    if (ff.dbg && blockIdx.x == 0 && lane == 0) {
+        for (int i = 0; i < 6; ++i) ff.dbg[wave * 8 + i] = tacc[i];
+        ff.dbg[wave * 8 + 6] = (unsigned long long)(t_end - t_begin);
+    }
 }
 
 // Finishes what the strip blocks could not: ROWMODE = false — the three output columns 32 j - 2 .. 32 j at every strip
@@ -586,6 +607,14 @@ extern "C" int hfagp_upconv_fir_fwd(const HfagpModconvArgs* a, void* scratch, vo
     p.out = a->y;
     fp.ff.colstrip = reinterpret_cast<float*>(scratch);
     fp.ff.rowstrip = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + ((fp.col_bytes + 255) & ~(size_t)255));
+    fp.ff.dbg = nullptr;
+    static unsigned long long* dbg_buf = nullptr;
+    const bool dbg = getenv("HFAGP_DEV_FIR_DBG") != nullptr;            // developer: per-phase clocks of block 0
+    if (dbg) {
+        if (!dbg_buf) (void)hipMalloc(&dbg_buf, 64 * sizeof(unsigned long long));
+        (void)hipMemsetAsync(dbg_buf, 0, 64 * sizeof(unsigned long long), s);
+        fp.ff.dbg = dbg_buf;
+    }
     const int kd = kind_of(a->precision);
     const int io = (a->x_f16 ? 1 : 0) | (a->y_f16 ? 2 : 0);
     if (kd == 1) {
@@ -601,6 +630,15 @@ extern "C" int hfagp_upconv_fir_fwd(const HfagpModconvArgs* a, void* scratch, vo
         rc = launch_fused<4, 0>(fp, a->Cin, s);
     }
     if (rc != HFAGP_OK) return rc;
+    if (dbg) {
+        unsigned long long h[64];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(h, dbg_buf, sizeof(h), hipMemcpyDeviceToHost);
+        for (int w = 0; w < 8; w += 4)
+            fprintf(stderr, "[upconv_fir dbg] wave %d, %llu tiles: K loop %llu | tile write + barrier %llu | FIR + exports %llu | barrier 2 %llu | "
+                            "tile prologue %llu clocks per tile\n", w, h[w * 8 + 6], h[w * 8 + 0] / h[w * 8 + 6], h[w * 8 + 1] / h[w * 8 + 6],
+                    h[w * 8 + 2] / h[w * 8 + 6], h[w * 8 + 3] / h[w * 8 + 6], h[w * 8 + 4] / h[w * 8 + 6]);
+    }
     StripFix f;
     f.dcoef = a->dcoef; f.noise = a->noise; f.bias = a->bias; f.y = a->y; f.y_absmax = a->y_absmax;
     f.B = a->B; f.H = a->H; f.W = a->W; f.C = a->Cout;

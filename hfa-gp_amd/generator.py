@@ -148,11 +148,13 @@ class TriPlaneGenerator(nn.Module):
         self.conv_precision = cfg.conv_precision
         self.sr_conv_precision = cfg.sr_conv_precision
         self.sr_storage = cfg.sr_storage
-        # up-sampling layers in ONE pass (FIR fused into the transposed conv, csrc/upconv_fir.hip): built, bit-for-bit-class
-        # parity with the two-kernel form (tests/test_gpu_round3.py), but measured SLOWER on the MI355X at every layer of this
-        # preset (profiles/r03_upfir/): the FIR arithmetic and the strip exports serialise with the GEMM inside the block's
-        # waves, whereas the stand-alone FIR kernel is a pure HBM stream.  Off unless asked for.
-        self.fuse_up_fir = os.environ.get("HFAGP_FUSE_UP_FIR", "0") == "1"
+        # up-sampling layers in ONE pass (FIR fused into the transposed conv, csrc/upconv_fir.hip).  Measured on the MI355X
+        # (profiles/r03_upfir/): the FIR arithmetic runs in the same waves as the GEMM, so the fused form only wins where the
+        # GEMM is short and the layer is dominated by the round trip of the raw result through HBM — Cin <= 64, i.e. the first
+        # super-resolution layer (32 -> 256 @128^2: 1.43 ms against 0.60 + 1.00 ms at B = 32); it ties or loses by 2 - 5 % on the
+        # 256- and 512-channel layers.  "auto" (default): fused for Cin <= 64 where the launch fills the chip; "1": wherever the
+        # library supports it; "0": never.
+        self.fuse_up_fir = os.environ.get("HFAGP_FUSE_UP_FIR", "auto")
         self._styles: Dict[int, tuple] = {}      # id(layer) -> (styles, dcoef) of the pass in flight
         self._absmax = None                      # (slot buffers, layer names) of the last pass: f16_range_report()
         self._rgb_part = None                    # partial toRGB sums of the conv just run (fused toRGB, ops.modconv)
@@ -328,7 +330,9 @@ class TriPlaneGenerator(nn.Module):
         # which kernel bench.py times
         key = ("modconv" if wt.dtype == torch.float32 else
                "modconv_f16" if wt.dtype == torch.float16 and wt.shape[0] == 1 else "modconv_split")
-        if layer.up == 2 and self.fuse_up_fir and ops.upconv_fir_supported(x, wt, cout, batch):
+        fuse = self.fuse_up_fir
+        fuse = fuse in (True, "1") or (fuse == "auto" and x.shape[3] <= 64)
+        if layer.up == 2 and fuse and ops.upconv_fir_supported(x, wt, cout, batch):
             # the whole up-sampling layer in one pass: the raw transposed-conv result stays on the chip (csrc/upconv_fir.hip)
             out = self._timed(key + "_upfir", flops, ops.upconv_fir, x, wt, cout, k_styles, k_dcoef, noise, ns, layer.bias,
                               "lrelu", cfg.lrelu_alpha, gain, conv_clamp, batch=batch, x_absmax=x_absmax,
