@@ -331,7 +331,8 @@ class TriPlaneGenerator(nn.Module):
         key = ("modconv" if wt.dtype == torch.float32 else
                "modconv_f16" if wt.dtype == torch.float16 and wt.shape[0] == 1 else "modconv_split")
         fuse = self.fuse_up_fir
-        fuse = fuse in (True, "1") or (fuse == "auto" and x.shape[3] <= 64)
+        # (fp16 STORAGE halves the stand-alone FIR kernel's traffic: there the two-kernel form measured 0.6 % ahead)
+        fuse = fuse in (True, "1") or (fuse == "auto" and x.shape[3] <= 64 and not half)
         if layer.up == 2 and fuse and ops.upconv_fir_supported(x, wt, cout, batch):
             # the whole up-sampling layer in one pass: the raw transposed-conv result stays on the chip (csrc/upconv_fir.hip)
             out = self._timed(key + "_upfir", flops, ops.upconv_fir, x, wt, cout, k_styles, k_dcoef, noise, ns, layer.bias,

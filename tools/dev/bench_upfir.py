@@ -75,7 +75,10 @@ if os.environ.get("UPFIR_NOSYN"):
 cfg = ffhq512_128()
 gen = TriPlaneGenerator(cfg, seed=0).requires_grad_(False).to(dev)
 ws, c, us, ui = [t.to(dev) for t in make_inputs(cfg, B)]
-for fuse in ("0", "auto", "1"):
-    gen.fuse_up_fir = fuse
-    t = timeit(lambda: gen.synthesis(ws, c, u_strat=us, u_imp=ui)["image"], n=8)
-    print(f"synthesis B={B} fuse_up_fir={fuse}: {t:.2f} ms/step = {B / t * 1e3:.0f} frames/s", flush=True)
+for sr, store in ((None, "f32"), ("f16", "f32"), ("f16", "f16")):
+    gen.sr_conv_precision, gen.sr_storage = sr, store
+    for fuse in ("0", "auto", "1"):
+        gen.fuse_up_fir = fuse
+        t = timeit(lambda: gen.synthesis(ws, c, u_strat=us, u_imp=ui)["image"], n=8)
+        print(f"synthesis B={B} sr_conv_precision={sr} sr_storage={store} fuse_up_fir={fuse}: {t:.2f} ms/step = {B / t * 1e3:.0f} frames/s",
+              flush=True)
