@@ -1,6 +1,6 @@
 // toRGB + skip connection of a backbone block as one streaming kernel (hfagp_torgb_skip_fwd, include/hfagp.h).
 //
-// BUILD NOTE: this translation unit is compiled with -fno-slp-vectorize (build.sh).  With the SLP vectoriser on, hipcc
+// BUILD NOTE: this translation unit — since round 3 EVERY unit — is compiled with -fno-slp-vectorize (build.sh).  With the SLP vectoriser on, hipcc
 // (ROCm 7.2) packs the epilogue's tap arithmetic into v_pk_fma_f32 with swapped op_sel halves next to v_mov writes of
 // the swapped source register, and on the MI355X the low-half result of such an instruction is sporadically not written
 // for lanes 48-63 (one upsample tap of ~1e-5 of the outputs missing, different positions every run; found by running the

@@ -21,7 +21,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     ("wgrad.hip", [r"wgrad_kernelI"]),
 ])
 def test_conv_kernels_do_not_spill(tmp_path, src, patterns):
-    out = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c",
+    out = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-c",     # (build.sh's flags)
                           os.path.join(ROOT, "hfa-gp_amd", "csrc", src), "-o", str(tmp_path / "x.o"),
                           "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -44,7 +44,7 @@ def test_torgb_skip_is_built_without_packed_fp32_fma(tmp_path):
     top of that file; tests/test_gpu_round2.py repeats the kernel 20 times bit for bit).  Guard both the build script and
     the instruction stream it produces; and no spills / at least 3 waves per SIMD (the kernel hides HBM latency with waves)."""
     build = open(os.path.join(ROOT, "hfa-gp_amd", "csrc", "build.sh")).read()
-    assert re.search(r"torgb_skip \]\] && extra=\(-fno-slp-vectorize\)", build), "build.sh lost the torgb_skip flag"
+    assert re.search(r"^FLAGS=\(.*-fno-slp-vectorize.*\)", build, re.M), "build.sh lost -fno-slp-vectorize (now applied to every unit)"
     asm = tmp_path / "t.s"
     out = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-S",
                           "--cuda-device-only", os.path.join(ROOT, "hfa-gp_amd", "csrc", "torgb_skip.hip"), "-o", str(asm),
