@@ -257,7 +257,7 @@ def test_full_size_parameter_gradients_three_way(dev):
           f"oracle32-vs-T {worst(orc_t, scalars)}")
     # How well conditioned is this gradient in fp32?  Badly: two runs of this test on two boxes gave, against the fp64 truth,
     #   d ws            HIP 6.5e-4 / 8.4e-4 (the second with the library rebuilt without the SLP vectoriser: another summation
-    #                   order inside the kernels), fp32 ORACLE 6.1e-4 / 4.7e-4 (another thread partitioning of the host's sums);
+    #                   order inside the kernels), fp32 ORACLE 6.1e-4 / 4.7e-4 (its (B) / (T) runs sample at the HIP forward's importance depths, which moved in their last bits);
     #   worst tensor    HIP 1.3e-3 / 1.9e-3, oracle 1.2e-3 / 1.0e-3;      worst scalar   HIP 1.5e-2 / 5.8e-2, oracle 2.2e-2 / 3.2e-2
     # i.e. either implementation moves by its own distance from the truth when the order of its fp32 sums changes: the residual
     # of (A) is the conditioning of the problem on both sides — not resampling (B explains a tenth to a fifth of it), not the
