@@ -553,7 +553,9 @@ static int fuse_plan(const HfagpModconvArgs* a, FusePlan& fp) {
     if (nseg > max_seg) nseg = max_seg;
     if (nseg < 1) nseg = 1;
     { const char* dev = getenv("HFAGP_DEV_FIR_NSEG"); if (dev) nseg = std::max(1, std::min(atoi(dev), p.tiles_h)); }
-    if (base * nseg < min_blocks) return HFAGP_OK;
+    // measured (32 -> 256 @128^2): with fewer than one strip block per CU the segments get too short for the row window to pay
+    // (B = 4: 0.26 ms against 0.22 for the two kernels, B = 8: a tie, B = 16: 0.83 vs 0.86, B = 32: 1.43 vs 1.60)
+    if (base * nseg < min_blocks || (!dev_min && base < kNumCU)) return HFAGP_OK;
     fp.ff.nseg = (int)nseg;
     fp.ff.Hp = 16 * p.tiles_h;
     fp.ff.Wp = 32 * p.tiles_w;

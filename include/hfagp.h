@@ -251,7 +251,7 @@ int hfagp_upfir_epilogue_fwd(const HfagpUpfirEpilogueArgs* a, void* stream);
  * `a` as for hfagp_modconv_fwd with mode = HFAGP_CONVT3X3_UP2, except that y is the FINAL tensor, dcoef / noise / bias / act /
  * alpha / gain / clamp / y_absmax apply (as in HfagpUpfirEpilogueArgs), workspace and ksplit are ignored and there is no
  * fused toRGB.  Precisions BF16X3, F16X3, F16 (x_f16 / y_f16 storage allowed with F16); Cin % 16 == 0, Cin <= 512,
- * Cout % 128 == 0; the launch must fill the chip (B * ceil((W+1)/16) * Cout/128 * segments >= 512 blocks).
+ * Cout % 128 == 0; the launch must fill the chip (B * ceil((W+1)/16) * Cout/128 >= 256 strips).
  * hfagp_upconv_fir_scratch_bytes(): bytes of `scratch` the call needs, or 0 when the shape is not supported — the caller
  * then uses the two-call form.                                                                                      */
 size_t hfagp_upconv_fir_scratch_bytes(const HfagpModconvArgs* a);
