@@ -126,7 +126,10 @@ __global__ void __launch_bounds__(256) weight_prep_kernel(const float* __restric
 // Each thread owns 4 channels of TWO adjacent output columns and walks a vertical strip: 5 input columns per
 // row feed both columns (2.5 loads per output row instead of 4), every input row of the strip is read once, and
 // the image borders are handled by clamped addresses with zeroed tap weights (no branches in the loop).
-constexpr int kStrip = 8;
+#ifndef HFAGP_FIR_STRIP
+#define HFAGP_FIR_STRIP 8
+#endif
+constexpr int kStrip = HFAGP_FIR_STRIP;     // output rows per thread of upfir_epilogue_kernel
 
 typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
 typedef float f2_t __attribute__((ext_vector_type(2)));
