@@ -257,6 +257,25 @@ class HeadNeRF_Audio(_ParamDriven):
     """Audio-feature-driven avatar (headnerf.py:222-279)."""
 
 
+def _conv1d_k3(x: torch.Tensor, conv: nn.Conv1d) -> torch.Tensor:
+    """`conv(x)` for the kernel-3, padding-1 Conv1d layers of AudioNet (stride 2) / AudioAttNet (stride 1) as ONE matmul over
+    the unfolded windows.  On the GPU nn.Conv1d goes through MIOpen, whose first call per shape benchmarks candidate kernels
+    (seconds on a fresh box) and whose pick depends on its find mode; these layers are [N, <= 64, <= 16] tensors — a GEMM of a
+    few kFLOP per window — so the MI355X path keeps them on rocBLAS.  Same parameters, same state_dict, same values up to
+    fp32 summation order (CPU tensors take nn.Conv1d itself: bit-identical to the reference there)."""
+    if not x.is_cuda:
+        return conv(x)
+    win = torch.nn.functional.pad(x, (1, 1)).unfold(2, 3, conv.stride[0])       # [N, C, L_out, 3]
+    y = torch.einsum("nclk,ock->nol", win, conv.weight)
+    return y + conv.bias[None, :, None] if conv.bias is not None else y
+
+
+def _run_conv1d_stack(x: torch.Tensor, seq: nn.Sequential) -> torch.Tensor:
+    for m in seq:
+        x = _conv1d_k3(x, m) if isinstance(m, nn.Conv1d) else m(x)
+    return x
+
+
 class AudioAttNet(nn.Module):
     """Attention over a window of per-frame audio features (:284-314): scores from the first `dim_aud`
     dims, weighted sum over all dims."""
@@ -273,14 +292,14 @@ class AudioAttNet(nn.Module):
 
     def forward(self, x):
         y = x[..., :self.dim_aud].permute(1, 0).unsqueeze(0)
-        y = self.attentionConvNet(y)
+        y = _run_conv1d_stack(y, self.attentionConvNet)
         y = self.attentionNet(y.view(1, self.seq_len)).view(self.seq_len, 1)
         return torch.sum(y * x, dim=0)
 
     def forward_windows(self, x):
         """Batched form for the reenactment harness: x [N, seq_len, D] (one smoothing window per frame) → [N, D];
         row n equals ``forward(x[n])``."""
-        y = self.attentionConvNet(x[..., :self.dim_aud].permute(0, 2, 1))          # [N, 1, seq_len]
+        y = _run_conv1d_stack(x[..., :self.dim_aud].permute(0, 2, 1), self.attentionConvNet)          # [N, 1, seq_len]
         y = self.attentionNet(y.view(-1, self.seq_len))                             # softmax over the window
         return torch.sum(y.unsqueeze(-1) * x, dim=1)
 
@@ -301,5 +320,5 @@ class AudioNet(nn.Module):
     def forward(self, x):
         half = int(self.win_size / 2)
         x = x[:, 8 - half: 8 + half, :].permute(0, 2, 1)
-        x = self.encoder_conv(x).squeeze(-1)
+        x = _run_conv1d_stack(x, self.encoder_conv).squeeze(-1)
         return self.encoder_fc1(x).squeeze()

@@ -563,3 +563,26 @@ def test_abi_allreduce_on_a_host_created_rccl_communicator(dev):
     finally:
         rccl.ncclCommDestroy.argtypes = [C.c_void_p]
         rccl.ncclCommDestroy(comm)
+
+
+def test_audio_nets_on_gpu_match_their_cpu_path(dev):
+    """AudioNet / AudioAttNet (headnerf.py:284-349) run their kernel-3 Conv1d layers as matmuls over unfolded windows on the GPU
+    (no MIOpen in the config-5 path); the CPU path is nn.Conv1d itself, pinned by the reference-generated golden vectors
+    (`audnet_y`, `audatt_y`).  Outputs and parameter gradients of the two paths must agree."""
+    import copy
+    from hfa_gp_amd import headnerf as H
+    torch.manual_seed(3)
+    for make, x in ((lambda: H.AudioNet(64, 16), torch.randn(24, 16, 29)), (lambda: H.AudioAttNet(), torch.randn(8, 64))):
+        cpu = make()
+        gpu = copy.deepcopy(cpu).to(dev)
+        yc, yg = cpu(x), gpu(x.to(dev))
+        close(yg, yc, atol=1e-5)
+        gy = torch.randn(yc.shape, generator=torch.Generator().manual_seed(1))
+        yc.backward(gy)
+        yg.backward(gy.to(dev))
+        for (n, pc), pg in zip(cpu.named_parameters(), gpu.parameters()):
+            close(pg.grad, pc.grad, atol=1e-5 * max(1.0, float(pc.grad.abs().max())))
+    att_c = H.AudioAttNet()
+    att_g = copy.deepcopy(att_c).to(dev)
+    w = torch.randn(5, 8, 64)
+    close(att_g.forward_windows(w.to(dev)), att_c.forward_windows(w), atol=1e-5)
