@@ -128,14 +128,17 @@ def cpu_topology() -> dict:
     return {"sockets": len(phys) or 1, "cores_per_socket": cores_per, "logical_cpus": logical}
 
 
-def cpu_baseline(cfg, state, runs: int, warmup: int, n1: bool):
+def cpu_baseline(cfg, state, runs: int, warmup: int, n1: bool, check=None):
     """Oracle (kind 'port') timed on this box's host cores: B=1 synthesis of the same workload; median of `runs`
-    after `warmup`; stage split backbone / ray-march / super-resolution."""
+    after `warmup`; stage split backbone / ray-march / super-resolution.
+    `check(ws, c, us, ui)` -> the HIP path's image of the same inputs (CPU tensor): the oracle's last image is then also the
+    CHECKER of this very run (`parity_vs_oracle`: max abs / MSE of the 512^2 image) — never the thing measured."""
     import torch
     from oracle import eg3d_oracle as O
     from hfa_gp_amd.synthetic import make_inputs
     ws, c, us, ui = make_inputs(cfg, 1, seed=10)
     res = cfg.neural_rendering_resolution
+    last = {}
 
     def one():
         t = [time.perf_counter()]
@@ -146,7 +149,7 @@ def cpu_baseline(cfg, state, runs: int, warmup: int, n1: bool):
         feat, _, _ = O.importance_renderer(state, cfg, p5, o, d, us, ui)
         t.append(time.perf_counter())
         fi = feat.permute(0, 2, 1).reshape(1, feat.shape[-1], res, res).contiguous()
-        O.superresolution(state, cfg, fi[:, :3], fi, ws)
+        last["image"] = O.superresolution(state, cfg, fi[:, :3], fi, ws)
         t.append(time.perf_counter())
         return [b - a for a, b in zip(t[:-1], t[1:])]
 
@@ -175,6 +178,11 @@ def cpu_baseline(cfg, state, runs: int, warmup: int, n1: bool):
                      f"{topo['sockets']} sockets x {topo['cores_per_socket']} cores, {med:.2f} s/frame",
            "runs_s": [round(t, 3) for t in totals],      # every timed run: the ATen CPU ops of this path vary 5 - 7.5 s/frame
            "stage_s": {"backbone": stages[0], "raymarch": stages[1], "superres": stages[2]}}   # run to run on this box
+    if check is not None and "image" in last:
+        err = (check(ws, c, us, ui).float() - last["image"]).double()
+        out["parity_vs_oracle"] = {"max_abs": float(err.abs().max()), "mse": float(err.pow(2).mean()),
+                                   "what": "512^2 image of the HIP path (this run's default precision) vs the oracle's, same ws / "
+                                           "camera / renderer uniforms, B = 1; north_star bar: MSE <= 1e-3 on [-1, 1] images"}
     if n1:
         torch.set_num_threads(1)
         med1, st1, _ = timed(1, 0)
@@ -842,7 +850,11 @@ def main():
             out["audio_reenactment"] = audio
         if state is not None:
             t_cpu = time.perf_counter()
-            out["cpu_baseline"] = cpu_baseline(cfg, state, args.cpu_runs, args.cpu_warmup, args.cpu_n1)
+            def hip_image(ws_, c_, us_, ui_):
+                gen.conv_precision, gen.sr_conv_precision, gen.sr_storage = cfg.conv_precision, cfg.sr_conv_precision, cfg.sr_storage
+                with torch.no_grad():
+                    return gen.synthesis(ws_.to(dev), c_.to(dev), noise_mode="const", u_strat=us_.to(dev), u_imp=ui_.to(dev))["image"].cpu()
+            out["cpu_baseline"] = cpu_baseline(cfg, state, args.cpu_runs, args.cpu_warmup, args.cpu_n1, check=hip_image)
             leg_s["cpu_baseline"] = round(time.perf_counter() - t_cpu, 2)
         out["leg_seconds"] = leg_s
         sys.stdout.flush()
