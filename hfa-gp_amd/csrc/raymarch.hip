@@ -61,6 +61,7 @@ __global__ void __launch_bounds__(256, 2) raymarch_kernel(const RayParams p) {
     const int j = lane & 15, g = lane >> 4;
     const int R = a.res * a.res;
 
+    constexpr bool kL1Lds = DEC16 && !FROM_STATE;   // layer 1 of the 16-bit decoder from LDS (raymarch_common.h decoder_fwd16_l1)
     typename std::conditional<DEC16, Dec16Regs, DecoderRegs>::type dec;
     if constexpr (FROM_STATE) {
         (void)dec; (void)j; (void)g;
@@ -68,6 +69,11 @@ __global__ void __launch_bounds__(256, 2) raymarch_kernel(const RayParams p) {
         DecoderRegs dec32;
         load_decoder(a, j, g, dec32);
         make_dec16(dec32, a.planes_absmax, lane, dec);
+        if constexpr (kL1Lds) {                  // layer 1 of the decoder -> workgroup-shared LDS image (behind the four wave windows)
+            if (wave == 0) store_dec16_l1(dec, reinterpret_cast<float*>(smem + 4 * sizeof(L)), lane);
+            prescale_dec16_l1(dec);              // (what stays in registers moves to base 2 as well)
+            __syncthreads();
+        }
     } else {
         load_decoder(a, j, g, dec);
     }
@@ -102,41 +108,76 @@ __global__ void __launch_bounds__(256, 2) raymarch_kernel(const RayParams p) {
             WAVE_SYNC();
 
             // ---- gather + decoder for one 16-sample tile starting at sample id `s0`
-            auto eval_tile = [&](int s0) {
+            // The gather runs in a quad layout — lanes 4q..4q+3 read the four 32-B channel groups of the SAME texel line of
+            // sample q — so that a load instruction touches 16 lines with 4 adjacent lanes each, not 64 lines with one lane
+            // each (4x fewer tag look-ups in the texture addresser: 2.6 -> 2.0 ms per 8 frames; 8 lanes per line with two
+            // samples per lane measured 2.3 ms).  The interpolated features then move to the MFMA layout (lane 16g + j <-
+            // lane 4j + g).
+            auto decode_tile = [&](int s0, float f[8]) {
                 const int s = s0 + j;
-                float f[8];
-                {
-                    // The gather runs in a quad layout — lanes 4q..4q+3 read the four 32-B channel groups of the SAME
-                    // texel line of sample q — so that a load instruction touches 16 lines with 4 adjacent lanes
-                    // each, not 64 lines with one lane each (4x fewer tag look-ups in the texture addresser: 2.6 ->
-                    // 2.0 ms per 8 frames; 8 lanes per line with two samples per lane measured 2.3 ms).  The
-                    // interpolated features then move to the MFMA layout (lane 16g + j <- lane 4j + g).
-                    PlaneTaps taps[3];
-                    sample_taps(p, o3, d3, lds.t[s0 + (lane >> 2)], taps);
-                    gather8(a, b, lane & 3, taps, f);
-                    const int src = 4 * j + g;
+                const int src = 4 * j + g;
     #pragma unroll
-                    for (int c = 0; c < 8; ++c) f[c] = __shfl(f[c], src);
-                }
-                f32x4 h[4], o[2];
+                for (int c = 0; c < 8; ++c) f[c] = __shfl(f[c], src);
+                f32x4 o[2];
                 float sigma;
-                if constexpr (DEC16) decoder_fwd16<false>(dec, f, h, h, sigma, o);
-                else decoder_fwd<false>(dec, f, h, h, sigma, o);
+                if constexpr (kL1Lds) {
+                    decoder_fwd16_l1(dec, reinterpret_cast<const float*>(smem + 4 * sizeof(L)), lane, f, sigma, o);
+                } else {
+                    f32x4 h[4];
+                    if constexpr (DEC16) decoder_fwd16<false>(dec, f, h, h, sigma, o);
+                    else decoder_fwd<false>(dec, f, h, h, sigma, o);
+                }
                 if (g == 0) lds.sig[s] = sigma;
     #pragma unroll
                 for (int ot = 0; ot < 2; ++ot) {
                     float4 cv;
-                    cv.x = sigmoid_f(o[ot][0]) * 1.002f - 0.001f;
-                    cv.y = sigmoid_f(o[ot][1]) * 1.002f - 0.001f;
-                    cv.z = sigmoid_f(o[ot][2]) * 1.002f - 0.001f;
-                    cv.w = sigmoid_f(o[ot][3]) * 1.002f - 0.001f;
+                    if constexpr (kL1Lds) {          // logits in base 2
+                        cv.x = sigmoid2_f(o[ot][0]) * 1.002f - 0.001f;
+                        cv.y = sigmoid2_f(o[ot][1]) * 1.002f - 0.001f;
+                        cv.z = sigmoid2_f(o[ot][2]) * 1.002f - 0.001f;
+                        cv.w = sigmoid2_f(o[ot][3]) * 1.002f - 0.001f;
+                    } else {
+                        cv.x = sigmoid_f(o[ot][0]) * 1.002f - 0.001f;
+                        cv.y = sigmoid_f(o[ot][1]) * 1.002f - 0.001f;
+                        cv.z = sigmoid_f(o[ot][2]) * 1.002f - 0.001f;
+                        cv.w = sigmoid_f(o[ot][3]) * 1.002f - 0.001f;
+                    }
                     *reinterpret_cast<float4*>(&lds.col[s * CS + 16 * ot + 4 * g]) = cv;
+                }
+            };
+            auto eval_tile = [&](int s0) {
+                float f[8];
+                PlaneTaps taps[3];
+                sample_taps(p, o3, d3, lds.t[s0 + (lane >> 2)], taps);
+                gather8(a, b, lane & 3, taps, f);
+                decode_tile(s0, f);
+            };
+            // forward kernel on the 16-bit decoder: every tile's 24 texel loads in flight at once (the 64 registers come from
+            // layer 1 of the decoder living in LDS).  Issuing the loads of tile t+1 BEFORE the decoder of tile t on top of that
+            // needs 108 registers live across the decoder: 85 spilled, not pursued; the tap arithmetic of tile t+1 placed under
+            // the load latency of tile t fits (238 registers) and measured 2 % SLOWER (profiles/r03_raymarch_valu.md).
+            auto eval_pass = [&](int first, int ntiles) {
+                if constexpr (kL1Lds) {
+    #pragma unroll 1
+                    for (int tile = 0; tile < ntiles; ++tile) {
+                        float f[8];
+                        {
+                            TileLoads tl;
+                            PlaneTaps taps[3];
+                            sample_taps(p, o3, d3, lds.t[first + 16 * tile + (lane >> 2)], taps);
+                            tile_issue(a, b, lane & 3, taps, tl);
+                            tile_reduce(tl, f);
+                        }
+                        decode_tile(first + 16 * tile, f);
+                    }
+                } else {
+    #pragma unroll 1
+                    for (int tile = 0; tile < ntiles; ++tile) eval_tile(first + 16 * tile);
                 }
             };
 
             // ---- coarse pass
-    #pragma unroll 1
-            for (int tile = 0; tile < NC; ++tile) eval_tile(16 * tile);
+            eval_pass(0, NC);
             WAVE_SYNC();
 
             // ---- coarse compositing weights (MipRayMarcher2) -> importance depths (sample_pdf)
@@ -170,8 +211,14 @@ __global__ void __launch_bounds__(256, 2) raymarch_kernel(const RayParams p) {
             WAVE_SYNC();
             if (lane < SF) {
                 const float u = a.u_imp[(size_t)ray * SF + lane];
+                // searchsorted(right=True) = #{k < SC-2 : cdf[k] <= u}; the cdf is a running sum of non-negative terms, so a
+                // bisection counts the same thing as the 46-step scan it replaces (6 LDS reads instead of 46)
                 int inds = 0;
-                for (int k = 0; k < SC - 2; ++k) inds += lds.cdf[k] <= u ? 1 : 0;   // searchsorted(right=True)
+#pragma unroll
+                for (int step = 32; step > 0; step >>= 1) {
+                    const int probe = inds + step;
+                    if (probe <= SC - 2 && lds.cdf[probe - 1] <= u) inds = probe;
+                }
                 const int below = max(inds - 1, 0), above = min(inds, SC - 3);
                 const float c0 = lds.cdf[below], c1 = lds.cdf[above];
                 const float b0 = lds.tmid[below], b1 = lds.tmid[above];
@@ -182,22 +229,47 @@ __global__ void __launch_bounds__(256, 2) raymarch_kernel(const RayParams p) {
             WAVE_SYNC();
 
             // ---- fine pass
-    #pragma unroll 1
-            for (int tile = 0; tile < NF; ++tile) eval_tile(SC + 16 * tile);
+            eval_pass(SC, NF);
             WAVE_SYNC();
 
-            // ---- merge: rank of every sample in the union (coarse is already ascending)
+            // ---- merge: rank of every sample in the union, stable, coarse before fine on ties.  The coarse depths are already
+            // ascending, so   rank(fine l)   = cf_l + #{fine k before l},   cf_l = #{coarse <= tf_l}   (bisection)
+            //                 rank(coarse i) = i + #{fine l : cf_l <= i}                             (histogram of cf + scan)
+            // and only "fine before fine" is a count over all SF values — strict comparisons, with the k < l tie-break taken
+            // on a (wave-uniform, rare) second pass when two fine depths are EQUAL, which the duplicate ranks reveal.
+            // 485 -> ~190 VALU instructions per ray.
             {
+                static_assert(SC < 64 && SF <= 64 && SF % 4 == 0, "one lane per coarse / fine sample, SC + 1 histogram bins");
                 const bool hc = lane < SC, hf = lane < SF;
                 const float tc = hc ? lds.t[lane] : 0.f;
                 const float tf = hf ? lds.t[SC + lane] : 0.f;
-                int rc = lane, rf = 0;
-                for (int k = 0; k < SF; ++k) {
-                    const float x = lds.t[SC + k];
-                    rc += x < tc ? 1 : 0;
-                    rf += (x < tf || (x == tf && k < lane)) ? 1 : 0;
+                int* bins = reinterpret_cast<int*>(lds.om);          // (om is written by the final compositing, after this)
+                if (lane <= SC) bins[lane] = 0;
+                lds.sid[lane] = 0;                                   // duplicate detector, indexed by rank
+                if (lane + 64 < S) lds.sid[lane + 64] = 0;
+                int cf = 0;
+#pragma unroll
+                for (int step = 32; step > 0; step >>= 1) {
+                    const int probe = cf + step;
+                    if (probe <= SC && lds.t[probe - 1] <= tf) cf = probe;
                 }
-                for (int k = 0; k < SC; ++k) rf += lds.t[k] <= tf ? 1 : 0;
+                WAVE_SYNC();
+                if (hf) atomicAdd(&bins[cf], 1);
+                int lt = 0;
+#pragma unroll
+                for (int k = 0; k < SF; k += 4) {
+                    const float4 x = *reinterpret_cast<const float4*>(&lds.t[SC + k]);      // broadcast reads
+                    lt += (x.x < tf ? 1 : 0) + (x.y < tf ? 1 : 0) + (x.z < tf ? 1 : 0) + (x.w < tf ? 1 : 0);
+                }
+                WAVE_SYNC();
+                const float below = wave_scan_add(lane <= SC ? (float)bins[lane] : 0.f, lane);   // #{fine : cf <= lane}: exact, <= SF
+                const int rc = lane + (int)below;
+                int rf = cf + lt;
+                const int before = hf ? atomicAdd(&lds.sid[rf], 1) : 0;
+                if (__builtin_amdgcn_ballot_w64(before != 0) != 0) {          // equal fine depths: the stable order
+                    for (int k = 0; k < SF; ++k) rf += (k < lane && lds.t[SC + k] == tf) ? 1 : 0;
+                }
+                WAVE_SYNC();
                 if (hc) { lds.ts[rc] = tc; lds.ss[rc] = lds.sig[lane]; lds.sid[rc] = lane; }
                 if (hf) { lds.ts[rf] = tf; lds.ss[rf] = lds.sig[SC + lane]; lds.sid[rf] = SC + lane; }
             }
@@ -337,7 +409,7 @@ __global__ void __launch_bounds__(256, 2) raymarch_kernel(const RayParams p) {
 
 template <int NC, int NF, bool GRADS, bool DEC16, bool FROM_STATE = false>
 static int launch(const RayParams& p, hipStream_t s) {
-    const size_t lds = 4 * sizeof(WaveLds<NC, NF>);
+    const size_t lds = 4 * sizeof(WaveLds<NC, NF>) + ((DEC16 && !FROM_STATE) ? kDecL1Floats * sizeof(float) : 0);
     int blocks = (p.total_rays + 3) / 4;
     const int cap = kNumCU * 2 * 4;          // 2 resident workgroups per CU, a few rounds each
     if (blocks > cap) blocks = cap;

@@ -480,6 +480,143 @@ __device__ __forceinline__ void decoder_fwd16(const Dec16Regs& w, const float f[
     }
 }
 
+// Layer 1 of the 16-bit decoder from a workgroup-shared LDS image (forward kernel): the 64 registers of w0h / w0l / b0c /
+// wsig become 8.5 KB of LDS — [hi|lo][mt][lane] 16-byte A operands (lane-linear: conflict-free ds_read_b128) and the compact
+// bias / sigma-row tables [mt][g][r] (broadcast reads) — and pay for the 64 registers of keeping all 24 texel loads of a tile
+// in flight (gather8_all).  Layer 2 stays in registers.
+constexpr int kDecL1Floats = 2 * 4 * 64 * 4 + 2 * 64;            // 2176 floats = 8704 bytes
+constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
+__device__ __forceinline__ void store_dec16_l1(const Dec16Regs& w, float* img, int lane) {
+    unsigned* u = reinterpret_cast<unsigned*>(img);
+    const int g = lane >> 4;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            u[((0 * 4 + mt) * 64 + lane) * 4 + q] = w.w0h[mt][q];
+            u[((1 * 4 + mt) * 64 + lane) * 4 + q] = w.w0l[mt][q];
+        }
+        if ((lane & 15) == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                img[2048 + (mt * 4 + g) * 4 + r] = w.b0c[mt][r] * kLog2e;        // base-2 pre-activations (see prescale_dec16_l1)
+                img[2048 + 64 + (mt * 4 + g) * 4 + r] = w.wsig[mt][r] * kLn2;
+            }
+        }
+    }
+}
+
+// The forward decoder works in BASE 2: v_exp_f32 / v_log_f32 are 2^x / log2 x, so exp(x) and log(x) each cost a multiply by
+// log2 e / ln 2 next to the transcendental.  With  x2 = x log2 e :
+//   softplus(x) = ln 2 * [ max(x2, 0) + log2(1 + 2^-|x2|) ]        sigmoid(y) = 1 / (1 + 2^-y2)
+// and the constants fold into what surrounds them: log2 e into the dequantisation scale and bias of each layer's accumulator
+// (u1, b0, u2, b1), ln 2 into the consumers of the hidden activations (the sigma row and the fp16 split scale sH).
+// 3 of the ~9 VALU instructions per softplus and 1 of 5 per sigmoid go away (24 values per lane per 16-sample tile).
+__device__ __forceinline__ void prescale_dec16_l1(Dec16Regs& w) {     // AFTER store_dec16_l1 (which scales b0 / wsig itself)
+    w.u1 *= kLog2e;
+    w.u2 *= kLog2e;
+    w.sH *= kLn2;
+    w.sF *= 0.3333333333333333f;      // tile_reduce hands over the SUM over the three planes, not their mean
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w.b1c[ot][r] *= kLog2e;
+}
+__device__ __forceinline__ float softplus2_f(float x2) {             // softplus(x) / ln 2 of x2 = x log2 e
+    return fmaxf(x2, 0.f) + __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(-fabsf(x2)));
+}
+__device__ __forceinline__ float sigmoid2_f(float y2) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-y2)); }
+
+// h: softplus / ln 2 of the hidden layer; o: the colour logits times log2 e (feed sigmoid2_f); sigma: as decoder_fwd16
+__device__ __forceinline__ void decoder_fwd16_l1(const Dec16Regs& w, const float* img, int lane, const float f[8], float& sigma,
+                                                 f32x4 o[2]) {
+    const int g = lane >> 4;
+    u32x4r fh, fl;
+    {
+        float fs[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) fs[t] = f[t] * w.sF;
+        split8_f16(fs, fh, fl);
+    }
+    f32x4 h[4];
+    float sg = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const u32x4r ah = *reinterpret_cast<const u32x4r*>(img + ((0 * 4 + mt) * 64 + lane) * 4);
+        const u32x4r al = *reinterpret_cast<const u32x4r*>(img + ((1 * 4 + mt) * 64 + lane) * 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(img + 2048 + (mt * 4 + g) * 4);
+        const float4 ws = *reinterpret_cast<const float4*>(img + 2048 + 64 + (mt * 4 + g) * 4);
+        const float b0v[4] = {b0.x, b0.y, b0.z, b0.w}, wsv[4] = {ws.x, ws.y, ws.z, ws.w};
+        const f32x4 acc = mfma3_f16(ah, al, fh, fl, f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            h[mt][r] = softplus2_f(fmaf(acc[r], w.u1, b0v[r]));
+            sg = fmaf(h[mt][r], wsv[r], sg);
+        }
+    }
+    sg += __shfl_xor(sg, 16);
+    sg += __shfl_xor(sg, 32);
+    sigma = sg + w.bsig;
+    u32x4r hh[2], hl[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        float hs[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) hs[c] = h[2 * ks + (c >> 2)][c & 3] * w.sH;
+        split8_f16(hs, hh[ks], hl[ks]);
+    }
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot) {
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) acc = mfma3_f16(w.w1h[ot][ks], w.w1l[ot][ks], hh[ks], hl[ks], acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[ot][r] = fmaf(acc[r], w.u2, w.b1c[ot][r]);
+    }
+}
+
+// The gather with ALL 24 texel loads (3 planes x 4 taps x 2 float4) of a 16-sample tile in flight at once, in two halves so that
+// the caller can put the decoder of the PREVIOUS tile between them: gather8 keeps one plane (8 loads, 32 registers) in flight at
+// a time — three serial memory round trips per tile, all exposed at two waves per SIMD.
+struct TileLoads {
+    float4 v0[3][4], v1[3][4];
+    float w[3][4];
+};
+__device__ __forceinline__ void tile_issue(const HfagpRaymarchArgs& a, int b, int g, const PlaneTaps taps[3], TileLoads& t) {
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+        const char* base = reinterpret_cast<const char*>(a.planes + ((size_t)(b * 3 + pl) * a.H * a.W) * 32);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned off = ((unsigned)taps[pl].idx[k] * 32u + 8u * g) * 4u;
+            t.v0[pl][k] = *reinterpret_cast<const float4*>(base + off);
+            t.v1[pl][k] = *reinterpret_cast<const float4*>(base + off + 16);
+            t.w[pl][k] = taps[pl].w[k];
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);          // (keep the 24 loads where they are: the scheduler sinks them to their uses otherwise)
+}
+// 3 x the mean over the planes (the 1/3 is folded into the feature down-scale: prescale_dec16_l1), as ONE chain of 12 FMAs per
+// channel: gather8's per-plane sums + plane adds + mean cost 136 instructions per tile, this costs 96.  (A different — equally
+// valid — fp32 summation order from ATen's: rounding-level differences only.)
+__device__ __forceinline__ void tile_reduce(const TileLoads& t, float f[8]) {
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+        const float4 *v0 = t.v0[pl], *v1 = t.v1[pl];
+        const float v[4][8] = {{v0[0].x, v0[0].y, v0[0].z, v0[0].w, v1[0].x, v1[0].y, v1[0].z, v1[0].w},
+                               {v0[1].x, v0[1].y, v0[1].z, v0[1].w, v1[1].x, v1[1].y, v1[1].z, v1[1].w},
+                               {v0[2].x, v0[2].y, v0[2].z, v0[2].w, v1[2].x, v1[2].y, v1[2].z, v1[2].w},
+                               {v0[3].x, v0[3].y, v0[3].z, v0[3].w, v1[3].x, v1[3].y, v1[3].z, v1[3].w}};
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float acc = pl == 0 ? v[0][c] * t.w[0][0] : fmaf(v[0][c], t.w[pl][0], f[c]);
+            acc = fmaf(v[1][c], t.w[pl][1], acc);
+            acc = fmaf(v[2][c], t.w[pl][2], acc);
+            f[c] = fmaf(v[3][c], t.w[pl][3], acc);
+        }
+    }
+}
+
 // ---- LDS images for the backward kernels (lane-linear rows of 64 dwords: every ds_read_b32 is conflict-free)
 // Dec16Regs image: rows 0-15 w0h[mt][q], 16-31 w0l, 32-47 w1h[ot][ks][q], 48-63 w1l, 64-79 b0c[mt][r], 80-95 wsig[mt][r],
 // 96-103 b1c[ot][r], 104 bsig, 105 sF, 106 sH, 107 u1, 108 u2
