@@ -80,10 +80,25 @@ __global__ void __launch_bounds__(256, 2) raymarch_kernel(const RayParams p) {
     constexpr int kStateFloats = S * 35;        // per ray: col [S][32] | ts [S] | ss [S] | sid [S]
 
     const RaySchedule sch = ray_schedule(p.total_rays, wave);
-    for (int seq = __builtin_amdgcn_readfirstlane((int)sch.begin); seq < (int)sch.end; seq += sch.stride) {
-        int b, pi, pj;                                         // wave-uniform -> scalar registers
-        ray_of(seq, a.res, b, pi, pj);
-        const int ray = __builtin_amdgcn_readfirstlane(b * R + pi * a.res + pj);   // index into the [B][R] tensors
+    // The set-up of a ray — position in the sequence -> (frame, pixel) with five integer divisions, the camera ray with seven
+    // IEEE divisions and a square root — is the same for all 64 lanes: computed per ray it was ~300 redundant instructions.
+    // Instead lane l prepares the wave's ray number l of the next 64, and the ray loop picks its values with v_readlane.
+    for (int seq0 = __builtin_amdgcn_readfirstlane((int)sch.begin); seq0 < (int)sch.end; seq0 += 64 * sch.stride) {
+    int b_l = 0, ray_l = 0;
+    float o_l[3] = {0.f, 0.f, 0.f}, d_l[3] = {0.f, 0.f, 0.f};
+    {
+        const long long sl = (long long)seq0 + (long long)lane * sch.stride;
+        if (sl < sch.end) {
+            int pi, pj;
+            ray_of((int)sl, a.res, b_l, pi, pj);
+            ray_l = b_l * R + pi * a.res + pj;                 // index into the [B][R] tensors
+            if constexpr (!FROM_STATE) ray_setup(a, b_l, pi, pj, o_l, d_l);
+        }
+    }
+    const int nbatch = __builtin_amdgcn_readfirstlane(min(64, ((int)sch.end - seq0 + sch.stride - 1) / sch.stride));
+    #pragma unroll 1
+    for (int k = 0; k < nbatch; ++k) {
+        const int b = __builtin_amdgcn_readlane(b_l, k), ray = __builtin_amdgcn_readlane(ray_l, k);    // wave-uniform -> scalar registers
         if constexpr (FROM_STATE) {
             const float* st = a.state + (size_t)ray * kStateFloats;
 #pragma unroll 4
@@ -95,7 +110,11 @@ __global__ void __launch_bounds__(256, 2) raymarch_kernel(const RayParams p) {
             }
         } else {
             float o3[3], d3[3];
-            ray_setup(a, b, pi, pj, o3, d3);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                o3[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(o_l[i]), k));
+                d3[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d_l[i]), k));
+            }
 
             // ---- stratified depths: torch.linspace(start, end, SC)[s] + u * delta
             if (lane < SC) {
@@ -164,8 +183,12 @@ __global__ void __launch_bounds__(256, 2) raymarch_kernel(const RayParams p) {
                         {
                             TileLoads tl;
                             PlaneTaps taps[3];
+                            // (priority: this wave's tap arithmetic and load issue go ahead of the other wave's decoder
+                            // arithmetic on the SIMD, so its loads are in flight under that decoder: -1.7 %)
+                            __builtin_amdgcn_s_setprio(3);
                             sample_taps(p, o3, d3, lds.t[first + 16 * tile + (lane >> 2)], taps);
                             tile_issue(a, b, lane & 3, taps, tl);
+                            __builtin_amdgcn_s_setprio(0);
                             tile_reduce(tl, f);
                         }
                         decode_tile(first + 16 * tile, f);
@@ -404,6 +427,7 @@ __global__ void __launch_bounds__(256, 2) raymarch_kernel(const RayParams p) {
             a.tminmax[2 * (size_t)ray + 1] = lds.ts[S - 1];
         }
         WAVE_SYNC();
+    }
     }
 }
 
