@@ -52,6 +52,8 @@ class GeneratorConfig:
     # "bf16x6" = 3 parts / 6 MFMAs (fp32-class).  Layers the split kernel cannot take run on the exact kernel.
     # "f16x3" (default) = operands split into hi+lo fp16 (11 + 11 mantissa bits), 3 fp16 MFMAs per product: relative
     # error of a layer ~1e-6 = the exact kernel's own summation noise, ~5 % slower than "bf16x3".
+    # "f16x2" (opt-in) = the f16x3 weight image against activations rounded to ONE fp16 part, 2 MFMAs per product: the TF32
+    # class the reference's cuDNN convs run in (relative error of a layer ~1e-4), +18 % frames/s.
     # "f16" = operands rounded to fp16, ONE fp16 MFMA per product, fp32 accumulation: the arithmetic of EG3D's own
     # fp16 blocks (relative error of a layer ~3e-4); never the default.
     conv_precision: str = "f16x3"

@@ -26,7 +26,7 @@ namespace hfagp {
 // and applies the style with packed fp16 multiplies), bit 1 = y is written as fp16
 template <int KD, int TM, int NTAPS, int IO = 0>
 __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p, const int phase0) {
-    constexpr int NP = kind_parts(KD);
+    constexpr int NP = kind_parts_a(KD), NPB = kind_parts(KD);    // parts of the activations (LDS patch) / of the weight image
     constexpr bool F16 = kind_f16(KD);
     constexpr bool XH = (IO & 1) != 0, YH = (IO & 2) != 0;
     constexpr int XB = XH ? 2 : 4;                       // bytes per input element
@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
             } else
 #endif
             split4<KD>(make_float4(ra[k].x * (sv.x * m), ra[k].y * (sv.y * m), ra[k].z * (sv.z * m),
-                                   ra[k].w * (sv.w * m)), parts);
+                                   ra[k].w * (sv.w * m)), parts);     // (F16X2: one saturating fp16 part)
 #pragma unroll
             for (int q = 0; q < NP; ++q)
                 *reinterpret_cast<uint2*>(As + BUF * A_BUF + q * A_PART + lds_a[k]) = parts[q];
@@ -180,9 +180,9 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
     // part products in the order they are issued: (A part, B part)
-    constexpr int NPROD = NP == 1 ? 1 : NP == 2 ? 3 : 6;
-    constexpr int PA[6] = {0, 1, 0, 1, 2, 0};
-    constexpr int PB[6] = {0, 0, 1, 1, 0, 2};
+    constexpr int NPROD = kind_nprod(KD);
+    constexpr int PA[6] = {kind_pa(KD, 0), kind_pa(KD, 1), kind_pa(KD, 2), kind_pa(KD, 3), kind_pa(KD, 4), kind_pa(KD, 5)};
+    constexpr int PB[6] = {kind_pb(KD, 0), kind_pb(KD, 1), kind_pb(KD, 2), kind_pb(KD, 3), kind_pb(KD, 4), kind_pb(KD, 5)};
 
     // the K loop for a compile-time tap count NT (9: 3x3, 4/2/1: the phases of the stride-2 transposed conv and
     // the 1x1 conv).  U chunks are unrolled so that U*NT is a multiple of the ring size: every item then has a
@@ -194,16 +194,16 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
 #define HFAGP_RB9 3
 #endif
         // ring size: divides U*NT (the single-pass fp16 mode has a third of the MFMA time per item: deeper ring)
-        constexpr int RB = NT == 9 ? (NP == 1 ? 6 : HFAGP_RB9) : NT == 4 ? 4 : 2;
+        constexpr int RB = NT == 9 ? (NPROD == 1 ? 6 : HFAGP_RB9) : NT == 4 ? 4 : 2;
         constexpr int U = 2;                                   // chunk pairs: chunk parity = A buffer = compile time
-        u32x4 bq[RB][TN][NP];
+        u32x4 bq[RB][TN][NPB];
         // loads of item (chunk c, tap t) into ring slot `slot`; c is clamped so that the look-ahead past the last
         // chunk re-reads valid memory instead of branching
         auto issue_b = [&](int c, auto t_tag, auto slot_tag) __attribute__((always_inline)) {
             constexpr int T = decltype(t_tag)::value, SL = decltype(slot_tag)::value;
             const int cc = min(c, c_end - 1);
 #pragma unroll
-            for (int q = 0; q < NP; ++q) {
+            for (int q = 0; q < NPB; ++q) {
                 const char* base = wb + (long long)(q * part_stride + wtap[T] + cc * 2 * p.Cout) * 16;   // uniform
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) bq[SL][tn][q] = *reinterpret_cast<const u32x4*>(base + bth[tn]);
@@ -476,13 +476,13 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
 // still fills the chip with the larger tile (make_plan).
 template <int KD, int NW, int IO = 0>
 __global__ void __launch_bounds__(NW * 64, 1) upconv_bf16_kernel(const ConvParams p) {
-    constexpr int NP = kind_parts(KD);
+    constexpr int NP = kind_parts_a(KD), NPB = kind_parts(KD);    // parts of the activations (LDS patch) / of the weight image
     constexpr bool F16 = kind_f16(KD);
     constexpr bool XH = (IO & 1) != 0, YH = (IO & 2) != 0;       // fp16 storage of x / y_t (see modconv_bf16_kernel)
     constexpr int XB = XH ? 2 : 4;
     static_assert(IO == 0 || KD == 1, "fp16 storage goes with the single-pass fp16 arithmetic");
     constexpr int NTH = NW * 64;
-    constexpr int TM = 2, TN = 1, WN = NW / 2, BM = 128, BNU = WN * TN * 32, PH = BM / PW, NITEM = 9, RB = NP == 1 ? 6 : 3;
+    constexpr int TM = 2, TN = 1, WN = NW / 2, BM = 128, BNU = WN * TN * 32, PH = BM / PW, NITEM = 9, RB = kind_nprod(KD) == 1 ? 6 : 3;
     constexpr int LPWB = RowPitch<NP>::value;
     constexpr int APOS = (PH + 2) * LPWB;
     constexpr int A_PART = APOS * APITCH, A_BUF = NP * A_PART;
@@ -567,7 +567,7 @@ __global__ void __launch_bounds__(NW * 64, 1) upconv_bf16_kernel(const ConvParam
             } else
 #endif
             split4<KD>(make_float4(ra[k].x * (sv.x * m), ra[k].y * (sv.y * m), ra[k].z * (sv.z * m),
-                                   ra[k].w * (sv.w * m)), parts);
+                                   ra[k].w * (sv.w * m)), parts);     // (F16X2: one saturating fp16 part)
 #pragma unroll
             for (int q = 0; q < NP; ++q)
                 *reinterpret_cast<uint2*>(As + BUF * A_BUF + q * A_PART + lds_a[k]) = parts[q];
@@ -598,16 +598,16 @@ __global__ void __launch_bounds__(NW * 64, 1) upconv_bf16_kernel(const ConvParam
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[f][tm][tn][r] = 0.f;
 
-    constexpr int NPROD = NP == 1 ? 1 : NP == 2 ? 3 : 6;
-    constexpr int PA[6] = {0, 1, 0, 1, 2, 0};
-    constexpr int PB[6] = {0, 0, 1, 1, 0, 2};
-    u32x4 bq[RB][TN][NP];
+    constexpr int NPROD = kind_nprod(KD);
+    constexpr int PA[6] = {kind_pa(KD, 0), kind_pa(KD, 1), kind_pa(KD, 2), kind_pa(KD, 3), kind_pa(KD, 4), kind_pa(KD, 5)};
+    constexpr int PB[6] = {kind_pb(KD, 0), kind_pb(KD, 1), kind_pb(KD, 2), kind_pb(KD, 3), kind_pb(KD, 4), kind_pb(KD, 5)};
+    u32x4 bq[RB][TN][NPB];
     u32x4 af[2][TM][NP];                  // A fragments of the current and the next shift group
     auto issue_b = [&](int c, auto i_tag, auto slot_tag) __attribute__((always_inline)) {
         constexpr int I = decltype(i_tag)::value, SL = decltype(slot_tag)::value;
         const int cc = min(c, c_end - 1);
 #pragma unroll
-        for (int q = 0; q < NP; ++q) {
+        for (int q = 0; q < NPB; ++q) {
             const char* base = wb + (long long)(q * part_stride + (I_W[I] * cq8 + cc * 2) * p.Cout) * 16;
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) bq[SL][tn][q] = *reinterpret_cast<const u32x4*>(base + bth[tn]);
@@ -745,7 +745,7 @@ static size_t bf16_lds_bytes(int cin) {
 template <int KD>
 static void launch_group(const Plan& pl, int phase0, int nphase, int ntaps, int cin, hipStream_t s) {
     const dim3 grid(pl.grid.x, (unsigned)nphase, 1);
-    const size_t lds = bf16_lds_bytes<kind_parts(KD), 2>(cin);
+    const size_t lds = bf16_lds_bytes<kind_parts_a(KD), 2>(cin);
     switch (ntaps) {
         case 9: modconv_bf16_kernel<KD, 2, 9><<<grid, 256, lds, s>>>(pl.p, phase0); break;
         case 4: modconv_bf16_kernel<KD, 2, 4><<<grid, 256, lds, s>>>(pl.p, phase0); break;
@@ -767,7 +767,7 @@ static void launch_up_io(const Plan& pl, int cin, int io, hipStream_t s) {
 
 template <int KD>
 static void launch_up(const Plan& pl, int cin, hipStream_t s) {
-    const size_t lds = bf16_lds_bytes<kind_parts(KD), 2>(cin);
+    const size_t lds = bf16_lds_bytes<kind_parts_a(KD), 2>(cin);
     if constexpr (KD != 3) {            // (three parts: the 8-wave variant would spill; make_plan never asks for it)
         if (pl.up_waves == 8) {
             upconv_bf16_kernel<KD, 8><<<pl.grid, 512, lds, s>>>(pl.p);
@@ -811,6 +811,7 @@ int launch_modconv_bf16(const HfagpModconvArgs* a, Plan& pl, hipStream_t s) {
             case 1: launch_up<1>(pl, a->Cin, s); break;
             case 2: launch_up<2>(pl, a->Cin, s); break;
             case 3: launch_up<3>(pl, a->Cin, s); break;
+            case 5: launch_up<5>(pl, a->Cin, s); break;
             default: launch_up<4>(pl, a->Cin, s); break;
         }
         return check_launch("modconv_fwd (16-bit MFMA, merged up-conv)");
@@ -824,6 +825,7 @@ int launch_modconv_bf16(const HfagpModconvArgs* a, Plan& pl, hipStream_t s) {
             case 1: launch_group<1>(pl, p0, n, nt, a->Cin, s); break;
             case 2: launch_group<2>(pl, p0, n, nt, a->Cin, s); break;
             case 3: launch_group<3>(pl, p0, n, nt, a->Cin, s); break;
+            case 5: launch_group<5>(pl, p0, n, nt, a->Cin, s); break;
             default: launch_group<4>(pl, p0, n, nt, a->Cin, s); break;
         }
         p0 += n;
@@ -844,6 +846,7 @@ __global__ void __launch_bounds__(256) weight_prep_split_kernel(const float* __r
     float r[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) r[e] = w[((size_t)co * Cin + 8 * g + e) * taps + t];
+    if (kd == 5) kd = 4;          // F16X2 reads the F16X3 image (two fp16 parts of the weights)
     if (kd == 1 || kd == 4) {
         unsigned u[4];
 #pragma unroll

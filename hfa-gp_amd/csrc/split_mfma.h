@@ -25,9 +25,18 @@ __device__ __forceinline__ unsigned pack_f16(float a, float b) {
 }
 
 // operand kinds KD of the kernels below: 1 = one fp16 part (HFAGP_PREC_F16), 2 / 3 = two / three bf16 parts
-// (BF16X3 / BF16X6), 4 = two fp16 parts (F16X3: 11 + 11 mantissa bits, the three products above 2^-22)
-constexpr int kind_parts(int kd) { return kd == 4 ? 2 : kd; }
-constexpr bool kind_f16(int kd) { return kd == 1 || kd == 4; }
+// (BF16X3 / BF16X6), 4 = two fp16 parts (F16X3: 11 + 11 mantissa bits, the three products above 2^-22),
+// 5 = F16X2: the WEIGHTS as two fp16 parts (the F16X3 image), the ACTIVATIONS as one — two MFMAs per product, an 11-bit
+// activation against a 22-bit weight: the class of TF32 (11 + 11 bits), which is what the reference's cuDNN convolutions run
+// in on Ampere-class GPUs (its scripts leave torch.backends.cudnn.allow_tf32 at its default).
+constexpr int kind_parts(int kd) { return kd == 4 || kd == 5 ? 2 : kd; }       // parts of the weight image (B operand)
+constexpr int kind_parts_a(int kd) { return kd == 5 ? 1 : kind_parts(kd); }     // parts of the activations (A operand)
+constexpr int kind_split(int kd) { return kd == 5 ? 1 : kd; }                   // split4<> kind of the activations
+constexpr bool kind_f16(int kd) { return kd == 1 || kd == 4 || kd == 5; }
+// part products in issue order (A part, B part): 1 | a0b0 a1b0 a0b1 | + a1b1 a2b0 a0b2 | F16X2: a0b0 a0b1
+constexpr int kind_nprod(int kd) { return kd == 1 ? 1 : kd == 5 ? 2 : kind_parts(kd) == 2 ? 3 : 6; }
+constexpr int kind_pa(int kd, int i) { return kd == 5 ? 0 : (i == 1 || i == 3) ? 1 : i == 4 ? 2 : 0; }
+constexpr int kind_pb(int kd, int i) { return kd == 5 ? i : (i == 2 || i == 3) ? 1 : i == 5 ? 2 : 0; }
 
 __device__ __forceinline__ float f16_lo_back(unsigned u) {       // fp16 in bits 0-15 -> float
     return (float)__builtin_bit_cast(f16x2, u)[0];
@@ -48,8 +57,8 @@ __device__ __forceinline__ f32x16 mfma16(u32x4 a, u32x4 b, f32x16 c) {
 // v (4 floats) -> parts x 4 elements (two dwords per part), each part the round-to-nearest 16-bit value of the
 // residual left by the parts before it
 template <int KD>
-__device__ __forceinline__ void split4(float4 v, uint2 (&out)[kind_parts(KD)]) {
-    constexpr int NP = kind_parts(KD);
+__device__ __forceinline__ void split4(float4 v, uint2 (&out)[kind_parts_a(KD)]) {
+    constexpr int NP = kind_parts_a(KD);
     if constexpr (kind_f16(KD)) {
         // saturating: an activation beyond fp16's range (never seen; the reference clamps its fp16 layers at 256) must
         // not turn into inf - inf = NaN in the residual
@@ -117,6 +126,7 @@ static inline int kind_of(int precision) {
         case HFAGP_PREC_BF16X3: return 2;
         case HFAGP_PREC_BF16X6: return 3;
         case HFAGP_PREC_F16X3: return 4;
+        case HFAGP_PREC_F16X2: return 5;
         default: return 0;
     }
 }

@@ -192,6 +192,7 @@ extern "C" int hfagp_torgb_skip_fwd(const HfagpTorgbSkipArgs* a, void* stream) {
         case 2: return launch_torgb_skip_kind<2>(a, s);
         case 3: return launch_torgb_skip_kind<3>(a, s);
         case 4: return launch_torgb_skip_kind<4>(a, s);
+        case 5: return launch_torgb_skip_kind<4>(a, s);     // F16X2: the toRGB products stay fp32-class (same weight image)
         default: break;
     }
     set_error("torgb_skip: precision %d has no 16-bit weight image", a->precision);

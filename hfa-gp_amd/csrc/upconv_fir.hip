@@ -629,7 +629,7 @@ extern "C" int hfagp_upconv_fir_fwd(const HfagpModconvArgs* a, void* scratch, vo
     } else if (kd == 2) {
         rc = launch_fused<2, 0>(fp, a->Cin, s);
     } else {
-        rc = launch_fused<4, 0>(fp, a->Cin, s);
+        rc = launch_fused<4, 0>(fp, a->Cin, s);     // (F16X2 as well: the fused layer is only picked for short-K layers, same weight image)
     }
     if (rc != HFAGP_OK) return rc;
     if (dbg) {

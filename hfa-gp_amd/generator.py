@@ -231,7 +231,9 @@ class TriPlaneGenerator(nn.Module):
         """Arithmetic of the conv GEMMs: 'fp32' (exact MFMA), 'bf16x3' / 'bf16x6' / 'f16x3' (split-operand MFMA, fp32
         accumulation; include/hfagp.h HFAGP_PREC_*), 'f16' (single-pass fp16 MFMA, fp32 accumulation: the
         arithmetic of EG3D's fp16 blocks).  'f16x3' (the default) splits each operand into two fp16 parts (22 mantissa
-        bits): fp32-class results at the cost of 'bf16x3'.  Layers whose shape the 16-bit kernels do not take
+        bits): fp32-class results at the cost of 'bf16x3'.  'f16x2' (opt-in): the 22-bit weights against activations rounded
+        to ONE fp16 part, two MFMAs per product — the class of TF32, which the reference's cuDNN convs run in on Ampere-class
+        GPUs (toRGB layers and gradient GEMMs stay as under 'f16x3').  Layers whose shape the 16-bit kernels do not take
         (Cin % 16, Cout % 128) always run on the exact fp32 kernel; gradient GEMMs of the fp16 kinds run in bf16x3 (a
         raw gradient has no place in fp16's exponent range without loss scaling)."""
         return self._conv_precision
@@ -253,21 +255,28 @@ class TriPlaneGenerator(nn.Module):
             raise ValueError(f"conv_precision must be one of {sorted(ops.PRECISIONS)}, got {value!r}")
         self._conv_precision = value
 
-    def _gemm_image(self, weight: torch.Tensor, transposed: bool = False) -> torch.Tensor:
-        """MFMA B-operand image of a conv weight (of its Cin/Cout transpose for the bwd-data GEMMs), in the layout
-        of the configured precision; cached until the parameter changes."""
+    def _precision_of(self, weight: torch.Tensor, transposed: bool = False) -> str:
+        """The precision a conv weight's GEMM runs in (the Cin/Cout transpose: the bwd-data GEMM)."""
         co, ci = weight.shape[:2]
         if transposed:
             co, ci = ci, co
         prec = self._conv_precision
         if self._sr_conv_precision is not None and self._is_sr_weight(weight):
             prec = self._sr_conv_precision
-        if prec in ("f16", "f16x3") and transposed:
+        if prec in ("f16", "f16x3", "f16x2") and transposed:
             prec = "bf16x3"       # gradient GEMMs: a raw gradient needs fp32's exponent range (bf16 parts have it)
-        if prec == "f16" and weight.shape[-1] == 1:
+        if prec in ("f16", "f16x2") and weight.shape[-1] == 1:
             prec = "f16x3"        # the toRGB products feed the tri-planes directly: keep them fp32-class
         if not ops.split_supported(ci, co):
             prec = "fp32"
+        return prec
+
+    def _gemm_image(self, weight: torch.Tensor, transposed: bool = False) -> torch.Tensor:
+        """MFMA B-operand image of a conv weight (of its Cin/Cout transpose for the bwd-data GEMMs), in the layout
+        of the configured precision; cached until the parameter changes."""
+        prec = self._precision_of(weight, transposed)
+        if prec == "f16x2":
+            prec = "f16x3"        # same image: two fp16 parts of the weights (the ACTIVATIONS are the single part)
         key = ("G", prec, transposed, id(weight))
         hit = self._prep.get(key)
         if hit is not None and hit[0] == weight._version and hit[1] == weight.data_ptr():
@@ -323,6 +332,7 @@ class TriPlaneGenerator(nn.Module):
             raise NotImplementedError("noise_mode must be 'const' or 'none' (HFA-GP passes 'const', headnerf.py:112)")
         cout = layer.weight.shape[0]
         gain = math.sqrt(2.0)
+        x_parts = 1 if self._precision_of(layer.weight) == "f16x2" else 0
         k_styles, k_dcoef = styles, dcoef       # (the fp16 kernels apply EG3D's fp16 range guard themselves)
         # algorithmic FLOPs: 2 * B * H_in * W_in * Cin * Cout * 9 (the up-conv is counted in its
         # polyphase / transposed form at INPUT resolution)
@@ -340,7 +350,7 @@ class TriPlaneGenerator(nn.Module):
                               y_absmax=y_absmax, y_f16=half)
         elif layer.up == 2:
             yt = self._timed(key + "_up", flops, ops.modconv, x, wt, cout, ops.CONVT3X3_UP2, styles=k_styles, batch=batch,
-                             x_absmax=x_absmax, y_f16=half)
+                             x_absmax=x_absmax, y_f16=half, x_parts=x_parts)
             out = ops.upfir_epilogue(yt, k_dcoef, noise, ns, layer.bias, "lrelu", cfg.lrelu_alpha, gain, conv_clamp,
                                      y_absmax=y_absmax)
         else:
@@ -352,7 +362,7 @@ class TriPlaneGenerator(nn.Module):
             out = self._timed(key, flops, ops.modconv, x, wt, cout, ops.CONV3X3, styles=k_styles, dcoef=k_dcoef,
                               noise=noise, noise_strength=ns, bias=layer.bias, act="lrelu", alpha=cfg.lrelu_alpha,
                               gain=gain, clamp=conv_clamp, batch=batch, x_absmax=x_absmax, y_absmax=y_absmax,
-                              rgb_w=rgb_w, y_f16=half,
+                              rgb_w=rgb_w, y_f16=half, x_parts=x_parts,
                               store_y=keep_out or rgb_w is None or tape is not None or y_absmax is not None)
             if rgb_w is not None:
                 out, self._rgb_part = out
@@ -455,7 +465,7 @@ class TriPlaneGenerator(nn.Module):
         # fp16 range tracking: the backbone has no clamp (conv_clamp None), so every conv publishes max |out| and the
         # next fp16-kind GEMM normalises its operand with it (one memset for all layers; row 2k / 2k+1 = conv0 / conv1
         # of block k).  Kept for `f16_range_report()`.
-        track = cfg.backbone_conv_clamp is None and (self._conv_precision in ("f16x3", "f16"))
+        track = cfg.backbone_conv_clamp is None and (self._conv_precision in ("f16x3", "f16x2", "f16"))
         am = ops.absmax_slots(2 * len(cfg.block_resolutions), ws.device) if track else None
         self._absmax = (am, [f"b{res}.{c}" for res in cfg.block_resolutions for c in ("conv0", "conv1")]) if track else None
         idx = 0

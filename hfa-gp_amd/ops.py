@@ -62,10 +62,13 @@ def weight_prep(weight: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     return wt, wsq
 
 
-PREC_F32, PREC_BF16X3, PREC_BF16X6, PREC_F16, PREC_F16X3 = 0, 1, 2, 3, 4
-PRECISIONS = {"fp32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16x6": PREC_BF16X6, "f16": PREC_F16, "f16x3": PREC_F16X3}
-NPARTS = {"fp32": 0, "f16": 1, "bf16x3": 2, "bf16x6": 3, "f16x3": 2}   # parts of the 16-bit weight image (0: fp32 image)
-_IMAGE_DTYPE = {"f16": torch.float16, "f16x3": torch.float16, "bf16x3": torch.bfloat16, "bf16x6": torch.bfloat16}
+PREC_F32, PREC_BF16X3, PREC_BF16X6, PREC_F16, PREC_F16X3, PREC_F16X2 = 0, 1, 2, 3, 4, 5
+# "f16x2" (TF32 class, NOT the default): the f16x3 weight image against activations rounded to one fp16 part — 2 MFMAs / product
+PRECISIONS = {"fp32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16x6": PREC_BF16X6, "f16": PREC_F16, "f16x3": PREC_F16X3,
+              "f16x2": PREC_F16X2}
+NPARTS = {"fp32": 0, "f16": 1, "bf16x3": 2, "bf16x6": 3, "f16x3": 2, "f16x2": 2}   # parts of the 16-bit weight image (0: fp32 image)
+_IMAGE_DTYPE = {"f16": torch.float16, "f16x3": torch.float16, "f16x2": torch.float16, "bf16x3": torch.bfloat16,
+                "bf16x6": torch.bfloat16}
 
 
 def split_supported(cin: int, cout: int, up: bool = False) -> bool:
@@ -217,7 +220,7 @@ def modconv(x: torch.Tensor, wt: torch.Tensor, cout: int, mode: int, styles: Opt
             alpha: float = 0.2, gain: float = 1.0, clamp: Optional[float] = None, batch: Optional[int] = None,
             ksplit: int = 0, x_absmax: Optional[torch.Tensor] = None,
             y_absmax: Optional[torch.Tensor] = None, rgb_w: Optional[torch.Tensor] = None, y_f16: bool = False,
-            store_y: bool = True):
+            store_y: bool = True, x_parts: int = 0):
     """x [B|1, H, W, Cin] channels-last.  mode CONV3X3 / CONV1X1: fused epilogue, returns [B,H,W,Cout];
     mode CONVT3X3_UP2: returns the RAW transposed-conv result [B, 2H+1, 2W+1, Cout].
     ``wt`` from :func:`weight_prep` (fp32, exact MFMA) or :func:`weight_prep_split` (bfloat16 parts: the
@@ -228,6 +231,8 @@ def modconv(x: torch.Tensor, wt: torch.Tensor, cout: int, mode: int, styles: Opt
     ``rgb_w`` [B, 3, Cout] (toRGB weight x its styles): fused toRGB — returns (y, rgb_part [parts, B, H, W, 4]) for
     `torgb_finish`; only where `fused_torgb_supported` says so.  ``store_y=False`` (with rgb_w): y is not written and None
     is returned in its place (last super-resolution layer of a forward-only call).
+    ``x_parts=1`` with the two-part float16 image: precision 'f16x2' — the activations as ONE fp16 part against the 22-bit
+    weights, two MFMAs per product (TF32 class; include/hfagp.h HFAGP_PREC_F16X2).
     fp16 STORAGE (single-pass fp16 weights only, `f16_storage_supported`): a float16 ``x`` is read as stored and
     ``y_f16`` writes the result as float16 (EG3D's fp16 super-resolution blocks keep their activations in fp16)."""
     x_f16 = x.dtype == torch.float16
@@ -254,6 +259,10 @@ def modconv(x: torch.Tensor, wt: torch.Tensor, cout: int, mode: int, styles: Opt
             a.precision = PREC_F16 if wt.shape[0] == 1 else PREC_F16X3
         else:
             a.precision = PREC_BF16X3 if wt.shape[0] == 2 else PREC_BF16X6
+        if x_parts == 1 and a.precision != PREC_F16:
+            if a.precision != PREC_F16X3:
+                raise RuntimeError("modconv: x_parts=1 ('f16x2') goes with the two-part float16 weight image")
+            a.precision = PREC_F16X2
     else:
         a.x, a.wt = _ptr(x), _ptr(_chk(wt, "wt"))
         a.precision = PREC_F32

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define HFAGP_ABI_VERSION 8
+#define HFAGP_ABI_VERSION 9
 
 enum { HFAGP_OK = 0, HFAGP_EBADARG = -1, HFAGP_EUNSUPPORTED = -2, HFAGP_ELAUNCH = -3 };
 
@@ -173,8 +173,12 @@ enum { HFAGP_ACT_LINEAR = 0, HFAGP_ACT_LRELU = 1 };
  *           undone on the accumulators: EG3D's fp16 pre-normalisation, exact); |x| itself must stay below 65504 unless
  *           the tensor's maximum is passed in x_absmax (then any fp32 magnitude is taken, see HfagpModconvArgs).
  * The 16-bit paths need Cin % 16 == 0 and Cout % 128 == 0 — or, except for HFAGP_CONVT3X3_UP2, Cout % 128 >= 96
- * (the 96-channel toRGB: computed on a 128-wide tile whose last columns are discarded) — HFAGP_EUNSUPPORTED otherwise.   */
-enum { HFAGP_PREC_F32 = 0, HFAGP_PREC_BF16X3 = 1, HFAGP_PREC_BF16X6 = 2, HFAGP_PREC_F16 = 3, HFAGP_PREC_F16X3 = 4 };
+ * (the 96-channel toRGB: computed on a 128-wide tile whose last columns are discarded) — HFAGP_EUNSUPPORTED otherwise.
+ * HFAGP_PREC_F16X2 (ABI 9): the F16X3 weight image (two fp16 parts, 22 bits) against activations rounded to ONE fp16 part —
+ *           two MFMAs per product.  The class of TF32 (11-bit x 11-bit), which the reference's cuDNN convolutions use on
+ *           Ampere-class GPUs; NOT the default.  hfagp_torgb_skip_fwd / hfagp_upconv_fir_fwd run it as F16X3.               */
+enum { HFAGP_PREC_F32 = 0, HFAGP_PREC_BF16X3 = 1, HFAGP_PREC_BF16X6 = 2, HFAGP_PREC_F16 = 3, HFAGP_PREC_F16X3 = 4,
+       HFAGP_PREC_F16X2 = 5 };
 
 typedef struct {
     const float* x;           /* [B][H][W][Cin]; x_batch_stride (elements) may be 0 (const)   */

@@ -586,3 +586,55 @@ def test_audio_nets_on_gpu_match_their_cpu_path(dev):
     att_g = copy.deepcopy(att_c).to(dev)
     w = torch.randn(5, 8, 64)
     close(att_g.forward_windows(w.to(dev)), att_c.forward_windows(w), atol=1e-5)
+
+
+# ----------------------------------------------------------------------------- 'f16x2': the TF32-class conv precision (opt-in)
+def test_f16x2_conv_is_tf32_class(dev):
+    """HFAGP_PREC_F16X2 (ops.modconv x_parts=1): 22-bit weights x activations rounded to ONE fp16 part.  Its result must be the
+    exact conv of the fp16-ROUNDED activations (to the f16x3 kernel's own 1e-6), i.e. the only error it adds is that rounding:
+    per product 2^-12 relative, the class of TF32 (2^-11 on both operands)."""
+    from hfa_gp_amd import ops
+    g = torch.Generator().manual_seed(5)
+    b, h, cin, cout = 2, 32, 64, 128
+    x = torch.randn(b, h, h, cin, generator=g).to(dev)
+    w = torch.randn(cout, cin, 3, 3, generator=g).to(dev) / 24.0
+    styles = (torch.rand(b, cin, generator=g) + 0.5).to(dev)
+    img = ops.weight_prep_prec(w, "f16x3")
+    y3 = ops.modconv(x, img, cout, ops.CONV3X3, styles=styles)
+    y2 = ops.modconv(x, img, cout, ops.CONV3X3, styles=styles, x_parts=1)
+    # the kernel rounds x * style (after its power-of-two range guard, which commutes with the rounding)
+    xs = (x * styles[:, None, None, :]).half().float()
+    y2_ref = ops.modconv(xs, img, cout, ops.CONV3X3)
+    scale = y3.abs().max().item()
+    assert (y2 - y2_ref).abs().max().item() <= 3e-6 * scale
+    err = (y2 - y3).abs().max().item() / scale
+    assert 1e-6 < err <= 5e-4, err            # it IS a different (coarser) arithmetic, and stays in the 2^-12 class
+    up3 = ops.modconv(x, img, cout, ops.CONVT3X3_UP2, styles=styles)
+    up2 = ops.modconv(x, img, cout, ops.CONVT3X3_UP2, styles=styles, x_parts=1)
+    up_ref = ops.modconv(xs, img, cout, ops.CONVT3X3_UP2)
+    assert (up2 - up_ref).abs().max().item() <= 3e-6 * up3.abs().max().item()
+    with pytest.raises(RuntimeError, match="x_parts"):
+        ops.modconv(x, ops.weight_prep_prec(w, "bf16x3"), cout, ops.CONV3X3, styles=styles, x_parts=1)
+
+
+def test_f16x2_synthesis_vs_oracle(dev):
+    """conv_precision='f16x2' end to end at the benched size against the oracle: the image error of a TF32-class conv stack —
+    orders inside north_star's 1e-3 MSE bar, well outside the default f16x3 path's 2e-5."""
+    from hfa_gp_amd.config import ffhq512_128
+    from hfa_gp_amd.generator import TriPlaneGenerator
+    from oracle import eg3d_oracle as O
+    cfg = dataclasses.replace(ffhq512_128(), conv_precision="f16x2")
+    gen = perturb_state(TriPlaneGenerator(cfg, seed=0))
+    P = state_cpu(gen)
+    gen = gen.to(dev)
+    ws, c, us, ui = make_inputs(cfg, 1)
+    ref = O.synthesis(P, cfg, ws, c, us, ui)
+    gen.timing = {}
+    out = gen.synthesis(ws.to(dev), c.to(dev), noise_mode="const", u_strat=us.to(dev), u_imp=ui.to(dev))
+    ran = {k: len(v) for k, v in gen.timing.items()}
+    gen.timing = None
+    assert ran.get("modconv_split", 0) + ran.get("modconv_split_up", 0) + ran.get("modconv_split_upfir", 0) >= 17, ran
+    err = out["image"].cpu() - ref["image"]
+    mse, mx = err.pow(2).mean().item(), err.abs().max().item()
+    print(f"f16x2 vs oracle: mse {mse:.2e} max {mx:.2e}")
+    assert mse <= 1e-7 and mx <= 1e-2, (mse, mx)
