@@ -268,7 +268,7 @@ __global__ void __launch_bounds__(256, 2) raymarch_kernel(const RayParams p) {
                 const float tf = hf ? lds.t[SC + lane] : 0.f;
                 int* bins = reinterpret_cast<int*>(lds.om);          // (om is written by the final compositing, after this)
                 if (lane <= SC) bins[lane] = 0;
-                lds.sid[lane] = 0;                                   // duplicate detector, indexed by rank
+                if (lane < S) lds.sid[lane] = 0;                     // duplicate detector, indexed by rank
                 if (lane + 64 < S) lds.sid[lane + 64] = 0;
                 int cf = 0;
 #pragma unroll
