@@ -29,7 +29,7 @@ class RaymarchArgs(C.Structure):
         ("Sc", C.c_int32), ("Sf", C.c_int32), ("plane_axes", C.c_int32), ("white_back", C.c_int32),
         ("ray_start", C.c_double), ("ray_end", C.c_double),
         ("box_warp", C.c_float), ("decoder_lr_mul", C.c_float),
-        ("planes_absmax", C.c_void_p), ("state", C.c_void_p), ("workspace", C.c_void_p),
+        ("planes_absmax", C.c_void_p), ("state", C.c_void_p),
     ]
 
 
@@ -136,7 +136,6 @@ SYMBOLS = {
     "hfagp_abi_version": (C.c_int, []),
     "hfagp_last_error": (C.c_char_p, []),
     "hfagp_raymarch_fwd": (C.c_int, [C.POINTER(RaymarchArgs), C.c_void_p]),
-    "hfagp_raymarch_workspace_bytes": (C.c_size_t, [C.POINTER(RaymarchArgs)]),
     "hfagp_style_fwd": (C.c_int, [C.POINTER(StyleArgs), C.c_void_p]),
     "hfagp_fc_fwd": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 3 + [C.c_float, C.c_int32, C.c_float, C.c_float, C.c_void_p]),
     "hfagp_weight_prep": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),

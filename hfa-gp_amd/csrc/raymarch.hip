@@ -27,24 +27,17 @@
 
 namespace hfagp {
 
-// COMPACT (forward kernel with the 16-bit decoder): the window holds the colours of the COARSE samples only — those of the
-// importance samples go to a per-wave global scratch line (or straight into HfagpRaymarchArgs::state) that stays in L2 — the
-// CDF scratch shares the omega array and the backward-only arrays are gone: 9.2 KB instead of 17 KB per wave, so that TWELVE
-// waves (three per SIMD) fit a CU instead of eight.
-template <int NC, int NF, bool COMPACT = false>
+template <int NC, int NF>
 struct WaveLds {
     static constexpr int SC = 16 * NC, SF = 16 * NF, S = SC + SF;
-    static_assert(!COMPACT || SF >= SC, "the CDF scratch (2 x SC floats) aliases om[S]");
-    float col[(COMPACT ? SC : S) * CS];
+    float col[S * CS];
     float t[S], sig[S];        // by sample id: coarse 0..SC-1, fine SC..S-1
     float ts[S], ss[S];        // sorted by depth
     float om[S];               // colour weight by sample id
     int sid[S];                // sorted position -> sample id
-    float cdf_[COMPACT ? 1 : SC], tmid_[COMPACT ? 1 : SC];
-    float pp[COMPACT ? 1 : S]; // backward: g . colour per sample
-    float g2[COMPACT ? 4 : 32];// backward: 2 * dL/dfeat of this ray   (COMPACT: padding to a multiple of 16 bytes)
-    __device__ __forceinline__ float* cdf() { return COMPACT ? om : cdf_; }          // (dead before om is first written)
-    __device__ __forceinline__ float* tmid() { return COMPACT ? om + SC : tmid_; }
+    float cdf[SC], tmid[SC];
+    float pp[S];               // backward: g . colour per sample
+    float g2[32];              // backward: 2 * dL/dfeat of this ray
 };
 
 // GRADS = false: the forward renderer.  GRADS = true: first half of the backward pass — the same forward
@@ -56,16 +49,10 @@ struct WaveLds {
 // FROM_STATE (GRADS only): the per-sample colours, densities, depths and sort order of every ray are READ from
 // HfagpRaymarchArgs::state, where the forward call of the same step left them (13.4 KB per ray), instead of being recomputed
 // — no gather, no decoder: the compositing adjoint alone.
-// COMPACT (forward, DEC16 only): 12 waves per workgroup, one workgroup per CU = three waves per SIMD instead of two — the kernel
-// is bound by the dependent chain of a 16-sample tile, so the third wave is worth more than the loads in flight it costs:
-// <= 168 registers (every decoder operand in the LDS image, one plane's 8 texel loads in flight at a time) and the
-// compact LDS window above.
-template <int NC, int NF, bool GRADS, bool DEC16, bool FROM_STATE = false, bool COMPACT = false>
-__global__ void __launch_bounds__(COMPACT ? 768 : 256, COMPACT ? 1 : 2) raymarch_kernel(const RayParams p) {
+template <int NC, int NF, bool GRADS, bool DEC16, bool FROM_STATE = false>
+__global__ void __launch_bounds__(256, 2) raymarch_kernel(const RayParams p) {
     static_assert(!FROM_STATE || GRADS, "the saved state is consumed by the backward pass");
-    static_assert(!COMPACT || (DEC16 && !GRADS), "the compact variant is the forward renderer with the 16-bit decoder");
-    constexpr int NW = COMPACT ? 12 : 4;            // waves per workgroup
-    using L = WaveLds<NC, NF, COMPACT>;
+    using L = WaveLds<NC, NF>;
     constexpr int SC = L::SC, SF = L::SF, S = L::S;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -82,8 +69,8 @@ __global__ void __launch_bounds__(COMPACT ? 768 : 256, COMPACT ? 1 : 2) raymarch
         DecoderRegs dec32;
         load_decoder(a, j, g, dec32);
         make_dec16(dec32, a.planes_absmax, lane, dec);
-        if constexpr (kL1Lds) {                  // layer 1 of the decoder (COMPACT: both layers) -> workgroup-shared LDS image behind the wave windows
-            if (wave == 0) store_dec16_l1<COMPACT>(dec, reinterpret_cast<float*>(smem + NW * sizeof(L)), lane);
+        if constexpr (kL1Lds) {                  // layer 1 of the decoder -> workgroup-shared LDS image (behind the four wave windows)
+            if (wave == 0) store_dec16_l1(dec, reinterpret_cast<float*>(smem + 4 * sizeof(L)), lane);
             prescale_dec16_l1(dec);              // (what stays in registers moves to base 2 as well)
             __syncthreads();
         }
@@ -92,9 +79,7 @@ __global__ void __launch_bounds__(COMPACT ? 768 : 256, COMPACT ? 1 : 2) raymarch
     }
     constexpr int kStateFloats = S * 35;        // per ray: col [S][32] | ts [S] | ss [S] | sid [S]
 
-    const RaySchedule sch = ray_schedule(p.total_rays, wave, NW);
-    // COMPACT: where this wave keeps the colours of the importance samples of its current ray ([SF][32] floats)
-    float* const wave_scratch = COMPACT && p.fine_scratch ? p.fine_scratch + ((size_t)blockIdx.x * NW + wave) * (SF * 32) : nullptr;
+    const RaySchedule sch = ray_schedule(p.total_rays, wave);
     // The set-up of a ray — position in the sequence -> (frame, pixel) with five integer divisions, the camera ray with seven
     // IEEE divisions and a square root — is the same for all 64 lanes: computed per ray it was ~300 redundant instructions.
     // Instead lane l prepares the wave's ray number l of the next 64, and the ray loop picks its values with v_readlane.
@@ -114,9 +99,6 @@ __global__ void __launch_bounds__(COMPACT ? 768 : 256, COMPACT ? 1 : 2) raymarch
     #pragma unroll 1
     for (int k = 0; k < nbatch; ++k) {
         const int b = __builtin_amdgcn_readlane(b_l, k), ray = __builtin_amdgcn_readlane(ray_l, k);    // wave-uniform -> scalar registers
-        // COMPACT: the colours of this ray's importance samples — in the saved state if the call keeps one, else in the wave's scratch
-        float* const fine_col = !COMPACT ? nullptr : a.state ? a.state + (size_t)ray * (S * 35) + SC * 32 : wave_scratch;
-        (void)fine_col;
         if constexpr (FROM_STATE) {
             const float* st = a.state + (size_t)ray * kStateFloats;
 #pragma unroll 4
@@ -158,7 +140,7 @@ __global__ void __launch_bounds__(COMPACT ? 768 : 256, COMPACT ? 1 : 2) raymarch
                 f32x4 o[2];
                 float sigma;
                 if constexpr (kL1Lds) {
-                    decoder_fwd16_l1<COMPACT>(dec, reinterpret_cast<const float*>(smem + NW * sizeof(L)), lane, f, sigma, o);
+                    decoder_fwd16_l1(dec, reinterpret_cast<const float*>(smem + 4 * sizeof(L)), lane, f, sigma, o);
                 } else {
                     f32x4 h[4];
                     if constexpr (DEC16) decoder_fwd16<false>(dec, f, h, h, sigma, o);
@@ -179,25 +161,14 @@ __global__ void __launch_bounds__(COMPACT ? 768 : 256, COMPACT ? 1 : 2) raymarch
                         cv.z = sigmoid_f(o[ot][2]) * 1.002f - 0.001f;
                         cv.w = sigmoid_f(o[ot][3]) * 1.002f - 0.001f;
                     }
-                    if constexpr (COMPACT) {      // importance samples: to the wave's L2-resident line, not to LDS
-                        if (s0 >= SC) *reinterpret_cast<float4*>(&fine_col[(s - SC) * 32 + 16 * ot + 4 * g]) = cv;
-                        else *reinterpret_cast<float4*>(&lds.col[s * CS + 16 * ot + 4 * g]) = cv;
-                    } else {
-                        *reinterpret_cast<float4*>(&lds.col[s * CS + 16 * ot + 4 * g]) = cv;
-                    }
+                    *reinterpret_cast<float4*>(&lds.col[s * CS + 16 * ot + 4 * g]) = cv;
                 }
             };
             auto eval_tile = [&](int s0) {
                 float f[8];
                 PlaneTaps taps[3];
                 sample_taps(p, o3, d3, lds.t[s0 + (lane >> 2)], taps);
-                if constexpr (COMPACT) {
-                    __builtin_amdgcn_s_setprio(3);      // (as in the 24-load variant below: the loads go out ahead of the other waves' decoders)
-                    gather8_sum(a, b, lane & 3, taps, f);
-                    __builtin_amdgcn_s_setprio(0);
-                } else {
-                    gather8(a, b, lane & 3, taps, f);
-                }
+                gather8(a, b, lane & 3, taps, f);
                 decode_tile(s0, f);
             };
             // forward kernel on the 16-bit decoder: every tile's 24 texel loads in flight at once (the 64 registers come from
@@ -205,10 +176,7 @@ __global__ void __launch_bounds__(COMPACT ? 768 : 256, COMPACT ? 1 : 2) raymarch
             // needs 108 registers live across the decoder: 85 spilled, not pursued; the tap arithmetic of tile t+1 placed under
             // the load latency of tile t fits (238 registers) and measured 2 % SLOWER (profiles/r03_raymarch_valu.md).
             auto eval_pass = [&](int first, int ntiles) {
-                if constexpr (COMPACT) {
-    #pragma unroll 1
-                    for (int tile = 0; tile < ntiles; ++tile) eval_tile(first + 16 * tile);      // one plane in flight: 168 registers
-                } else if constexpr (kL1Lds) {
+                if constexpr (kL1Lds) {
     #pragma unroll 1
                     for (int tile = 0; tile < ntiles; ++tile) {
                         float f[8];
@@ -245,7 +213,7 @@ __global__ void __launch_bounds__(COMPACT ? 768 : 256, COMPACT ? 1 : 2) raymarch
                     const float alpha = 1.f - exp_f(-(dm * (t1 - t0)));
                     sh = 1.f - alpha + 1e-10f;
                     w = alpha;
-                    lds.tmid()[lane] = 0.5f * (t0 + t1);
+                    lds.tmid[lane] = 0.5f * (t0 + t1);
                 }
                 const float incl = wave_scan_mul(sh, lane);
                 float T = __shfl_up(incl, 1);
@@ -261,7 +229,7 @@ __global__ void __launch_bounds__(COMPACT ? 768 : 256, COMPACT ? 1 : 2) raymarch
                 const float tot = wave_sum(pw);
                 const float pdf = inpdf ? pw / tot : 0.f;
                 const float c = wave_scan_add(pdf, lane);
-                if (lane <= SC - 3) lds.cdf()[lane] = lane == 0 ? 0.f : c;   // SC-2 entries
+                if (lane <= SC - 3) lds.cdf[lane] = lane == 0 ? 0.f : c;   // SC-2 entries
             }
             WAVE_SYNC();
             if (lane < SF) {
@@ -272,11 +240,11 @@ __global__ void __launch_bounds__(COMPACT ? 768 : 256, COMPACT ? 1 : 2) raymarch
 #pragma unroll
                 for (int step = 32; step > 0; step >>= 1) {
                     const int probe = inds + step;
-                    if (probe <= SC - 2 && lds.cdf()[probe - 1] <= u) inds = probe;
+                    if (probe <= SC - 2 && lds.cdf[probe - 1] <= u) inds = probe;
                 }
                 const int below = max(inds - 1, 0), above = min(inds, SC - 3);
-                const float c0 = lds.cdf()[below], c1 = lds.cdf()[above];
-                const float b0 = lds.tmid()[below], b1 = lds.tmid()[above];
+                const float c0 = lds.cdf[below], c1 = lds.cdf[above];
+                const float b0 = lds.tmid[below], b1 = lds.tmid[above];
                 float den = c1 - c0;
                 if (den < 1e-5f) den = 1.f;
                 lds.t[SC + lane] = b0 + (u - c0) / den * (b1 - b0);
@@ -285,7 +253,6 @@ __global__ void __launch_bounds__(COMPACT ? 768 : 256, COMPACT ? 1 : 2) raymarch
 
             // ---- fine pass
             eval_pass(SC, NF);
-            if constexpr (COMPACT) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // the colours written to fine_col: stores issued
             WAVE_SYNC();
 
             // ---- merge: rank of every sample in the union, stable, coarse before fine on ties.  The coarse depths are already
@@ -335,7 +302,7 @@ __global__ void __launch_bounds__(COMPACT ? 768 : 256, COMPACT ? 1 : 2) raymarch
             if (a.state) {                          // forward of a step that will be differentiated: leave the state behind
                 float* st = a.state + (size_t)ray * kStateFloats;
 #pragma unroll 4
-                for (int i = lane; i < (COMPACT ? SC : S) * 32; i += 64) st[i] = lds.col[(i >> 5) * CS + (i & 31)];   // (COMPACT: the rest is there already)
+                for (int i = lane; i < S * 32; i += 64) st[i] = lds.col[(i >> 5) * CS + (i & 31)];
                 for (int i = lane; i < S; i += 64) {
                     st[S * 32 + i] = lds.ts[i];
                     st[S * 33 + i] = lds.ss[i];
@@ -446,28 +413,7 @@ __global__ void __launch_bounds__(COMPACT ? 768 : 256, COMPACT ? 1 : 2) raymarch
         {
             const int c = lane & 31, hf = lane >> 5;
             float acc = 0.f;
-            if constexpr (COMPACT) {
-                // half-wave 0: the coarse samples from LDS; half-wave 1: the importance samples from the wave's global line
-                // (written by other lanes of this wave with plain stores — the vector L1 is write-through — and read back here with
-                // agent-scope loads, which bypass that L1; an agent-scope FENCE instead writes back / invalidates the XCD's whole
-                // L2 per ray: 5x the kernel time)
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                if (hf == 0) {
-                    for (int s = 0; s < SC; ++s) acc = fmaf(lds.om[s], lds.col[s * CS + c], acc);
-                } else {
-#pragma unroll 1
-                    for (int s0 = 0; s0 < SF; s0 += 16) {         // 16 loads in flight
-                        float v[16];
-#pragma unroll
-                        for (int s = 0; s < 16; ++s)
-                            v[s] = __hip_atomic_load(&fine_col[(s0 + s) * 32 + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                        for (int s = 0; s < 16; ++s) acc = fmaf(lds.om[SC + s0 + s], v[s], acc);
-                    }
-                }
-            } else {
-                for (int s = hf * (S / 2); s < (hf + 1) * (S / 2); ++s) acc = fmaf(lds.om[s], lds.col[s * CS + c], acc);
-            }
+            for (int s = hf * (S / 2); s < (hf + 1) * (S / 2); ++s) acc = fmaf(lds.om[s], lds.col[s * CS + c], acc);
             acc += __shfl_xor(acc, 32);
             if (a.white_back) acc = acc + 1.f - wsum;
             if (lane < 32) a.feat[(size_t)ray * 32 + c] = acc * 2.f - 1.f;
@@ -485,56 +431,37 @@ __global__ void __launch_bounds__(COMPACT ? 768 : 256, COMPACT ? 1 : 2) raymarch
     }
 }
 
-constexpr int kCompactRounds = 4;      // workgroups per CU of the compact kernel's grid (one resident at a time)
-
-template <int NC, int NF, bool GRADS, bool DEC16, bool FROM_STATE = false, bool COMPACT = false>
+template <int NC, int NF, bool GRADS, bool DEC16, bool FROM_STATE = false>
 static int launch(const RayParams& p, hipStream_t s) {
-    constexpr int NW = COMPACT ? 12 : 4;
-    const size_t lds = NW * sizeof(WaveLds<NC, NF, COMPACT>) +
-                       ((DEC16 && !FROM_STATE) ? (COMPACT ? kDecL12Floats : kDecL1Floats) * sizeof(float) : 0);
-    int blocks = (p.total_rays + NW - 1) / NW;
-    const int cap = COMPACT ? kNumCU * kCompactRounds : kNumCU * 2 * 4;          // resident workgroups per CU x a few rounds each
+    const size_t lds = 4 * sizeof(WaveLds<NC, NF>) + ((DEC16 && !FROM_STATE) ? kDecL1Floats * sizeof(float) : 0);
+    int blocks = (p.total_rays + 3) / 4;
+    const int cap = kNumCU * 2 * 4;          // 2 resident workgroups per CU, a few rounds each
     if (blocks > cap) blocks = cap;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&raymarch_kernel<NC, NF, GRADS, DEC16, FROM_STATE, COMPACT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&raymarch_kernel<NC, NF, GRADS, DEC16, FROM_STATE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             set_error("raymarch: cannot raise dynamic LDS to %zu bytes: %s", lds, hipGetErrorString(e));
             return HFAGP_ELAUNCH;
         }
     }
-    raymarch_kernel<NC, NF, GRADS, DEC16, FROM_STATE, COMPACT><<<blocks, NW * 64, lds, s>>>(p);
+    raymarch_kernel<NC, NF, GRADS, DEC16, FROM_STATE><<<blocks, 256, lds, s>>>(p);
     return check_launch(GRADS ? "raymarch_bwd/samples" : "raymarch_fwd");
 }
 
-template <bool GRADS, bool DEC16, bool FROM_STATE = false, bool COMPACT = false>
+template <bool GRADS, bool DEC16, bool FROM_STATE = false>
 static int launch_n(const RayParams& p, hipStream_t s) {
     const int n = p.a.Sc / 16;
-    return n == 3   ? launch<3, 3, GRADS, DEC16, FROM_STATE, COMPACT>(p, s)
-           : n == 2 ? launch<2, 2, GRADS, DEC16, FROM_STATE, COMPACT>(p, s)
-                    : launch<1, 1, GRADS, DEC16, FROM_STATE, COMPACT>(p, s);
+    return n == 3 ? launch<3, 3, GRADS, DEC16, FROM_STATE>(p, s) : n == 2 ? launch<2, 2, GRADS, DEC16, FROM_STATE>(p, s)
+                                                                          : launch<1, 1, GRADS, DEC16, FROM_STATE>(p, s);
 }
 
 int launch_raymarch(const RayParams& p, bool grads, hipStream_t s) {
     const bool dec16 = p.a.planes_absmax != nullptr;
     if (grads && p.a.state) return launch_n<true, false, true>(p, s);        // (no decoder in this variant)
     if (grads) return dec16 ? launch_n<true, true>(p, s) : launch_n<true, false>(p, s);
-    // forward with the 16-bit decoder: the compact three-waves-per-SIMD variant when the colours of the importance samples have
-    // somewhere to go (the saved state, or HfagpRaymarchArgs::workspace)
-    if (dec16 && (p.a.state || p.fine_scratch)) return launch_n<false, true, false, true>(p, s);
     return dec16 ? launch_n<false, true>(p, s) : launch_n<false, false>(p, s);
 }
-
-}  // namespace hfagp
-
-// bytes of HfagpRaymarchArgs::workspace that let hfagp_raymarch_fwd take its compact variant (0: not applicable)
-extern "C" size_t hfagp_raymarch_workspace_bytes(const HfagpRaymarchArgs* a) {
-    if (!a || !a->planes_absmax || a->state || a->Sf <= 0) return 0;
-    return (size_t)hfagp::kNumCU * hfagp::kCompactRounds * 12 * (size_t)a->Sf * 32 * sizeof(float);
-}
-
-namespace hfagp {
-
 
 }  // namespace hfagp
 
@@ -546,6 +473,5 @@ extern "C" int hfagp_raymarch_fwd(const HfagpRaymarchArgs* a, void* stream) {
     RayParams p;
     const int rc = fill_ray_params(a, p, "raymarch_fwd");
     if (rc != HFAGP_OK) return rc;
-    p.fine_scratch = a->workspace;
     return launch_raymarch(p, false, (hipStream_t)stream);
 }

@@ -18,7 +18,6 @@ struct RayParams {
     int total_rays;
     const float* g_feat; // backward only: [B][R][32]
     float* rec;          // backward only: per-sample records [B*R][S][4] = (depth, omega, d sigma, -)
-    float* fine_scratch; // compact forward kernel: [blocks][12 waves][Sf][32] colours of the importance samples (or NULL)
 };
 
 inline int fill_ray_params(const HfagpRaymarchArgs* a, RayParams& p, const char* who) {
@@ -37,7 +36,6 @@ inline int fill_ray_params(const HfagpRaymarchArgs* a, RayParams& p, const char*
     HFAGP_REQUIRE(total < (1ll << 31), HFAGP_EUNSUPPORTED, "%s: too many rays", who);
     p.total_rays = (int)total;
     p.g_feat = nullptr;
-    p.fine_scratch = nullptr;
     p.rec = nullptr;
     return HFAGP_OK;
 }
@@ -487,10 +485,7 @@ __device__ __forceinline__ void decoder_fwd16(const Dec16Regs& w, const float f[
 // bias / sigma-row tables [mt][g][r] (broadcast reads) — and pay for the 64 registers of keeping all 24 texel loads of a tile
 // in flight (gather8_all).  Layer 2 stays in registers.
 constexpr int kDecL1Floats = 2 * 4 * 64 * 4 + 2 * 64;            // 2176 floats = 8704 bytes
-// + layer 2 (compact kernel): [hi|lo][ot * 2 + ks][lane] 16-byte A operands and the bias table [ot][g][r]
-constexpr int kDecL12Floats = kDecL1Floats + 2 * 4 * 64 * 4 + 32;    // 4256 floats = 17024 bytes
 constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
-template <bool WITH_L2 = false>
 __device__ __forceinline__ void store_dec16_l1(const Dec16Regs& w, float* img, int lane) {
     unsigned* u = reinterpret_cast<unsigned*>(img);
     const int g = lane >> 4;
@@ -509,22 +504,6 @@ __device__ __forceinline__ void store_dec16_l1(const Dec16Regs& w, float* img, i
             }
         }
     }
-    if constexpr (WITH_L2) {
-#pragma unroll
-        for (int ot = 0; ot < 2; ++ot) {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    u[kDecL1Floats + ((0 * 4 + ot * 2 + ks) * 64 + lane) * 4 + q] = w.w1h[ot][ks][q];
-                    u[kDecL1Floats + ((1 * 4 + ot * 2 + ks) * 64 + lane) * 4 + q] = w.w1l[ot][ks][q];
-                }
-            if ((lane & 15) == 0) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) img[kDecL1Floats + 2048 + (ot * 4 + g) * 4 + r] = w.b1c[ot][r] * kLog2e;
-            }
-        }
-    }
 }
 
 // The forward decoder works in BASE 2: v_exp_f32 / v_log_f32 are 2^x / log2 x, so exp(x) and log(x) each cost a multiply by
@@ -533,12 +512,11 @@ __device__ __forceinline__ void store_dec16_l1(const Dec16Regs& w, float* img, i
 // and the constants fold into what surrounds them: log2 e into the dequantisation scale and bias of each layer's accumulator
 // (u1, b0, u2, b1), ln 2 into the consumers of the hidden activations (the sigma row and the fp16 split scale sH).
 // 3 of the ~9 VALU instructions per softplus and 1 of 5 per sigmoid go away (24 values per lane per 16-sample tile).
-// SUM_PLANES: the gather hands over the SUM over the three planes (tile_reduce), not their mean (gather8)
-__device__ __forceinline__ void prescale_dec16_l1(Dec16Regs& w, bool sum_planes = true) {     // AFTER store_dec16_l1 (which scales b0 / wsig / b1 itself)
+__device__ __forceinline__ void prescale_dec16_l1(Dec16Regs& w) {     // AFTER store_dec16_l1 (which scales b0 / wsig itself)
     w.u1 *= kLog2e;
     w.u2 *= kLog2e;
     w.sH *= kLn2;
-    if (sum_planes) w.sF *= 0.3333333333333333f;
+    w.sF *= 0.3333333333333333f;      // tile_reduce hands over the SUM over the three planes, not their mean
 #pragma unroll
     for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
@@ -550,8 +528,6 @@ __device__ __forceinline__ float softplus2_f(float x2) {             // softplus
 __device__ __forceinline__ float sigmoid2_f(float y2) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-y2)); }
 
 // h: softplus / ln 2 of the hidden layer; o: the colour logits times log2 e (feed sigmoid2_f); sigma: as decoder_fwd16
-// L2_LDS: layer 2's operands and biases from the image as well (store_dec16_l1<true>): nothing of the weights in registers
-template <bool L2_LDS = false>
 __device__ __forceinline__ void decoder_fwd16_l1(const Dec16Regs& w, const float* img, int lane, const float f[8], float& sigma,
                                                  f32x4 o[2]) {
     const int g = lane >> 4;
@@ -592,50 +568,10 @@ __device__ __forceinline__ void decoder_fwd16_l1(const Dec16Regs& w, const float
 #pragma unroll
     for (int ot = 0; ot < 2; ++ot) {
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-        if constexpr (L2_LDS) {
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const u32x4r ah = *reinterpret_cast<const u32x4r*>(img + kDecL1Floats + ((0 * 4 + ot * 2 + ks) * 64 + lane) * 4);
-                const u32x4r al = *reinterpret_cast<const u32x4r*>(img + kDecL1Floats + ((1 * 4 + ot * 2 + ks) * 64 + lane) * 4);
-                acc = mfma3_f16(ah, al, hh[ks], hl[ks], acc);
-            }
-            const float4 b1 = *reinterpret_cast<const float4*>(img + kDecL1Floats + 2048 + (ot * 4 + g) * 4);
-            const float b1v[4] = {b1.x, b1.y, b1.z, b1.w};
+        for (int ks = 0; ks < 2; ++ks) acc = mfma3_f16(w.w1h[ot][ks], w.w1l[ot][ks], hh[ks], hl[ks], acc);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[ot][r] = fmaf(acc[r], w.u2, b1v[r]);
-        } else {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) acc = mfma3_f16(w.w1h[ot][ks], w.w1l[ot][ks], hh[ks], hl[ks], acc);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[ot][r] = fmaf(acc[r], w.u2, w.b1c[ot][r]);
-        }
-    }
-}
-
-// gather8 as ONE chain of 12 FMAs per channel (tile_reduce's arithmetic: the SUM over the planes, the 1/3 folded into the feature
-// scale) with one plane's 8 loads in flight at a time — the compact forward kernel's gather (32 registers of loads).
-__device__ __forceinline__ void gather8_sum(const HfagpRaymarchArgs& a, int b, int g, const PlaneTaps taps[3], float f[8]) {
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
-        const char* base = reinterpret_cast<const char*>(a.planes + ((size_t)(b * 3 + pl) * a.H * a.W) * 32);
-        float4 v0[4], v1[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const unsigned off = ((unsigned)taps[pl].idx[k] * 32u + 8u * g) * 4u;
-            v0[k] = *reinterpret_cast<const float4*>(base + off);
-            v1[k] = *reinterpret_cast<const float4*>(base + off + 16);
-        }
-        const float v[4][8] = {{v0[0].x, v0[0].y, v0[0].z, v0[0].w, v1[0].x, v1[0].y, v1[0].z, v1[0].w},
-                               {v0[1].x, v0[1].y, v0[1].z, v0[1].w, v1[1].x, v1[1].y, v1[1].z, v1[1].w},
-                               {v0[2].x, v0[2].y, v0[2].z, v0[2].w, v1[2].x, v1[2].y, v1[2].z, v1[2].w},
-                               {v0[3].x, v0[3].y, v0[3].z, v0[3].w, v1[3].x, v1[3].y, v1[3].z, v1[3].w}};
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            float acc = pl == 0 ? v[0][c] * taps[0].w[0] : fmaf(v[0][c], taps[pl].w[0], f[c]);
-            acc = fmaf(v[1][c], taps[pl].w[1], acc);
-            acc = fmaf(v[2][c], taps[pl].w[2], acc);
-            f[c] = fmaf(v[3][c], taps[pl].w[3], acc);
-        }
+        for (int r = 0; r < 4; ++r) o[ot][r] = fmaf(acc[r], w.u2, w.b1c[ot][r]);
     }
 }
 

@@ -544,16 +544,8 @@ def raymarch(planes: torch.Tensor, cam2world: torch.Tensor, intrinsics: torch.Te
         if state.shape != (b, r, (sc + sf) * 35):
             raise RuntimeError(f"raymarch: state must be [B, R, {(sc + sf) * 35}] (raymarch_state), got {tuple(state.shape)}")
         a.state = _ptr(_chk(state, "state"))
-    # scratch of the three-waves-per-SIMD forward variant (hfagp.h HfagpRaymarchArgs::workspace): taken from torch's caching
-    # allocator per call, so launches on different streams never share it.  HFAGP_RAY_COMPACT=0: the two-wave variant (calls without `state`).
-    ws_bytes = L.lib().hfagp_raymarch_workspace_bytes(C.byref(a)) if RAY_COMPACT else 0
-    workspace = torch.empty(ws_bytes // 4, device=dev, dtype=torch.float32) if ws_bytes else None
-    a.workspace = _ptr(workspace)
     L.check(L.lib().hfagp_raymarch_fwd(C.byref(a), _stream()), "raymarch_fwd")
     return feat, depth, wsum, tmm
-
-
-RAY_COMPACT = os.environ.get("HFAGP_RAY_COMPACT", "1") != "0"      # developer switch (A/B of the forward variants)
 
 
 def raymarch_state(b: int, res: int, sc: int, sf: int, device) -> torch.Tensor:

@@ -85,15 +85,9 @@ typedef struct {
      * given the same buffer (fwd.state) reads them instead of gathering and decoding every sample again for the
      * compositing adjoint.  NULL: nothing is saved / everything is recomputed.                                       */
     float*       state;
-    /* optional (ABI 9), hfagp_raymarch_workspace_bytes(a) bytes of scratch for hfagp_raymarch_fwd: with it (or with `state`) and
-     * planes_absmax the forward runs its three-waves-per-SIMD variant, which parks the colours of the importance samples of the
-     * ray a wave is working on here (19 MB: L2 resident).  NULL: the two-waves-per-SIMD variant, same results to rounding.
-     * Not shared between launches that may overlap (one buffer per stream).                                           */
-    float*       workspace;
 } HfagpRaymarchArgs;
 
 int hfagp_raymarch_fwd(const HfagpRaymarchArgs* a, void* stream);
-size_t hfagp_raymarch_workspace_bytes(const HfagpRaymarchArgs* a);   /* 0: the compact variant does not apply (no planes_absmax, or state given) */
 
 /* ------------------------------------------------------------------ styles
  * styles[b][i] = (w[b] . A[i]) / sqrt(w_dim) * 1 + bias[i]   (then * style_gain)
