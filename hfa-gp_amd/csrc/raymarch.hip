@@ -22,30 +22,22 @@
 //     transmittance / CDF scans are wavefront shuffle scans; the 48+48 merge is a rank count.
 //   * final colour = sum_j omega_j c_j with omega_j = (w_{j-1} + w_j)/2 — algebraically the
 //     midpoint rule of MipRayMarcher2, without forming the 95 midpoint colours.
-#include <cstdlib>
 #include <type_traits>
 #include "raymarch_common.h"
 
 namespace hfagp {
 
-// PIPE (forward kernel with the 16-bit decoder): the colours of the samples live in REGISTERS, the CDF scratch shares the omega
-// array, the backward-only arrays shrink to nothing, and the 17 KB that frees hold a 16 KB LANDING ZONE for the texel loads of the
-// next tile (raymarch_common.h pre_issue).
-template <int NC, int NF, bool PIPE = false>
+template <int NC, int NF>
 struct WaveLds {
     static constexpr int SC = 16 * NC, SF = 16 * NF, S = SC + SF;
-    static_assert(!PIPE || SF >= SC, "the CDF scratch (2 x SC floats) aliases om[S]");
-    float col[PIPE ? 4 : S * CS];
+    float col[S * CS];
     float t[S], sig[S];        // by sample id: coarse 0..SC-1, fine SC..S-1
     float ts[S], ss[S];        // sorted by depth
     float om[S];               // colour weight by sample id
     int sid[S];                // sorted position -> sample id
-    float cdf_[PIPE ? 4 : SC], tmid_[PIPE ? 4 : SC];
-    float pp[PIPE ? 4 : S];    // backward: g . colour per sample
-    float g2[PIPE ? 4 : 32];   // backward: 2 * dL/dfeat of this ray
-    float4 land[PIPE ? 16 * 64 : 1];   // PIPE: [slot = plane * 8 + tap * 2 + half][lane] 16-byte pieces written by the LDS-DMA loads
-    __device__ __forceinline__ float* cdf() { return PIPE ? om : cdf_; }          // (dead before om is first written)
-    __device__ __forceinline__ float* tmid() { return PIPE ? om + SC : tmid_; }
+    float cdf[SC], tmid[SC];
+    float pp[S];               // backward: g . colour per sample
+    float g2[32];              // backward: 2 * dL/dfeat of this ray
 };
 
 // GRADS = false: the forward renderer.  GRADS = true: first half of the backward pass — the same forward
@@ -57,16 +49,10 @@ struct WaveLds {
 // FROM_STATE (GRADS only): the per-sample colours, densities, depths and sort order of every ray are READ from
 // HfagpRaymarchArgs::state, where the forward call of the same step left them (13.4 KB per ray), instead of being recomputed
 // — no gather, no decoder: the compositing adjoint alone.
-// PIPE (forward, DEC16): 8-wave workgroups, one per CU (the same two waves per SIMD); per pass the texel loads of tile t+1 are in
-// flight under the decoder of tile t — what the kernel waits for is the round trip of the gather, once per tile, and more waves do
-// not help (three per SIMD with 8 loads in flight each: 12 % slower; profiles/r03_raymarch_valu.md) — with planes 0 and 1 landing in
-// LDS and plane 2 in 32 registers.  The tile loops are unrolled (the colours of tile t are registers colr[t]).
-template <int NC, int NF, bool GRADS, bool DEC16, bool FROM_STATE = false, bool PIPE = false>
-__global__ void __launch_bounds__(PIPE ? 512 : 256, PIPE ? 1 : 2) raymarch_kernel(const RayParams p) {
+template <int NC, int NF, bool GRADS, bool DEC16, bool FROM_STATE = false>
+__global__ void __launch_bounds__(256, 2) raymarch_kernel(const RayParams p) {
     static_assert(!FROM_STATE || GRADS, "the saved state is consumed by the backward pass");
-    static_assert(!PIPE || (DEC16 && !GRADS), "the pipelined variant is the forward renderer with the 16-bit decoder");
-    constexpr int NW = PIPE ? 8 : 4;            // waves per workgroup
-    using L = WaveLds<NC, NF, PIPE>;
+    using L = WaveLds<NC, NF>;
     constexpr int SC = L::SC, SF = L::SF, S = L::S;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -84,7 +70,7 @@ __global__ void __launch_bounds__(PIPE ? 512 : 256, PIPE ? 1 : 2) raymarch_kerne
         load_decoder(a, j, g, dec32);
         make_dec16(dec32, a.planes_absmax, lane, dec);
         if constexpr (kL1Lds) {                  // layer 1 of the decoder -> workgroup-shared LDS image (behind the four wave windows)
-            if (wave == 0) store_dec16_l1(dec, reinterpret_cast<float*>(smem + NW * sizeof(L)), lane);
+            if (wave == 0) store_dec16_l1(dec, reinterpret_cast<float*>(smem + 4 * sizeof(L)), lane);
             prescale_dec16_l1(dec);              // (what stays in registers moves to base 2 as well)
             __syncthreads();
         }
@@ -93,7 +79,7 @@ __global__ void __launch_bounds__(PIPE ? 512 : 256, PIPE ? 1 : 2) raymarch_kerne
     }
     constexpr int kStateFloats = S * 35;        // per ray: col [S][32] | ts [S] | ss [S] | sid [S]
 
-    const RaySchedule sch = ray_schedule(p.total_rays, wave, NW);
+    const RaySchedule sch = ray_schedule(p.total_rays, wave);
     // The set-up of a ray — position in the sequence -> (frame, pixel) with five integer divisions, the camera ray with seven
     // IEEE divisions and a square root — is the same for all 64 lanes: computed per ray it was ~300 redundant instructions.
     // Instead lane l prepares the wave's ray number l of the next 64, and the ray loop picks its values with v_readlane.
@@ -113,8 +99,6 @@ __global__ void __launch_bounds__(PIPE ? 512 : 256, PIPE ? 1 : 2) raymarch_kerne
     #pragma unroll 1
     for (int k = 0; k < nbatch; ++k) {
         const int b = __builtin_amdgcn_readlane(b_l, k), ray = __builtin_amdgcn_readlane(ray_l, k);    // wave-uniform -> scalar registers
-        float4 colr[PIPE ? NC + NF : 1][2];     // PIPE: colours of sample 16 t + j, channels 16 ot + 4 g .. + 3, of this lane (j, g)
-        (void)colr;
         if constexpr (FROM_STATE) {
             const float* st = a.state + (size_t)ray * kStateFloats;
 #pragma unroll 4
@@ -148,7 +132,7 @@ __global__ void __launch_bounds__(PIPE ? 512 : 256, PIPE ? 1 : 2) raymarch_kerne
             // each (4x fewer tag look-ups in the texture addresser: 2.6 -> 2.0 ms per 8 frames; 8 lanes per line with two
             // samples per lane measured 2.3 ms).  The interpolated features then move to the MFMA layout (lane 16g + j <-
             // lane 4j + g).
-            auto decode_tile = [&](int s0, float f[8], float4* creg = nullptr) {
+            auto decode_tile = [&](int s0, float f[8]) {
                 const int s = s0 + j;
                 const int src = 4 * j + g;
     #pragma unroll
@@ -156,7 +140,7 @@ __global__ void __launch_bounds__(PIPE ? 512 : 256, PIPE ? 1 : 2) raymarch_kerne
                 f32x4 o[2];
                 float sigma;
                 if constexpr (kL1Lds) {
-                    decoder_fwd16_l1(dec, reinterpret_cast<const float*>(smem + NW * sizeof(L)), lane, f, sigma, o);
+                    decoder_fwd16_l1(dec, reinterpret_cast<const float*>(smem + 4 * sizeof(L)), lane, f, sigma, o);
                 } else {
                     f32x4 h[4];
                     if constexpr (DEC16) decoder_fwd16<false>(dec, f, h, h, sigma, o);
@@ -177,43 +161,8 @@ __global__ void __launch_bounds__(PIPE ? 512 : 256, PIPE ? 1 : 2) raymarch_kerne
                         cv.z = sigmoid_f(o[ot][2]) * 1.002f - 0.001f;
                         cv.w = sigmoid_f(o[ot][3]) * 1.002f - 0.001f;
                     }
-                    if constexpr (PIPE) {
-                        creg[ot] = cv;
-                        if (a.state) *reinterpret_cast<float4*>(a.state + (size_t)ray * kStateFloats + s * 32 + 16 * ot + 4 * g) = cv;
-                    } else {
-                        *reinterpret_cast<float4*>(&lds.col[s * CS + 16 * ot + 4 * g]) = cv;
-                    }
+                    *reinterpret_cast<float4*>(&lds.col[s * CS + 16 * ot + 4 * g]) = cv;
                 }
-            };
-            // PIPE: one pass (TB = 0: coarse, NC: fine) with the gather of tile t + 1 issued before the decoder of tile t
-            auto pipe_tiles = [&](auto tb_tag, auto t_tag, TilePre& tp, auto&& self) __attribute__((always_inline)) -> void {
-                constexpr int TB = decltype(tb_tag)::value, T = decltype(t_tag)::value, NT = TB == 0 ? NC : NF;
-                if constexpr (T < NT) {
-                    float f[8];
-                    pre_reduce(tp, lds.land, lane, f);
-                    if constexpr (T + 1 < NT) {
-                        WAVE_SYNC();                       // the landing zone has been read: it may be written again
-                        PlaneTaps taps[3];
-                        __builtin_amdgcn_s_setprio(3);
-                        sample_taps(p, o3, d3, lds.t[16 * (TB + T + 1) + (lane >> 2)], taps);
-                        pre_issue(a, b, lane & 3, taps, tp, lds.land);
-                        __builtin_amdgcn_s_setprio(0);
-                    }
-                    decode_tile(16 * (TB + T), f, colr[PIPE ? TB + T : 0]);
-                    self(tb_tag, std::integral_constant<int, T + 1>{}, tp, self);
-                }
-            };
-            auto pipe_pass = [&](auto tb_tag) __attribute__((always_inline)) {
-                constexpr int TB = decltype(tb_tag)::value;
-                TilePre tp;
-                {
-                    PlaneTaps taps[3];
-                    __builtin_amdgcn_s_setprio(3);
-                    sample_taps(p, o3, d3, lds.t[16 * TB + (lane >> 2)], taps);
-                    pre_issue(a, b, lane & 3, taps, tp, lds.land);
-                    __builtin_amdgcn_s_setprio(0);
-                }
-                pipe_tiles(tb_tag, std::integral_constant<int, 0>{}, tp, pipe_tiles);
             };
             auto eval_tile = [&](int s0) {
                 float f[8];
@@ -251,8 +200,7 @@ __global__ void __launch_bounds__(PIPE ? 512 : 256, PIPE ? 1 : 2) raymarch_kerne
             };
 
             // ---- coarse pass
-            if constexpr (PIPE) pipe_pass(std::integral_constant<int, 0>{});
-            else eval_pass(0, NC);
+            eval_pass(0, NC);
             WAVE_SYNC();
 
             // ---- coarse compositing weights (MipRayMarcher2) -> importance depths (sample_pdf)
@@ -265,7 +213,7 @@ __global__ void __launch_bounds__(PIPE ? 512 : 256, PIPE ? 1 : 2) raymarch_kerne
                     const float alpha = 1.f - exp_f(-(dm * (t1 - t0)));
                     sh = 1.f - alpha + 1e-10f;
                     w = alpha;
-                    lds.tmid()[lane] = 0.5f * (t0 + t1);
+                    lds.tmid[lane] = 0.5f * (t0 + t1);
                 }
                 const float incl = wave_scan_mul(sh, lane);
                 float T = __shfl_up(incl, 1);
@@ -281,7 +229,7 @@ __global__ void __launch_bounds__(PIPE ? 512 : 256, PIPE ? 1 : 2) raymarch_kerne
                 const float tot = wave_sum(pw);
                 const float pdf = inpdf ? pw / tot : 0.f;
                 const float c = wave_scan_add(pdf, lane);
-                if (lane <= SC - 3) lds.cdf()[lane] = lane == 0 ? 0.f : c;   // SC-2 entries
+                if (lane <= SC - 3) lds.cdf[lane] = lane == 0 ? 0.f : c;   // SC-2 entries
             }
             WAVE_SYNC();
             if (lane < SF) {
@@ -292,11 +240,11 @@ __global__ void __launch_bounds__(PIPE ? 512 : 256, PIPE ? 1 : 2) raymarch_kerne
 #pragma unroll
                 for (int step = 32; step > 0; step >>= 1) {
                     const int probe = inds + step;
-                    if (probe <= SC - 2 && lds.cdf()[probe - 1] <= u) inds = probe;
+                    if (probe <= SC - 2 && lds.cdf[probe - 1] <= u) inds = probe;
                 }
                 const int below = max(inds - 1, 0), above = min(inds, SC - 3);
-                const float c0 = lds.cdf()[below], c1 = lds.cdf()[above];
-                const float b0 = lds.tmid()[below], b1 = lds.tmid()[above];
+                const float c0 = lds.cdf[below], c1 = lds.cdf[above];
+                const float b0 = lds.tmid[below], b1 = lds.tmid[above];
                 float den = c1 - c0;
                 if (den < 1e-5f) den = 1.f;
                 lds.t[SC + lane] = b0 + (u - c0) / den * (b1 - b0);
@@ -304,8 +252,7 @@ __global__ void __launch_bounds__(PIPE ? 512 : 256, PIPE ? 1 : 2) raymarch_kerne
             WAVE_SYNC();
 
             // ---- fine pass
-            if constexpr (PIPE) pipe_pass(std::integral_constant<int, NC>{});
-            else eval_pass(SC, NF);
+            eval_pass(SC, NF);
             WAVE_SYNC();
 
             // ---- merge: rank of every sample in the union, stable, coarse before fine on ties.  The coarse depths are already
@@ -354,10 +301,8 @@ __global__ void __launch_bounds__(PIPE ? 512 : 256, PIPE ? 1 : 2) raymarch_kerne
         if constexpr (!GRADS) {
             if (a.state) {                          // forward of a step that will be differentiated: leave the state behind
                 float* st = a.state + (size_t)ray * kStateFloats;
-                if constexpr (!PIPE) {              // (PIPE: decode_tile stored the colours from its registers)
 #pragma unroll 4
-                    for (int i = lane; i < S * 32; i += 64) st[i] = lds.col[(i >> 5) * CS + (i & 31)];
-                }
+                for (int i = lane; i < S * 32; i += 64) st[i] = lds.col[(i >> 5) * CS + (i & 31)];
                 for (int i = lane; i < S; i += 64) {
                     st[S * 32 + i] = lds.ts[i];
                     st[S * 33 + i] = lds.ss[i];
@@ -465,39 +410,7 @@ __global__ void __launch_bounds__(PIPE ? 512 : 256, PIPE ? 1 : 2) raymarch_kerne
         if constexpr (GRADS) continue;      // the forward outputs are not needed again
 
         // ---- colour: rgb[c] = sum_s omega_s * col[s][c]   (two half-ranges of samples per channel)
-        if constexpr (PIPE) {
-            // lane (j, g) holds the colours of samples 16 t + j: weight them, then sum over the 16 samples of the row of lanes
-            float acc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-            for (int t = 0; t < NC + NF; ++t) {
-                const float w = lds.om[16 * t + j];
-#pragma unroll
-                for (int ot = 0; ot < 2; ++ot) {
-                    acc[ot][0] = fmaf(w, colr[t][ot].x, acc[ot][0]);
-                    acc[ot][1] = fmaf(w, colr[t][ot].y, acc[ot][1]);
-                    acc[ot][2] = fmaf(w, colr[t][ot].z, acc[ot][2]);
-                    acc[ot][3] = fmaf(w, colr[t][ot].w, acc[ot][3]);
-                }
-            }
-#pragma unroll
-            for (int m = 1; m < 16; m <<= 1)
-#pragma unroll
-                for (int ot = 0; ot < 2; ++ot)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[ot][r] += __shfl_xor(acc[ot][r], m);
-            if (j == 0) {
-#pragma unroll
-                for (int ot = 0; ot < 2; ++ot) {
-                    float v[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        v[r] = a.white_back ? acc[ot][r] + 1.f - wsum : acc[ot][r];
-                        v[r] = v[r] * 2.f - 1.f;
-                    }
-                    *reinterpret_cast<float4*>(a.feat + (size_t)ray * 32 + 16 * ot + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
-                }
-            }
-        } else {
+        {
             const int c = lane & 31, hf = lane >> 5;
             float acc = 0.f;
             for (int s = hf * (S / 2); s < (hf + 1) * (S / 2); ++s) acc = fmaf(lds.om[s], lds.col[s * CS + c], acc);
@@ -518,40 +431,35 @@ __global__ void __launch_bounds__(PIPE ? 512 : 256, PIPE ? 1 : 2) raymarch_kerne
     }
 }
 
-template <int NC, int NF, bool GRADS, bool DEC16, bool FROM_STATE = false, bool PIPE = false>
+template <int NC, int NF, bool GRADS, bool DEC16, bool FROM_STATE = false>
 static int launch(const RayParams& p, hipStream_t s) {
-    constexpr int NW = PIPE ? 8 : 4;
-    const size_t lds = NW * sizeof(WaveLds<NC, NF, PIPE>) + ((DEC16 && !FROM_STATE) ? kDecL1Floats * sizeof(float) : 0);
-    int blocks = (p.total_rays + NW - 1) / NW;
-    const int cap = kNumCU * (PIPE ? 1 : 2) * 4;          // resident workgroups per CU, a few rounds each
+    const size_t lds = 4 * sizeof(WaveLds<NC, NF>) + ((DEC16 && !FROM_STATE) ? kDecL1Floats * sizeof(float) : 0);
+    int blocks = (p.total_rays + 3) / 4;
+    const int cap = kNumCU * 2 * 4;          // 2 resident workgroups per CU, a few rounds each
     if (blocks > cap) blocks = cap;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&raymarch_kernel<NC, NF, GRADS, DEC16, FROM_STATE, PIPE>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&raymarch_kernel<NC, NF, GRADS, DEC16, FROM_STATE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             set_error("raymarch: cannot raise dynamic LDS to %zu bytes: %s", lds, hipGetErrorString(e));
             return HFAGP_ELAUNCH;
         }
     }
-    raymarch_kernel<NC, NF, GRADS, DEC16, FROM_STATE, PIPE><<<blocks, NW * 64, lds, s>>>(p);
+    raymarch_kernel<NC, NF, GRADS, DEC16, FROM_STATE><<<blocks, 256, lds, s>>>(p);
     return check_launch(GRADS ? "raymarch_bwd/samples" : "raymarch_fwd");
 }
 
-template <bool GRADS, bool DEC16, bool FROM_STATE = false, bool PIPE = false>
+template <bool GRADS, bool DEC16, bool FROM_STATE = false>
 static int launch_n(const RayParams& p, hipStream_t s) {
     const int n = p.a.Sc / 16;
-    return n == 3   ? launch<3, 3, GRADS, DEC16, FROM_STATE, PIPE>(p, s)
-           : n == 2 ? launch<2, 2, GRADS, DEC16, FROM_STATE, PIPE>(p, s)
-                    : launch<1, 1, GRADS, DEC16, FROM_STATE, PIPE>(p, s);
+    return n == 3 ? launch<3, 3, GRADS, DEC16, FROM_STATE>(p, s) : n == 2 ? launch<2, 2, GRADS, DEC16, FROM_STATE>(p, s)
+                                                                          : launch<1, 1, GRADS, DEC16, FROM_STATE>(p, s);
 }
 
 int launch_raymarch(const RayParams& p, bool grads, hipStream_t s) {
     const bool dec16 = p.a.planes_absmax != nullptr;
     if (grads && p.a.state) return launch_n<true, false, true>(p, s);        // (no decoder in this variant)
     if (grads) return dec16 ? launch_n<true, true>(p, s) : launch_n<true, false>(p, s);
-    // forward with the 16-bit decoder: the pipelined variant (HFAGP_DEV_RAY_PIPE=0: developer switch back to the plain one)
-    static const bool pipe = [] { const char* e = getenv("HFAGP_DEV_RAY_PIPE"); return !(e && e[0] == '0'); }();
-    if (dec16 && pipe) return launch_n<false, true, false, true>(p, s);
     return dec16 ? launch_n<false, true>(p, s) : launch_n<false, false>(p, s);
 }
 

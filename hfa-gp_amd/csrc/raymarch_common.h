@@ -617,61 +617,6 @@ __device__ __forceinline__ void tile_reduce(const TileLoads& t, float f[8]) {
     }
 }
 
-// ---- the PIPELINED gather of the forward kernel (raymarch.hip, PIPE): the 24 texel loads of tile t+1 are issued BEFORE the
-// decoder of tile t.  In registers that is 96 more live across the decoder (85 spilled); here the two float4 of the 8 taps of
-// planes 0 and 1 go STRAIGHT TO LDS (global_load_lds_dwordx4: lane l's 16 bytes land at slot * 1 KB + 16 l of the wave's
-// landing zone — no register until they are read back) and only plane 2's eight loads (32 registers) wait in registers.
-struct TilePre {
-    float4 v0[4], v1[4];        // plane 2
-    float w[3][4];
-};
-typedef __attribute__((address_space(3))) void* lds_dma_ptr;
-typedef __attribute__((address_space(1))) const void* global_dma_ptr;
-__device__ __forceinline__ void pre_issue(const HfagpRaymarchArgs& a, int b, int g, const PlaneTaps taps[3], TilePre& t, float4* land) {
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
-        const char* base = reinterpret_cast<const char*>(a.planes + ((size_t)(b * 3 + pl) * a.H * a.W) * 32);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const unsigned off = ((unsigned)taps[pl].idx[k] * 32u + 8u * g) * 4u;
-            if (pl < 2) {
-                __builtin_amdgcn_global_load_lds((global_dma_ptr)(base + off), (lds_dma_ptr)(land + (pl * 8 + 2 * k) * 64), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((global_dma_ptr)(base + off + 16), (lds_dma_ptr)(land + (pl * 8 + 2 * k + 1) * 64), 16, 0, 0);
-            } else {
-                t.v0[k] = *reinterpret_cast<const float4*>(base + off);
-                t.v1[k] = *reinterpret_cast<const float4*>(base + off + 16);
-            }
-            t.w[pl][k] = taps[pl].w[k];
-        }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-}
-// same arithmetic, same order as tile_reduce (bit-identical features)
-__device__ __forceinline__ void pre_reduce(const TilePre& t, const float4* land, int lane, float f[8]) {
-    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): the LDS-DMA pieces have landed (and plane 2 is in its registers)
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
-        float4 v0[4], v1[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            v0[k] = pl < 2 ? land[(pl * 8 + 2 * k) * 64 + lane] : t.v0[k];
-            v1[k] = pl < 2 ? land[(pl * 8 + 2 * k + 1) * 64 + lane] : t.v1[k];
-        }
-        const float v[4][8] = {{v0[0].x, v0[0].y, v0[0].z, v0[0].w, v1[0].x, v1[0].y, v1[0].z, v1[0].w},
-                               {v0[1].x, v0[1].y, v0[1].z, v0[1].w, v1[1].x, v1[1].y, v1[1].z, v1[1].w},
-                               {v0[2].x, v0[2].y, v0[2].z, v0[2].w, v1[2].x, v1[2].y, v1[2].z, v1[2].w},
-                               {v0[3].x, v0[3].y, v0[3].z, v0[3].w, v1[3].x, v1[3].y, v1[3].z, v1[3].w}};
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            float acc = pl == 0 ? v[0][c] * t.w[0][0] : fmaf(v[0][c], t.w[pl][0], f[c]);
-            acc = fmaf(v[1][c], t.w[pl][1], acc);
-            acc = fmaf(v[2][c], t.w[pl][2], acc);
-            f[c] = fmaf(v[3][c], t.w[pl][3], acc);
-        }
-    }
-}
-
 // ---- LDS images for the backward kernels (lane-linear rows of 64 dwords: every ds_read_b32 is conflict-free)
 // Dec16Regs image: rows 0-15 w0h[mt][q], 16-31 w0l, 32-47 w1h[ot][ks][q], 48-63 w1l, 64-79 b0c[mt][r], 80-95 wsig[mt][r],
 // 96-103 b1c[ot][r], 104 bsig, 105 sF, 106 sH, 107 u1, 108 u2
