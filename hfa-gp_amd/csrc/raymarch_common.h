@@ -381,6 +381,10 @@ struct Dec16Regs {
     float bsig;
     float sF, sH;                     // down-scales of the features / hidden units
     float u1, u2;                     // up-scales of the layer-1 / layer-2 accumulators
+    // the sigma row of W1 as a THIRD layer-2 M tile (row 0 = the row, rows 1..15 zero; K step ks, same K order as w1h) with its
+    // own weight scale, and the up-scale of that accumulator (decoder_fwd16_l1: sigma on the matrix pipe, not a 16-FMA dot)
+    u32x4r wsh[2], wsl[2];
+    float u2s;
 };
 
 // from the fp32 register image + the bound M on |planes| (max over the HFAGP_ABSMAX_SLOTS slots)
@@ -434,6 +438,24 @@ __device__ __forceinline__ void make_dec16(const DecoderRegs& w, const float* pl
         for (int r = 0; r < 4; ++r) d.b1c[ot][r] = w.b1c[ot][r];
     }
     d.bsig = w.bsig;
+    {
+        float ms = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ms = fmaxf(ms, fabsf(w.wsig[mt][r]));
+        float uWs;
+        const float sWs = down_scale(wave_max(ms), &uWs);
+        d.u2s = uH * uWs;
+        const bool row0 = (lane & 15) == 0;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            float v[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] = row0 ? w.wsig[2 * ks + (c >> 2)][c & 3] * sWs : 0.f;
+            split8_f16(v, d.wsh[ks], d.wsl[ks]);
+        }
+    }
 }
 
 // drop-in for decoder_fwd: same inputs / outputs / register layouts
@@ -527,7 +549,7 @@ __device__ __forceinline__ float softplus2_f(float x2) {             // softplus
 }
 __device__ __forceinline__ float sigmoid2_f(float y2) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-y2)); }
 
-// h: softplus / ln 2 of the hidden layer; o: the colour logits times log2 e (feed sigmoid2_f); sigma: as decoder_fwd16
+// h: softplus / ln 2 of the hidden layer; o: the colour logits times log2 e (feed sigmoid2_f); sigma: on the lanes g == 0 only
 __device__ __forceinline__ void decoder_fwd16_l1(const Dec16Regs& w, const float* img, int lane, const float f[8], float& sigma,
                                                  f32x4 o[2]) {
     const int g = lane >> 4;
@@ -539,24 +561,16 @@ __device__ __forceinline__ void decoder_fwd16_l1(const Dec16Regs& w, const float
         split8_f16(fs, fh, fl);
     }
     f32x4 h[4];
-    float sg = 0.f;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         const u32x4r ah = *reinterpret_cast<const u32x4r*>(img + ((0 * 4 + mt) * 64 + lane) * 4);
         const u32x4r al = *reinterpret_cast<const u32x4r*>(img + ((1 * 4 + mt) * 64 + lane) * 4);
         const float4 b0 = *reinterpret_cast<const float4*>(img + 2048 + (mt * 4 + g) * 4);
-        const float4 ws = *reinterpret_cast<const float4*>(img + 2048 + 64 + (mt * 4 + g) * 4);
-        const float b0v[4] = {b0.x, b0.y, b0.z, b0.w}, wsv[4] = {ws.x, ws.y, ws.z, ws.w};
+        const float b0v[4] = {b0.x, b0.y, b0.z, b0.w};
         const f32x4 acc = mfma3_f16(ah, al, fh, fl, f32x4{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            h[mt][r] = softplus2_f(fmaf(acc[r], w.u1, b0v[r]));
-            sg = fmaf(h[mt][r], wsv[r], sg);
-        }
+        for (int r = 0; r < 4; ++r) h[mt][r] = softplus2_f(fmaf(acc[r], w.u1, b0v[r]));
     }
-    sg += __shfl_xor(sg, 16);
-    sg += __shfl_xor(sg, 32);
-    sigma = sg + w.bsig;
     u32x4r hh[2], hl[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -564,6 +578,13 @@ __device__ __forceinline__ void decoder_fwd16_l1(const Dec16Regs& w, const float
 #pragma unroll
         for (int c = 0; c < 8; ++c) hs[c] = h[2 * ks + (c >> 2)][c & 3] * w.sH;
         split8_f16(hs, hh[ks], hl[ks]);
+    }
+    {   // sigma = row 0 of a third M tile of layer 2 (6 MFMAs on a pipe that is 20 % busy instead of 16 FMAs + 2 shuffles + the
+        // row's LDS reads on the vector ALU that bounds the kernel); C row 0 = register 0 of the lanes g == 0, column j = sample
+        f32x4 as = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) as = mfma3_f16(w.wsh[ks], w.wsl[ks], hh[ks], hl[ks], as);
+        sigma = fmaf(as[0], w.u2s, w.bsig);       // (valid on the lanes g == 0: the only ones that store it)
     }
 #pragma unroll
     for (int ot = 0; ot < 2; ++ot) {
