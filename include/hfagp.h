@@ -17,6 +17,26 @@
  *                              (in-repo twin: fused_leaky_relu, code/networks/encoder3d.py:7-8)
  *   hfagp_torgb_fwd         <- ToRGBLayer for img_channels=3 + upsample2d(img) skip add
  *   hfagp_skip_upsample_add <- img = upsample2d(img, resample_filter) + y   (SynthesisBlock 'skip')
+ *   hfagp_torgb_skip_fwd    <- ToRGBLayer (96 tri-plane channels) + the skip add, one streaming pass
+ *   hfagp_torgb_finish_fwd  <- bias + clamp + skip add of a 3-channel ToRGBLayer whose sums rode in the conv's epilogue
+ *   hfagp_upconv_fir_fwd    <- conv2d_resample(up=2) + bias_act of a SynthesisLayer in one pass (+ _scratch_bytes)
+ *   hfagp_style_batch_fwd   <- the affine + demodulation of EVERY layer of one synthesis() call, one launch
+ *   hfagp_fc_fwd            <- FullyConnectedLayer (MappingNetwork; EqualLinear twin: code/networks/encoder3d.py:112-139)
+ *   hfagp_weight_prep[_split|_prec] <- (no reference counterpart: MFMA operand images of a conv weight, per weight version)
+ *   hfagp_qr_gram_fwd / hfagp_qr_refine_fwd <- torch.qr(bases.T) of get_latent (code/networks/headnerf.py:91,187,246)
+ *   hfagp_planes_to_nhwc    <- planes.view(N, 3, 32, H, W) of TriPlaneGenerator.synthesis (layout change for the gather)
+ *   hfagp_nchw_to_nhwc / hfagp_nhwc_to_nchw <- tensor layout at the module boundary (reference tensors are NCHW)
+ *   hfagp_pool_mse_fwd/_bwd <- face_pool (AdaptiveAvgPool2d) + MSELoss of gen_update (code/trainer_rgb.py:63,84-85) and its backward
+ *   hfagp_blur_down_fwd/_bwd<- Blur + stride-2 sampling in front of the ResBlock skip (code/networks/encoder3d.py:59-73,142-199)
+ *   hfagp_allreduce_f32     <- the gradient all-reduce DistributedDataParallel does for the reference
+ *                              (code/trainer_rgb.py:56, code/trainer_3dmm.py:29, code/trainer_audio.py:30-34; NCCL group: code/train_rgb.py:57)
+ * backward (the reference gets these from torch.autograd through EG3D's custom ops; g_loss.backward(), code/trainer_rgb.py:93):
+ *   hfagp_raymarch_bwd      <- autograd of the renderer: grid_sample / decoder / compositing adjoints
+ *   hfagp_modconv_fwd modes HFAGP_CONV3X3_BWD / HFAGP_CONVS2_BWD <- conv2d_gradfix data gradients (the same GEMM kernel)
+ *   hfagp_conv_wgrad (+ _workspace_bytes) <- conv2d_gradfix weight gradients
+ *   hfagp_pointwise_bwd     <- bias_act backward + noise-strength / bias gradients + demodulation adjoint of a SynthesisLayer
+ *   hfagp_upfir_bwd, hfagp_upsample2d_bwd, hfagp_upfirdn2d_bwd, hfagp_bias_act_bwd <- upfirdn2d / bias_act backward
+ *   hfagp_style_bwd / hfagp_style_batch_bwd, hfagp_affine_grad, hfagp_channel_sum <- affine / demodulation / bias gradients
  *
  * Contract:
  *   - plain pointers and sizes only; all pointers are DEVICE pointers owned by the caller;
