@@ -84,9 +84,11 @@ def weight_prep_prec(weight: torch.Tensor, precision: str) -> torch.Tensor:
     _chk(weight, "weight")
     co, ci, kh, kw = weight.shape
     nparts = NPARTS[precision]
-    # + 512 B behind the image: with Cout % 128 != 0 the 128-wide tile reads one partial row past it (hfagp.h)
+    # + 512 B behind the image: with Cout % 128 != 0 the 128-wide tile reads one partial row past it (hfagp.h).  Only readable
+    # memory is needed there — the columns fed from it are never stored — so nothing is cleared (the RGB fitting step re-builds
+    # 21 images per step: clearing them was 0.24 ms of fill kernels).
     numel = nparts * kh * kw * (ci // 8) * co * 8
-    flat = torch.zeros(numel + 256, device=weight.device, dtype=_IMAGE_DTYPE[precision])
+    flat = torch.empty(numel + 256, device=weight.device, dtype=_IMAGE_DTYPE[precision])
     wb = flat[:numel].view(nparts, kh * kw, ci // 8, co, 8)
     L.check(L.lib().hfagp_weight_prep_prec(_ptr(weight), wb.data_ptr(), co, ci, kh * kw, PRECISIONS[precision], _stream()),
             "weight_prep_prec")
