@@ -83,7 +83,8 @@ __global__ void __launch_bounds__(256, 2) raymarch_kernel(const RayParams p) {
     // The set-up of a ray — position in the sequence -> (frame, pixel) with five integer divisions, the camera ray with seven
     // IEEE divisions and a square root — is the same for all 64 lanes: computed per ray it was ~300 redundant instructions.
     // Instead lane l prepares the wave's ray number l of the next 64, and the ray loop picks its values with v_readlane.
-    for (int seq0 = __builtin_amdgcn_readfirstlane((int)sch.begin); seq0 < (int)sch.end; seq0 += 64 * sch.stride) {
+    for (long long q0 = sch.begin; q0 < sch.end; q0 += 64ll * sch.stride) {      // (64-bit: the last step may pass 2^31)
+    const int seq0 = __builtin_amdgcn_readfirstlane((int)q0);
     int b_l = 0, ray_l = 0;
     float o_l[3] = {0.f, 0.f, 0.f}, d_l[3] = {0.f, 0.f, 0.f};
     {
