@@ -221,7 +221,7 @@ def test_shard_range_and_epoch_batches():
                 assert abs(per_rank[r][s][1] - counts[r] * world / sum(counts)) < 1e-12
 
 
-def _fit_worker(rank, world, port, out):
+def _fit_worker(rank, world, port, out, nframes=3):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -230,7 +230,7 @@ def _fit_worker(rank, world, port, out):
         tr = make_trainer(seed=10 + rank, world_size=world, rank=rank)
         tr.optimizer = torch.optim.SGD(tr.gen.parameters(), lr=0.05)
         start = tr.gen.bases.detach().clone()
-        reals, labels, params = _frame_set(3)
+        reals, labels, params = _frame_set(nframes)
         losses = fit_frames(tr, reals, labels, params, epochs=1, batch=1)
         out[rank] = {"bases": tr.gen.bases.detach().clone(), "n": len(losses), "start": start,
                      "fc0": tr.gen.weights_3dmm.fc[0].weight.detach().clone()}
@@ -264,6 +264,29 @@ def test_fit_frames_two_ranks_ragged_equals_single_rank_global_batch():
     # (the test-only oracle generator gives every sample the same renderer uniforms, so the two runs are comparable:
     # compare the UPDATES, which are ~3e-4 on an O(1) basis)
     want, got = tr.gen.bases.detach() - start, r0["bases"] - start
+    assert want.abs().max() > 1e-4
+    assert (got - want).abs().max() <= 2e-3 * want.abs().max(), ((got - want).abs().max(), want.abs().max())
+
+
+def test_fit_frames_four_ranks_ragged_equals_single_rank_global_batch():
+    """The same with FOUR ranks (BASELINE config 4 shards frames over 8): 5 frames, batch 1 per rank — shards [0,2) [2,3) [3,4)
+    [4,5): step 0 trains on frames {0, 2, 3, 4}, step 1 on frame 1 alone while three ranks join with empty batches."""
+    from hfa_gp_amd.trainer import shard_range
+    world, port = 4, _free_port()
+    assert [shard_range(5, r, world) for r in range(world)] == [(0, 2), (2, 3), (3, 4), (4, 5)]
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_fit_worker, args=(world, port, out, 5), nprocs=world, join=True)
+        res = [out[r] for r in range(world)]
+    assert all(r["n"] == 2 for r in res)
+    assert all(torch.equal(res[0]["bases"], r["bases"]) and torch.equal(res[0]["fc0"], r["fc0"]) for r in res[1:])
+    tr = make_trainer(seed=10)
+    tr.optimizer = torch.optim.SGD(tr.gen.parameters(), lr=0.05)
+    start = tr.gen.bases.detach().clone()
+    reals, labels, params = _frame_set(5)
+    for idx in ([0, 2, 3, 4], [1]):
+        tr.gen_update(reals[idx], labels[idx].clone(), params[idx])
+    want, got = tr.gen.bases.detach() - start, res[0]["bases"] - start
     assert want.abs().max() > 1e-4
     assert (got - want).abs().max() <= 2e-3 * want.abs().max(), ((got - want).abs().max(), want.abs().max())
 
