@@ -167,10 +167,15 @@ def cpu_baseline(cfg, state, runs: int, warmup: int, n1: bool, check=None):
     topo = cpu_topology()
     # n = all PHYSICAL cores of the box (torch's default pool is that already on the GPU box: 2 x 64)
     phys = topo["sockets"] * topo["cores_per_socket"]
+    threads_before = torch.get_num_threads()
     if phys > 0:
         torch.set_num_threads(phys)
     threads = torch.get_num_threads()
-    med, stages, totals = timed(runs, warmup)
+    try:
+        med, stages, totals = timed(runs, warmup)
+    except BaseException:
+        torch.set_num_threads(threads_before)
+        raise
     out = {"value": 1.0 / med, "unit": "frames/s", "cores": threads, "kind": "port", "cpu_model": cpu_model(),
            "topology": topo,
            "sample": f"median of {runs} x synthesis(B=1) of the {cfg.name} workload with the fp32 PyTorch-CPU oracle "
@@ -183,12 +188,14 @@ def cpu_baseline(cfg, state, runs: int, warmup: int, n1: bool, check=None):
         out["parity_vs_oracle"] = {"max_abs": float(err.abs().max()), "mse": float(err.pow(2).mean()),
                                    "what": "512^2 image of the HIP path (this run's default precision) vs the oracle's, same ws / "
                                            "camera / renderer uniforms, B = 1; north_star bar: MSE <= 1e-3 on [-1, 1] images"}
-    if n1:
-        torch.set_num_threads(1)
-        med1, st1, _ = timed(1, 0)
-        torch.set_num_threads(threads)
-        out["n1"] = {"value": 1.0 / med1, "cores": 1, "s_per_frame": med1,
-                     "stage_s": {"backbone": st1[0], "raymarch": st1[1], "superres": st1[2]}}
+    try:
+        if n1:
+            torch.set_num_threads(1)
+            med1, st1, _ = timed(1, 0)
+            out["n1"] = {"value": 1.0 / med1, "cores": 1, "s_per_frame": med1,
+                         "stage_s": {"backbone": st1[0], "raymarch": st1[1], "superres": st1[2]}}
+    finally:
+        torch.set_num_threads(threads_before)        # (the caller's thread count is restored whatever happens)
     return out
 
 
@@ -241,7 +248,7 @@ def train_legs(args, cfg_name, dev, rank, world, dist):
     3DMM-driven (config 4); ONE in-place all-reduce of the flat shared-gradient buffer per step when world > 1."""
     import torch
     from hfa_gp_amd.trainer import Trainer
-    from hfa_gp_amd.synthetic import look_at_label
+    from hfa_gp_amd.synthetic import look_at_label, perturb_state
     out = {}
     # (torch.backends.cudnn.benchmark = True makes the Encoder 0.7 ms per step faster — and MIOpen's exhaustive search took
     #  3.5 minutes of a fresh box's first run: left off)
@@ -251,6 +258,7 @@ def train_legs(args, cfg_name, dev, rank, world, dist):
         fa.generator_preset = cfg_name
         torch.manual_seed(0)
         tr_ = Trainer(fa, dev, rank=rank, world_size=world, mode=mode, lpips=lpips)
+        perturb_state(tr_.gen.generator)              # (the state of the own-size step parity tests, tests/test_gpu_round4.py)
         tr_.force_collective = os.environ.get("HFAGP_BENCH_FORCE_DIST") == "1"
         return fa, tr_
 
@@ -290,8 +298,25 @@ def train_legs(args, cfg_name, dev, rank, world, dist):
         phases = {k: sum(a.elapsed_time(b) for a, b in v) / max(len(v), 1) for k, v in spans.items()}
         return dt / steps * 1e3, phases
 
+    def kernel_events(tr, fa, B, steps=3):
+        """A SECOND pass of the same step with HIP events around the kernel families that carry it (generator.timing; the
+        events cost host time per launch, so the timed pass runs without them): {key: (ms per step, units per step, launches
+        per step)} — what `roofline_train` is computed from."""
+        real, params, label = inputs(fa, B, torch.Generator().manual_seed(40 + rank))
+        g = tr.gen.generator
+        g.timing = {}
+        for _ in range(steps):
+            if tr.mode == "rgb":
+                tr.gen_update(real, label.clone())
+            else:
+                tr.gen_update(real, label.clone(), params)
+        torch.cuda.synchronize()
+        table, g.timing = g.timing, None
+        return {k: (sum(e0.elapsed_time(e1) for e0, e1, _ in v) / steps, sum(u for _, _, u in v) / steps, len(v) / steps)
+                for k, v in table.items()}
+
     B = args.train_batch
-    batches = [B] if args.no_sweep else sorted({1, B, 4})
+    batches = [B] if (args.no_sweep or world > 1) else sorted({1, B, 4})
     for mode in ("3dmm", "rgb"):
         fa, tr = make(mode, "none")
         leg = {"frozen": {}, "tuned": {}, "shared_grad_bytes": None}
@@ -299,6 +324,7 @@ def train_legs(args, cfg_name, dev, rank, world, dist):
             ms, phases = timed(tr, fa, args.train_steps, b)
             leg["frozen"][b] = {"step_ms": ms, "phases_ms": phases}
         leg["shared_grad_bytes"] = 4 * tr.flat_grads().numel
+        leg["kernel_events"] = kernel_events(tr, fa, B)
         # after tune_iter the reference also trains the generator (trainer_rgb.py:69-71): all 30.7 M parameters get
         # gradients, which live in the same flat buffer and are all-reduced with the basis / driver gradients
         tr.tune_generator()
@@ -308,7 +334,7 @@ def train_legs(args, cfg_name, dev, rank, world, dist):
         out[mode] = leg
         del tr
         torch.cuda.empty_cache()
-    if args.lpips:
+    if args.lpips and world == 1:
         from hfa_gp_amd.lpips_alex import LPIPSAlex
         torch.manual_seed(1234)               # seeded random weights
         fa, tr = make("rgb", LPIPSAlex().to(dev))
@@ -465,7 +491,12 @@ def main():
         # no launcher: start the N ranks ourselves, exactly as the driver does
         env = dict(os.environ)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        sys.exit(subprocess.run(launcher_command(args.gpus, sys.argv[1:], _free_port()), env=env).returncode)
+        env.setdefault("NCCL_DEBUG", "WARN")          # RCCL's own warnings (ring build-up, IPC) reach stderr of the run
+        port = _free_port()
+        sys.stderr.write(f"[bench] no launcher (WORLD_SIZE unset): starting {args.gpus} ranks under torch.distributed.run, "
+                         f"rendezvous 127.0.0.1:{port}\n")
+        sys.stderr.flush()
+        sys.exit(subprocess.run(launcher_command(args.gpus, sys.argv[1:], port), env=env).returncode)
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -474,7 +505,7 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); no CPU fallback")
+        raise SystemExit(f"bench.py needs an MI355X (torch.cuda.is_available() is False); no CPU fallback [rank {rank} of {world}]")
     if args.share_device:
         local_rank = 0
     elif torch.cuda.device_count() < world:
@@ -495,6 +526,7 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        os.environ.setdefault("NCCL_DEBUG", "WARN")          # RCCL's own warnings on stderr (fd 1 points there too, see above)
         import datetime
         # a rank that dies (or never starts) must end the job with a message, not hang its peers for the default 10 - 30 min
         tmo = datetime.timedelta(seconds=args.dist_timeout)
@@ -524,10 +556,12 @@ def main():
 
     from hfa_gp_amd.config import PRESETS
     from hfa_gp_amd.generator import TriPlaneGenerator
-    from hfa_gp_amd.synthetic import make_inputs, state_cpu
+    from hfa_gp_amd.synthetic import make_inputs, perturb_state, state_cpu
 
     cfg = PRESETS[args.preset]()
-    gen = TriPlaneGenerator(cfg, seed=0).requires_grad_(False)
+    # the generator the parity tests run the oracle against at this batch (tests/test_gpu_round3.py::benched): EG3D init
+    # + non-zero biases and noise strengths, so that the timed state is the tested state
+    gen = perturb_state(TriPlaneGenerator(cfg, seed=0)).requires_grad_(False)
     state = state_cpu(gen) if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
     gen = gen.to(dev)
     B = args.batch
@@ -600,8 +634,15 @@ def main():
 
     def timed_leg(name, fn, *a):
         t = time.perf_counter()
-        out_ = fn(*a)
-        torch.cuda.synchronize()
+        try:
+            out_ = fn(*a)
+            torch.cuda.synchronize()
+        except BaseException as e:  # noqa: BLE001 — name the rank and device, then fail the run (a collective that lost a peer
+            # surfaces here as a timeout on EVERY surviving rank: the first line in the log names the one that broke)
+            sys.stderr.write(f"[bench rank {rank}/{world} on cuda:{local_rank}, pid {os.getpid()}] leg '{name}' failed: "
+                             f"{type(e).__name__}: {e}\n")
+            sys.stderr.flush()
+            raise
         leg_s[name] = round(leg_s.get(name, 0.0) + time.perf_counter() - t, 2)
         return out_
 
@@ -631,16 +672,19 @@ def main():
     _, _, timing = timed_leg("render", render_leg, prec)
     timing["step"] = timing_head["step"]
     dt32 = timing32 = dtb3 = None
-    if prec != "fp32" and not args.no_fp32_leg:
+    # single-GPU diagnostics (other precisions, batch sweeps, the LPIPS-cost leg, the CPU baseline) are skipped at N > 1: a
+    # multi-GPU run measures the headline, the fitting legs with their collectives and the sharded fits — nothing else
+    diag = n_ranks == 1
+    if prec != "fp32" and not args.no_fp32_leg and diag:
         dt32, _, timing32 = timed_leg("render_other_precisions", render_leg, "fp32")
         if prec != "bf16x3":
             dtb3, _, _ = timed_leg("render_other_precisions", render_leg, "bf16x3", None, False)
     dtx2 = timingx2 = None
-    if prec != "f16x2" and not args.no_f16_leg:
+    if prec != "f16x2" and not args.no_f16_leg and diag:
         # TF32 class (not the headline): 22-bit weights x activations rounded to one fp16 part, 2 MFMAs per product
         dtx2, _, timingx2 = timed_leg("render_other_precisions", render_leg, "f16x2")
     dt16sr = dt16 = dt16srh = timing16 = None
-    if not args.no_f16_leg:
+    if not args.no_f16_leg and diag:
         # the reference's CUDA defaults: fp32-class backbone, fp16 super-resolution; then every conv in fp16
         dt16sr, _, timing16 = timed_leg("render_other_precisions", render_leg, prec, "f16")
         dt16, _, _ = timed_leg("render_other_precisions", render_leg, "f16", None, False)
@@ -648,7 +692,7 @@ def main():
         dt16srh, _, _ = timed_leg("render_other_precisions", render_leg, prec, "f16", False, "f16")
         gen.sr_storage = "f32"
     sweep = None
-    if not args.no_sweep:
+    if not args.no_sweep and diag:
         # (64 and 128 frames per call: what the 288 GB of HBM allow beyond the headline's batch — not the headline, whose batch
         # is the one the parity tests run the oracle at)
         sweep = {}
@@ -869,6 +913,58 @@ def main():
                                                   f"({args.backend})") if n_ranks > 1 else None}
             if "rgb_lpips" in train:
                 out["train_step_ms_lpips"] = train["rgb_lpips"]
+
+            def roofline_train(ev, step_ms):
+                """Roofline objects of the BACKWARD kernel families of one fitting step ('train-step ms ... plus
+                roofline fraction'), from HIP events around every launch of a second pass of the same step (`kernel_events`).
+                  bwd-data GEMMs: algorithmic flops 2 M N K of the adjoint conv (gradients run in bf16x3: 3 MFMAs per product ->
+                    2.5 PF / 3 = 833 TF ceiling); the figure includes the split-K reducer launches that follow a GEMM;
+                  pointwise_bwd: bytes of the full-size tensors it reads + writes against HBM;
+                  ray-march backward (both passes + the zero fill of d planes): against a floor of re-gather + scatter through L2
+                    (2 x the forward's 12-line gather per sample / 34.5 TB/s) + decoder recompute and adjoint (2 x the forward
+                    decoder flops at the split-operand rate)."""
+                res_ = {"batch": train_B, "step_ms": step_ms}
+                peak_g = MFMA_BF16_PEAK_TFLOPS / 3
+                tot_ms = tot_fl = 0.0
+                for key, name in (("bwd_data", "3x3 bwd-data (modconv_bf16_kernel, mode CONV3X3_BWD)"),
+                                  ("bwd_data_up", "adjoint of the up-sampling conv (mode CONVS2_BWD, 4 parity phases)"),
+                                  ("bwd_data_1x1", "96-channel toRGB adjoint (mode CONV1X1)")):
+                    if key in ev:
+                        ms, fl, n = ev[key]
+                        tot_ms, tot_fl = tot_ms + ms, tot_fl + fl
+                        res_[key] = {"kernel": name, "ms_per_step": ms, "launches_per_step": n,
+                                     "achieved": fl / (ms * 1e-3) / 1e12, "frac": fl / (ms * 1e-3) / 1e12 / peak_g}
+                if tot_ms > 0:
+                    res_["bwd_data_gemms"] = {"bound": "mfma", "achieved": tot_fl / (tot_ms * 1e-3) / 1e12, "peak": peak_g,
+                                              "unit": "TFLOP/s", "frac": tot_fl / (tot_ms * 1e-3) / 1e12 / peak_g,
+                                              "ms_per_step": tot_ms, "share_of_step": tot_ms / step_ms}
+                if "pointwise_bwd" in ev:
+                    ms, by, n = ev["pointwise_bwd"]
+                    gbs = by / (ms * 1e-3) / 1e9
+                    res_["pointwise_bwd"] = {"bound": "hbm", "kernel": "pointwise_bwd_kernel (+ its partial-sum reducer)",
+                                             "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                             "frac_of_measured_copy_ceiling_6290": gbs / 6290.0,
+                                             "ms_per_step": ms, "launches_per_step": n, "share_of_step": ms / step_ms,
+                                             "traffic": profiled_traffic("pointwise_bwd_kernel")}
+                if "raymarch_bwd" in ev:
+                    ms, fr, n = ev["raymarch_bwd"]
+                    gb = fr * r * s_tot * 3 * 4 * 32 * 4
+                    fl = fr * r * s_tot * 2.0 * (32 * 64 + 64 * 33)
+                    floor = (2.0 * gb / (L2_PEAK_GBS * 1e9) + 2.0 * fl / (MFMA_BF16_PEAK_TFLOPS / 3 * 1e12)) * 1e3
+                    res_["raymarch_bwd"] = {"bound": "l2+mfma", "kernel": "raymarch_kernel<GRADS> (compositing adjoint from the saved "
+                                                                          "state) + raymarch_bwd_cols_kernel + zero fill of d planes",
+                                            "ms_per_step": ms, "ms_per_frame": ms / max(fr, 1), "floor_ms_per_step": floor,
+                                            "frac": floor / ms, "share_of_step": ms / step_ms,
+                                            "scatter_updates_per_frame": r * s_tot * 12,
+                                            "traffic": profiled_traffic("raymarch_bwd_cols_kernel")}
+                if "raymarch" in ev:
+                    res_["raymarch_fwd_ms_per_step"] = ev["raymarch"][0]
+                fwd = sum(ev[k][0] for k in ev if k.startswith("modconv"))
+                if fwd:
+                    res_["conv_fwd_ms_per_step"] = fwd
+                return res_
+            out["roofline_train"] = {"rgb": roofline_train(trgb["kernel_events"], trgb["frozen"][train_B]["step_ms"]),
+                                     "3dmm": roofline_train(t3["kernel_events"], t3["frozen"][train_B]["step_ms"])}
         if fit is not None:
             out["fit_rgb"] = fit
         if fit3 is not None:

@@ -37,6 +37,28 @@ class _Backward:
         self.released = set()      # ids already handed to the gradient sink
         self.pending = []          # style gradients of the whole pass: (item for ops.style_bwd_batch, affine module)
 
+    # bench.py's roofline_train: HIP events around the three kernel families that carry the backward pass (gen.timing keys
+    # "bwd_data" [algorithmic flops 2 M N K of the adjoint conv], "pointwise_bwd" [bytes of the full-size tensors read +
+    # written], "raymarch_bwd" [frames]); plain calls when timing is off
+    def bwd_data(self, g: torch.Tensor, weight: torch.Tensor, cin: int, mode: int) -> torch.Tensor:
+        if self.gen.timing is None:
+            return ops.modconv(g, self.wt_t(weight), cin, mode)
+        if mode == ops.CONVS2_BWD:                 # g = parity images [2,2,B,H+1,W+1,Cout] of the y_t gradient, output B x H x W
+            n_pos = g.shape[2] * (g.shape[3] - 1) * (g.shape[4] - 1)
+        else:
+            n_pos = g.shape[0] * g.shape[1] * g.shape[2]
+        taps = weight.shape[2] * weight.shape[3]
+        flops = 2.0 * n_pos * weight.shape[0] * weight.shape[1] * taps
+        key = {ops.CONV3X3_BWD: "bwd_data", ops.CONVS2_BWD: "bwd_data_up", ops.CONV1X1: "bwd_data_1x1"}[mode]
+        return self.gen._timed(key, flops, ops.modconv, g, self.wt_t(weight), cin, mode)
+
+    def pointwise(self, x: torch.Tensor, **kw):
+        if self.gen.timing is None:
+            return ops.pointwise_bwd(x, **kw)
+        nbytes = 4.0 * (2 * x.numel() + sum(kw[k].numel() for k in ("dxs_conv", "dxs_rgb", "g_direct")
+                                            if kw.get(k) is not None))
+        return self.gen._timed("pointwise_bwd", nbytes, ops.pointwise_bwd, x, **kw)
+
     def _acc(self, param: torch.Tensor, g: torch.Tensor):
         key = id(param)
         self.grads[key] = g if key not in self.grads else self.grads[key] + g
@@ -97,11 +119,11 @@ class _Backward:
                       s_small=rgb["styles"])
         else:
             g_y = _masked(g_img, rgb["y"], rgb["clamp"]).contiguous()
-            dxs_rgb = ops.modconv(g_y, self.wt_t(tr.weight), cin, ops.CONV1X1)
+            dxs_rgb = self.bwd_data(g_y, tr.weight, cin, ops.CONV1X1)
             kw = dict(dxs_rgb=dxs_rgb, s_rgb=rgb["styles"])
         # ---- X = conv1 output: consumers = next conv0 (+) toRGB; producer = conv1
-        g_conv1, sums = ops.pointwise_bwd(x1, dxs_conv=dxs_next, s_conv=s_next, producer=c1["producer"],
-                                          param_grads=self.pg, **kw)
+        g_conv1, sums = self.pointwise(x1, dxs_conv=dxs_next, s_conv=s_next, producer=c1["producer"],
+                                       param_grads=self.pg, **kw)
         if next_layer_rec is not None:
             next_layer_rec["ds"] = sums[:, 0]
         ds_rgb = sums[:, 2] if rgb["small"] else sums[:, 1]
@@ -123,19 +145,19 @@ class _Backward:
             self.layer_param_grads(c1, sums, g_conv1)
         # ---- conv1 bwd-data
         c1_cin = c1["layer"].weight.shape[1]
-        dxs1 = ops.modconv(g_conv1, self.wt_t(c1["layer"].weight), c1_cin, ops.CONV3X3_BWD)
+        dxs1 = self.bwd_data(g_conv1, c1["layer"].weight, c1_cin, ops.CONV3X3_BWD)
         if c0 is None:
             # b4: the input is the learned constant (broadcast over the batch): only the style gradient is needed
             xc = c1["x"].expand(dxs1.shape[0], -1, -1, -1).contiguous()
-            gconst, s0 = ops.pointwise_bwd(xc, dxs_conv=dxs1, s_conv=c1["styles"])
+            gconst, s0 = self.pointwise(xc, dxs_conv=dxs1, s_conv=c1["styles"])
             c1["ds"] = s0[:, 0]
             self.finish_layer(c1)
             if self.pg:
                 self._acc(rec["const"], gconst.sum(0).permute(2, 0, 1).contiguous())
             return None, None, g_img_prev
         # ---- X = conv0 output: consumer = conv1; producer = conv0 (up-sampling layer)
-        g_conv0, s0 = ops.pointwise_bwd(c0["out"], dxs_conv=dxs1, s_conv=c1["styles"], producer=c0["producer"],
-                                        param_grads=self.pg)
+        g_conv0, s0 = self.pointwise(c0["out"], dxs_conv=dxs1, s_conv=c1["styles"], producer=c0["producer"],
+                                     param_grads=self.pg)
         c1["ds"] = s0[:, 0]
         c0["dd"] = s0[:, 3]
         self.finish_layer(c1)
@@ -143,7 +165,7 @@ class _Backward:
         if self.pg:
             self.layer_param_grads(c0, s0, gph)
         c0_cin = c0["layer"].weight.shape[1]
-        dxs0 = ops.modconv(gph, self.wt_t(c0["layer"].weight), c0_cin, ops.CONVS2_BWD)
+        dxs0 = self.bwd_data(gph, c0["layer"].weight, c0_cin, ops.CONVS2_BWD)
         return dxs0, c0, g_img_prev
 
     def layer_param_grads(self, rec: dict, sums_out: torch.Tensor, g: torch.Tensor):
@@ -232,15 +254,15 @@ class SynthesisFn(torch.autograd.Function):
         g_direct[..., :3] = g_rgb_raw.permute(0, 2, 3, 1)
         if g_raw is not None:
             g_direct[..., :3] += g_raw.permute(0, 2, 3, 1)
-        g_feat, s = ops.pointwise_bwd(feat_img.contiguous(), dxs_conv=dxs, s_conv=c0rec0["styles"], g_direct=g_direct)
+        g_feat, s = bw.pointwise(feat_img.contiguous(), dxs_conv=dxs, s_conv=c0rec0["styles"], g_direct=g_direct)
         c0rec0["ds"] = s[:, 0]
         bw.finish_layer(c0rec0)
         # ---- renderer
         res = cfg.neural_rendering_resolution
-        rb = ops.raymarch_bwd(g_feat.view(b, res * res, 32), tape["planes"], u_strat=tape["u_strat"],
-                              u_imp=tape["u_imp"], decoder_grads=ctx.pg, planes_absmax=tape.get("planes_absmax"),
-                              state=tape.get("ray_state"),
-                              **gen._render_args(tape["c"]))
+        rb = gen._timed("raymarch_bwd", float(b), ops.raymarch_bwd, g_feat.view(b, res * res, 32), tape["planes"],
+                        u_strat=tape["u_strat"], u_imp=tape["u_imp"], decoder_grads=ctx.pg,
+                        planes_absmax=tape.get("planes_absmax"), state=tape.get("ray_state"),
+                        **gen._render_args(tape["c"]))
         if ctx.pg:
             d_planes, dec = rb
             net = gen.decoder.net

@@ -125,13 +125,6 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
                 parts[0] = make_uint2(__builtin_bit_cast(unsigned, x01 * __builtin_convertvector(s01, f16x2)),
                                       __builtin_bit_cast(unsigned, x23 * __builtin_convertvector(s23, f16x2)));
             } else
-#ifdef HFAGP_ABL_PRESPLIT   // (developer ablation: what would activations stored as (hi, lo) halves save? timing only)
-            if constexpr (NP == 2) {
-                parts[0] = make_uint2(__builtin_bit_cast(unsigned, ra[k].x), __builtin_bit_cast(unsigned, ra[k].y));
-                parts[1] = make_uint2(__builtin_bit_cast(unsigned, ra[k].z), __builtin_bit_cast(unsigned, ra[k].w));
-                (void)m; (void)sv;
-            } else
-#endif
             split4<KD>(make_float4(ra[k].x * (sv.x * m), ra[k].y * (sv.y * m), ra[k].z * (sv.z * m),
                                    ra[k].w * (sv.w * m)), parts);     // (F16X2: one saturating fp16 part)
 #pragma unroll
@@ -234,10 +227,8 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
             // this buffer: the next chunk's patch is published by the barrier in between)
             // (sched_barrier: without it the scheduler sinks every load to just before its first use to save
             // registers, i.e. it undoes the look-ahead)
-#ifndef HFAGP_ABL_NOA            // (HFAGP_ABL_*: developer ablation builds, tools/dev/conv_ablation.sh — never in the product)
             if constexpr (T + 1 < NT) read_a(u_tag, std::integral_constant<int, T + 1>{});
-#endif
-#if HFAGP_B_EARLY && !defined(HFAGP_ABL_NOB)
+#if HFAGP_B_EARLY
             {   // B fragments of the item RB-1 ahead, into the slot the PREVIOUS item has just finished with: issued in
                 // front of this item's MFMAs, so the youngest load at the loop's back edge (where hipcc drains vmcnt
                 // to 0) is a whole item old instead of brand new
@@ -253,7 +244,6 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn)
                         acc[tm][tn] = mfma16<F16>(af[T & 1][tm][PA[pr]], bq[SL][tn][PB[pr]], acc[tm][tn]);
-#ifndef HFAGP_ABL_NOSTAGE
 #pragma unroll
             for (int k = 0; k < A_PER_T; ++k) {
                 const int tk = NT - A_PER_T + k < 0 ? 0 : NT - A_PER_T + k;      // tap that carries slot k
@@ -263,13 +253,11 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
                     if (k == 2) store_a(min(c + 1, c_end - 1), std::integral_constant<int, 1 - UU>{}, std::integral_constant<int, 2>{});
                 }
             }
-#endif
             // refill the slot with the item RB ahead
             constexpr int T2 = (T + RB) % NT, DC = (T + RB) / NT;
-#if !HFAGP_B_EARLY && !defined(HFAGP_ABL_NOB)
+#if !HFAGP_B_EARLY
             issue_b(c + DC, std::integral_constant<int, T2>{}, std::integral_constant<int, SL>{});
 #endif
-#ifndef HFAGP_ABL_NOSTAGE
             // 9 taps: the patch of chunk c+1 is fetched at the FIRST tap of chunk c and converted under its last taps, so
             // nothing but B fragments is in flight at the loop's back edge, where hipcc drains vmcnt to 0 (its wait-count
             // analysis is conservative at loop headers) — with the fetch at the last tap that drain waited for HBM.
@@ -279,16 +267,10 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
             } else {
                 if constexpr (T == NT - 1) load_a(min(c + 2, c_end - 1));
             }
-#endif
             __builtin_amdgcn_sched_barrier(0);
         };
         auto chunk = [&](int c, auto u_tag) __attribute__((always_inline)) {
-#ifndef HFAGP_ABL_NOBAR
             __syncthreads();                                // publishes the patch of chunk c
-#endif
-#ifdef HFAGP_ABL_NOA
-            if (c == c_begin)
-#endif
             read_a(u_tag, std::integral_constant<int, 0>{});
             __builtin_amdgcn_sched_barrier(0);
             item(c, u_tag, std::integral_constant<int, 0>{});
@@ -349,30 +331,6 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
 #pragma unroll
         for (int i = 0; i < TMW * 16 * 3; ++i) rgbp[i] = 0.f;
     }
-#ifdef HFAGP_ABL_STORE4     // (developer ablation, TIMING ONLY — values land in the wrong places: the store pattern of a transposed
-    // accumulator layout, lane = position, 4 consecutive channels per 16-byte store; same bytes, a quarter of the instructions)
-    if (p.out && p.fused) {
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-            for (int tm = 0; tm < TMW; ++tm) {
-                const int m = m0 + 2 * (wm * TMW + tm) + (l31 >> 4), n = n0 + (l31 & 15);
-                if (m < ph.mh && n < ph.mw) {
-                    float* dst = out + (((size_t)b * p.Ho + m) * p.Wo + n) * p.Cout + co0 + (wn * TN + tn) * 32 + 4 * h;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float4 v;
-                        v.x = lrelu_gain_clamp(acc[tm][tn][4 * j + 0] * sback, p.act, p.alpha, p.gain, p.clamp);
-                        v.y = lrelu_gain_clamp(acc[tm][tn][4 * j + 1] * sback, p.act, p.alpha, p.gain, p.clamp);
-                        v.z = lrelu_gain_clamp(acc[tm][tn][4 * j + 2] * sback, p.act, p.alpha, p.gain, p.clamp);
-                        v.w = lrelu_gain_clamp(acc[tm][tn][4 * j + 3] * sback, p.act, p.alpha, p.gain, p.clamp);
-                        *reinterpret_cast<float4*>(dst + 8 * j) = v;
-                    }
-                }
-            }
-        return;
-    }
-#endif
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
         const int co = co0 + (wn * TN + tn) * 32 + l31;
@@ -413,9 +371,6 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
                     if (p.fused) v = lrelu_gain_clamp(v * d + bs + nz[q], p.act, p.alpha, p.gain, p.clamp);
                     else if constexpr (F16) v *= sback;
                     vmax = fmaxf(vmax, fabsf(v));
-#ifdef HFAGP_ABL_NOSTORE    // (developer ablation: one store per 16 values)
-                    if (q == 0 && rw == 0)
-#endif
                     if (p.out) {                 // (NULL: the caller only wants the fused toRGB sums — last SR layer, forward only)
                         if constexpr (YH) rowh[n * cstep] = (_Float16)v;
                         else rowp[n * cstep] = v;
@@ -559,13 +514,6 @@ __global__ void __launch_bounds__(NW * 64, 1) upconv_bf16_kernel(const ConvParam
                 parts[0] = make_uint2(__builtin_bit_cast(unsigned, x01 * __builtin_convertvector(s01, f16x2)),
                                       __builtin_bit_cast(unsigned, x23 * __builtin_convertvector(s23, f16x2)));
             } else
-#ifdef HFAGP_ABL_PRESPLIT   // (developer ablation: what would activations stored as (hi, lo) halves save? timing only)
-            if constexpr (NP == 2) {
-                parts[0] = make_uint2(__builtin_bit_cast(unsigned, ra[k].x), __builtin_bit_cast(unsigned, ra[k].y));
-                parts[1] = make_uint2(__builtin_bit_cast(unsigned, ra[k].z), __builtin_bit_cast(unsigned, ra[k].w));
-                (void)m; (void)sv;
-            } else
-#endif
             split4<KD>(make_float4(ra[k].x * (sv.x * m), ra[k].y * (sv.y * m), ra[k].z * (sv.z * m),
                                    ra[k].w * (sv.w * m)), parts);     // (F16X2: one saturating fp16 part)
 #pragma unroll
@@ -685,24 +633,6 @@ __global__ void __launch_bounds__(NW * 64, 1) upconv_bf16_kernel(const ConvParam
     // ---- raw stores of the four phases: y_t[2m + (f>>1)][2n + (f&1)], extents (H+1-(f>>1)) x (W+1-(f&1));
     // one 64-bit row pointer per (phase, tile, patch row), 32-bit column offsets
     float* out = p.out + (size_t)ks * p.slab;
-#ifdef HFAGP_ABL_STORE4     // (developer ablation, TIMING ONLY: see modconv_bf16_kernel)
-    if constexpr (!YH) {
-#pragma unroll
-        for (int f = 0; f < 4; ++f)
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm) {
-                const int m = m0 + 2 * (wm * TM + tm) + (l31 >> 4), n = n0 + (l31 & 15);
-                if (m < p.H + 1 - (f >> 1) && n < p.W + 1 - (f & 1)) {
-                    float* dst = out + (((size_t)b * p.Ho + 2 * m + (f >> 1)) * p.Wo + 2 * n + (f & 1)) * p.Cout + co0 + wn * 32 + 4 * h;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        *reinterpret_cast<float4*>(dst + 8 * j) = make_float4(acc[f][tm][0][4 * j], acc[f][tm][0][4 * j + 1],
-                                                                              acc[f][tm][0][4 * j + 2], acc[f][tm][0][4 * j + 3]);
-                }
-            }
-        return;
-    }
-#endif
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
         const int mh = p.H + 1 - (f >> 1), mw = p.W + 1 - (f & 1);
@@ -722,9 +652,6 @@ __global__ void __launch_bounds__(NW * 64, 1) upconv_bf16_kernel(const ConvParam
                     for (int q = 0; q < 8; ++q) {
                         const int n = n0 + 8 * (q >> 2) + 4 * h + (q & 3);
                         if (n >= mw) continue;
-#ifdef HFAGP_ABL_NOSTORE
-                        if (q == 0 && rw == 0)
-#endif
                         {
                             const float v = F16 ? acc[f][tm][tn][8 * rw + q] * sback : acc[f][tm][tn][8 * rw + q];
                             if constexpr (YH) rowh[2 * n * p.Cout] = (_Float16)v;

@@ -526,11 +526,7 @@ raymarch_bwd_cols_kernel(const RayParams p, float* __restrict__ d_planes, const 
 #pragma unroll
                     for (int sm = 0; sm < 16; ++sm) dfc[sm] = lds.df[sm * 32 + c];
 #pragma unroll 1
-#ifdef HFAGP_ABL_NOXY        // (developer ablation, timing only: the plane (x,y) scatter compiled out)
-                    for (int pk = 2; pk < 2; ++pk) {
-#else
                     for (int pk = 0; pk < 2; ++pk) {
-#endif
                         const int k = 2 * pk + hf;
                         float wv[16];
                         int tv[16];
@@ -586,11 +582,7 @@ raymarch_bwd_cols_kernel(const RayParams p, float* __restrict__ d_planes, const 
                     cache[slot * 32 + c] = fmaf(dfv, wgt, accv);
                 };
 #pragma unroll 1
-#ifdef HFAGP_ABL_NOWALK      // (developer ablation, timing only: the row-update walk compiled out)
-                for (int e0 = NU; e0 < NU; e0 += 64) {
-#else
                 for (int e0 = 0; e0 < NU; e0 += 64) {
-#endif
                     const int u = e0 + lane;
                     const int4 me = tiles[u >> 5].upd[u & 31];
                     const bool mine = me.x >= 0 && (me.x % kColWaves) == wave;

@@ -203,12 +203,8 @@ __device__ __forceinline__ void gather8(const HfagpRaymarchArgs& a, int b, int g
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const unsigned off = ((unsigned)taps[pl].idx[k] * 32u + 8u * g) * 4u;      // < 2^32: one plane
-#ifndef HFAGP_ABL_NOGATHER  // (developer ablation: texel loads compiled out)
             v0[k] = *reinterpret_cast<const float4*>(base + off);
             v1[k] = *reinterpret_cast<const float4*>(base + off + 16);
-#else
-            v0[k] = make_float4((float)off, 1.f, 2.f, 3.f); v1[k] = v0[k];
-#endif
         }
         const float v[4][8] = {{v0[0].x, v0[0].y, v0[0].z, v0[0].w, v1[0].x, v1[0].y, v1[0].z, v1[0].w},
                                {v0[1].x, v0[1].y, v0[1].z, v0[1].w, v1[1].x, v1[1].y, v1[1].z, v1[1].w},
@@ -271,12 +267,8 @@ __device__ __forceinline__ void decoder_fwd(const DecoderRegs& w, const float f[
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         h[mt] = f32x4{w.b0c[mt][0], w.b0c[mt][1], w.b0c[mt][2], w.b0c[mt][3]};
-#ifndef HFAGP_ABL_NODEC     // (developer ablation: decoder MFMAs compiled out)
 #pragma unroll
         for (int t = 0; t < 8; ++t) h[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w0a[mt][t], f[t], h[mt], 0, 0, 0);
-#else
-        h[mt][0] += f[mt] + f[mt + 4];
-#endif
     }
     float sg = 0.f;
 #pragma unroll
@@ -297,11 +289,7 @@ __device__ __forceinline__ void decoder_fwd(const DecoderRegs& w, const float f[
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-#ifndef HFAGP_ABL_NODEC
                 o[ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w1a[ot][mt * 4 + r], h[mt][r], o[ot], 0, 0, 0);
-#else
-                o[ot][r] += h[mt][r];
-#endif
             }
     }
 }

@@ -21,9 +21,6 @@
 #ifndef HFAGP_FIR_UNROLL
 #define HFAGP_FIR_UNROLL 1
 #endif
-#ifndef HFAGP_FIR_ABL      // developer ablation builds (tools/dev/upfir_ablation.sh): bit 0 no y stores, 1 no strip exports,
-#define HFAGP_FIR_ABL 0    // 2 no FIR arithmetic, 3 no LDS tile writes, 4 no epilogue at all, 5 no noise loads — never in the product
-#endif
 
 namespace hfagp {
 
@@ -31,7 +28,6 @@ struct FirFuse {
     float* colstrip;     // [B][tiles_w - 1][Hp][6][Cout]: y_t columns 32 j - 3 .. 32 j + 2 around strip boundary j
     float* rowstrip;     // [B][nseg - 1][6][Wp][Cout]:    y_t rows R - 3 .. R + 2 around segment boundary R = 16 * first tile
     int nseg, Hp, Wp;    // Hp = 16 tiles_h, Wp = 32 tiles_w
-    unsigned long long* dbg;   // developer (HFAGP_DEV_FIR_DBG): per-phase clock sums of block 0
 };
 
 // strip layouts (element offsets): a tile's export for one channel group is one contiguous run
@@ -122,11 +118,6 @@ __global__ void __launch_bounds__(512, 1) upconv_fir_kernel(const ConvParams p, 
     const int C0 = 32 * tw;
     float vmax = 0.f;
 
-    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;   // K loop | tile write + barrier | FIR | barrier 2 | tile prologue
-    auto tick = [&](int slot) __attribute__((always_inline)) {
-        if (ff.dbg) { const unsigned long long now = __builtin_readcyclecounter(); tacc[slot] += now - tprev; tprev = now; }
-    };
-    if (ff.dbg) tprev = __builtin_readcyclecounter();
 #pragma unroll 1
     for (int th = t_begin; th < t_end; ++th) {
         const int m0 = th * PH;
@@ -239,7 +230,6 @@ __global__ void __launch_bounds__(512, 1) upconv_fir_kernel(const ConvParams p, 
         };
         static_assert((2 * NITEM) % RB == 0 && RB <= NITEM, "ring slots must repeat every chunk pair");
         {
-            tick(4);
             __syncthreads();                                    // styles / zeroed windows in LDS; the FIR tile of the tile above is consumed
             load_a(c_begin);
             issue_b(c_begin, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
@@ -274,14 +264,13 @@ __global__ void __launch_bounds__(512, 1) upconv_fir_kernel(const ConvParams p, 
             const int k = tid >> 5, col = tid & 31;
             const int oy = R0 + k - 2, ox = C0 + col;
             float nz = 0.f;
-            if (p.noise && !(HFAGP_FIR_ABL & 32) && oy >= 0 && oy < Ho2 && ox < Wo2) nz = p.noise[(size_t)oy * Wo2 + ox] * p.noise_strength;
+            if (p.noise && oy >= 0 && oy < Ho2 && ox < Wo2) nz = p.noise[(size_t)oy * Wo2 + ox] * p.noise_strength;
             NZ[tid] = nz;                   // (NZ is outside the staging buffers; read after the barriers below)
         }
         __syncthreads();                    // the K loop is done with the staging buffers: they become the FIR tile
-        tick(0);
 #pragma unroll 1
-        for (int g = 0; g < ((HFAGP_FIR_ABL & 16) ? 0 : 4); ++g) {
-            if (wn == g && !(HFAGP_FIR_ABL & 8)) {
+        for (int g = 0; g < 4; ++g) {
+            if (wn == g) {
 #pragma unroll
                 for (int f = 0; f < 4; ++f)
 #pragma unroll
@@ -296,10 +285,9 @@ __global__ void __launch_bounds__(512, 1) upconv_fir_kernel(const ConvParams p, 
             }
             const int co4 = co0 + g * 32 + 4 * q4;
             __syncthreads();
-            tick(1);
             const float4 d = *reinterpret_cast<const float4*>(DB + g * 32 + 4 * q4);
             const float4 bs = *reinterpret_cast<const float4*>(DB + 128 + g * 32 + 4 * q4);
-            if (!(HFAGP_FIR_ABL & 4)) {
+            {
                 // source rows u = -3 .. 15 of this round: u < 0 -> window row u + 3 (the tile above), u >= 0 -> tile row u;
                 // y_t columns fcol - 1 .. fcol + 2 of the strip (strip 0: column -1 IS the zero padding; columns >= 32
                 // only feed outputs that belong to upfir_strip_kernel).
@@ -340,7 +328,7 @@ __global__ void __launch_bounds__(512, 1) upconv_fir_kernel(const ConvParams p, 
                 // raw strips for upfir_strip_kernel: the three columns on either side of a strip boundary leave from the
                 // threads that have them in registers anyway (tile rows k0 .. k0 + 7 of column fcol)
                 const int ebnd = fcol < 3 ? tw : tw + 1;               // boundary j sits between strips j - 1 and j
-                const bool exp_col = (fcol < 3 || fcol >= 29) && ebnd >= 1 && ebnd <= p.tiles_w - 1 && !(HFAGP_FIR_ABL & 2);
+                const bool exp_col = (fcol < 3 || fcol >= 29) && ebnd >= 1 && ebnd <= p.tiles_w - 1;
                 float* ecol = exp_col ? ff.colstrip + colstrip_at(b, p.tiles_w - 1, ebnd, p.Cout, ff.Hp, R0 + k0,
                                                                   fcol < 3 ? 3 + fcol : fcol - 29, co4) : nullptr;
                 float4 h0 = hrow(k0 - 3), h1 = hrow(k0 - 2), h2 = hrow(k0 - 1);
@@ -359,8 +347,7 @@ __global__ void __launch_bounds__(512, 1) upconv_fir_kernel(const ConvParams p, 
                         o.w = fin(fmaf(3.f, h1.w + h2.w, h0.w + h3.w), dg.w, nzg + bg.w);
                         vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
                         const size_t e = (((size_t)b * Ho2 + oy) * Wo2 + ox) * p.Cout + co4;
-                        if ((HFAGP_FIR_ABL & 1) && o.x != 12345.f) {
-                        } else if constexpr (YH) {
+                        if constexpr (YH) {
                             typedef _Float16 h4 __attribute__((ext_vector_type(4)));
                             const h4 hv = {(_Float16)o.x, (_Float16)o.y, (_Float16)o.z, (_Float16)o.w};
                             *reinterpret_cast<h4*>(reinterpret_cast<_Float16*>(p.out) + e) = hv;
@@ -371,7 +358,7 @@ __global__ void __launch_bounds__(512, 1) upconv_fir_kernel(const ConvParams p, 
                     h0 = h1; h1 = h2; h2 = h3;
                 }
             }
-            if (!(HFAGP_FIR_ABL & 2)) {
+            {
                 // ---- raw strips: the three rows on either side of a segment boundary (first / last tile of a segment only)
                 if (exp_top || exp_bot) {
 #pragma unroll
@@ -390,10 +377,8 @@ __global__ void __launch_bounds__(512, 1) upconv_fir_kernel(const ConvParams p, 
                     }
                 }
             }
-            tick(2);
             __syncthreads();                // every thread is done with the tile and the window of group g
-            tick(3);
-            if (wn == g && wm == 1 && !(HFAGP_FIR_ABL & 8)) {       // rows 13, 14, 15 of this tile -> window of the tile below
+            if (wn == g && wm == 1) {       // rows 13, 14, 15 of this tile -> window of the tile below
                 float* Wd = Wn + g * 3 * FT_PLANE;
 #pragma unroll
                 for (int fx = 0; fx < 2; ++fx)
@@ -409,10 +394,6 @@ __global__ void __launch_bounds__(512, 1) upconv_fir_kernel(const ConvParams p, 
         }
     }
     if (p.y_absmax) publish_absmax(p.y_absmax, vmax, blockIdx.x * 8 + wave);
-    if (ff.dbg && blockIdx.x == 0 && lane == 0) {
-        for (int i = 0; i < 6; ++i) ff.dbg[wave * 8 + i] = tacc[i];
-        ff.dbg[wave * 8 + 6] = (unsigned long long)(t_end - t_begin);
-    }
 }
 
 // Finishes what the strip blocks could not: ROWMODE = false — the three output columns 32 j - 2 .. 32 j at every strip
@@ -609,14 +590,6 @@ extern "C" int hfagp_upconv_fir_fwd(const HfagpModconvArgs* a, void* scratch, vo
     p.out = a->y;
     fp.ff.colstrip = reinterpret_cast<float*>(scratch);
     fp.ff.rowstrip = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + ((fp.col_bytes + 255) & ~(size_t)255));
-    fp.ff.dbg = nullptr;
-    static unsigned long long* dbg_buf = nullptr;
-    const bool dbg = getenv("HFAGP_DEV_FIR_DBG") != nullptr;            // developer: per-phase clocks of block 0
-    if (dbg) {
-        if (!dbg_buf) (void)hipMalloc(&dbg_buf, 64 * sizeof(unsigned long long));
-        (void)hipMemsetAsync(dbg_buf, 0, 64 * sizeof(unsigned long long), s);
-        fp.ff.dbg = dbg_buf;
-    }
     const int kd = kind_of(a->precision);
     const int io = (a->x_f16 ? 1 : 0) | (a->y_f16 ? 2 : 0);
     if (kd == 1) {
@@ -632,15 +605,6 @@ extern "C" int hfagp_upconv_fir_fwd(const HfagpModconvArgs* a, void* scratch, vo
         rc = launch_fused<4, 0>(fp, a->Cin, s);     // (F16X2 as well: the fused layer is only picked for short-K layers, same weight image)
     }
     if (rc != HFAGP_OK) return rc;
-    if (dbg) {
-        unsigned long long h[64];
-        (void)hipStreamSynchronize(s);
-        (void)hipMemcpy(h, dbg_buf, sizeof(h), hipMemcpyDeviceToHost);
-        for (int w = 0; w < 8; w += 4)
-            fprintf(stderr, "[upconv_fir dbg] wave %d, %llu tiles: K loop %llu | tile write + barrier %llu | FIR + exports %llu | barrier 2 %llu | "
-                            "tile prologue %llu clocks per tile\n", w, h[w * 8 + 6], h[w * 8 + 0] / h[w * 8 + 6], h[w * 8 + 1] / h[w * 8 + 6],
-                    h[w * 8 + 2] / h[w * 8 + 6], h[w * 8 + 3] / h[w * 8 + 6], h[w * 8 + 4] / h[w * 8 + 6]);
-    }
     StripFix f;
     f.dcoef = a->dcoef; f.noise = a->noise; f.bias = a->bias; f.y = a->y; f.y_absmax = a->y_absmax;
     f.B = a->B; f.H = a->H; f.W = a->W; f.C = a->Cout;

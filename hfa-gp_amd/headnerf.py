@@ -165,9 +165,20 @@ class _LatentBasis(nn.Module):
         out = weights @ q.T                              # == sum_k diag(alpha) Q^T  (headnerf.py:96-98)
         return out.view(weights.shape[0], -1, self.dim) + delta.view(-1, self.dim)
 
-    def get_image(self, latent: torch.Tensor, label: torch.Tensor) -> torch.Tensor:
+    def get_image(self, latent: torch.Tensor, label: torch.Tensor, **renderer_uniforms) -> torch.Tensor:
         flip_label_(label)                               # in place, on the caller's tensor
-        return self.generator.synthesis(latent, c=label, noise_mode="const")["image"]
+        return self._synthesis(latent, label, renderer_uniforms)
+
+    def _synthesis(self, latent, label, renderer_uniforms) -> torch.Tensor:
+        """`generator.synthesis(latent, c=label, noise_mode='const')['image']` (headnerf.py:112).  `renderer_uniforms`
+        (keyword-only `u_strat` [B,R,Sc], `u_imp` [B*R,Sf]) is a TEST HOOK: EG3D's renderer draws its stratified-jitter and
+        importance-sampling uniforms inside the call, which makes two renders of one frame differ; a parity
+        test hands the same draws to both sides.  Absent (every reference call site), the generator draws them itself."""
+        bad = set(renderer_uniforms) - {"u_strat", "u_imp"}
+        if bad:
+            raise TypeError(f"unexpected keyword arguments {sorted(bad)}")
+        kw = {k: v for k, v in renderer_uniforms.items() if v is not None}
+        return self.generator.synthesis(latent, c=label, noise_mode="const", **kw)["image"]
 
 
 class HeadNeRF_final(_LatentBasis):
@@ -203,14 +214,14 @@ class HeadNeRF_final(_LatentBasis):
     def get_weights(self, image):
         return self.encoder(image)          # (weights, pose) when out_pose
 
-    def forward(self, image, label, person_2=False):
+    def forward(self, image, label, person_2=False, **renderer_uniforms):
         flip_label_(label)
         if self.out_pose:
             weights, pose = self.encoder(image)
         else:
             weights, pose = self.encoder(image), None
         latent = self.get_latent(weights, person_2)
-        img = self.generator.synthesis(latent, c=label, noise_mode="const")["image"]
+        img = self._synthesis(latent, label, renderer_uniforms)
         return (img, pose) if self.out_pose else img
 
 
@@ -243,10 +254,10 @@ class _ParamDriven(_LatentBasis):
     def get_weights(self, params):
         return self.weights_3dmm(params)
 
-    def forward(self, params, label, person_2=False):
+    def forward(self, params, label, person_2=False, **renderer_uniforms):
         flip_label_(label)
         latent = self.get_latent(self.weights_3dmm(params), person_2)
-        return self.generator.synthesis(latent, c=label, noise_mode="const")["image"]
+        return self._synthesis(latent, label, renderer_uniforms)
 
 
 class HeadNeRF_3DMM(_ParamDriven):

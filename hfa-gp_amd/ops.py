@@ -86,7 +86,9 @@ def weight_prep_prec(weight: torch.Tensor, precision: str) -> torch.Tensor:
     nparts = NPARTS[precision]
     # + 512 B behind the image: with Cout % 128 != 0 the 128-wide tile reads one partial row past it (hfagp.h).  Only readable
     # memory is needed there — the columns fed from it are never stored — so nothing is cleared (the RGB fitting step re-builds
-    # 21 images per step: clearing them was 0.24 ms of fill kernels).
+    # 21 images per step: clearing them was 0.24 ms of fill kernels).  INVARIANT the kernels keep: no consumer reduces over the
+    # discarded columns (each output column of the GEMM depends on its own B column only; the fused toRGB sums and the absmax
+    # reduction run over stored columns) — tests/test_gpu_parity.py::test_torgb96_on_padded_split_tile runs with the pad poisoned.
     numel = nparts * kh * kw * (ci // 8) * co * 8
     flat = torch.empty(numel + 256, device=weight.device, dtype=_IMAGE_DTYPE[precision])
     wb = flat[:numel].view(nparts, kh * kw, ci // 8, co, 8)
@@ -358,7 +360,20 @@ def _up_layer_args(x, wt, cout, styles, dcoef, noise, noise_strength, bias, act,
     return a, b, h, w
 
 
-_FIR_SCRATCH = {}        # device -> scratch tensor of upconv_fir (grown on demand; one launch stream per device)
+_FIR_SCRATCH = {}        # (device, stream) -> scratch tensor of upconv_fir, grown on demand to the next power of two
+_FIR_RETIRED = []        # outgrown scratch tensors stay alive: a HIP graph captured earlier may still replay against them
+_FIR_BYTES = {}          # (shape, precision, storage, developer switches) -> hfagp_upconv_fir_scratch_bytes (0 = not supported)
+
+
+def _fir_scratch_bytes(a, x_f16: bool) -> int:
+    """hfagp_upconv_fir_scratch_bytes, memoised per layer shape: the library builds the whole launch plan to answer, and the
+    generator asks twice per up-sampling layer call (supported? / how much scratch?)."""
+    key = (a.B, a.H, a.W, a.Cin, a.Cout, a.precision, x_f16, a.x_batch_stride == 0,
+           os.environ.get("HFAGP_DEV_FIR_MIN_BLOCKS"), os.environ.get("HFAGP_DEV_FIR_NSEG"))
+    n = _FIR_BYTES.get(key)
+    if n is None:
+        n = _FIR_BYTES[key] = int(L.lib().hfagp_upconv_fir_scratch_bytes(C.byref(a)))
+    return n
 
 
 def upconv_fir_supported(x: torch.Tensor, wt: torch.Tensor, cout: int, batch: Optional[int] = None) -> bool:
@@ -369,7 +384,7 @@ def upconv_fir_supported(x: torch.Tensor, wt: torch.Tensor, cout: int, batch: Op
     if (x.dtype == torch.float16) and not (wt.dtype == torch.float16 and wt.shape[0] == 1):
         return False
     a, *_ = _up_layer_args(x, wt, cout, None, None, None, 0.0, None, "linear", 0.2, 1.0, None, batch, None, None, False)
-    return L.lib().hfagp_upconv_fir_scratch_bytes(C.byref(a)) > 0
+    return _fir_scratch_bytes(a, x.dtype == torch.float16) > 0
 
 
 def upconv_fir(x: torch.Tensor, wt: torch.Tensor, cout: int, styles: Optional[torch.Tensor], dcoef: Optional[torch.Tensor],
@@ -389,13 +404,16 @@ def upconv_fir(x: torch.Tensor, wt: torch.Tensor, cout: int, styles: Optional[to
         raise RuntimeError("upconv_fir: needs a 16-bit weight image from weight_prep_prec")
     a, b, h, w = _up_layer_args(x, wt, cout, styles, dcoef, noise, noise_strength, bias, act, alpha, gain, clamp, batch,
                                 x_absmax, y_absmax, y_f16)
-    nbytes = L.lib().hfagp_upconv_fir_scratch_bytes(C.byref(a))
+    nbytes = _fir_scratch_bytes(a, x.dtype == torch.float16)
     if nbytes == 0:
         raise RuntimeError("upconv_fir: this layer shape / precision / batch is not supported (upconv_fir_supported)")
     key = (x.device, torch.cuda.current_stream(x.device).cuda_stream)
     scratch = _FIR_SCRATCH.get(key)
     if scratch is None or scratch.numel() * 4 < nbytes:
-        scratch = _FIR_SCRATCH[key] = torch.empty((nbytes + 3) // 4, device=x.device, dtype=torch.float32)
+        if scratch is not None:
+            _FIR_RETIRED.append(scratch)
+        grown = 1 << max(nbytes - 1, 1).bit_length()           # powers of two: a handful of growth steps per process at most
+        scratch = _FIR_SCRATCH[key] = torch.empty(grown // 4, device=x.device, dtype=torch.float32)
     y = torch.empty(b, 2 * h, 2 * w, cout, device=x.device, dtype=torch.float16 if y_f16 else torch.float32)
     a.y = y.data_ptr()
     L.check(L.lib().hfagp_upconv_fir_fwd(C.byref(a), _ptr(scratch), _stream()), "upconv_fir_fwd")

@@ -180,6 +180,7 @@ class BucketedAllReduce:
             off += p.numel()
         self.active = False
         self.last_order: List[int] = []
+        self.generator_ids = set()     # ids of generator parameters (`_StepScope`): their hook also fires without a write
         self.reset()
 
     def reset(self):
@@ -191,6 +192,7 @@ class BucketedAllReduce:
         self.left = list(self.size)
         self.works = [None] * len(self.size)
         self.seen = set()
+        self.declared_absent = set()   # ids the caller declared gradient-free for this step (begin_step)
         self.next = 0                  # the next bucket to go out: buckets < next are in flight or done
         self.order = []                # buckets in the order their collectives were started (tests / diagnostics)
 
@@ -199,6 +201,8 @@ class BucketedAllReduce:
         step and must not hold their bucket back."""
         self.reset()
         self.active = True
+        absent = list(absent)
+        self.declared_absent = {id(p) for p in absent}
         for p in absent:
             self._count(p)
         self._advance()
@@ -230,7 +234,19 @@ class BucketedAllReduce:
         caught where they happen (`sink`)."""
         if not self.active:
             return                     # a backward pass outside gen_update (autograd.grad, a sample): nothing to overlap
-        if self.bucket_of.get(id(p)) is None or id(p) in self.seen:
+        b = self.bucket_of.get(id(p))
+        if b is None:
+            return
+        if id(p) in self.seen:
+            # generator parameters pass here a second time without a write (see above).  Anything ELSE that is already counted
+            # was declared absent for this step (`begin_step(absent=...)`) and has received a gradient after all: its bucket may
+            # be in flight with the stale zeros, the ranks would diverge silently and `step_skipping` would hide the gradient
+            # from Adam — refuse (ADVICE r3)
+            if id(p) in self.declared_absent and id(p) not in self.generator_ids:
+                raise RuntimeError("BucketedAllReduce: a parameter that was declared ABSENT for this step received a gradient "
+                                   f"(shape {tuple(p.shape)}, bucket {b}, collective {'in flight' if self.works[b] is not None else 'pending'}); "
+                                   "fix Trainer.absent_parameters — absent parameters are skipped by Adam and their bucket "
+                                   "does not wait for them")
             return
         self._count(p)
         self._advance()
@@ -353,6 +369,8 @@ class _StepScope:
 
     def __enter__(self):
         if self.b is not None:
+            if not self.b.generator_ids:
+                self.b.generator_ids = {id(p) for g in self.gens for p in g.parameters()}
             self.b.begin_step(self.absent)
             for g in self.gens:
                 g._grad_sink = self.b.sink
@@ -517,12 +535,15 @@ class Trainer(nn.Module):
         if self.timing is not None:
             self.timing.setdefault(key, []).append((e0, e1))
 
-    def gen_update(self, real_image, label, params=None, person_2=False, loss_weight: float = 1.0):
+    def gen_update(self, real_image, label, params=None, person_2=False, loss_weight: float = 1.0, *,
+                   u_strat: Optional[torch.Tensor] = None, u_imp: Optional[torch.Tensor] = None):
         """One optimisation step.  rgb mode: `gen_update(real, label, person_2=...)` → (l2, lpips, image);
         3dmm mode: `gen_update(real, label, params, person_2)` → (l2_3dmm, l2, lpips, image) — the reference's
         signatures and return arity (trainer_rgb.py:73-98, trainer_3dmm.py:43-67; train_3dmm.py:128 unpacks four).
         `loss_weight` rescales this rank's loss before the all-reduce mean (ragged frame shards, `epoch_batches`);
-        an EMPTY batch skips the forward/backward and contributes zero gradients to the collective."""
+        an EMPTY batch skips the forward/backward and contributes zero gradients to the collective.
+        `u_strat` / `u_imp` (keyword-only, TEST HOOK): the renderer's uniforms for this step instead of fresh draws
+        (`_LatentBasis._synthesis`) — parity tests and the exact multi-rank equalities need two steps to sample alike."""
         if self.mode == "rgb" and isinstance(params, bool):          # reference call form gen_update(real, label, person_2)
             params, person_2 = None, params
         self.gen.train()
@@ -545,9 +566,9 @@ class Trainer(nn.Module):
                     if isinstance(weights, tuple):
                         weights = weights[0]
                     latent = self.gen.get_latent(weights, person_2)
-                    generated = self.gen.get_image(latent, label)
+                    generated = self.gen.get_image(latent, label, u_strat=u_strat, u_imp=u_imp)
                 else:
-                    generated = self.gen(params, label, person_2)
+                    generated = self.gen(params, label, person_2, u_strat=u_strat, u_imp=u_imp)
                 full = generated
                 # LPIPSAlex folds a 2 x 2 pool into its first conv: the L2 term then keeps the fused pool + MSE pass and no
                 # pooled image with a gradient is needed (lpips_alex.LPIPSAlex._features_of_unpooled)
@@ -622,13 +643,16 @@ class Trainer(nn.Module):
 
 def fit_frames(trainer: "Trainer", reals: torch.Tensor, labels: torch.Tensor, params: Optional[torch.Tensor] = None,
                epochs: int = 1, batch: Optional[int] = None, tune_iter: Optional[int] = None,
-               start_iter: int = 0, on_step: Optional[Callable] = None) -> List[torch.Tensor]:
+               start_iter: int = 0, on_step: Optional[Callable] = None,
+               uniforms: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> List[torch.Tensor]:
     """The fitting loop of train_rgb.py:114-154 / train_3dmm.py:113-150 over a frame set resident on the device:
     frames are sharded in contiguous blocks over the ranks (`shard_range`), every rank walks its shard in
     batches of `batch` (default: args.batch_size // world_size, at least 1 — the reference's integer division can
     give 0), ragged tails are handled by `epoch_batches`, the shared gradients are averaged by the
     trainer's one flat all-reduce, and the generator starts being tuned once `i + 1 >= tune_iter`.
     `reals` [N,3,s,s], `labels` [N,25] (un-flipped, as the data set yields them), `params` [N,P] (3dmm mode).
+    `uniforms` (TEST HOOK) = (u_strat [N,R,Sc], u_imp [N,R,Sf]): per-FRAME renderer uniforms, so that a frame samples alike
+    whichever rank and batch position renders it (exact multi-rank equalities); default: fresh draws per call.
     Returns the per-step L2 losses of THIS rank (device scalars; no host sync inside the loop)."""
     tr = trainer
     n = reals.shape[0]
@@ -643,11 +667,15 @@ def fit_frames(trainer: "Trainer", reals: torch.Tensor, labels: torch.Tensor, pa
             lo = int(idx[0]) if idx.numel() else 0
             sl = slice(lo, lo + idx.numel())
             real, label = reals[sl], labels[sl].clone()         # the label flip is in place: never on the data set
+            kw = {}
+            if uniforms is not None and idx.numel():
+                kw = dict(u_strat=uniforms[0][sl].contiguous(),
+                          u_imp=uniforms[1][sl].reshape(-1, uniforms[1].shape[-1]).contiguous())
             if tr.mode == "rgb":
-                out = tr.gen_update(real, label, loss_weight=weight)
+                out = tr.gen_update(real, label, loss_weight=weight, **kw)
                 l2 = out[0]
             else:
-                out = tr.gen_update(real, label, params[sl], loss_weight=weight)
+                out = tr.gen_update(real, label, params[sl], loss_weight=weight, **kw)
                 l2 = out[1]
             losses.append(l2)
             if on_step is not None:
@@ -764,7 +792,9 @@ class AudioTrainer(nn.Module):
             aud = self.AudNet(self.auds[img_i].reshape(-1, *self.auds.shape[1:]).squeeze(1))
         return aud.unsqueeze(0) if aud.dim() == 1 else aud
 
-    def gen_update(self, real_image, label, params, global_step: int, img_i: int, person_2: bool = False):
+    def gen_update(self, real_image, label, params, global_step: int, img_i: int, person_2: bool = False, *,
+                   u_strat: Optional[torch.Tensor] = None, u_imp: Optional[torch.Tensor] = None):
+        """trainer_audio.py:55-113.  `u_strat` / `u_imp`: the renderer-uniform test hook of `Trainer.gen_update`."""
         self.gen.train(), self.AudNet.train(), self.AudAttNet.train()
         flat = self.flat_grads()
         bucketer = self._overlap(flat)
@@ -776,7 +806,8 @@ class AudioTrainer(nn.Module):
         if not smooth:                     # the attention net is not on the path yet (trainer_audio.py:88-94)
             absent = absent + [p for p in self.AudAttNet.parameters() if p.requires_grad]
         with _StepScope(bucketer, [self.gen.generator], absent):
-            generated = self.gen(self._drive(global_step, img_i, self.i_train), label, person_2)
+            generated = self.gen(self._drive(global_step, img_i, self.i_train), label, person_2,
+                                 u_strat=u_strat, u_imp=u_imp)
             l2_3dmm = torch.zeros(1, device=self.device)
             l2, generated = pooled_l2(self.face_pool, real_image, generated, self.lpips_loss is not None)
             lp = (torch.squeeze(self.lpips_loss(real_image, generated)).mean() if self.lpips_loss is not None

@@ -267,6 +267,11 @@ def test_torgb96_on_padded_split_tile(dev, prec, b, h, cin, ksplit):
                     w.repeat(b, 1, 1, 1), groups=b).reshape(b, 96, h, h) + bias[None, :, None, None]
     wb = ops.weight_prep_prec(w.to(dev), prec)
     assert wb.shape == (ops.NPARTS[prec], 1, cin // 8, 96, 8) and wb.is_contiguous()
+    # the 512 B behind the image (read by the tile's discarded columns, left uninitialised by weight_prep_prec): poison them —
+    # no stored value may depend on what is there
+    whole = torch.empty(0, dtype=wb.dtype, device=dev).set_(wb.untyped_storage())
+    assert whole.numel() == wb.numel() + 256
+    whole[wb.numel():] = float("nan")
     y = ops.modconv(ops.nchw_to_nhwc(x.to(dev)), wb, 96, ops.CONV1X1, styles=s.to(dev), bias=bias.to(dev), act="linear",
                     gain=1.0, ksplit=ksplit)
     assert y.shape == (b, h, h, 96)

@@ -325,85 +325,13 @@ def test_fit_frames_ragged_and_empty_batches_on_gpu(dev):
     assert len(losses) == 3 and not torch.equal(tr.gen.bases.detach(), b0)
 
 
-# ----------------------------------------------------------------------------- N > 1 on RCCL (needs >= 2 GPUs)
+# ----------------------------------------------------------------------------- N > 1 on the GPU
+# (the two-rank cases — gloo on one device, RCCL on two — live in tests/test_gpu_round4.py since round 4: with the renderer-
+#  uniform hook they are EXACT equalities instead of the 20 % statistical bar they had here)
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
-
-
-def _nccl_worker(rank, world, port, out, backend="nccl"):
-    import torch.distributed as dist
-    from hfa_gp_amd.synthetic import make_frame_set
-    from hfa_gp_amd.trainer import Trainer
-    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    local = rank if backend == "nccl" else 0            # gloo: both ranks share cuda:0 (RCCL refuses that)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if backend == "nccl":
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    else:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        torch.manual_seed(10 + rank)                        # rank 0's parameters must win (broadcast)
-        tr = Trainer(FitArgs(), dev, rank=rank, world_size=world, mode="3dmm", lpips="none")
-        tr.optimizer = torch.optim.SGD(tr.gen.parameters(), lr=0.0)
-        data = make_frame_set(tr.gen, 2, size=FitArgs.size, seed=42, params_len=76)
-        sl = slice(rank, rank + 1)                          # rank r owns frame r
-        tr.gen_update(data["real"][sl], data["label"][sl].clone(), data["params"][sl])
-        img = tr.sample(None, data["label"][sl].clone(), data["params"][sl])
-        out[rank] = {"grad": tr.gen.bases.grad.detach().cpu(), "start": tr.gen.bases.detach().cpu(), "img": img.cpu()}
-    finally:
-        dist.destroy_process_group()
-
-
-def test_two_ranks_sharing_the_gpu_over_gloo(dev):
-    """The N > 1 fitting path with TWO PROCESSES on the GPU (both on cuda:0, collective over gloo — what a 1-GPU box can
-    run; RCCL needs one device per rank): rank 0's parameters win the broadcast, the bucketed in-place all-reduce gives both
-    ranks the same gradient, and it is the mean of the two per-frame gradients (statistically: the renderer draws fresh
-    uniforms per call)."""
-    import torch.multiprocessing as mp
-    from hfa_gp_amd.synthetic import make_frame_set
-    from hfa_gp_amd.trainer import Trainer
-    world, port = 2, _free_port()
-    with mp.Manager() as mgr:
-        out = mgr.dict()
-        mp.spawn(_nccl_worker, args=(world, port, out, "gloo"), nprocs=world, join=True)
-        r0, r1 = out[0], out[1]
-    assert torch.equal(r0["start"], r1["start"]) and torch.equal(r0["grad"], r1["grad"])
-    assert r0["grad"].abs().sum() > 0 and torch.isfinite(r0["img"]).all() and torch.isfinite(r1["img"]).all()
-    torch.manual_seed(10)
-    tr = Trainer(FitArgs(), dev, mode="3dmm", lpips="none")
-    assert torch.equal(tr.gen.bases.detach().cpu(), r0["start"])
-    tr.optimizer = torch.optim.SGD(tr.gen.parameters(), lr=0.0)
-    data = make_frame_set(tr.gen, 2, size=FitArgs.size, seed=42, params_len=76)
-    tr.gen_update(data["real"], data["label"].clone(), data["params"])
-    want = tr.gen.bases.grad.cpu()
-    assert (r0["grad"] - want).norm() <= 0.2 * want.norm()
-
-
-@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs (RCCL refuses two ranks on one device)")
-def test_two_ranks_nccl_step_equals_two_frame_single_rank_step(dev):
-    """W = 2 over RCCL: the all-reduced basis gradient of two ranks holding one frame each equals the gradient of the
-    two-frame batch on one rank (same renderer uniforms are NOT guaranteed across batch positions, so compare loosely),
-    both ranks end with identical parameters, and each rank's render equals an independent render."""
-    import torch.multiprocessing as mp
-    from hfa_gp_amd.synthetic import make_frame_set
-    from hfa_gp_amd.trainer import Trainer
-    world, port = 2, _free_port()
-    with mp.Manager() as mgr:
-        out = mgr.dict()
-        mp.spawn(_nccl_worker, args=(world, port, out), nprocs=world, join=True)
-        r0, r1 = out[0], out[1]
-    assert torch.equal(r0["start"], r1["start"]) and torch.equal(r0["grad"], r1["grad"])
-    torch.manual_seed(10)
-    tr = Trainer(FitArgs(), dev, mode="3dmm", lpips="none")
-    tr.optimizer = torch.optim.SGD(tr.gen.parameters(), lr=0.0)
-    data = make_frame_set(tr.gen, 2, size=FitArgs.size, seed=42, params_len=76)
-    tr.gen_update(data["real"], data["label"].clone(), data["params"])
-    want = tr.gen.bases.grad.cpu()
-    assert (r0["grad"] - want).norm() <= 0.2 * want.norm()      # fresh sampling uniforms per call: statistical agreement
 
 
 def test_plain_c_host_launches_kernels(dev, tmp_path):

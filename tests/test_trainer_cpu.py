@@ -31,7 +31,7 @@ class OracleGenerator(TriPlaneGenerator):
         gen.labels_seen = []
         return gen
 
-    def synthesis(self, ws, c=None, noise_mode="const", **_):
+    def synthesis(self, ws, c=None, noise_mode="const", u_strat=None, u_imp=None, **_):
         assert noise_mode == "const"
         self.labels_seen.append(c.detach().clone())
         P = dict(self.named_parameters())
@@ -39,8 +39,13 @@ class OracleGenerator(TriPlaneGenerator):
         g = torch.Generator().manual_seed(self.seed)
         b, r = ws.shape[0], self.cfg.neural_rendering_resolution ** 2
         # every sample of a batch sees the SAME uniforms, so a frame renders identically at any batch position
+        # (or the caller's: the `u_strat` / `u_imp` test hook of HeadNeRF_*.get_image / Trainer.gen_update)
         us = torch.rand(1, r, self.cfg.depth_resolution, 1, generator=g).expand(b, -1, -1, -1).contiguous()
         ui = torch.rand(r, self.cfg.depth_resolution_importance, generator=g).repeat(b, 1)
+        if u_strat is not None:
+            us = u_strat.reshape(b, r, self.cfg.depth_resolution, 1)
+        if u_imp is not None:
+            ui = u_imp.reshape(b * r, self.cfg.depth_resolution_importance)
         return O.synthesis(P, self.cfg, ws, c, us, ui)
 
 
@@ -557,6 +562,29 @@ def test_bucket_launch_order_is_rank_independent_with_empty_batches():
     assert len({len(o) for o in r0["orders"][2:]}) == 1 and len(r0["orders"][2]) == r0["nb"]
     for k in ("bases", "enc", "gw"):
         assert torch.equal(r0[k], r1[k]), k
+
+
+def test_gradient_for_a_parameter_declared_absent_is_refused():
+    """a non-generator parameter listed by `absent_parameters` that receives a gradient after all would be summed
+    into a bucket that is already in flight (ranks diverge silently) and hidden from Adam by `step_skipping`: the bucketer
+    raises instead.  Forced here by declaring the ACTIVE identity's basis absent."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(_free_port())
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        tr = make_rgb_trainer(seed=3, world_size=1)
+        tr.force_collective = True
+        real, label, _ = frame(7)
+        tr.gen_update(real, label.clone(), False)                            # a legal step first
+        honest = tr.absent_parameters
+        tr.absent_parameters = lambda person_2=False: honest(person_2) + [tr.gen.bases]
+        with pytest.raises(RuntimeError, match="declared ABSENT"):
+            tr.gen_update(real, label.clone(), False)
+        tr.absent_parameters = honest
+        tr.gen_update(real, label.clone(), False)                            # and the trainer is usable afterwards
+        assert not tr._bucketer.active
+    finally:
+        dist.destroy_process_group()
 
 
 def test_bucketer_overlap_state_and_absent_parameters():

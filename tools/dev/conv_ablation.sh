@@ -3,7 +3,7 @@
 # variants travel to the GPU box with gpurun; there:  bash tools/dev/conv_ablation.sh run
 set -euo pipefail
 here="$(cd "$(dirname "${BASH_SOURCE[0]}")/../.." && pwd)"
-csrc="$here/hfa-gp_amd/csrc"
+csrc="${CSRC:-$here/hfa-gp_amd/csrc}"   # ablation variants: see tools/dev/patches/README.md
 variants=(base "nostore:-DHFAGP_ABL_NOSTORE" "old:-DHFAGP_LOADA_EARLY=0 -DHFAGP_B_EARLY=0" "aearly:-DHFAGP_LOADA_EARLY=1 -DHFAGP_B_EARLY=0" "bearly:-DHFAGP_LOADA_EARLY=0 -DHFAGP_B_EARLY=1"
           "nob:-DHFAGP_ABL_NOB" "noa:-DHFAGP_ABL_NOA" "nostage:-DHFAGP_ABL_NOSTAGE"
           "mfmaonly:-DHFAGP_ABL_NOB -DHFAGP_ABL_NOA -DHFAGP_ABL_NOSTAGE -DHFAGP_ABL_NOBAR" "presplit:-DHFAGP_ABL_PRESPLIT")

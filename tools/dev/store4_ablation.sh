@@ -3,7 +3,7 @@
 # buy the 16-bit conv kernels?  Timing-only build (values land in the wrong places).  build HERE, `run` on the GPU box.
 set -euo pipefail
 here="$(cd "$(dirname "${BASH_SOURCE[0]}")/../.." && pwd)"
-csrc="$here/hfa-gp_amd/csrc"
+csrc="${CSRC:-$here/hfa-gp_amd/csrc}"   # ablation variants: see tools/dev/patches/README.md
 if [[ "${1:-build}" == "build" ]]; then
     bash "$csrc/build.sh" >/dev/null
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -DHFAGP_ABL_STORE4 -c "$csrc/modconv_bf16.hip" -o /tmp/mcb_store4.o

@@ -3,7 +3,7 @@
 # (cross-compile), the variants travel to the GPU box with gpurun; there:  bash tools/dev/upfir_ablation.sh run
 set -euo pipefail
 here="$(cd "$(dirname "${BASH_SOURCE[0]}")/../.." && pwd)"
-csrc="$here/hfa-gp_amd/csrc"
+csrc="${CSRC:-$here/hfa-gp_amd/csrc}"   # ablation variants: see tools/dev/patches/README.md
 variants=(base "nostore:1" "noexport:2" "nofir:4" "nostore_noexport:3" "nofir_nostore_noexport:7" "noldswrite:15" "noepilogue:16" "nonoise:32")
 [[ -n "${ABL_VARIANTS:-}" ]] && read -r -a variants <<< "$ABL_VARIANTS"
 if [[ "${1:-build}" == "build" ]]; then
