@@ -50,7 +50,12 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
     char* As = lds_raw;                                   // [2][NP][APOS][48 B]
     float* Ss = reinterpret_cast<float*>(lds_raw + 2 * A_BUF);   // [Cin] styles of this sample (or ones)
 
-    const Phase& ph = p.phase[phase0 + blockIdx.y];   // every phase of one launch has NTAPS taps
+    // NTAPS = 0: the adjoint of the up-sampling conv (mode CONVS2_BWD) MERGED — the four parity phases (4 | 2 | 2 | 1 taps, each
+    // reading its own parity image of the y_t gradient) run one after the other in this block into ONE accumulator set, so the
+    // result is written once (round 3 launched the three tap counts separately, each into its own slab, and summed the slabs
+    // in splitk_epilogue_kernel: 4 launches and 4 x the output traffic per layer).  All four phases share the output grid.
+    constexpr bool MERGED_S2 = NTAPS == 0;
+    const Phase& ph = p.phase[MERGED_S2 ? 0 : phase0 + blockIdx.y];   // every phase of one launch has NTAPS taps
     // (readfirstlane: the divisions by run-time values are done on the vector ALU; without it every index derived
     // from the block coordinates stays in VGPRs and the uniform address arithmetic of the K loop — chunk x Cout
     // products, clamps — is issued as quarter-rate vector multiplies between the MFMAs)
@@ -78,7 +83,7 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
     constexpr int A_PER_T = ((PH + 2) * (PW + 2) * 4 + 255) / 256;
     static_assert(A_PER_T == 3, "the staging schedule below is written for three slots per thread");
     float4 ra[A_PER_T];
-    const char* xb = reinterpret_cast<const char*>(p.x) + (ph.in_off + (long long)b * p.x_batch_stride) * XB;
+    const char* xb = reinterpret_cast<const char*>(p.x) + (ph.in_off + (long long)b * p.x_batch_stride) * XB;   // (MERGED_S2: per phase)
     for (int i = tid; i < p.Cin; i += 256) Ss[i] = p.styles ? p.styles[(size_t)b * p.Cin + i] : 1.f;
     float sback = 1.f, sdown = 1.f;                      // 2^e, 2^-e of the fp16 range guard (1 for the bf16 kinds)
     if constexpr (F16) sdown = style_range_guard(p.styles ? p.styles + (size_t)b * p.Cin : nullptr, p.Cin, lane, &sback, p.x_absmax);
@@ -163,6 +168,15 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
 #pragma unroll
     for (int t = 0; t < 4; ++t)
         toff[t] = t < ph.ntaps ? ((ph.dy[t] - p.dymin) * LPWB + (ph.dx[t] - p.dxmin)) * APITCH : 0;
+    // (MERGED_S2) switch the phase-dependent state — input image, weight taps, LDS tap offsets — to parity phase q
+    auto enter_phase = [&](const Phase& q) __attribute__((always_inline)) {
+        xb = reinterpret_cast<const char*>(p.x) + (q.in_off + (long long)b * p.x_batch_stride) * XB;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            wtap[t] = t < q.ntaps ? q.widx[t] * cq8 * p.Cout : 0;
+            toff[t] = t < q.ntaps ? ((q.dy[t] - p.dymin) * LPWB + (q.dx[t] - p.dxmin)) * APITCH : 0;
+        }
+    };
 
     f32x16 acc[TMW][TN];
 #pragma unroll
@@ -315,7 +329,17 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
             chunk(cg + 1, std::integral_constant<int, 1>{});
         }
     };
-    run(std::integral_constant<int, NTAPS>{});
+    if constexpr (MERGED_S2) {
+        run(std::integral_constant<int, 4>{});            // parity (0,0): phase[0] is the state set up above
+        enter_phase(p.phase[1]);
+        run(std::integral_constant<int, 2>{});
+        enter_phase(p.phase[2]);
+        run(std::integral_constant<int, 2>{});
+        enter_phase(p.phase[3]);
+        run(std::integral_constant<int, 1>{});
+    } else {
+        run(std::integral_constant<int, NTAPS>{});
+    }
 
     // ---- epilogue.  C/D layout of 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5): the 16 registers of
     // a tile are 2 patch rows (r>>3) x columns 8*((r>>2)&1) + 4h + (r&3).  One 64-bit row pointer per (tile, patch
@@ -681,6 +705,12 @@ static void launch_group(const Plan& pl, int phase0, int nphase, int ntaps, int 
     }
 }
 
+// mode CONVS2_BWD, the four parity phases merged in one block (make_plan: merged_s2; grid.y = 1)
+template <int KD>
+static void launch_s2_merged(const Plan& pl, int cin, hipStream_t s) {
+    modconv_bf16_kernel<KD, 2, 0><<<pl.grid, 256, bf16_lds_bytes<kind_parts_a(KD), 2>(cin), s>>>(pl.p, 0);
+}
+
 // fp16-storage variants (KD = 1 only): io = x_f16 | y_f16 << 1
 static void launch_up_io(const Plan& pl, int cin, int io, hipStream_t s) {
     const size_t lds = bf16_lds_bytes<1, 2>(cin);
@@ -742,6 +772,16 @@ int launch_modconv_bf16(const HfagpModconvArgs* a, Plan& pl, hipStream_t s) {
             default: launch_up<4>(pl, a->Cin, s); break;
         }
         return check_launch("modconv_fwd (16-bit MFMA, merged up-conv)");
+    }
+    if (pl.merged_s2) {
+        switch (kd) {
+            case 1: launch_s2_merged<1>(pl, a->Cin, s); break;
+            case 2: launch_s2_merged<2>(pl, a->Cin, s); break;
+            case 3: launch_s2_merged<3>(pl, a->Cin, s); break;
+            case 5: launch_s2_merged<5>(pl, a->Cin, s); break;
+            default: launch_s2_merged<4>(pl, a->Cin, s); break;
+        }
+        return check_launch("modconv_fwd (16-bit MFMA, merged adjoint of the up-conv)");
     }
     for (int p0 = 0; p0 < p.nphase;) {
         int n = 1;

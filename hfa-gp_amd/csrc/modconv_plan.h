@@ -43,6 +43,7 @@ struct Plan {
     int bm;           // M tile: pixels per block
     dim3 grid;
     bool merged_up;   // split-bf16 CONVT3X3_UP2: one block computes all four output phases (upconv_bf16_kernel)
+    bool merged_s2;   // split-bf16 CONVS2_BWD: one block runs the four parity phases into one accumulator set (no slabs)
     int up_waves;     // merged_up: 4 (N = 64 per block) or 8 waves (N = 128 per block, two waves per SIMD)
     size_t ws_bytes;
 };
@@ -143,6 +144,11 @@ static inline int make_plan(const HfagpModconvArgs* a, Plan& pl, int ck) {
     p.slab = (long long)a->B * p.Ho * p.Wo * a->Cout;
 
     pl.merged_up = a->precision != HFAGP_PREC_F32 && a->mode == HFAGP_CONVT3X3_UP2;
+    pl.merged_s2 = a->precision != HFAGP_PREC_F32 && a->mode == HFAGP_CONVS2_BWD;
+    if (pl.merged_s2) {                // the parity phases accumulate in registers: one slab (hfagp_modconv_workspace_bytes follows)
+        p.nslab = 1;
+        for (int q = 0; q < 4; ++q) p.phase[q].slab = 0;
+    }
     // the 8-wave up-conv block owns a whole CU: take it when N = 128 tiles alone give every CU two blocks
     pl.up_waves = 4;
 #ifndef HFAGP_UP_WAVES8_MIN_BLOCKS
@@ -152,7 +158,7 @@ static inline int make_plan(const HfagpModconvArgs* a, Plan& pl, int ck) {
         (long long)p.tiles_h * p.tiles_w * a->B * (a->Cout / 128) >= HFAGP_UP_WAVES8_MIN_BLOCKS) pl.up_waves = 8;
     { static const char* dev = getenv("HFAGP_DEV_UP_WAVES"); if (dev && pl.merged_up) pl.up_waves = atoi(dev) == 8 && a->Cout % 128 == 0 ? 8 : 4; }
     const int grid_tiles_n = pl.merged_up ? a->Cout / (pl.up_waves == 8 ? 128 : 64) : p.tiles_n;
-    const int grid_phases = pl.merged_up ? 1 : p.nphase;
+    const int grid_phases = (pl.merged_up || pl.merged_s2) ? 1 : p.nphase;
     const long long base_blocks = (long long)p.tiles_h * p.tiles_w * a->B * grid_tiles_n * grid_phases;
     int ks = a->ksplit;
     if (ks <= 0) {
