@@ -46,66 +46,91 @@ __global__ void __launch_bounds__(256) pointwise_bwd_kernel(const HfagpPointwise
         for (int k = 0; k < 4; ++k) acc[r][k] = 0.f;
 
     const bool pvalid = pl < npl;        // 256 % C4 != 0 leaves idle threads
-    if (pvalid && c4 < C4)
-        for (int p = p_begin + pl; p < p_end; p += npl) {
-            const size_t e = base + (size_t)p * C4 + c4;
-            const float4 x = reinterpret_cast<const float4*>(a.x)[e];
-            float gx[4] = {0, 0, 0, 0};
-            const float xv[4] = {x.x, x.y, x.z, x.w};
-            if (a.dxs_conv) {
-                const float4 g = reinterpret_cast<const float4*>(a.dxs_conv)[e];
-                const float gv[4] = {g.x, g.y, g.z, g.w}, sv[4] = {s_c.x, s_c.y, s_c.z, s_c.w};
+    // reciprocals once per thread instead of three IEEE divisions per element (~40 instructions each 4-channel group)
+    const float rgain = 1.f / a.gain, ralpha = 1.f / a.alpha;
+    const float dv[4] = {d_p.x, d_p.y, d_p.z, d_p.w}, bv[4] = {b_p.x, b_p.y, b_p.z, b_p.w};
+    const float rdv[4] = {1.f / d_p.x, 1.f / d_p.y, 1.f / d_p.z, 1.f / d_p.w};
+    // one pixel of this thread's 4 channels; the loads of TWO pixels are issued before either is used (round 4: one pixel
+    // per iteration left one 16-byte load per operand in flight per thread — 2.0 - 2.4 TB/s on the 512^2 layers)
+    auto pixel = [&](int p, const float4 x, const float4 gc, const float4 gr, const float4 gd, const float nraw,
+                     const float gs0, const float gs1, const float gs2, const float gs3) __attribute__((always_inline)) {
+        const size_t e = base + (size_t)p * C4 + c4;
+        float gx[4] = {0, 0, 0, 0};
+        const float xv[4] = {x.x, x.y, x.z, x.w};
+        if (a.dxs_conv) {
+            const float gv[4] = {gc.x, gc.y, gc.z, gc.w}, sv[4] = {s_c.x, s_c.y, s_c.z, s_c.w};
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { gx[k] += gv[k] * sv[k]; acc[0][k] += gv[k] * xv[k]; }
-            }
-            if (a.dxs_rgb) {
-                const float4 g = reinterpret_cast<const float4*>(a.dxs_rgb)[e];
-                const float gv[4] = {g.x, g.y, g.z, g.w}, sv[4] = {s_r.x, s_r.y, s_r.z, s_r.w};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { gx[k] += gv[k] * sv[k]; acc[1][k] += gv[k] * xv[k]; }
-            }
-            if (a.g_rgb_small) {
-                float t[4] = {0, 0, 0, 0};
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    if (c < a.Co) {
-                        const float g = a.g_rgb_small[((size_t)b * a.Co + c) * HW + p];
-                        t[0] += g * wsm[c].x; t[1] += g * wsm[c].y; t[2] += g * wsm[c].z; t[3] += g * wsm[c].w;
-                        if (a.param_grads) {
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) acc[6 + c][k] += g * xv[k];
-                        }
-                    }
-                const float sv[4] = {s_sm.x, s_sm.y, s_sm.z, s_sm.w};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { gx[k] += t[k] * sv[k]; acc[2][k] += t[k] * xv[k]; }
-            }
-            if (a.g_direct) {
-                const float4 g = reinterpret_cast<const float4*>(a.g_direct)[e];
-                gx[0] += g.x; gx[1] += g.y; gx[2] += g.z; gx[3] += g.w;
-            }
-            // producer layer P: through clamp / gain / leaky-ReLU, then the demodulation
-            const float nraw = a.noise_p ? a.noise_p[p] : 0.f;
-            const float nz = nraw * a.noise_strength_p;
-            const float dv[4] = {d_p.x, d_p.y, d_p.z, d_p.w}, bv[4] = {b_p.x, b_p.y, b_p.z, b_p.w};
-            float go[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float g = gx[k];
-                float pre = xv[k];
-                if (a.has_producer) {
-                    if (a.clamp >= 0.f && fabsf(xv[k]) >= a.clamp) g = 0.f;
-                    g *= a.gain;
-                    pre = xv[k] / a.gain;
-                    if (a.act_p == HFAGP_ACT_LRELU && !(xv[k] > 0.f)) { g *= a.alpha; pre /= a.alpha; }   // (alpha at 0, as ATen / EG3D)
-                    acc[3][k] += g * (pre - bv[k] - nz) / dv[k];
-                    if (a.param_grads) { acc[4][k] += g; acc[5][k] += g * nraw; }
-                    g *= dv[k];
-                }
-                go[k] = g;
-            }
-            reinterpret_cast<float4*>(a.g_out)[e] = make_float4(go[0], go[1], go[2], go[3]);
+            for (int k = 0; k < 4; ++k) { gx[k] += gv[k] * sv[k]; acc[0][k] += gv[k] * xv[k]; }
         }
+        if (a.dxs_rgb) {
+            const float gv[4] = {gr.x, gr.y, gr.z, gr.w}, sv[4] = {s_r.x, s_r.y, s_r.z, s_r.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { gx[k] += gv[k] * sv[k]; acc[1][k] += gv[k] * xv[k]; }
+        }
+        if (a.g_rgb_small) {
+            float t[4] = {0, 0, 0, 0};
+            const float gsm[4] = {gs0, gs1, gs2, gs3};
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < a.Co) {
+                    const float g = gsm[c];
+                    t[0] += g * wsm[c].x; t[1] += g * wsm[c].y; t[2] += g * wsm[c].z; t[3] += g * wsm[c].w;
+                    if (a.param_grads) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) acc[6 + c][k] += g * xv[k];
+                    }
+                }
+            const float sv[4] = {s_sm.x, s_sm.y, s_sm.z, s_sm.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { gx[k] += t[k] * sv[k]; acc[2][k] += t[k] * xv[k]; }
+        }
+        if (a.g_direct) { gx[0] += gd.x; gx[1] += gd.y; gx[2] += gd.z; gx[3] += gd.w; }
+        // producer layer P: through clamp / gain / leaky-ReLU, then the demodulation
+        const float nz = nraw * a.noise_strength_p;
+        float go[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float g = gx[k];
+            if (a.has_producer) {
+                if (a.clamp >= 0.f && fabsf(xv[k]) >= a.clamp) g = 0.f;
+                g *= a.gain;
+                float pre = xv[k] * rgain;
+                if (a.act_p == HFAGP_ACT_LRELU && !(xv[k] > 0.f)) { g *= a.alpha; pre *= ralpha; }   // (alpha at 0, as ATen / EG3D)
+                acc[3][k] += g * (pre - bv[k] - nz) * rdv[k];
+                if (a.param_grads) { acc[4][k] += g; acc[5][k] += g * nraw; }
+                g *= dv[k];
+            }
+            go[k] = g;
+        }
+        reinterpret_cast<float4*>(a.g_out)[e] = make_float4(go[0], go[1], go[2], go[3]);
+    };
+    if (pvalid && c4 < C4) {
+        const float4 z4 = make_float4(0, 0, 0, 0);
+        const float4* X = reinterpret_cast<const float4*>(a.x);
+        const float4* GC = reinterpret_cast<const float4*>(a.dxs_conv);
+        const float4* GR = reinterpret_cast<const float4*>(a.dxs_rgb);
+        const float4* GD = reinterpret_cast<const float4*>(a.g_direct);
+        auto small = [&](int p, int c) { return (a.g_rgb_small && c < a.Co) ? a.g_rgb_small[((size_t)b * a.Co + c) * HW + p] : 0.f; };
+        int p = p_begin + pl;
+        for (; p + npl < p_end; p += 2 * npl) {
+            const int q = p + npl;
+            const size_t e0 = base + (size_t)p * C4 + c4, e1 = base + (size_t)q * C4 + c4;
+            const float4 x0 = X[e0], x1 = X[e1];
+            const float4 c0 = GC ? GC[e0] : z4, c1 = GC ? GC[e1] : z4;
+            const float4 r0 = GR ? GR[e0] : z4, r1 = GR ? GR[e1] : z4;
+            const float4 d0 = GD ? GD[e0] : z4, d1 = GD ? GD[e1] : z4;
+            const float n0 = a.noise_p ? a.noise_p[p] : 0.f, n1 = a.noise_p ? a.noise_p[q] : 0.f;
+            const float s00 = small(p, 0), s01 = small(p, 1), s02 = small(p, 2), s03 = small(p, 3);
+            const float s10 = small(q, 0), s11 = small(q, 1), s12 = small(q, 2), s13 = small(q, 3);
+            pixel(p, x0, c0, r0, d0, n0, s00, s01, s02, s03);
+            pixel(q, x1, c1, r1, d1, n1, s10, s11, s12, s13);
+        }
+        if (p < p_end) {
+            const size_t e0 = base + (size_t)p * C4 + c4;
+            pixel(p, X[e0], GC ? GC[e0] : z4, GR ? GR[e0] : z4, GD ? GD[e0] : z4, a.noise_p ? a.noise_p[p] : 0.f,
+                  small(p, 0), small(p, 1), small(p, 2), small(p, 3));
+        }
+    }
     // ---- block reduction over the pixel lanes, then one deterministic partial per (b, chunk)
     float* mine = red + ((size_t)pl * kRed) * a.C + c4 * 4;
 #pragma unroll
@@ -119,21 +144,38 @@ __global__ void __launch_bounds__(256) pointwise_bwd_kernel(const HfagpPointwise
     }
 }
 
-// sums[b][r][c] = sum over chunks of partial[b][chunk][r][c]
+// sums[b][r][c] = sum over chunks of partial[b][chunk][r][c].  Block = 16 consecutive outputs x 16 chunk lanes: lane q sums
+// chunks q, q + 16, ... (eight loads in flight), then the 16 lane sums are added in a fixed tree — deterministic, and a
+// thread's serial chain is nchunks / 16 loads (one thread per output walked all chunks: 13 us at 256 chunks, and the chunk
+// count could not grow with the batch-1 layers that need more blocks).
 __global__ void __launch_bounds__(256) reduce_partials_kernel(const float* __restrict__ partial,
                                                               float* __restrict__ sums, int B, int nchunks, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // over B * n
-    if (i >= B * n) return;
-    const int b = i / n, k = i % n;
-    const float* src = partial + (size_t)b * nchunks * n + k;
-    float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};          // fixed order -> deterministic
-    int q = 0;
-    for (; q + 8 <= nchunks; q += 8) {
+    __shared__ float red[16][17];
+    const int kk = threadIdx.x & 15, q0 = threadIdx.x >> 4;
+    const int k = blockIdx.x * 16 + kk, b = blockIdx.y;
+    float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (k < n) {
+        const float* src = partial + (size_t)b * nchunks * n + k;
+        int q = q0;
+        for (; q + 7 * 16 < nchunks; q += 8 * 16) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) part[u] += src[(size_t)(q + u) * n];
+            for (int u = 0; u < 8; ++u) part[u] += src[(size_t)(q + 16 * u) * n];
+        }
+        for (; q < nchunks; q += 16) part[0] += src[(size_t)q * n];
     }
-    for (; q < nchunks; ++q) part[0] += src[(size_t)q * n];
-    sums[i] = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
+    red[q0][kk] = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
+    __syncthreads();
+    if (q0 == 0 && k < n) {
+        float t[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) t[u] = red[u][kk];
+#pragma unroll
+        for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (u < w) t[u] += t[u + w];
+        sums[(size_t)b * n + k] = t[0];
+    }
 }
 
 // ---------------------------------------------------------------- adjoint of (FIR pad 1 gain 4) + parity split
@@ -389,7 +431,7 @@ int hfagp_pointwise_bwd(const HfagpPointwiseBwdArgs* a, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     pointwise_bwd_kernel<<<dim3(a->nchunks, a->B), 256, lds, s>>>(*a, rows);
     const int n = kRed * a->C;
-    reduce_partials_kernel<<<(a->B * n + 255) / 256, 256, 0, s>>>(a->partial, a->sums, a->B, a->nchunks, n);
+    reduce_partials_kernel<<<dim3((n + 15) / 16, a->B), 256, 0, s>>>(a->partial, a->sums, a->B, a->nchunks, n);
     return check_launch("pointwise_bwd");
 }
 

@@ -734,7 +734,9 @@ def pointwise_bwd(x: torch.Tensor, dxs_conv=None, s_conv=None, dxs_rgb=None, s_r
     # blocks per sample: at most 4 pixels per thread (the low-resolution layers are latency-bound otherwise: one block
     # walking 64 pixels of 512 channels took 45 us), at most 256 (the partial sums are reduced by a second kernel)
     npl = max(1, 256 // (c // 4))
-    nchunks = max(1, min(256, -(-(h * w) // (npl * 4))))
+    # ... and enough blocks to fill the chip at batch 1 - 2 (the 512^2 layers ran 256 blocks = 4 waves per CU at B = 1: 2 TB/s);
+    # the chunk-parallel reducer (reduce_partials_kernel) makes up to 1024 chunks per sample cheap
+    nchunks = max(1, min(max(256, 1024 // b), -(-(h * w) // (npl * 4))))
     a = L.PointwiseBwdArgs()
     g_out = torch.empty_like(x)
     partial = torch.empty(b, nchunks, 10, c, device=x.device, dtype=torch.float32)
