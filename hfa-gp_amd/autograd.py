@@ -99,8 +99,33 @@ class _Backward:
                       style_gain, accumulate=True)
 
     # ------------------------------------------------------------------ one SynthesisBlock, in reverse
+    def image_chain(self, recs: List[dict], g_img: torch.Tensor, side) -> List[tuple]:
+        """The image-gradient side chain of the backbone, run AHEAD on the second stream (generator.side_stream): per block
+        (last first) the adjoint of `upsample2d(img)` and the toRGB adjoint `dxs_rgb` depend on the block's image gradient
+        only — never on the conv chain — so all of them are enqueued here while the launch stream walks the blocks; `block`
+        waits for its entry's event.  Returns [(g_img_prev, g_y, dxs_rgb, event)] in walking order."""
+        main = torch.cuda.current_stream(g_img.device)
+        for rec in recs:                          # transposed weight images are cached on the generator: build them on the
+            self.wt_t(rec["rgb"]["torgb"].weight)  # launch stream, where later steps will also find them
+        side.wait_stream(main)
+        g_img.record_stream(side)
+        out = []
+        with torch.cuda.stream(side):
+            g = g_img
+            for rec in recs:
+                rgb = rec["rgb"]
+                tr = rgb["torgb"]
+                g_prev = ops.upsample2d_bwd(g, channels_last=True) if rec["img_in"] is not None else None
+                g_y = _masked(g, rgb["y"], rgb["clamp"]).contiguous()
+                dxs_rgb = self.bwd_data(g_y, tr.weight, tr.weight.shape[1], ops.CONV1X1)
+                ev = torch.cuda.Event()
+                ev.record(side)
+                out.append((g_prev, g_y, dxs_rgb, ev))
+                g = g_prev
+        return out
+
     def block(self, rec: dict, g_img, dxs_next: Optional[torch.Tensor], s_next: Optional[torch.Tensor],
-              next_layer_rec: Optional[dict]):
+              next_layer_rec: Optional[dict], ahead: Optional[tuple] = None):
         """g_img: gradient of the block's output skip image (NCHW small / NHWC 96-ch).
         dxs_next / s_next: raw bwd-data of the NEXT block's conv0 w.r.t. (x*s) and its styles (or None).
         Returns (dxs of this block's conv0 w.r.t. its modulated input | None, conv0 rec | None, g_img_prev)."""
@@ -110,10 +135,19 @@ class _Backward:
         x1 = c1["out"]
         # ---- toRGB + skip
         g_img_prev = None
-        if rec["img_in"] is not None:
+        if ahead is not None:
+            # computed ahead on the side stream (image_chain): join here, where this block's fused pass consumes it
+            g_img_prev, g_y, dxs_rgb, ev = ahead
+            main = torch.cuda.current_stream(x1.device)
+            main.wait_event(ev)
+            for t in (g_y, dxs_rgb):
+                t.record_stream(main)
+            kw = dict(dxs_rgb=dxs_rgb, s_rgb=rgb["styles"])
+        elif rec["img_in"] is not None:
             g_img_prev = ops.upsample2d_bwd(g_img, channels_last=not rgb["small"])
-        kw = {}
-        if rgb["small"]:
+        if ahead is not None:
+            pass
+        elif rgb["small"]:
             g_y = _masked(g_img, rgb["y_pre"], rgb["clamp"]).contiguous()
             kw = dict(g_rgb_small=g_y, w_rgb_small=tr.weight.detach().reshape(tr.weight.shape[0], cin),
                       s_small=rgb["styles"])
@@ -274,13 +308,18 @@ class SynthesisFn(torch.autograd.Function):
         # ---- backbone, last block first
         g_img_b = ops.planes_to_nhwc(d_planes)
         dxs, nxt = None, None
-        for rec in reversed(tape["backbone"]):
+        walk = list(reversed(tape["backbone"]))
+        side = gen.side_stream(b, dev) if all(not r["rgb"]["small"] for r in walk) else None
+        ahead = bw.image_chain(walk, g_img_b, side) if side is not None else None
+        for k, rec in enumerate(walk):
             s_next = nxt["styles"] if nxt is not None else None
-            dxs_new, c0, g_img_b = bw.block(rec, g_img_b, dxs, s_next, nxt)
+            dxs_new, c0, g_img_b = bw.block(rec, g_img_b, dxs, s_next, nxt, ahead[k] if ahead is not None else None)
             if nxt is not None:
                 bw.finish_layer(nxt)
             dxs, nxt = dxs_new, c0
             bw.release_ready()
+        if side is not None:
+            torch.cuda.current_stream(dev).wait_stream(side)     # (nothing of this pass is left on the side stream)
         bw.flush_styles()
         bw.release_ready()
         ctx.tape = None

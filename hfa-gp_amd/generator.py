@@ -15,6 +15,8 @@ device generator, or passed in as ``u_strat`` / ``u_imp`` for reproducible parit
 """
 from __future__ import annotations
 
+import contextlib
+
 import math
 import os
 from typing import Dict, Optional
@@ -155,6 +157,15 @@ class TriPlaneGenerator(nn.Module):
         # 256- and 512-channel layers.  "auto" (default): fused for Cin <= 64 where the launch fills the chip; "1": wherever the
         # library supports it; "0": never.
         self.fuse_up_fir = os.environ.get("HFAGP_FUSE_UP_FIR", "auto")
+        # The image side chain of the backbone — toRGB + skip of block k — depends on conv1 of block k and on the image of block
+        # k - 1 only; conv0 / conv1 of block k + 1 never read it.  At small batch every kernel of the 4^2 ... 64^2 blocks is a
+        # latency-sized launch on a mostly empty chip, so for batches up to `side_stream_max_batch` the side chain (and, in the
+        # backward pass, the whole image-gradient chain: upsample2d adjoint + toRGB adjoint of every block) is enqueued on a
+        # SECOND HIP stream and joined where its result is consumed (the tri-planes before the ray march; `dxs_rgb` before the
+        # fused pointwise pass of its block).  Same kernels, same arithmetic, same bits; 0 disables it.  At large batch the
+        # chip is full and two streams measured slower (profiles/r02d_two_streams_experiment.txt).
+        self.side_stream_max_batch = int(os.environ.get("HFAGP_SIDE_STREAM_MAX_BATCH", "4"))
+        self._side_streams: Dict[int, "torch.cuda.Stream"] = {}
         self._styles: Dict[int, tuple] = {}      # id(layer) -> (styles, dcoef) of the pass in flight
         self._absmax = None                      # (slot buffers, layer names) of the last pass: f16_range_report()
         self._rgb_part = None                    # partial toRGB sums of the conv just run (fused toRGB, ops.modconv)
@@ -177,6 +188,17 @@ class TriPlaneGenerator(nn.Module):
         for k in drop:
             del state_dict[k]
         self.ignored_checkpoint_keys = [k[len(prefix):] for k in drop]
+
+    def side_stream(self, batch: int, device) -> Optional["torch.cuda.Stream"]:
+        """The second launch stream of `device` for the image side chain, or None when the batch is too large for it to pay
+        (or while a HIP graph is being captured on the launch stream: a capture owns one stream)."""
+        if batch > self.side_stream_max_batch or torch.cuda.is_current_stream_capturing():
+            return None
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        st = self._side_streams.get(idx)
+        if st is None:
+            st = self._side_streams[idx] = torch.cuda.Stream(device=device)
+        return st
 
     def _timed(self, key: str, units: float, fn, *args, **kwargs):
         """Run ``fn`` bracketed by HIP events on the current stream when bench.py enabled timing."""
@@ -411,17 +433,29 @@ class TriPlaneGenerator(nn.Module):
                                       styles, tr.bias, img, conv_clamp, y_pre)
         else:
             wt, _ = self._prepared(tr.weight)
-            # the block that writes the tri-planes also publishes max |planes|: the bound the ray marcher's 16-bit
-            # decoder scales its operands by (ops.raymarch planes_absmax)
-            self._planes_absmax = ops.absmax_slots(1, x.device)[0] if last else None
-            if conv_clamp is None and x.shape[0] == batch and ops.torgb_skip_supported(x, wt, tr.weight.shape[0]):
-                # toRGB and the skip connection in one streaming pass (the toRGB output is never stored)
-                img = ops.torgb_skip(x, wt, tr.weight.shape[0], styles, tr.bias, img, plane_major=last, x_absmax=am1,
-                                     out_absmax=self._planes_absmax)
-            else:
-                y = ops.modconv(x, wt, tr.weight.shape[0], ops.CONV1X1, styles=styles, bias=tr.bias, act="linear",
-                                gain=1.0, clamp=conv_clamp, batch=batch, x_absmax=am1)
-                img = ops.skip_upsample_add(img, y, plane_major=last, out_absmax=self._planes_absmax)
+            side = self.side_stream(batch, x.device)
+            main = torch.cuda.current_stream(x.device) if side is not None else None
+            if side is not None:
+                side.wait_stream(main)               # conv1's output (and everything before it) is ordered before the side chain
+                for t in (x, styles):                # main-stream tensors read on the side stream: not to be recycled under it
+                    t.record_stream(side)
+            with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                # the block that writes the tri-planes also publishes max |planes|: the bound the ray marcher's 16-bit
+                # decoder scales its operands by (ops.raymarch planes_absmax)
+                self._planes_absmax = ops.absmax_slots(1, x.device)[0] if last else None
+                if conv_clamp is None and x.shape[0] == batch and ops.torgb_skip_supported(x, wt, tr.weight.shape[0]):
+                    # toRGB and the skip connection in one streaming pass (the toRGB output is never stored)
+                    img = ops.torgb_skip(x, wt, tr.weight.shape[0], styles, tr.bias, img, plane_major=last, x_absmax=am1,
+                                         out_absmax=self._planes_absmax)
+                else:
+                    y = ops.modconv(x, wt, tr.weight.shape[0], ops.CONV1X1, styles=styles, bias=tr.bias, act="linear",
+                                    gain=1.0, clamp=conv_clamp, batch=batch, x_absmax=am1)
+                    img = ops.skip_upsample_add(img, y, plane_major=last, out_absmax=self._planes_absmax)
+            if side is not None and last:
+                # join: the tri-planes (and their |max| slots) are consumed on the launch stream from here on
+                main.wait_stream(side)
+                img.record_stream(main)
+                self._planes_absmax.record_stream(main)
         if tape is not None:
             rec["rgb"] = dict(torgb=tr, x=x, styles=styles, row=row, small=small_rgb, clamp=conv_clamp,
                               y=y if conv_clamp is not None else None, y_pre=y_pre)
@@ -479,6 +513,9 @@ class TriPlaneGenerator(nn.Module):
                                  (prev, am[2 * k], am[2 * k + 1]) if track else None)
             prev = am[2 * k + 1] if track else None
             idx += n_conv
+        side = self._side_streams.get(ws.device.index if ws.device.index is not None else torch.cuda.current_device())
+        if side is not None:
+            torch.cuda.current_stream(ws.device).wait_stream(side)     # (join of the image side chain, whatever block ended it)
         return img
 
     def f16_range_report(self) -> Optional[Dict[str, float]]:
