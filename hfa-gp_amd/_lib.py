@@ -14,7 +14,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # (HFAGP_LIB_PATH: developer override, used by the ablation builds of tools/dev/ — the product loads the in-tree library)
 LIB_PATH = os.environ.get("HFAGP_LIB_PATH") or os.path.join(_HERE, "libhfagp_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 c_float_p = C.c_void_p  # device pointers travel as integers
 
@@ -128,7 +128,8 @@ class StyleBwdItem(C.Structure):
 
 class RaymarchBwdArgs(C.Structure):
     _fields_ = [("fwd", RaymarchArgs), ("g_feat", C.c_void_p), ("d_planes", C.c_void_p), ("rec", C.c_void_p),
-                ("d_dec_w0", C.c_void_p), ("d_dec_b0", C.c_void_p), ("d_dec_w1", C.c_void_p), ("d_dec_b1", C.c_void_p)]
+                ("d_dec_w0", C.c_void_p), ("d_dec_b0", C.c_void_p), ("d_dec_w1", C.c_void_p), ("d_dec_b1", C.c_void_p),
+                ("df_scratch", C.c_void_p)]
 
 
 # every symbol include/hfagp.h declares: name -> (restype, argtypes)

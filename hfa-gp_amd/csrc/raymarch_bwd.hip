@@ -653,6 +653,308 @@ raymarch_bwd_cols_kernel(const RayParams p, float* __restrict__ d_planes, const 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Round 4: pass 2 of the column variant as TWO kernels.  In raymarch_bwd_cols_kernel the 12 waves of the one workgroup a CU
+// holds (64 KB cache + 44 KB decoder images + tiles) move in lock step — tile arithmetic | barrier | scatter | barrier — so
+// the gather / MFMA latencies of the arithmetic and the LDS / atomic latencies of the two scatters never overlap: 0.6 ms of
+// arithmetic + 0.95 ms of scatter per 2 frames (profiles/r03_raybwd_phases.txt), each alone a third of that.  Split:
+//   raymarch_bwd_df_kernel      gather -> decoder forward -> decoder backward per 16-sample tile, dL/dF to a scratch buffer
+//                               [ray][sample][32] (201 MB per frame); no barrier in its loop, two 4-wave workgroups per CU;
+//   raymarch_bwd_scatter_kernel the column chunk's scatter alone: tiles stream dL/dF back in (2 KB per tile, one pass), taps are
+//                               recomputed from the saved depths, plane (x,y) run-merged atomics + plane (x,z) line cache as before.
+// The scratch round trip is 0.4 GB per frame of streaming traffic; taken when the caller provides HfagpRaymarchBwdArgs::df_scratch.
+constexpr int kDfWaves = 4;      // two workgroups per CU (254 VGPRs: two waves per SIMD, as the forward kernel)
+
+template <int S, bool DEC16>
+__global__ void __launch_bounds__(kDfWaves * 64, 2)
+raymarch_bwd_df_kernel(const RayParams p, float* __restrict__ df_out) {
+    __shared__ float w1t[4 * 8 * 64];
+    __shared__ float w0t[2 * 16 * 64];
+    __shared__ float wfwd[kDecLdsRows * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const HfagpRaymarchArgs& a = p.a;
+    const int j = lane & 15, g = lane >> 4;
+    const int R = a.res * a.res;
+    constexpr int NT = S / 16;
+    if (wave == 0) {
+        DecoderRegs dec;
+        load_decoder(a, j, g, dec);
+        if constexpr (DEC16) {
+            Dec16Regs d16;
+            make_dec16(dec, a.planes_absmax, lane, d16);
+            store_dec16_lds(d16, wfwd, lane);
+        } else {
+            store_decoder_lds(dec, wfwd, lane);
+        }
+    }
+    if constexpr (DEC16) {
+        build_grad16_lds(a, w1t, w0t, lane, wave, kDfWaves);
+    } else {
+        const float g0 = a.decoder_lr_mul * 0.17677669529663687f, g1 = a.decoder_lr_mul * 0.125f;
+        for (int i = threadIdx.x; i < 4 * 8 * 64; i += kDfWaves * 64) {
+            const int l = i & 63, st = (i >> 6) & 7, mt = i >> 9, jj = l & 15, gg = l >> 4;
+            w1t[i] = a.dec_w1[(1 + 16 * (st >> 2) + 4 * gg + (st & 3)) * 64 + 16 * mt + jj] * g1;
+        }
+        for (int i = threadIdx.x; i < 2 * 16 * 64; i += kDfWaves * 64) {
+            const int l = i & 63, st = (i >> 6) & 15, ft = i >> 10, jj = l & 15, gg = l >> 4;
+            w0t[i] = a.dec_w0[(16 * (st >> 2) + 4 * gg + (st & 3)) * 32 + 16 * ft + jj] * g0;
+        }
+    }
+    __syncthreads();
+    const RaySchedule sch = ray_schedule((long long)p.total_rays * NT, wave, kDfWaves);
+    for (long long tile = sch.begin; tile < sch.end; tile += sch.stride) {
+        const int tt = __builtin_amdgcn_readfirstlane((int)(tile % NT));
+        int b, pi, pj;
+        ray_of(__builtin_amdgcn_readfirstlane((int)(tile / NT)), a.res, b, pi, pj);
+        const int ray = __builtin_amdgcn_readfirstlane(b * R + pi * a.res + pj);
+        float o3[3], d3[3];
+        ray_setup(a, b, pi, pj, o3, d3);
+        const int s = 16 * tt + j;
+        const float4 rec = *reinterpret_cast<const float4*>(p.rec + ((size_t)ray * S + s) * 4);   // depth, omega, dsigma
+        float f[8];
+        {
+            PlaneTaps tq[3];
+            sample_taps(p, o3, d3, p.rec[((size_t)ray * S + 16 * tt + (lane >> 2)) * 4], tq);
+            gather8(a, b, lane & 3, tq, f);
+            const int src = 4 * j + g;
+#pragma unroll
+            for (int cc = 0; cc < 8; ++cc) f[cc] = __shfl(f[cc], src);
+        }
+        f32x4 hp[4], h[4], o[2];
+        float sigma;
+        if constexpr (DEC16) decoder_fwd16_lds<true>(wfwd, lane, f, hp, h, sigma, o);
+        else decoder_fwd_lds<true>(wfwd, lane, f, hp, h, sigma, o);
+        f32x4 dO[2];
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot) {
+            const float4 gf = *reinterpret_cast<const float4*>(p.g_feat + (size_t)ray * 32 + 16 * ot + 4 * g);
+            const float gv[4] = {gf.x, gf.y, gf.z, gf.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float sg = sigmoid_f(o[ot][r]);
+                dO[ot][r] = rec.y * 2.f * gv[r] * 1.002f * sg * (1.f - sg);
+            }
+        }
+        f32x4 dH[4];
+        f32x4 dF2[2];
+        if constexpr (DEC16) decoder_bwd16_lds(wfwd, w1t, w0t, lane, dO, rec.z, hp, dH, dF2);
+#pragma unroll
+        for (int mt = 0; mt < (DEC16 ? 0 : 4); ++mt) {
+            const float* ws_ = wfwd + (48 + mt * 4) * 64 + lane;
+            dH[mt] = f32x4{ws_[0] * rec.z, ws_[64] * rec.z, ws_[128] * rec.z, ws_[192] * rec.z};
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float wA = w1t[(mt * 8 + ot * 4 + r) * 64 + lane];
+                    dH[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wA, dO[ot][r], dH[mt], 0, 0, 0);
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dH[mt][r] *= sigmoid_f(hp[mt][r]);
+        }
+        // lane (j, g), register r -> feature channel 16ft + 4g + r of sample j: 16-byte stores, two per 128-byte sample line
+        float* dst = df_out + ((size_t)ray * S + s) * 32 + 4 * g;
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft) {
+            f32x4 dF = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (DEC16) {
+                dF = dF2[ft];
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float wA = w0t[(ft * 16 + mt * 4 + r) * 64 + lane];
+                        dF = __builtin_amdgcn_mfma_f32_16x16x4f32(wA, dH[mt][r], dF, 0, 0, 0);
+                    }
+            }
+            *reinterpret_cast<float4*>(dst + 16 * ft) = make_float4(dF[0], dF[1], dF[2], dF[3]);
+        }
+    }
+}
+
+template <int S>
+__global__ void __launch_bounds__(kColWaves * 64, 1)
+raymarch_bwd_scatter_kernel(const RayParams p, const float* __restrict__ df_in, float* __restrict__ d_planes, const int nchunks,
+                            const int chunks_per_col) {
+    constexpr int NT = S / 16, RPR = kColWaves / NT;       // tiles per ray, rays per round
+    static_assert(RPR >= 1, "at least one ray per round");
+    extern __shared__ __attribute__((aligned(16))) unsigned char cols_smem[];
+    float* cache = reinterpret_cast<float*>(cols_smem);                                   // [rows*2][32]
+    int* tag = reinterpret_cast<int*>(cache + kColMaxRows * kColSlots * 32);              // [rows*2]: column or -1
+    ColTileLds* tiles = reinterpret_cast<ColTileLds*>(tag + kColMaxRows * kColSlots);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    ColTileLds& lds = tiles[wave];
+    const HfagpRaymarchArgs& a = p.a;
+    const int j = lane & 15, g = lane >> 4;
+    const int R = a.res * a.res;
+    const int nslots = a.H * kColSlots;
+    const int c = lane & 31, hf = lane >> 5;
+    for (int i = threadIdx.x; i < nslots; i += kColWaves * 64) tag[i] = -1;
+    __syncthreads();
+
+    for (int chunk = (int)xcd_remap(blockIdx.x, gridDim.x); chunk < nchunks; chunk += gridDim.x) {
+        const int col_id = chunk / chunks_per_col, piece = chunk % chunks_per_col;
+        const int b = col_id / a.res, pj = col_id % a.res;
+        const int row0 = piece * kColRays, row1 = min(a.res, row0 + kColRays);
+        float* const pb0 = d_planes + (size_t)b * 3 * a.H * a.W * 32 + c;            // plane (x,y), this lane's channel
+        float* const pb1 = pb0 + (size_t)a.H * a.W * 32;                             // plane (x,z)
+        for (int pr = row0; pr < row1; pr += RPR) {
+            const int pi = pr + wave / NT, tt = wave % NT;
+            const bool active = wave < RPR * NT && pi < row1;
+            if (active) {
+                const int ray = __builtin_amdgcn_readfirstlane(b * R + pi * a.res + pj);
+                float o3[3], d3[3];
+                ray_setup(a, b, pi, pj, o3, d3);
+                const int s = 16 * tt + j;
+                // the tile's dL/dF: 2 KB, contiguous in the scratch buffer -> LDS [sample][channel] as is
+                {
+                    const float4* src = reinterpret_cast<const float4*>(df_in + ((size_t)ray * S + 16 * tt) * 32);
+                    const float4 v0 = src[lane], v1 = src[lane + 64];
+                    reinterpret_cast<float4*>(lds.df)[lane] = v0;
+                    reinterpret_cast<float4*>(lds.df)[lane + 64] = v1;
+                }
+                const float depth = p.rec[((size_t)ray * S + s) * 4];
+                PlaneTaps taps[3];
+                sample_taps(p, o3, d3, depth, taps);
+                if (g == 0) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        lds.idx0[k * 16 + j] = taps[0].idx[k];
+                        lds.wgt0[k * 16 + j] = taps[0].w[k] * 0.3333333333333333f;
+                    }
+                }
+                if (g == 1) {
+#pragma unroll
+                    for (int zr = 0; zr < 2; ++zr) {
+                        const float wa = taps[1].w[2 * zr] * 0.3333333333333333f, wb = taps[1].w[2 * zr + 1] * 0.3333333333333333f;
+                        int row = -1, x0 = 0;
+                        if (wa != 0.f) { row = taps[1].idx[2 * zr] / a.W; x0 = taps[1].idx[2 * zr] % a.W; }
+                        else if (wb != 0.f) { row = taps[1].idx[2 * zr + 1] / a.W; x0 = taps[1].idx[2 * zr + 1] % a.W - 1; }
+                        lds.upd[zr * 16 + j] = make_int4(row, x0, __float_as_int(wa), __float_as_int(wb));
+                    }
+                }
+                WAVE_SYNC();
+                // ---- plane (x,y): run-merged global atomics
+                {
+                    float dfc[16];
+#pragma unroll
+                    for (int sm = 0; sm < 16; ++sm) dfc[sm] = lds.df[sm * 32 + c];
+#pragma unroll 1
+                    for (int pk = 0; pk < 2; ++pk) {
+                        const int k = 2 * pk + hf;
+                        float wv[16];
+                        int tv[16];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float4 w4 = *reinterpret_cast<const float4*>(&lds.wgt0[k * 16 + 4 * q]);
+                            const int4 t4 = *reinterpret_cast<const int4*>(&lds.idx0[k * 16 + 4 * q]);
+                            wv[4 * q] = w4.x; wv[4 * q + 1] = w4.y; wv[4 * q + 2] = w4.z; wv[4 * q + 3] = w4.w;
+                            tv[4 * q] = t4.x; tv[4 * q + 1] = t4.y; tv[4 * q + 2] = t4.z; tv[4 * q + 3] = t4.w;
+                        }
+                        int cur = -1;
+                        float run = 0.f;
+#pragma unroll
+                        for (int sm = 0; sm < 16; ++sm) {
+                            const float wgt = wv[sm];
+                            const int t = tv[sm];
+                            const float v = dfc[sm] * wgt;
+                            if (wgt != 0.f) {
+                                if (t == cur) {
+                                    run += v;
+                                } else {
+                                    if (cur >= 0) unsafeAtomicAdd(pb0 + (size_t)cur * 32, run);
+                                    cur = t;
+                                    run = v;
+                                }
+                            }
+                        }
+                        if (cur >= 0) unsafeAtomicAdd(pb0 + (size_t)cur * 32, run);
+                    }
+                }
+            } else if (lane < 32) {
+                lds.upd[lane] = make_int4(-1, 0, 0, 0);
+            }
+            __syncthreads();
+            // ---- plane (x,z): wave w applies the row-updates of ITS rows to its cache lines (as raymarch_bwd_cols_kernel)
+            {
+                constexpr int NU = kColWaves * 32;
+                auto apply = [&](int row, int col, float wgt, float dfv, int have, float accv) {
+                    const int slot = row * kColSlots + (col & 1);
+                    if (have != col) {
+                        if (have >= 0) unsafeAtomicAdd(pb1 + ((size_t)row * a.W + have) * 32, accv);
+                        accv = 0.f;
+                        if (c == 0) tag[slot] = col;
+                    }
+                    cache[slot * 32 + c] = fmaf(dfv, wgt, accv);
+                };
+#pragma unroll 1
+                for (int e0 = 0; e0 < NU; e0 += 64) {
+                    const int u = e0 + lane;
+                    const int4 me = tiles[u >> 5].upd[u & 31];
+                    const bool mine = me.x >= 0 && (me.x % kColWaves) == wave;
+                    unsigned long long mask = __ballot(mine);
+                    while (mask) {
+                        int ii[4], rw[4], n = 0;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            ii[k] = 0; rw[k] = -1 - k;
+                            if (mask) {
+                                ii[k] = __builtin_ctzll(mask);
+                                mask &= mask - 1;
+                                rw[k] = __builtin_amdgcn_readlane(me.x, ii[k]);
+                                n = k + 1;
+                            }
+                        }
+                        const bool distinct = rw[0] != rw[1] && rw[0] != rw[2] && rw[0] != rw[3] && rw[1] != rw[2] &&
+                                              rw[1] != rw[3] && rw[2] != rw[3];
+                        int colk[4], havek[4];
+                        float wk[4], dk[4], acck[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int x0 = __builtin_amdgcn_readlane(me.y, ii[k]);
+                            const float wa = __int_as_float(__builtin_amdgcn_readlane(me.z, ii[k]));
+                            const float wb = __int_as_float(__builtin_amdgcn_readlane(me.w, ii[k]));
+                            const int ue = e0 + ii[k];
+                            colk[k] = x0 + hf;
+                            wk[k] = k < n ? (hf ? wb : wa) : 0.f;
+                            dk[k] = tiles[ue >> 5].df[(ue & 15) * 32 + c];
+                        }
+                        if (distinct) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const int slot = max(rw[k], 0) * kColSlots + (colk[k] & 1);
+                                havek[k] = tag[slot];
+                                acck[k] = cache[slot * 32 + c];
+                            }
+#pragma unroll
+                            for (int k = 0; k < 4; ++k)
+                                if (wk[k] != 0.f) apply(rw[k], colk[k], wk[k], dk[k], havek[k], acck[k]);
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k)
+                                if (wk[k] != 0.f) {
+                                    const int slot = rw[k] * kColSlots + (colk[k] & 1);
+                                    apply(rw[k], colk[k], wk[k], dk[k], tag[slot], cache[slot * 32 + c]);
+                                }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        for (int row = wave; row < a.H; row += kColWaves) {
+            const int slot = row * kColSlots + hf;
+            const int col = tag[slot];
+            if (col >= 0) unsafeAtomicAdd(pb1 + ((size_t)row * a.W + col) * 32, cache[slot * 32 + c]);
+        }
+        WAVE_SYNC();
+        for (int row = wave; row < a.H; row += kColWaves)
+            if (lane < kColSlots) tag[row * kColSlots + lane] = -1;
+        __syncthreads();
+    }
+}
+
 // d_planes[b][2][x][z][:] = d_planes[b][1][z][x][:]   (one float4 per thread, full 128-byte lines both ways)
 __global__ void __launch_bounds__(256) mirror_plane_kernel(float* __restrict__ d_planes, int B, int N) {
     const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -693,6 +995,11 @@ static void launch_tiles(bool pg, bool mirror, unsigned blocks, const RayParams&
     else launch_tiles2<S, false>(pg, mirror, blocks, p, d_planes, dg, s);
 }
 
+static size_t scatter_lds_bytes() {
+    return (size_t)kColMaxRows * kColSlots * 32 * sizeof(float) + (size_t)kColMaxRows * kColSlots * sizeof(int) +
+           kColWaves * sizeof(ColTileLds);
+}
+
 static size_t cols_lds_bytes() {
     return (size_t)kColMaxRows * kColSlots * 32 * sizeof(float) + (size_t)kColMaxRows * kColSlots * sizeof(int) +
            (size_t)(4 * 8 * 64 + 2 * 16 * 64 + kDecLdsRows * 64) * sizeof(float) + kColWaves * sizeof(ColTileLds);
@@ -708,6 +1015,25 @@ static int launch_cols2(unsigned blocks, size_t lds, const RayParams& p, float* 
         return HFAGP_ELAUNCH;
     }
     raymarch_bwd_cols_kernel<S, DEC16><<<blocks, kColWaves * 64, lds, s>>>(p, d_planes, nchunks, chunks_per_col);
+    return HFAGP_OK;
+}
+
+// the two-kernel form of the column variant (df_scratch given): dL/dF to the scratch buffer, then the scatter alone
+template <int S>
+static int launch_df_scatter(const RayParams& p, float* df, float* d_planes, unsigned cblocks, int nchunks, int chunks_per_col,
+                             hipStream_t s) {
+    const long long ntiles = (long long)p.total_rays * (S / 16);
+    const unsigned dblocks = (unsigned)std::min<long long>((ntiles + kDfWaves - 1) / kDfWaves, (long long)kNumCU * 2 * 8);
+    if (p.a.planes_absmax) raymarch_bwd_df_kernel<S, true><<<dblocks, kDfWaves * 64, 0, s>>>(p, df);
+    else raymarch_bwd_df_kernel<S, false><<<dblocks, kDfWaves * 64, 0, s>>>(p, df);
+    const size_t lds = scatter_lds_bytes();
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&raymarch_bwd_scatter_kernel<S>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+        set_error("raymarch_bwd: cannot raise dynamic LDS to %zu bytes: %s", lds, hipGetErrorString(e));
+        return HFAGP_ELAUNCH;
+    }
+    raymarch_bwd_scatter_kernel<S><<<cblocks, kColWaves * 64, lds, s>>>(p, df, d_planes, nchunks, chunks_per_col);
     return HFAGP_OK;
 }
 
@@ -754,7 +1080,12 @@ extern "C" int hfagp_raymarch_bwd(const HfagpRaymarchBwdArgs* a, void* stream) {
         const size_t lds = cols_lds_bytes();
         unsigned cblocks = (unsigned)std::min<long long>(nchunks, (long long)kNumCU * 4);
         int rcl = HFAGP_OK;
-        if (S == 96) rcl = launch_cols<96>(cblocks, lds, p, a->d_planes, nchunks, chunks_per_col, s);
+        if (a->df_scratch) {
+            if (S == 96) rcl = launch_df_scatter<96>(p, a->df_scratch, a->d_planes, cblocks, nchunks, chunks_per_col, s);
+            else if (S == 64) rcl = launch_df_scatter<64>(p, a->df_scratch, a->d_planes, cblocks, nchunks, chunks_per_col, s);
+            else rcl = launch_df_scatter<32>(p, a->df_scratch, a->d_planes, cblocks, nchunks, chunks_per_col, s);
+        }
+        else if (S == 96) rcl = launch_cols<96>(cblocks, lds, p, a->d_planes, nchunks, chunks_per_col, s);
         else if (S == 64) rcl = launch_cols<64>(cblocks, lds, p, a->d_planes, nchunks, chunks_per_col, s);
         else rcl = launch_cols<32>(cblocks, lds, p, a->d_planes, nchunks, chunks_per_col, s);
         if (rcl != HFAGP_OK) return rcl;

@@ -906,7 +906,8 @@ def raymarch_bwd(g_feat: torch.Tensor, planes: torch.Tensor, cam2world, intrinsi
                  dec_w1, dec_b1, res: int, ray_start: float, ray_end: float, box_warp: float,
                  decoder_lr_mul: float = 1.0, plane_axes: int = 0, white_back: bool = False,
                  return_rec: bool = False, decoder_grads: bool = False, decoder_precision: str = "f16x3",
-                 planes_absmax: Optional[torch.Tensor] = None, state: Optional[torch.Tensor] = None):
+                 planes_absmax: Optional[torch.Tensor] = None, state: Optional[torch.Tensor] = None,
+                 two_kernel: bool = False):
     """g_feat [B,R,32] → d planes [B,3,H,W,32] (fp32 atomics into a zero-initialised buffer).  ``state``: what the forward
     call of this step left behind (`raymarch(..., state=)`): the compositing adjoint reads it instead of recomputing."""
     _chk(planes, "planes")
@@ -930,6 +931,13 @@ def raymarch_bwd(g_feat: torch.Tensor, planes: torch.Tensor, cam2world, intrinsi
             raise RuntimeError(f"raymarch_bwd: state must be [B, R, {(sc + sf) * 35}], got {tuple(state.shape)}")
         f.state = _ptr(_chk(state, "state"))
     a.g_feat, a.d_planes, a.rec = _ptr(g_feat), _ptr(d_planes), _ptr(rec)
+    # pass 2 as two kernels (dL/dF through a scratch buffer, then the scatter alone: hfagp.h `df_scratch`) where the column
+    # variant applies; 201 MB per frame at 128^2 rays x 96 samples.  OFF by default: measured SLOWER than the fused kernel
+    # (B = 2: dL/dF 0.51 ms + scatter 1.41 ms against 1.58 ms fused — the scatter alone is the bound, the arithmetic already
+    # hides under it; profiles/r04_raybwd_split.txt).  Kept as the vehicle for work on the scatter.
+    if two_kernel and plane_axes == 0 and h == w and h <= 256 and b * r * (sc + sf) * 128 <= (4 << 30):
+        df = torch.empty(b, r, sc + sf, 32, device=planes.device, dtype=torch.float32)
+        a.df_scratch = _ptr(df)
     dec = None
     if decoder_grads:
         dec = tuple(torch.zeros_like(t) for t in (dec_w0, dec_b0, dec_w1, dec_b1))

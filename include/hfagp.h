@@ -60,7 +60,7 @@
 extern "C" {
 #endif
 
-#define HFAGP_ABI_VERSION 9
+#define HFAGP_ABI_VERSION 10
 
 enum { HFAGP_OK = 0, HFAGP_EBADARG = -1, HFAGP_EUNSUPPORTED = -2, HFAGP_ELAUNCH = -3 };
 
@@ -444,6 +444,10 @@ typedef struct {
     float*       d_dec_b0;    /* [64] */
     float*       d_dec_w1;    /* [33][64] */
     float*       d_dec_b1;    /* [33] */
+    /* optional (ABI 10): scratch [B][R][Sc+Sf][32] floats.  Given (and the column variant applies: plane_axes = 0, square planes
+     * up to 256^2), pass 2 runs as two kernels — dL/dF of every sample into the scratch buffer, then the scatter alone — instead
+     * of one whose waves alternate between the two in lock step; same arithmetic, the atomic order differs as it does run to run. */
+    float*       df_scratch;
 } HfagpRaymarchBwdArgs;
 
 int hfagp_raymarch_bwd(const HfagpRaymarchBwdArgs* a, void* stream);

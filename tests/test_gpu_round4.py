@@ -229,3 +229,28 @@ def test_two_ranks_on_the_gpu_equal_the_single_process_step(dev, n_frames):
 @pytest.mark.parametrize("n_frames", [2, 3])
 def test_two_ranks_over_rccl_equal_the_single_process_step(dev, n_frames):
     _two_rank_case(dev, "nccl", n_frames)
+
+
+# ----------------------------------------------------------------------------- ray-march backward as two kernels (ABI 10, off by default)
+def test_raymarch_backward_two_kernel_form_equals_the_fused_kernel(dev):
+    """HfagpRaymarchBwdArgs::df_scratch: dL/dF of every sample through a scratch buffer, then the scatter alone — the same
+    arithmetic as the fused column kernel (only the order of the atomic adds differs, as it does from run to run)."""
+    from hfa_gp_amd import ops
+    from hfa_gp_amd.config import ffhq512_128
+    from hfa_gp_amd.generator import TriPlaneGenerator
+    from tests.util import make_inputs
+    cfg = ffhq512_128()
+    gen = perturb_state(TriPlaneGenerator(cfg, seed=0)).requires_grad_(False).to(dev)
+    b = 2
+    ws, c, us, ui = (t.to(dev) for t in make_inputs(cfg, b, seed=12))
+    with torch.no_grad():
+        planes = gen.backbone_planes(ws)
+        u_s, u_i = gen._uniforms(b, dev, us, ui)
+        g = torch.randn(b, cfg.neural_rendering_resolution ** 2, 32, device=dev, generator=torch.Generator(device=dev).manual_seed(4))
+        kw = gen._render_args(c)
+        pam = gen._planes_absmax
+        fused = ops.raymarch_bwd(g, planes, u_strat=u_s, u_imp=u_i, planes_absmax=pam, two_kernel=False, **kw)
+        split = ops.raymarch_bwd(g, planes, u_strat=u_s, u_imp=u_i, planes_absmax=pam, two_kernel=True, **kw)
+    scale = fused.abs().max().item()
+    assert scale > 0 and torch.isfinite(split).all()
+    assert (split - fused).abs().max().item() <= 1e-5 * scale

@@ -18,13 +18,21 @@ with torch.no_grad():
     u_s, u_i = gen._uniforms(B, dev, us, ui)
     g = torch.randn(B, 128 * 128, 32, device=dev)
     kw = gen._render_args(c)
-    for _ in range(2):
-        ops.raymarch_bwd(g, planes, u_strat=u_s, u_imp=u_i, **kw)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        d = ops.raymarch_bwd(g, planes, u_strat=u_s, u_imp=u_i, **kw)
-    e1.record()
-    torch.cuda.synchronize()
-print(f"raymarch_bwd B={B}: {e0.elapsed_time(e1)/iters:.3f} ms/call ({e0.elapsed_time(e1)/iters/B:.3f} ms/frame), checksum {d.double().abs().sum().item():.4f}")
+    pam = getattr(gen, "_planes_absmax", None)
+    res = {}
+    for two in ((False, True, False, True) if len(sys.argv) <= 3 else (sys.argv[3] == "2",)):
+        for _ in range(2):
+            ops.raymarch_bwd(g, planes, u_strat=u_s, u_imp=u_i, planes_absmax=pam, two_kernel=two, **kw)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            d = ops.raymarch_bwd(g, planes, u_strat=u_s, u_imp=u_i, planes_absmax=pam, two_kernel=two, **kw)
+        e1.record()
+        torch.cuda.synchronize()
+        res[two] = d
+        print(f"raymarch_bwd B={B} two_kernel={two}: {e0.elapsed_time(e1)/iters:.3f} ms/call ({e0.elapsed_time(e1)/iters/B:.3f} ms/frame), "
+              f"checksum {d.double().abs().sum().item():.4f}")
+    if len(res) == 2:
+        diff = (res[True] - res[False]).abs().max().item()
+        print(f"max |two-kernel - fused| = {diff:.3e} (scale {res[False].abs().max().item():.3e})")
