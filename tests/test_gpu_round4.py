@@ -60,9 +60,10 @@ def test_gen_update_at_own_size_matches_oracle_step(dev, mode):
     """ONE composed fitting step at 512^2 / 128^2 rays / 48+48 samples, B = 2, generator frozen (the reference's first 50 000
     iterations): driver net -> QR latent basis -> HIP generator -> fused pool + MSE -> backward (conv bwd-data on split bf16,
     ray-march backward from the saved state, pointwise / style adjoints, QR adjoint, driver net) against the identical step
-    with the generator replaced by the CPU oracle under autograd.  Bars are those of the full-size three-way gradient test
-    (test_gpu_round3.py): that test measured d ws of the HIP path 6.5-9.3e-4 from the oracle (the fp32 oracle itself sits
-    4.7-6.1e-4 from the fp64 truth), and every gradient here is a linear image of d ws."""
+    with the generator replaced by the CPU oracle under autograd.  Measured on the MI355X (round 4): loss equal to 2e-7,
+    pooled image to 3e-6, bases.grad / delta.grad to 4.4-4.9e-6 rel-L2, the worst of the 16 (3DMM) / 45 (RGB: Encoder trunk on the
+    HIP conv kernels) driver tensors 5.6e-6 / 2.3e-5.  (The loss gradient is a smooth, well-conditioned functional of the image;
+    the 6.5-9.3e-4 of the three-way test in test_gpu_round3.py belongs to its white-noise cotangent.)  Bar: 2e-4."""
     from hfa_gp_amd import headnerf
     from hfa_gp_amd.trainer import Trainer
     from tests.test_trainer_cpu import OracleGenerator
@@ -109,7 +110,7 @@ def test_gen_update_at_own_size_matches_oracle_step(dev, mode):
     assert pooled_err <= 2e-5                                               # the 256^2 pooled image the loss is taken on
     for n in absent:
         assert float(got[n].abs().max()) == 0.0 if n in got else True
-    bad = {n: e for n, e in errs.items() if not (e <= 3e-3)}
+    bad = {n: e for n, e in errs.items() if not (e <= 2e-4)}
     assert not bad, bad
     assert all(float(want[n].abs().max()) > 0 for n in on_path)             # nothing compared is trivially zero
 
@@ -212,9 +213,9 @@ def _two_rank_case(dev, backend, n_frames):
     print(f"2 ranks ({backend}), {n_frames} frames {counts}: all-reduced vs recomputed pieces {worst_a:.2e}, vs the joint "
           f"{n_frames}-frame single-process step {worst_b:.2e} (rel-L2, worst of {len(GRAD_KEYS)} tensors)")
     # the same kernels on the same frames, batch shapes and uniforms: only the order of the ray marcher's atomic adds differs
-    assert worst_a <= 2e-5, worst_a
+    assert worst_a <= 5e-6, worst_a                      # (measured 4.3e-7)
     # another batch size (batch-dependent split-K plans: another fp32 summation order through 14 layers), same mathematics
-    assert worst_b <= 2e-4, worst_b
+    assert worst_b <= 2e-5, worst_b                      # (measured 4.3e-7 / 5.7e-7)
 
 
 @pytest.mark.parametrize("n_frames", [2, 3])
