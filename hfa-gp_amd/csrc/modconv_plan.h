@@ -162,9 +162,14 @@ static inline int make_plan(const HfagpModconvArgs* a, Plan& pl, int ck) {
     const long long base_blocks = (long long)p.tiles_h * p.tiles_w * a->B * grid_tiles_n * grid_phases;
     int ks = a->ksplit;
     if (ks <= 0) {
+        // split K until every CU has ONE block, and no further (round 4 sweep, tools/dev/ksplit_sweep.py: the old target of two
+        // blocks per CU, rounded up, over-split the 32^2 ... 64^2 layers at batch 1 - 2 — every extra slab is another pass over
+        // the output for the GEMM and for the reducer: 512 -> 512 up-conv to 64^2 at B = 2 59 -> 51 us with ks 3 -> 1, B = 1
+        // 59 -> 38 us with ks 5 -> 2; 3x3 at 32^2 B = 1 41 -> 36 us with ks 16 -> 8)
         ks = 1;
-        const long long target = 2 * kNumCU;
-        if (base_blocks < target) ks = (int)((target + base_blocks - 1) / base_blocks);
+        const long long target = kNumCU;
+        if (base_blocks < target) ks = (int)(target / base_blocks);
+        if (ks < 1) ks = 1;
         const int max_ks = p.nchunks / 2 > 0 ? p.nchunks / 2 : 1;   // at least 2 chunks per split
         if (ks > max_ks) ks = max_ks;
         if (ks > 64) ks = 64;
