@@ -128,6 +128,61 @@ def cpu_topology() -> dict:
     return {"sockets": len(phys) or 1, "cores_per_socket": cores_per, "logical_cpus": logical}
 
 
+def _cpu_parallel_worker(rank, threads, frames, preset, state, barrier, out):
+    """One of P oracle processes of `cpu_baseline`'s `parallel` leg: `threads` intra-op threads, one warm-up frame, then
+    `frames` B = 1 synthesis calls between a common barrier and its own finish time."""
+    import torch
+    torch.set_num_threads(threads)
+    from oracle import eg3d_oracle as O
+    from hfa_gp_amd.config import PRESETS
+    from hfa_gp_amd.synthetic import make_inputs
+    cfg = PRESETS[preset]()
+    ws, c, us, ui = make_inputs(cfg, 1, seed=10 + rank)
+    with torch.no_grad():
+        O.synthesis(state, cfg, ws, c, us, ui)
+        barrier.wait()
+        t0 = time.time()
+        for _ in range(frames):
+            img = O.synthesis(state, cfg, ws, c, us, ui)["image"]
+        out.put((rank, t0, time.time(), bool(torch.isfinite(img).all())))
+
+
+def cpu_parallel(cfg, state, phys: int, frames: int = 2, threads: int = 16):
+    """the ATen CPU ops of this path do not scale with threads at batch 1 (one frame on 128 threads is no
+    faster than on one), so "128 cores" above is a thread count.  This leg keeps all physical cores BUSY instead: P = cores /
+    16 oracle processes of 16 threads each, every one rendering `frames` frames of its own; frames/s = P * frames / wall."""
+    import torch.multiprocessing as mp
+    threads = max(1, min(threads, phys))
+    procs = max(1, phys // threads)
+    ctx = mp.get_context("spawn")
+    barrier, out = ctx.Barrier(procs), ctx.Queue()
+    shared = {k: v.share_memory_() for k, v in state.items()}
+    ps = [ctx.Process(target=_cpu_parallel_worker, args=(r, threads, frames, cfg.name, shared, barrier, out)) for r in range(procs)]
+    for p_ in ps:
+        p_.start()
+    import queue
+    rows, deadline = [], time.time() + 600
+    while len(rows) < procs:
+        try:
+            rows.append(out.get(timeout=2))
+        except queue.Empty:
+            dead = [p_.exitcode for p_ in ps if p_.exitcode not in (None, 0)]
+            if dead or time.time() > deadline:          # a worker that died (or a wedged one) must not hold the run for minutes
+                for p_ in ps:
+                    if p_.is_alive():
+                        p_.terminate()
+                raise RuntimeError(f"oracle worker exit codes {dead}" if dead else "oracle workers timed out")
+    for p_ in ps:
+        p_.join(timeout=60)
+    t0, t1 = min(r[1] for r in rows), max(r[2] for r in rows)
+    assert all(r[3] for r in rows)
+    return {"value": procs * frames / (t1 - t0), "unit": "frames/s", "processes": procs, "threads_per_process": threads,
+            "cores": procs * threads, "frames_per_process": frames, "wall_s": t1 - t0,
+            "s_per_frame_per_process": (t1 - t0) / frames,
+            "what": "all physical cores busy: independent oracle processes, one frame at a time each (frame-parallel, as the GPU "
+                    "path scales); the B = 1 figures above are the latency of ONE frame on the whole box"}
+
+
 def cpu_baseline(cfg, state, runs: int, warmup: int, n1: bool, check=None):
     """Oracle (kind 'port') timed on this box's host cores: B=1 synthesis of the same workload; median of `runs`
     after `warmup`; stage split backbone / ray-march / super-resolution.
@@ -189,6 +244,11 @@ def cpu_baseline(cfg, state, runs: int, warmup: int, n1: bool, check=None):
                                    "what": "512^2 image of the HIP path (this run's default precision) vs the oracle's, same ws / "
                                            "camera / renderer uniforms, B = 1; north_star bar: MSE <= 1e-3 on [-1, 1] images"}
     try:
+        if phys > 1 and os.environ.get("HFAGP_BENCH_NO_CPU_PARALLEL") != "1":
+            try:
+                out["parallel"] = cpu_parallel(cfg, state, phys)
+            except Exception as e:  # noqa: BLE001 — context only: a failed side leg must not lose the line
+                out["parallel"] = {"error": f"{type(e).__name__}: {e}"}
         if n1:
             torch.set_num_threads(1)
             med1, st1, _ = timed(1, 0)

@@ -106,7 +106,8 @@ class PointwiseBwdArgs(C.Structure):
         "dxs_conv", "s_conv", "dxs_rgb", "s_rgb", "g_rgb_small", "w_rgb_small", "s_small", "g_direct", "x",
         "dcoef_p", "bias_p", "noise_p", "g_out", "partial", "sums")] + \
         [(n, C.c_int32) for n in ("B", "H", "W", "C", "Co", "nchunks", "has_producer", "act_p", "param_grads")] + \
-        [(n, C.c_float) for n in ("noise_strength_p", "alpha", "gain", "clamp")]
+        [(n, C.c_float) for n in ("noise_strength_p", "alpha", "gain", "clamp")] + \
+        [(n, C.c_void_p) for n in ("y_rgb_small", "g_nchw3_a", "g_nchw3_b")] + [("clamp_rgb_small", C.c_float)]
 
 
 class StyleBwdArgs(C.Structure):
@@ -137,6 +138,7 @@ SYMBOLS = {
     "hfagp_abi_version": (C.c_int, []),
     "hfagp_last_error": (C.c_char_p, []),
     "hfagp_raymarch_fwd": (C.c_int, [C.POINTER(RaymarchArgs), C.c_void_p]),
+    "hfagp_depth_clamp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "hfagp_style_fwd": (C.c_int, [C.POINTER(StyleArgs), C.c_void_p]),
     "hfagp_fc_fwd": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 3 + [C.c_float, C.c_int32, C.c_float, C.c_float, C.c_void_p]),
     "hfagp_weight_prep": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),

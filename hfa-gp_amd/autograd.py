@@ -55,7 +55,7 @@ class _Backward:
     def pointwise(self, x: torch.Tensor, **kw):
         if self.gen.timing is None:
             return ops.pointwise_bwd(x, **kw)
-        nbytes = 4.0 * (2 * x.numel() + sum(kw[k].numel() for k in ("dxs_conv", "dxs_rgb", "g_direct")
+        nbytes = 4.0 * (2 * x.numel() + sum(kw[k].numel() for k in ("dxs_conv", "dxs_rgb", "g_direct", "g_nchw3_a", "g_nchw3_b")
                                             if kw.get(k) is not None))
         return self.gen._timed("pointwise_bwd", nbytes, ops.pointwise_bwd, x, **kw)
 
@@ -148,9 +148,12 @@ class _Backward:
         if ahead is not None:
             pass
         elif rgb["small"]:
-            g_y = _masked(g_img, rgb["y_pre"], rgb["clamp"]).contiguous()
-            kw = dict(g_rgb_small=g_y, w_rgb_small=tr.weight.detach().reshape(tr.weight.shape[0], cin),
-                      s_small=rgb["styles"])
+            if self.pg:          # (the bias gradient below sums the masked gradient itself)
+                g_y = _masked(g_img, rgb["y_pre"], rgb["clamp"]).contiguous()
+                kw = dict(g_rgb_small=g_y)
+            else:                # generator frozen: the fused pass applies the clamp mask [|y_pre| < clamp] while it reads
+                kw = dict(g_rgb_small=g_img.contiguous(), y_rgb_small=rgb["y_pre"], clamp_rgb_small=rgb["clamp"])
+            kw.update(w_rgb_small=tr.weight.detach().reshape(tr.weight.shape[0], cin), s_small=rgb["styles"])
         else:
             g_y = _masked(g_img, rgb["y"], rgb["clamp"]).contiguous()
             dxs_rgb = self.bwd_data(g_y, tr.weight, cin, ops.CONV1X1)
@@ -284,11 +287,9 @@ class SynthesisFn(torch.autograd.Function):
         bw.finish_layer(c0rec)
         # ---- feature image: consumer = SR block0.conv0, plus the first 3 channels through image_raw
         feat_img = tape["feat_img"]
-        g_direct = torch.zeros_like(feat_img)
-        g_direct[..., :3] = g_rgb_raw.permute(0, 2, 3, 1)
-        if g_raw is not None:
-            g_direct[..., :3] += g_raw.permute(0, 2, 3, 1)
-        g_feat, s = bw.pointwise(feat_img.contiguous(), dxs_conv=dxs, s_conv=c0rec0["styles"], g_direct=g_direct)
+        # (image_raw = channels 0..2 of the feature image: the two NCHW gradients are added inside the fused pass)
+        g_feat, s = bw.pointwise(feat_img.contiguous(), dxs_conv=dxs, s_conv=c0rec0["styles"],
+                                 g_nchw3_a=g_rgb_raw.contiguous(), g_nchw3_b=None if g_raw is None else g_raw.float().contiguous())
         c0rec0["ds"] = s[:, 0]
         bw.finish_layer(c0rec0)
         # ---- renderer

@@ -85,6 +85,14 @@ __global__ void __launch_bounds__(256) pointwise_bwd_kernel(const HfagpPointwise
             for (int k = 0; k < 4; ++k) { gx[k] += t[k] * sv[k]; acc[2][k] += t[k] * xv[k]; }
         }
         if (a.g_direct) { gx[0] += gd.x; gx[1] += gd.y; gx[2] += gd.z; gx[3] += gd.w; }
+        if (c4 == 0 && (a.g_nchw3_a || a.g_nchw3_b)) {       // image_raw = channels 0..2: NCHW gradients added in place
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const size_t q = ((size_t)b * 3 + k) * HW + p;
+                if (a.g_nchw3_a) gx[k] += a.g_nchw3_a[q];
+                if (a.g_nchw3_b) gx[k] += a.g_nchw3_b[q];
+            }
+        }
         // producer layer P: through clamp / gain / leaky-ReLU, then the demodulation
         const float nz = nraw * a.noise_strength_p;
         float go[4];
@@ -110,7 +118,14 @@ __global__ void __launch_bounds__(256) pointwise_bwd_kernel(const HfagpPointwise
         const float4* GC = reinterpret_cast<const float4*>(a.dxs_conv);
         const float4* GR = reinterpret_cast<const float4*>(a.dxs_rgb);
         const float4* GD = reinterpret_cast<const float4*>(a.g_direct);
-        auto small = [&](int p, int c) { return (a.g_rgb_small && c < a.Co) ? a.g_rgb_small[((size_t)b * a.Co + c) * HW + p] : 0.f; };
+        // (the small toRGB's clamp mask [|y| < clamp] applied here when the caller hands over y: three framework kernels less)
+        const bool mask_small = a.y_rgb_small != nullptr && a.clamp_rgb_small >= 0.f;
+        auto small = [&](int p, int c) {
+            if (!(a.g_rgb_small && c < a.Co)) return 0.f;
+            const size_t q = ((size_t)b * a.Co + c) * HW + p;
+            const float g = a.g_rgb_small[q];
+            return (mask_small && !(fabsf(a.y_rgb_small[q]) < a.clamp_rgb_small)) ? 0.f : g;
+        };
         int p = p_begin + pl;
         for (; p + npl < p_end; p += 2 * npl) {
             const int q = p + npl;
@@ -176,6 +191,25 @@ __global__ void __launch_bounds__(256) reduce_partials_kernel(const float* __res
                 if (u < w) t[u] += t[u + w];
         sums[(size_t)b * n + k] = t[0];
     }
+}
+
+// depth[i] = clamp(depth[i], min_j t[j].x, max_j t[j].y) for the whole batch, one workgroup (hfagp_depth_clamp)
+__global__ void __launch_bounds__(1024) depth_clamp_kernel(float* __restrict__ depth, const float2* __restrict__ t, int n) {
+    __shared__ float smin[16], smax[16];
+    float lo = INFINITY, hi = -INFINITY;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const float2 v = t[i];
+        lo = fminf(lo, v.x);
+        hi = fmaxf(hi, v.y);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o)); hi = fmaxf(hi, __shfl_xor(hi, o)); }
+    if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = lo; smax[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    lo = smin[0]; hi = smax[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) { lo = fminf(lo, smin[w]); hi = fmaxf(hi, smax[w]); }
+    for (int i = threadIdx.x; i < n; i += 1024) depth[i] = fminf(fmaxf(depth[i], lo), hi);
 }
 
 // ---------------------------------------------------------------- adjoint of (FIR pad 1 gain 4) + parity split
@@ -433,6 +467,13 @@ int hfagp_pointwise_bwd(const HfagpPointwiseBwdArgs* a, void* stream) {
     const int n = kRed * a->C;
     reduce_partials_kernel<<<dim3((n + 15) / 16, a->B), 256, 0, s>>>(a->partial, a->sums, a->B, a->nchunks, n);
     return check_launch("pointwise_bwd");
+}
+
+int hfagp_depth_clamp(float* depth, const float* tminmax, int64_t n, void* stream) {
+    HFAGP_REQUIRE(depth && tminmax && n > 0, HFAGP_EBADARG, "depth_clamp: null pointer / n <= 0");
+    HFAGP_REQUIRE(n <= 65536, HFAGP_EUNSUPPORTED, "depth_clamp: n=%lld > 65536 rays (one-workgroup kernel: small batches only)", (long long)n);
+    depth_clamp_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(depth, reinterpret_cast<const float2*>(tminmax), (int)n);
+    return check_launch("depth_clamp");
 }
 
 int hfagp_upfir_bwd(const float* gy, float* gph, int32_t B, int32_t H, int32_t W, int32_t C, void* stream) {

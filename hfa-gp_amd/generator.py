@@ -626,7 +626,7 @@ class TriPlaneGenerator(nn.Module):
             ray_state = ops.raymarch_state(b, res, cfg.depth_resolution, cfg.depth_resolution_importance, ws.device)
         feat, depth, wsum, tmm = self.render(planes, c, u_strat, u_imp, planes_absmax=pam, state=ray_state)
         # MipRayMarcher2 clamps the expected depth to the GLOBAL min/max sample depth of the batch
-        depth = torch.clamp(depth, tmm[..., 0].min(), tmm[..., 1].max())
+        depth = ops.depth_clamp_(depth, tmm)
         feat_img = feat.view(b, res, res, 32)                             # channels-last
         rgb_raw = feat_img[..., :3].permute(0, 3, 1, 2).contiguous()      # NCHW, 'image_raw'
         img = self.superres(rgb_raw, feat_img, ws, sr_tape)

@@ -568,6 +568,18 @@ def raymarch(planes: torch.Tensor, cam2world: torch.Tensor, intrinsics: torch.Te
     return feat, depth, wsum, tmm
 
 
+def depth_clamp_(depth: torch.Tensor, tminmax: torch.Tensor) -> torch.Tensor:
+    """In place: depth.clamp_(tminmax[..., 0].min(), tminmax[..., 1].max()) — MipRayMarcher2's batch-global depth clamp — as ONE
+    launch for up to 65536 rays (hfagp_depth_clamp); above that, the same with the framework's reductions."""
+    _chk(depth, "depth")
+    _chk(tminmax, "tminmax")
+    n = depth.numel()
+    if n > 65536:
+        return depth.clamp_(tminmax[..., 0].min(), tminmax[..., 1].max())
+    L.check(L.lib().hfagp_depth_clamp(_ptr(depth), _ptr(tminmax), n, _stream()), "depth_clamp")
+    return depth
+
+
 def raymarch_state(b: int, res: int, sc: int, sf: int, device) -> torch.Tensor:
     """Buffer for `raymarch(..., state=)` / `raymarch_bwd(..., state=)`: [B, R, 35 (Sc + Sf)] floats = 13.4 KB per ray at 48 + 48."""
     return torch.empty(b, res * res, (sc + sf) * 35, device=device, dtype=torch.float32)
@@ -725,7 +737,8 @@ def nhwc_to_nchw(x: torch.Tensor) -> torch.Tensor:
 # ----------------------------------------------------------------------------- backward pass
 def pointwise_bwd(x: torch.Tensor, dxs_conv=None, s_conv=None, dxs_rgb=None, s_rgb=None, g_rgb_small=None,
                   w_rgb_small=None, s_small=None, g_direct=None, producer: Optional[dict] = None,
-                  param_grads: bool = False):
+                  param_grads: bool = False, y_rgb_small=None, clamp_rgb_small: Optional[float] = None,
+                  g_nchw3_a=None, g_nchw3_b=None):
     """Fused streaming pass over the saved activation x [B,H,W,C] (see include/hfagp.h).  `producer` =
     dict(dcoef, bias, noise, noise_strength, act, alpha, gain, clamp) of the layer that produced x, or None.
     Returns (g_out [B,H,W,C], sums [B,10,C])."""
@@ -746,6 +759,12 @@ def pointwise_bwd(x: torch.Tensor, dxs_conv=None, s_conv=None, dxs_rgb=None, s_r
     a.g_rgb_small, a.w_rgb_small, a.s_small, a.g_direct = _ptr(g_rgb_small), _ptr(w_rgb_small), _ptr(s_small), _ptr(g_direct)
     a.B, a.H, a.W, a.C, a.nchunks = b, h, w, c, nchunks
     a.Co = g_rgb_small.shape[1] if g_rgb_small is not None else 0
+    a.y_rgb_small = _ptr(y_rgb_small) if (y_rgb_small is not None and clamp_rgb_small is not None) else None
+    a.clamp_rgb_small = -1.0 if clamp_rgb_small is None else float(clamp_rgb_small)
+    for t in (g_nchw3_a, g_nchw3_b):
+        if t is not None and tuple(t.shape) != (b, 3, h, w):
+            raise RuntimeError(f"pointwise_bwd: g_nchw3_* must be [B, 3, H, W] = {(b, 3, h, w)}, got {tuple(t.shape)}")
+    a.g_nchw3_a, a.g_nchw3_b = _ptr(g_nchw3_a), _ptr(g_nchw3_b)
     a.clamp = -1.0
     a.param_grads = int(param_grads)
     if producer is not None:

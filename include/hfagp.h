@@ -354,7 +354,8 @@ int hfagp_torgb_finish_fwd(const HfagpTorgbFinishArgs* a, void* stream);
 /* One fused streaming pass per activation tensor X [B][H][W][C] (output of layer P, input of its
  * consumers): sums the consumers' input gradients, reduces their style gradients, and pushes the result
  * through P's clamp / gain / leaky-ReLU / demodulation.
- *   gX      = dxs_conv*s_conv + dxs_rgb*s_rgb + s_small * (w_rgb_small^T g_rgb_small) + g_direct
+ *   gX      = dxs_conv*s_conv + dxs_rgb*s_rgb + s_small * (w_rgb_small^T g_rgb_small) + g_direct + [c < 3] (g_nchw3_a + g_nchw3_b)
+ *             (g_rgb_small is masked with [|y_rgb_small| < clamp_rgb_small] when y_rgb_small is given: the clamp of the small toRGB)
  *   g_out   = has_producer ? gX * gain * lrelu'(X) * [|X|<clamp] * dcoef_p : gX
  *   sums[b][0] = sum_pix dxs_conv*X   sums[b][1] = sum_pix dxs_rgb*X   sums[b][2] = sum_pix (w^T g)*X
  *   sums[b][3] = sum_pix g_pre * conv_p      (gradient of P's demodulation coefficients)
@@ -380,9 +381,20 @@ typedef struct {
     float*       sums;        /* out [B][10][C] */
     int32_t B, H, W, C, Co, nchunks, has_producer, act_p, param_grads;
     float noise_strength_p, alpha, gain, clamp;
+    /* ABI 10 (all optional): */
+    const float* y_rgb_small; /* NCHW [B][Co][H][W]: the small toRGB's pre-clamp output; with clamp_rgb_small >= 0 the kernel masks
+                                 g_rgb_small itself (the caller then passes the UN-masked gradient) */
+    const float* g_nchw3_a;   /* NCHW [B][3][H][W] gradients added to channels 0..2 of gX (image_raw = first three channels of  */
+    const float* g_nchw3_b;   /* the feature image: the super-resolution skip path and the caller's d image_raw), or NULL          */
+    float clamp_rgb_small;
 } HfagpPointwiseBwdArgs;
 
 int hfagp_pointwise_bwd(const HfagpPointwiseBwdArgs* a, void* stream);
+
+/* MipRayMarcher2's depth clamp (EG3D: `torch.clamp(depth, min(sample depths), max(sample depths))` over the WHOLE batch) in one
+ * launch: depth [n] is clamped in place to [min_i tminmax[i][0], max_i tminmax[i][1]] (tminmax as hfagp_raymarch_fwd writes it).
+ * One workgroup: meant for small batches (n <= 65536 rays; -2 above that — the caller then uses its framework's reductions). */
+int hfagp_depth_clamp(float* depth, const float* tminmax, int64_t n, void* stream);
 
 /* adjoint of hfagp_upfir_epilogue_fwd's FIR: g_y [B][2H][2W][C] -> four parity images of the y_t gradient,
  * gph [2][2][B][H+1][W+1][C] (input of hfagp_modconv_fwd mode HFAGP_CONVS2_BWD)                          */
