@@ -197,7 +197,11 @@ class TriPlaneGenerator(nn.Module):
         idx = device.index if device.index is not None else torch.cuda.current_device()
         st = self._side_streams.get(idx)
         if st is None:
-            st = self._side_streams[idx] = torch.cuda.Stream(device=device)
+            # from the HIGH-priority pool: PyTorch hands out its 32 default-priority pool streams round robin, and the collective
+            # back ends take theirs from that same pool (gloo: one per asynchronous work) — a side stream from it ends up ALIASED
+            # with a collective's copy stream every few steps and the image chain then queues behind host-side all-reduces
+            # (measured: the 2-rank RGB fitting step 49 ms -> 2982 ms).  The high-priority pool is not used by them.
+            st = self._side_streams[idx] = torch.cuda.Stream(device=device, priority=-1)
         return st
 
     def _timed(self, key: str, units: float, fn, *args, **kwargs):
