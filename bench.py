@@ -974,7 +974,21 @@ def main():
             if "rgb_lpips" in train:
                 out["train_step_ms_lpips"] = train["rgb_lpips"]
 
-            def roofline_train(ev, step_ms):
+            def train_traffic(prefix, mode_):
+                """HBM bytes per launch of a backward kernel family from the committed PMC passes of the fitting step
+                (profiles/traffic_train.json, written by profiles/train_pmc.sh), only if batch and mode match."""
+                try:
+                    t = json.load(open(os.path.join(ROOT, "profiles", "traffic_train.json")))
+                    if t.get("batch") != train_B or t.get("mode") != mode_:
+                        return None
+                    for k, v in t.items():
+                        if k.startswith(prefix):
+                            return v["hbm_bytes"]
+                except Exception:
+                    pass
+                return None
+
+            def roofline_train(ev, step_ms, mode_="3dmm"):
                 """Roofline objects of the BACKWARD kernel families of one fitting step ('train-step ms ... plus
                 roofline fraction'), from HIP events around every launch of a second pass of the same step (`kernel_events`).
                   bwd-data GEMMs: algorithmic flops 2 M N K of the adjoint conv (gradients run in bf16x3: 3 MFMAs per product ->
@@ -987,13 +1001,15 @@ def main():
                 peak_g = MFMA_BF16_PEAK_TFLOPS / 3
                 tot_ms = tot_fl = 0.0
                 for key, name in (("bwd_data", "3x3 bwd-data (modconv_bf16_kernel, mode CONV3X3_BWD)"),
-                                  ("bwd_data_up", "adjoint of the up-sampling conv (mode CONVS2_BWD, 4 parity phases)"),
+                                  ("bwd_data_up", "adjoint of the up-sampling conv (mode CONVS2_BWD, four parity phases merged in one kernel)"),
                                   ("bwd_data_1x1", "96-channel toRGB adjoint (mode CONV1X1)")):
                     if key in ev:
                         ms, fl, n = ev[key]
                         tot_ms, tot_fl = tot_ms + ms, tot_fl + fl
                         res_[key] = {"kernel": name, "ms_per_step": ms, "launches_per_step": n,
-                                     "achieved": fl / (ms * 1e-3) / 1e12, "frac": fl / (ms * 1e-3) / 1e12 / peak_g}
+                                     "achieved": fl / (ms * 1e-3) / 1e12, "frac": fl / (ms * 1e-3) / 1e12 / peak_g,
+                                     "traffic": train_traffic({"bwd_data": "modconv_bf16_kernel<2, 2, 9", "bwd_data_up": "modconv_bf16_kernel<2, 2, 0",
+                                                               "bwd_data_1x1": "modconv_bf16_kernel<2, 2, 1"}[key], mode_)}
                 if tot_ms > 0:
                     res_["bwd_data_gemms"] = {"bound": "mfma", "achieved": tot_fl / (tot_ms * 1e-3) / 1e12, "peak": peak_g,
                                               "unit": "TFLOP/s", "frac": tot_fl / (tot_ms * 1e-3) / 1e12 / peak_g,
@@ -1005,7 +1021,8 @@ def main():
                                              "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                                              "frac_of_measured_copy_ceiling_6290": gbs / 6290.0,
                                              "ms_per_step": ms, "launches_per_step": n, "share_of_step": ms / step_ms,
-                                             "traffic": profiled_traffic("pointwise_bwd_kernel")}
+                                             "traffic": train_traffic("pointwise_bwd_kernel", mode_),
+                                             "algorithmic_bytes_per_step": by}
                 if "raymarch_bwd" in ev:
                     ms, fr, n = ev["raymarch_bwd"]
                     gb = fr * r * s_tot * 3 * 4 * 32 * 4
@@ -1016,15 +1033,15 @@ def main():
                                             "ms_per_step": ms, "ms_per_frame": ms / max(fr, 1), "floor_ms_per_step": floor,
                                             "frac": floor / ms, "share_of_step": ms / step_ms,
                                             "scatter_updates_per_frame": r * s_tot * 12,
-                                            "traffic": profiled_traffic("raymarch_bwd_cols_kernel")}
+                                            "traffic": train_traffic("raymarch_bwd_cols_kernel", mode_)}
                 if "raymarch" in ev:
                     res_["raymarch_fwd_ms_per_step"] = ev["raymarch"][0]
                 fwd = sum(ev[k][0] for k in ev if k.startswith("modconv"))
                 if fwd:
                     res_["conv_fwd_ms_per_step"] = fwd
                 return res_
-            out["roofline_train"] = {"rgb": roofline_train(trgb["kernel_events"], trgb["frozen"][train_B]["step_ms"]),
-                                     "3dmm": roofline_train(t3["kernel_events"], t3["frozen"][train_B]["step_ms"])}
+            out["roofline_train"] = {"rgb": roofline_train(trgb["kernel_events"], trgb["frozen"][train_B]["step_ms"], "rgb"),
+                                     "3dmm": roofline_train(t3["kernel_events"], t3["frozen"][train_B]["step_ms"], "3dmm")}
         if fit is not None:
             out["fit_rgb"] = fit
         if fit3 is not None:

@@ -15,6 +15,8 @@ gen = TriPlaneGenerator(cfg, seed=0).to(dev)
 ws, c, us, ui = [t.to(dev) for t in make_inputs(cfg, B)]
 with torch.no_grad():
     planes = gen.backbone_planes(ws)
+    if os.environ.get("PLANES_SCALE"):                 # developer: 0 -> constant density, no clustering of the importance samples
+        planes = planes * float(os.environ["PLANES_SCALE"])
     u_s, u_i = gen._uniforms(B, dev, us, ui)
     g = torch.randn(B, 128 * 128, 32, device=dev)
     kw = gen._render_args(c)
