@@ -266,6 +266,10 @@ static int ck_of(const HfagpModconvArgs* a) { return a && a->precision != HFAGP_
 
 size_t hfagp_modconv_workspace_bytes(const HfagpModconvArgs* a) {
     if (validate(a, ck_of(a)) != HFAGP_OK) return 0;
+    if (smallconv_takes(a)) {
+        const int ks = smallconv_ksplit(a);
+        return ks > 1 ? (size_t)ks * a->B * a->H * a->W * a->Cout * sizeof(float) : 0;
+    }
     Plan pl;
     if (make_plan(a, pl, ck_of(a)) != HFAGP_OK) return 0;
     return pl.ws_bytes;
@@ -281,6 +285,15 @@ int hfagp_modconv_fwd(const HfagpModconvArgs* a, void* stream) {
     if (rc != HFAGP_OK) return rc;
     ConvParams& p = pl.p;
     HFAGP_REQUIRE((a->rgb_w == nullptr) == (a->rgb_part == nullptr), HFAGP_EBADARG, "modconv: rgb_w and rgb_part go together");
+    if (smallconv_takes(a)) {
+        rc = launch_smallconv(a, pl, (hipStream_t)stream);
+        if (rc != HFAGP_OK || p.ksplit == 1) return rc;
+        const long long n4 = p.slab / 4;           // the slabs: summed (in order) and finished by the reducer, as below
+        splitk_epilogue_kernel<<<(unsigned)((n4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+            a->workspace, a->y, a->dcoef, a->noise, a->bias, p.slab, p.ksplit, p.Ho * p.Wo, a->Cout, 1, a->act,
+            a->noise_strength, a->alpha, a->gain, a->clamp, a->y_absmax);
+        return check_launch("modconv_fwd/splitk (small-image kernel)");
+    }
     HFAGP_REQUIRE(!a->rgb_part || (a->precision != HFAGP_PREC_F32 && p.ksplit * p.nslab == 1 && p.fused && a->Cout % 128 == 0 &&
                                    (a->mode == HFAGP_CONV3X3 || a->mode == HFAGP_CONV1X1)),
                   HFAGP_EUNSUPPORTED, "modconv: the fused toRGB needs a 16-bit precision, mode 0 / 2, Cout %% 128 == 0 and no "

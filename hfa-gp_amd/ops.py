@@ -304,21 +304,21 @@ def modconv(x: torch.Tensor, wt: torch.Tensor, cout: int, mode: int, styles: Opt
 
 def f16_storage_supported(h: int, w: int, cin: int, cout: int, batch: int) -> bool:
     """Whether a 3x3 / up-sampling modconv on an h x w input grid can keep its activations in fp16 (`modconv` y_f16,
-    float16 x): 128-channel output tiles and a launch the library does not split along K (its rule: at least 2 x 256
-    blocks of 8 x 16 positions x 128 channels, or fewer than four 16-channel K chunks)."""
+    float16 x): 128-channel output tiles and a launch the library does not split along K (its rule, modconv_plan.h: more than
+    half a block per CU — 129 blocks of 8 x 16 positions x 128 channels — or fewer than four 16-channel K chunks)."""
     if cin % 16 != 0 or cout % 128 != 0:
         return False
-    return cin < 64 or batch * ((h + 7) // 8) * ((w + 15) // 16) * (cout // 128) >= 512
+    return cin < 64 or batch * ((h + 7) // 8) * ((w + 15) // 16) * (cout // 128) >= 129
 
 
 def fused_torgb_supported(x: torch.Tensor, wt: torch.Tensor, cout: int, batch: int) -> bool:
     """Whether `modconv(..., mode=CONV3X3, rgb_w=...)` can form the toRGB sums in its epilogue: 16-bit weight image,
     Cout a multiple of 128, and a grid large enough that the library does not split K (then the epilogue lives in the
-    reducer): the library's own rule, 2 x 256 CUs blocks of 8 x 16 positions x 128 channels."""
+    reducer): the library's own rule, at least 129 blocks of 8 x 16 positions x 128 channels (modconv_plan.h)."""
     if wt.dtype == torch.float32 or cout % 128 != 0:
         return False
     h, w = x.shape[1], x.shape[2]
-    return batch * ((h + 7) // 8) * ((w + 15) // 16) * (cout // 128) >= 512
+    return batch * ((h + 7) // 8) * ((w + 15) // 16) * (cout // 128) >= 129
 
 
 def torgb_finish(part: torch.Tensor, bias: torch.Tensor, rgb_in: Optional[torch.Tensor], clamp: Optional[float],

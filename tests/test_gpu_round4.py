@@ -255,3 +255,57 @@ def test_raymarch_backward_two_kernel_form_equals_the_fused_kernel(dev):
     scale = fused.abs().max().item()
     assert scale > 0 and torch.isfinite(split).all()
     assert (split - fused).abs().max().item() <= 1e-5 * scale
+
+
+# ----------------------------------------------------------------------------- the small-image conv kernel (csrc/smallconv.hip)
+@pytest.mark.parametrize("prec", ["f16x3", "bf16x3", "bf16x6", "f16"])
+@pytest.mark.parametrize("b,h,w,cin,cout", [(1, 4, 4, 512, 512), (2, 8, 8, 512, 512), (3, 16, 16, 256, 512), (2, 5, 7, 64, 96),
+                                            (1, 16, 16, 512, 96), (2, 13, 3, 32, 64)])
+def test_small_image_conv_kernel_vs_reference_conv(dev, prec, b, h, w, cin, cout):
+    """hfagp_modconv_fwd on images of at most 256 positions takes `smallconv_kernel` (whole K range per block, epilogue in
+    the same launch, no workspace) for the 3x3 conv, its data adjoint and the 1x1 conv: against torch's conv2d of the
+    modulated input in fp64, with the full epilogue (demodulation, noise, bias, leaky ReLU, clamp), ragged tiles (5 x 7,
+    13 x 3), Cout = 96 (the toRGB) and a broadcast input (the learned constant); and against the 128 x 128-tile kernel with a
+    forced split (`ksplit=2`), which the small kernel must agree with to the fp32 summation order."""
+    import math
+    import torch.nn.functional as F
+    from hfa_gp_amd import ops
+    g = torch.Generator().manual_seed(b * 1000 + h * 10 + cin)
+    tol = {"f16x3": 3e-6, "bf16x6": 3e-6, "bf16x3": 6e-5, "f16": 2e-3}[prec]
+    x = torch.randn(b, cin, h, w, generator=g)
+    s = torch.randn(b, cin, generator=g)
+    xd, sd = ops.nchw_to_nhwc(x.to(dev)), s.to(dev)
+    xs = (x * s[:, :, None, None]).double()
+    # --- 3x3 with the full epilogue
+    w3 = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(9 * cin)
+    dco = torch.rand(b, cout, generator=g) + 0.5
+    bias = torch.randn(cout, generator=g)
+    noise = torch.randn(h, w, generator=g)
+    wt = ops.weight_prep_prec(w3.to(dev), prec)
+    kw = dict(styles=sd, dcoef=dco.to(dev), noise=noise.to(dev), noise_strength=0.3, bias=bias.to(dev), act="lrelu", alpha=0.2,
+              gain=math.sqrt(2.0), clamp=1.5)
+    y = ops.modconv(xd, wt, cout, ops.CONV3X3, **kw)
+    y_old = ops.modconv(xd, wt, cout, ops.CONV3X3, ksplit=2, **kw) if cout % 128 == 0 and cin >= 64 else None
+    pre = F.conv2d(xs, w3.double(), padding=1) * dco.double()[:, :, None, None] + 0.3 * noise.double() + bias.double()[None, :, None, None]
+    want = (F.leaky_relu(pre, 0.2) * math.sqrt(2.0)).clamp(-1.5, 1.5)
+    scale = float(pre.abs().max())
+    assert (ops.nhwc_to_nchw(y).double().cpu() - want).abs().max().item() <= tol * scale + 1e-6
+    if y_old is not None:
+        assert (y - y_old).abs().max().item() <= 2 * tol * scale + 1e-6
+    # --- its data adjoint: dx = conv_transpose(g, W) = corr(g, flipped W^T)
+    gy = torch.randn(b, cout, h, w, generator=g)
+    gprec = "bf16x3" if prec in ("f16", "f16x3") else prec          # (gradient GEMMs never run on fp16 parts: generator._precision_of)
+    wt_t = ops.weight_prep_prec(w3.transpose(0, 1).contiguous().to(dev), gprec)
+    dx = ops.modconv(ops.nchw_to_nhwc(gy.to(dev)), wt_t, cin, ops.CONV3X3_BWD)
+    want_dx = F.conv_transpose2d(gy.double(), w3.double(), padding=1)
+    gtol = {"bf16x3": 6e-5, "bf16x6": 3e-6}[gprec]
+    assert (ops.nhwc_to_nchw(dx).double().cpu() - want_dx).abs().max().item() <= gtol * float(want_dx.abs().max()) + 1e-6
+    # --- 1x1 (toRGB: linear, bias), input broadcast over the batch as the learned constant is
+    if cout % 32 == 0:
+        w1 = torch.randn(cout, cin, 1, 1, generator=g) / math.sqrt(cin)
+        p1 = "f16x3" if prec == "f16" else prec                     # (the toRGB products stay fp32-class)
+        y1 = ops.modconv(xd[:1].contiguous(), ops.weight_prep_prec(w1.to(dev), p1), cout, ops.CONV1X1, styles=sd, bias=bias.to(dev),
+                         act="linear", gain=1.0, batch=b)
+        want1 = F.conv2d((x[:1] * s[:, :, None, None]).double(), w1.double()) + bias.double()[None, :, None, None]
+        t1 = {"f16x3": 3e-6, "bf16x6": 3e-6, "bf16x3": 6e-5}[p1]
+        assert (ops.nhwc_to_nchw(y1).double().cpu() - want1).abs().max().item() <= t1 * float(want1.abs().max()) + 1e-6

@@ -17,6 +17,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 @pytest.mark.parametrize("src,patterns", [
     ("modconv_bf16.hip", [r"modconv_bf16_kernelILi[124]E", r"upconv_bf16_kernelILi[124]E"]),
     ("modconv.hip", [r"modconv_kernelI"]),
+    ("smallconv.hip", [r"smallconv_kernelILi[1245]E"]),
     ("wgrad_bf16.hip", [r"wgrad_bf16_kernelI"]),
     ("wgrad.hip", [r"wgrad_kernelI"]),
 ])
