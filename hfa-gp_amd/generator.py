@@ -162,9 +162,14 @@ class TriPlaneGenerator(nn.Module):
         # latency-sized launch on a mostly empty chip, so for batches up to `side_stream_max_batch` the side chain (and, in the
         # backward pass, the whole image-gradient chain: upsample2d adjoint + toRGB adjoint of every block) is enqueued on a
         # SECOND HIP stream and joined where its result is consumed (the tri-planes before the ray march; `dxs_rgb` before the
-        # fused pointwise pass of its block).  Same kernels, same arithmetic, same bits; 0 disables it.  At large batch the
-        # chip is full and two streams measured slower (profiles/r02d_two_streams_experiment.txt).
-        self.side_stream_max_batch = int(os.environ.get("HFAGP_SIDE_STREAM_MAX_BATCH", "4"))
+        # fused pointwise pass of its block).  Same kernels, same arithmetic, same bits.  At large batch the chip is full and two
+        # streams measured slower (profiles/r02d_two_streams_experiment.txt).
+        # OFF by default (0).  Measured, round 4: one forward-only frame 1.93 -> 1.91 ms (1 %), the 6-step fitting-step timing
+        # unchanged — and a 250-step RGB fitting pass 13.5 -> 31.8 ms per step (tensors handed between the streams carry
+        # `record_stream` marks, and in a sustained loop the caching allocator then defers / re-allocates blocks every step), after
+        # the first version had aliased a collective's pool stream (2-rank RGB step 49 -> 2982 ms).  Two pathologies for one per
+        # cent: the code path stays for single-frame inference (`HFAGP_SIDE_STREAM_MAX_BATCH=1`), nothing enables it by itself.
+        self.side_stream_max_batch = int(os.environ.get("HFAGP_SIDE_STREAM_MAX_BATCH", "0"))
         self._side_streams: Dict[int, "torch.cuda.Stream"] = {}
         self._styles: Dict[int, tuple] = {}      # id(layer) -> (styles, dcoef) of the pass in flight
         self._absmax = None                      # (slot buffers, layer names) of the last pass: f16_range_report()

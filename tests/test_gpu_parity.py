@@ -281,10 +281,13 @@ def test_torgb96_on_padded_split_tile(dev, prec, b, h, cin, ksplit):
 def test_split_bf16_rejects_unsupported_shapes(dev):
     """Cin % 16 / Cout % 128 are the split kernel's shape contract: anything else is an error, not a fallback."""
     from hfa_gp_amd import ops
-    x = torch.randn(1, 4, 4, 16, device=dev)
+    x = torch.randn(1, 20, 20, 16, device=dev)
     wb = ops.weight_prep_split(torch.randn(64, 16, 3, 3, device=dev), 2)
     with pytest.raises(RuntimeError, match="multiple of"):
         ops.modconv(x, wb, 64, ops.CONV3X3)
+    # (images of at most 256 positions take the small-image kernel, whose tiles are 32 channels wide: round 4, csrc/smallconv.hip)
+    y = ops.modconv(x[:, :4, :4].contiguous(), wb, 64, ops.CONV3X3)
+    assert y.shape == (1, 4, 4, 64) and torch.isfinite(y).all()
     assert not ops.split_supported(16, 64) and not ops.split_supported(8, 128) and ops.split_supported(32, 256)
 
 

@@ -309,3 +309,38 @@ def test_small_image_conv_kernel_vs_reference_conv(dev, prec, b, h, w, cin, cout
         want1 = F.conv2d((x[:1] * s[:, :, None, None]).double(), w1.double()) + bias.double()[None, :, None, None]
         t1 = {"f16x3": 3e-6, "bf16x6": 3e-6, "bf16x3": 6e-5}[p1]
         assert (ops.nhwc_to_nchw(y1).double().cpu() - want1).abs().max().item() <= t1 * float(want1.abs().max()) + 1e-6
+
+
+def test_image_side_stream_gives_the_same_bits(dev):
+    """generator.side_stream_max_batch (off by default: see generator.py): the backbone's toRGB + skip chain — and in the backward
+    pass the image-gradient chain — on a second HIP stream is the same kernels in another order of ISSUE, never of arithmetic:
+    image, planes and d ws must be bit-identical with and without it."""
+    from hfa_gp_amd.config import ffhq512_128
+    from hfa_gp_amd.generator import TriPlaneGenerator
+    from tests.util import make_inputs
+    cfg = ffhq512_128()
+    gen = perturb_state(TriPlaneGenerator(cfg, seed=0)).requires_grad_(False).to(dev)
+    ws, c, us, ui = (t.to(dev) for t in make_inputs(cfg, 1, seed=14))
+    gimg = torch.randn(1, 3, 512, 512, device=dev, generator=torch.Generator(device=dev).manual_seed(2))
+    res = {}
+    real_bwd = __import__("hfa_gp_amd.ops", fromlist=["ops"]).raymarch_bwd
+    from hfa_gp_amd import ops
+
+    def fixed_scatter(g_feat, planes, *a, **kw):            # (the ray marcher's atomic scatter is not bit-repeatable: take it out)
+        return torch.ones_like(planes) * 1e-3
+    ops.raymarch_bwd = fixed_scatter
+    try:
+        for side in (0, 1, 0, 1):
+            gen.side_stream_max_batch = side
+            wsg = ws.clone().requires_grad_(True)
+            out = gen.synthesis(wsg, c, u_strat=us, u_imp=ui, return_planes=True)
+            (out["image"] * gimg).sum().backward()
+            torch.cuda.synchronize()
+            cur = {"image": out["image"].detach().clone(), "planes": out["planes"].detach().clone(), "d_ws": wsg.grad.clone()}
+            if side in res:
+                assert all(torch.equal(cur[k], res[side][k]) for k in cur)
+            res[side] = cur
+        assert all(torch.equal(res[0][k], res[1][k]) for k in res[0]), [k for k in res[0] if not torch.equal(res[0][k], res[1][k])]
+    finally:
+        ops.raymarch_bwd = real_bwd
+        gen.side_stream_max_batch = 0
