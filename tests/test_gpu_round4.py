@@ -323,8 +323,8 @@ def test_image_side_stream_gives_the_same_bits(dev):
     ws, c, us, ui = (t.to(dev) for t in make_inputs(cfg, 1, seed=14))
     gimg = torch.randn(1, 3, 512, 512, device=dev, generator=torch.Generator(device=dev).manual_seed(2))
     res = {}
-    real_bwd = __import__("hfa_gp_amd.ops", fromlist=["ops"]).raymarch_bwd
     from hfa_gp_amd import ops
+    real_bwd = ops.raymarch_bwd
 
     def fixed_scatter(g_feat, planes, *a, **kw):            # (the ray marcher's atomic scatter is not bit-repeatable: take it out)
         return torch.ones_like(planes) * 1e-3
