@@ -371,6 +371,8 @@ class TriPlaneGenerator(nn.Module):
         # which kernel bench.py times
         key = ("modconv" if wt.dtype == torch.float32 else
                "modconv_f16" if wt.dtype == torch.float16 and wt.shape[0] == 1 else "modconv_split")
+        if layer.up != 2 and wt.dtype != torch.float32 and x.shape[1] * x.shape[2] <= 256:
+            key = "modconv_small"          # the library runs these on smallconv_kernel (csrc/smallconv.hip): not the roofline kernel
         fuse = self.fuse_up_fir
         # (fp16 STORAGE halves the stand-alone FIR kernel's traffic: there the two-kernel form measured 0.6 % ahead)
         fuse = fuse in (True, "1") or (fuse == "auto" and x.shape[3] <= 64 and not half)
