@@ -24,6 +24,7 @@
  *   hfagp_fc_fwd            <- FullyConnectedLayer (MappingNetwork; EqualLinear twin: code/networks/encoder3d.py:112-139)
  *   hfagp_weight_prep[_split|_prec] <- (no reference counterpart: MFMA operand images of a conv weight, per weight version)
  *   hfagp_qr_gram_fwd / hfagp_qr_refine_fwd <- torch.qr(bases.T) of get_latent (code/networks/headnerf.py:91,187,246)
+ *   hfagp_depth_clamp       <- MipRayMarcher2's torch.clamp(depth, min sample depth, max sample depth) over the batch, one launch (ABI 10)
  *   hfagp_planes_to_nhwc    <- planes.view(N, 3, 32, H, W) of TriPlaneGenerator.synthesis (layout change for the gather)
  *   hfagp_nchw_to_nhwc / hfagp_nhwc_to_nchw <- tensor layout at the module boundary (reference tensors are NCHW)
  *   hfagp_pool_mse_fwd/_bwd <- face_pool (AdaptiveAvgPool2d) + MSELoss of gen_update (code/trainer_rgb.py:63,84-85) and its backward
