@@ -203,6 +203,64 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
     dW[wi] = acc - weight[wi] * dem;
 }
 
+// Tiled reducer (round 4): the reducer above stores dW[(co * Cin + ci) * wtaps + tap] from threads that are consecutive in co —
+// 4-byte writes 18 KB apart (and the same gather on `weight`, also when dd is null and the product is 0): the 512 x 512 layers
+// took 69 us for 38 MB of slab reads.  Here a block owns 32 co x 8 ci for ALL taps of the launch(es): slab reads stay coalesced
+// in co, the sums go through LDS and leave as contiguous runs of 8 ci x wtaps floats per co (the parameter layout), and
+// `weight` is only touched when the demodulation term exists.  Each tap names its own slab region, so the four parity
+// launches of the up-sampling mode are reduced by ONE launch over all nine taps.
+struct RedTap { long long base; long long kstride; int widx; };     // slab of split k at slabs + base + k * kstride + ci * Cout + co
+struct RedTaps { RedTap t[9]; };
+
+__global__ void __launch_bounds__(256) wgrad_reduce_tiled_kernel(const float* __restrict__ slabs, const float* __restrict__ weight,
+                                                                 const float* __restrict__ dd, const float* __restrict__ dcoef,
+                                                                 const float* __restrict__ styles, float* __restrict__ dW,
+                                                                 int ksplit, int ntaps, int Cin, int Cout, int B, int wtaps,
+                                                                 const RedTaps taps) {
+    __shared__ float tile[32][8 * 9 + 1];                       // [co][ci * ntaps + tap slot]
+    const int tid = threadIdx.x, col = tid & 31, row = tid >> 5;
+    const int ci0 = blockIdx.x * 8, co0 = blockIdx.y * 32;
+    const int ci = ci0 + row, co = co0 + col;
+    for (int t = 0; t < ntaps; ++t) {
+        const float* src = slabs + taps.t[t].base + (size_t)ci * Cout + co;
+        const long long ks = taps.t[t].kstride;
+        float part[4] = {0.f, 0.f, 0.f, 0.f};
+        int k = 0;
+        for (; k + 4 <= ksplit; k += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) part[u] += src[(size_t)(k + u) * ks];
+        }
+        for (; k < ksplit; ++k) part[0] += src[(size_t)k * ks];
+        tile[col][row * ntaps + t] = (part[0] + part[1]) + (part[2] + part[3]);
+    }
+    __syncthreads();
+    // out: for each co a run of 8 ci x ntaps values; consecutive threads -> consecutive (ci, tap slot) of one co
+    const int per_co = 8 * ntaps;
+    for (int e = tid; e < 32 * per_co; e += 256) {
+        const int c = e / per_co, rem = e - c * per_co;
+        const int r = rem / ntaps, t = rem - r * ntaps;
+        const size_t wi = ((size_t)(co0 + c) * Cin + ci0 + r) * wtaps + taps.t[t].widx;
+        float v = tile[c][rem];
+        if (dd) {
+            float dem = 0.f;
+            for (int b = 0; b < B; ++b) {
+                const float d = dcoef[(size_t)b * Cout + co0 + c], sv = styles[(size_t)b * Cin + ci0 + r];
+                dem += dd[(size_t)b * Cout + co0 + c] * d * d * d * sv * sv;
+            }
+            v -= weight[wi] * dem;
+        }
+        dW[wi] = v;
+    }
+}
+
+// reduce `ntaps` taps described by `taps` (tap slots in widx order give contiguous stores); falls back to the per-element reducer
+// for shapes the tiles do not divide
+static int launch_wgrad_reduce(const HfagpWgradArgs* a, const RedTaps& rt, int ntaps, int wtaps, hipStream_t s) {
+    wgrad_reduce_tiled_kernel<<<dim3((unsigned)(a->Cin / 8), (unsigned)(a->Cout / 32)), 256, 0, s>>>(
+        a->workspace, a->weight, a->dd, a->dcoef, a->styles, a->dweight, a->ksplit, ntaps, a->Cin, a->Cout, a->B, wtaps, rt);
+    return check_launch("conv_wgrad/reduce");
+}
+
 // dA[i][k] = wgain * sum_b dstot[b][i] * w[b][k];  db[i] = sum_b dstot[b][i]   (accumulating)
 __global__ void __launch_bounds__(256) affine_grad_kernel(const float* __restrict__ dstot, const float* __restrict__ w,
                                                           float* __restrict__ dA, float* __restrict__ db, int B, int Cin,
@@ -252,13 +310,13 @@ __global__ void __launch_bounds__(256) channel_sum_final_kernel(const float* __r
 
 namespace hfagp {      // wgrad_bf16.hip
 int launch_wgrad3x3_bf16(const HfagpWgradArgs* a, hipStream_t s);
-int launch_wgrad_parity_bf16(const HfagpWgradArgs* a, const float* g_par, int parity, hipStream_t s);
+int launch_wgrad_parity_bf16(const HfagpWgradArgs* a, const float* g_par, int parity, float* slabs, hipStream_t s);
 }
 
 using namespace hfagp;
 
 template <int NT, int SHARE>
-static int run_wgrad(WgradParams& p, const HfagpWgradArgs* a, hipStream_t s) {
+static int run_wgrad(WgradParams& p, const HfagpWgradArgs* a, hipStream_t s, bool defer_reduce = false) {
     p.ntaps = NT;
     const size_t lds = (size_t)4 * PPH * PPW * WS * sizeof(float);        // two buffers x (x patch + g patch)
     dim3 grid((a->Cin + WT - 1) / WT, (a->Cout + WT - 1) / WT, a->ksplit);
@@ -270,11 +328,19 @@ static int run_wgrad(WgradParams& p, const HfagpWgradArgs* a, hipStream_t s) {
     wgrad_kernel<NT, SHARE><<<grid, 256, lds, s>>>(p);
     int rc = check_launch("conv_wgrad");
     if (rc != HFAGP_OK) return rc;
+    if (defer_reduce) return HFAGP_OK;
+    const int wtaps = a->mode == HFAGP_CONV1X1 ? 1 : 9;
+    if (a->Cin % 8 == 0 && a->Cout % 32 == 0) {
+        RedTaps rt;
+        const long long plane = (long long)a->Cin * a->Cout;
+        for (int t = 0; t < NT; ++t) rt.t[t] = RedTap{(long long)(p.slabs - a->workspace) + t * plane, NT * plane, p.tap[t].widx};
+        return launch_wgrad_reduce(a, rt, NT, wtaps, s);
+    }
     WTaps9 taps;
     for (int t = 0; t < 9; ++t) taps.t[t] = p.tap[t];
     const dim3 rgrid((unsigned)((a->Cin * a->Cout + 255) / 256), (unsigned)NT);
-    wgrad_reduce_kernel<<<rgrid, 256, 0, s>>>(a->workspace, a->weight, a->dd, a->dcoef, a->styles, a->dweight, a->ksplit, NT,
-                                              a->Cin, a->Cout, a->B, a->mode == HFAGP_CONV1X1 ? 1 : 9, taps);
+    wgrad_reduce_kernel<<<rgrid, 256, 0, s>>>(p.slabs, a->weight, a->dd, a->dcoef, a->styles, a->dweight, a->ksplit, NT,
+                                              a->Cin, a->Cout, a->B, wtaps, taps);
     return check_launch("conv_wgrad/reduce");
 }
 
@@ -282,7 +348,8 @@ extern "C" {
 
 size_t hfagp_wgrad_workspace_bytes(const HfagpWgradArgs* a) {
     if (!a || a->ksplit <= 0) return 0;
-    const int ntaps = a->mode == HFAGP_CONV1X1 ? 1 : (a->mode == HFAGP_CONVT3X3_UP2 ? 4 : 9);
+    // (up-sampling mode: the four parity launches write disjoint regions — 4 + 2 + 2 + 1 taps — and ONE reducer finishes them)
+    const int ntaps = a->mode == HFAGP_CONV1X1 ? 1 : 9;
     return (size_t)a->ksplit * ntaps * a->Cin * a->Cout * sizeof(float);
 }
 
@@ -303,12 +370,10 @@ int hfagp_conv_wgrad(const HfagpWgradArgs* a, void* stream) {
             // split-bf16 MFMA kernel (slab t = tap t, like the taps above), then the shared reducer
             int rc = launch_wgrad3x3_bf16(a, s);
             if (rc != HFAGP_OK) return rc;
-            WTaps9 taps;
-            for (int t = 0; t < 9; ++t) taps.t[t] = p.tap[t];
-            const dim3 rgrid((unsigned)((a->Cin * a->Cout + 255) / 256), 9u);
-            wgrad_reduce_kernel<<<rgrid, 256, 0, s>>>(a->workspace, a->weight, a->dd, a->dcoef, a->styles, a->dweight, a->ksplit,
-                                                      9, a->Cin, a->Cout, a->B, 9, taps);
-            return check_launch("conv_wgrad/reduce");
+            RedTaps rt;
+            const long long plane = (long long)a->Cin * a->Cout;
+            for (int t = 0; t < 9; ++t) rt.t[t] = RedTap{t * plane, 9 * plane, t};
+            return launch_wgrad_reduce(a, rt, 9, 9, s);
         }
         HFAGP_REQUIRE(a->precision == HFAGP_PREC_F32 || a->precision == HFAGP_PREC_BF16X3, HFAGP_EBADARG,
                       "conv_wgrad: precision %d (F32 or BF16X3)", a->precision);
@@ -327,15 +392,25 @@ int hfagp_conv_wgrad(const HfagpWgradArgs* a, void* stream) {
         static const int taps_of[4][4] = {{0, 2, 6, 8}, {1, 7, -1, -1}, {3, 5, -1, -1}, {4, -1, -1, -1}};
         static const int ntaps_of[4] = {4, 2, 2, 1};
         const bool split16 = a->precision == HFAGP_PREC_BF16X3 && a->Cin % 64 == 0 && a->Cout % 64 == 0;
+        // one reducer for the four parity launches when the tiles divide the layer: parity ph writes its own slab region
+        const bool one_reduce = a->Cin % 8 == 0 && a->Cout % 32 == 0;
+        const long long plane = (long long)a->Cin * a->Cout;
+        static const int first_tap[4] = {0, 4, 6, 8};             // slab planes in front of parity ph, per split
+        RedTaps rt;
         for (int ph = 0; ph < 4; ++ph) {
             p.g = a->g + ph * img;
+            const long long region = one_reduce ? (long long)a->ksplit * first_tap[ph] * plane : 0;
+            p.slabs = a->workspace + region;
+            for (int k = 0; k < ntaps_of[ph]; ++k)
+                rt.t[first_tap[ph] + k] = RedTap{region + k * plane, ntaps_of[ph] * plane, taps_of[ph][k]};
             for (int k = 0; k < ntaps_of[ph]; ++k) {
                 const int t = taps_of[ph][k], ti = t / 3, tj = t % 3;
                 p.tap[k] = WTap{0, 0, (signed char)(ti >> 1), (signed char)(tj >> 1), (signed char)t};
             }
             if (split16) {      // split-bf16 MFMA kernel (tap slots in the order of taps_of[ph]), then the shared reducer
-                int rc = launch_wgrad_parity_bf16(a, p.g, ph, s);
+                int rc = launch_wgrad_parity_bf16(a, p.g, ph, p.slabs, s);
                 if (rc != HFAGP_OK) return rc;
+                if (one_reduce) continue;
                 WTaps9 taps;
                 for (int t = 0; t < 9; ++t) taps.t[t] = p.tap[t];
                 const dim3 rgrid((unsigned)((a->Cin * a->Cout + 255) / 256), (unsigned)ntaps_of[ph]);
@@ -345,10 +420,11 @@ int hfagp_conv_wgrad(const HfagpWgradArgs* a, void* stream) {
                 if (rc != HFAGP_OK) return rc;
                 continue;
             }
-            const int rc = ntaps_of[ph] == 4 ? run_wgrad<4, 2>(p, a, s) : ntaps_of[ph] == 2 ? run_wgrad<2, 2>(p, a, s)
-                                                                                          : run_wgrad<1, 2>(p, a, s);
+            const int rc = ntaps_of[ph] == 4 ? run_wgrad<4, 2>(p, a, s, one_reduce) : ntaps_of[ph] == 2 ? run_wgrad<2, 2>(p, a, s, one_reduce)
+                                                                                                      : run_wgrad<1, 2>(p, a, s, one_reduce);
             if (rc != HFAGP_OK) return rc;
         }
+        if (one_reduce) return launch_wgrad_reduce(a, rt, 9, 9, s);
         return HFAGP_OK;
     }
     set_error("conv_wgrad: unsupported mode %d", a->mode);

@@ -262,9 +262,9 @@ int launch_wgrad3x3_bf16(const HfagpWgradArgs* a, hipStream_t s) {
 
 // ... and one parity image of the y_t gradient of the up-conv: g_par [B][H+1][W+1][Cout], taps = shifts
 // {0, +1} x {0, +1} (parity 0), {0, +1} x {0} (1), {0} x {0, +1} (2), {0} x {0} (3); slabs [ksplit][ntaps][Cin][Cout]
-int launch_wgrad_parity_bf16(const HfagpWgradArgs* a, const float* g_par, int parity, hipStream_t s) {
+int launch_wgrad_parity_bf16(const HfagpWgradArgs* a, const float* g_par, int parity, float* slabs, hipStream_t s) {
     Wg16Params p{};
-    p.a = g_par; p.b = a->x; p.styles = a->styles; p.slabs = a->workspace;
+    p.a = g_par; p.b = a->x; p.styles = a->styles; p.slabs = slabs;       // (slabs: this parity's region of the workspace)
     p.B = a->B; p.aH = a->H + 1; p.aW = a->W + 1; p.aC = a->Cout; p.bH = a->H; p.bW = a->W; p.bC = a->Cin;
     p.Cin = a->Cin; p.Cout = a->Cout; p.ksplit = a->ksplit;
     p.tiles_h = (a->H + QH - 1) / QH; p.tiles_w = (a->W + QW - 1) / QW;
