@@ -846,6 +846,17 @@ def main():
                                              "at INPUT resolution)", "achieved": tf_up, "frac": tf_up / peak,
                                    "avg_launch_ms": ms_up / n_up, "launches": n_up}
                 roof["all_conv_gemms"] = {"achieved": tf_all, "frac": tf_all / peak}
+            # every up-sampling LAYER as a whole: transposed-conv GEMM + FIR epilogue (or the fused kernel + its strip
+            # fix-ups), algorithmic flops at input resolution against the same ceiling
+            ups = []
+            for kname in sorted(timing):
+                if kname.startswith("up_layer:"):
+                    ms_l, fl_l, n_l = agg(kname)
+                    if n_l:
+                        ups.append({"layer": kname[len("up_layer:"):], "ms_per_launch": ms_l / n_l, "achieved": fl_l / (ms_l * 1e-3) / 1e12,
+                                    "frac": fl_l / (ms_l * 1e-3) / 1e12 / peak, "launches": n_l})
+            if ups:
+                roof["up_layers"] = ups
             # the up-sampling LAYER fused with its FIR + epilogue (csrc/upconv_fir.hip; taken for short-K layers: the first
             # super-resolution layer): the whole layer is one launch (+ two strip fix-ups), so this is the layer's rate
             ms_uf, flops_uf, n_uf = agg("modconv_split_upfir")

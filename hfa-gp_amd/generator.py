@@ -378,14 +378,19 @@ class TriPlaneGenerator(nn.Module):
         fuse = fuse in (True, "1") or (fuse == "auto" and x.shape[3] <= 64 and not half)
         if layer.up == 2 and fuse and ops.upconv_fir_supported(x, wt, cout, batch):
             # the whole up-sampling layer in one pass: the raw transposed-conv result stays on the chip (csrc/upconv_fir.hip)
-            out = self._timed(key + "_upfir", flops, ops.upconv_fir, x, wt, cout, k_styles, k_dcoef, noise, ns, layer.bias,
-                              "lrelu", cfg.lrelu_alpha, gain, conv_clamp, batch=batch, x_absmax=x_absmax,
-                              y_absmax=y_absmax, y_f16=half)
+            def fused_layer():
+                return self._timed(key + "_upfir", flops, ops.upconv_fir, x, wt, cout, k_styles, k_dcoef, noise, ns, layer.bias,
+                                   "lrelu", cfg.lrelu_alpha, gain, conv_clamp, batch=batch, x_absmax=x_absmax,
+                                   y_absmax=y_absmax, y_f16=half)
+            out = self._timed(f"up_layer:{x.shape[3]}->{cout}@{2 * x.shape[1]}:fused", flops, fused_layer)
         elif layer.up == 2:
-            yt = self._timed(key + "_up", flops, ops.modconv, x, wt, cout, ops.CONVT3X3_UP2, styles=k_styles, batch=batch,
-                             x_absmax=x_absmax, y_f16=half, x_parts=x_parts)
-            out = ops.upfir_epilogue(yt, k_dcoef, noise, ns, layer.bias, "lrelu", cfg.lrelu_alpha, gain, conv_clamp,
-                                     y_absmax=y_absmax)
+            def two_kernels():
+                yt = self._timed(key + "_up", flops, ops.modconv, x, wt, cout, ops.CONVT3X3_UP2, styles=k_styles, batch=batch,
+                                 x_absmax=x_absmax, y_f16=half, x_parts=x_parts)
+                return ops.upfir_epilogue(yt, k_dcoef, noise, ns, layer.bias, "lrelu", cfg.lrelu_alpha, gain, conv_clamp,
+                                          y_absmax=y_absmax)
+            # (bench.py `roofline.up_layers`: the LAYER — transposed-conv GEMM + FIR epilogue — per shape)
+            out = self._timed(f"up_layer:{x.shape[3]}->{cout}@{2 * x.shape[1]}", flops, two_kernels)
         else:
             # rgb = (toRGB weight [3, Cout], toRGB styles [B, Cout]): form the block's toRGB sums in this conv's epilogue
             # when the kernel can (ops.fused_torgb_supported); the caller finishes them with ops.torgb_finish
