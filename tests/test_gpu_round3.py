@@ -633,7 +633,9 @@ def test_f16x2_synthesis_vs_oracle(dev):
     out = gen.synthesis(ws.to(dev), c.to(dev), noise_mode="const", u_strat=us.to(dev), u_imp=ui.to(dev))
     ran = {k: len(v) for k, v in gen.timing.items()}
     gen.timing = None
-    assert ran.get("modconv_split", 0) + ran.get("modconv_split_up", 0) + ran.get("modconv_split_upfir", 0) >= 17, ran
+    # (17 conv layers on the split-operand kernels; the 4^2 ... 16^2 ones on the small-image kernel: key "modconv_small")
+    assert (ran.get("modconv_split", 0) + ran.get("modconv_split_up", 0) + ran.get("modconv_split_upfir", 0) +
+            ran.get("modconv_small", 0)) >= 17, ran
     err = out["image"].cpu() - ref["image"]
     mse, mx = err.pow(2).mean().item(), err.abs().max().item()
     print(f"f16x2 vs oracle: mse {mse:.2e} max {mx:.2e}")
