@@ -735,6 +735,9 @@ def nhwc_to_nchw(x: torch.Tensor) -> torch.Tensor:
 
 
 # ----------------------------------------------------------------------------- backward pass
+_DEV_PW_CHUNKS = os.environ.get("HFAGP_DEV_PW_CHUNKS")
+
+
 def pointwise_bwd(x: torch.Tensor, dxs_conv=None, s_conv=None, dxs_rgb=None, s_rgb=None, g_rgb_small=None,
                   w_rgb_small=None, s_small=None, g_direct=None, producer: Optional[dict] = None,
                   param_grads: bool = False, y_rgb_small=None, clamp_rgb_small: Optional[float] = None,
@@ -747,9 +750,12 @@ def pointwise_bwd(x: torch.Tensor, dxs_conv=None, s_conv=None, dxs_rgb=None, s_r
     # blocks per sample: at most 4 pixels per thread (the low-resolution layers are latency-bound otherwise: one block
     # walking 64 pixels of 512 channels took 45 us), at most 256 (the partial sums are reduced by a second kernel)
     npl = max(1, 256 // (c // 4))
-    # ... and enough blocks to fill the chip at batch 1 - 2 (the 512^2 layers ran 256 blocks = 4 waves per CU at B = 1: 2 TB/s);
-    # the chunk-parallel reducer (reduce_partials_kernel) makes up to 1024 chunks per sample cheap
-    nchunks = max(1, min(max(256, 1024 // b), -(-(h * w) // (npl * 4))))
+    # ... and enough blocks to fill the chip at batch 1 (the 512^2 layers ran 256 blocks = 4 waves per CU there: 2 TB/s).  Sweep
+    # (tools/dev/pointwise_sweep.py, kernel + reducer): ~512 blocks in total is the optimum at every size — 4.5 - 4.9 TB/s; more
+    # chunks only feed the reducer (B = 2, 128^2 x 256: 27 us at 256 chunks, 35 at 512, 47 at 1024)
+    nchunks = max(1, min(512 if b == 1 else 256, -(-(h * w) // (npl * 4))))
+    if _DEV_PW_CHUNKS:                                  # developer sweep (tools/dev/pointwise_sweep.py)
+        nchunks = max(1, min(int(_DEV_PW_CHUNKS), h * w))
     a = L.PointwiseBwdArgs()
     g_out = torch.empty_like(x)
     partial = torch.empty(b, nchunks, 10, c, device=x.device, dtype=torch.float32)
