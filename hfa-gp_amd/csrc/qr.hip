@@ -17,15 +17,23 @@
 namespace hfagp {
 
 constexpr int kQrMax = 64;
+constexpr int kQrPerThread = kQrMax * kQrMax / 256;          // elements of a K x K matrix per thread of the 256
 
 __global__ void __launch_bounds__(256) qr_gram_kernel(const float* __restrict__ G_in, const float* __restrict__ T_in,
                                                       float* __restrict__ R_out, float* __restrict__ Rinv_out, int n) {
     __shared__ float G[kQrMax][kQrMax + 1], T[kQrMax][kQrMax + 1], Ri[kQrMax][kQrMax + 1];
-    __shared__ float w[kQrMax], v[kQrMax];
+    __shared__ float w[kQrMax], v[kQrMax], r[kQrMax];
     const int tid = threadIdx.x;
     for (int i = tid; i < n * n; i += 256) {
         G[i / n][i % n] = G_in[i];
         T[i / n][i % n] = T_in[i];
+    }
+    int ea[kQrPerThread], ec[kQrPerThread];                    // this thread's elements e = tid + 256 k -> (row, column)
+#pragma unroll
+    for (int k = 0; k < kQrPerThread; ++k) {
+        const int e = tid + 256 * k;
+        ea[k] = e < n * n ? e / n : n;                          // (row n: out of range, skipped)
+        ec[k] = e < n * n ? e % n : 0;
     }
     __syncthreads();
     for (int j = 0; j < n; ++j) {
@@ -35,20 +43,34 @@ __global__ void __launch_bounds__(256) qr_gram_kernel(const float* __restrict__ 
         const bool reflect = xnorm2 > 0.f && norm2 > 0.f;       // LAPACK larfg: xnorm == 0 -> H = I
         const float beta = reflect ? (p >= 0.f ? -sqrtf(norm2) : sqrtf(norm2)) : p;
         const float tau = reflect ? 1.f / (norm2 - beta * p) : 0.f;       // 2 / (v^T v), v = x - beta e_j
+        // round 4: TWO barriers per step instead of three — the new row j of T (= row j of R, the vector the Gram matrix is
+        // down-dated with) is formed here from the OLD values together with w and v, so the update of T's rows > j and the
+        // down-date of G no longer wait for each other
         if (tid < n) {
-            w[tid] = G[tid][j] - beta * T[j][tid];
+            const float wt = G[tid][j] - beta * T[j][tid];
+            w[tid] = wt;
             v[tid] = tid == j ? p - beta : (tid > j ? T[tid][j] : 0.f);
+            r[tid] = tid == j ? beta : T[j][tid] - tau * (p - beta) * wt;     // (exact diagonal: the update would round it)
         }
         __syncthreads();
-        for (int e = tid; e < (n - j) * n; e += 256) {
-            const int i = j + e / n, c = e % n;
-            T[i][c] -= tau * v[i] * w[c];
+        // one pass over the thread's FIXED elements (row / column computed once, outside the step loop: the two integer
+        // divisions per element were most of a step — 3.3 us per step, 165 us per call)
+        // (all reads first, then all writes: a thread's elements are its own, but the compiler cannot know that T[a][c] of one
+        // iteration is not T[a'][c'] of the next and would serialise 32 LDS round trips per step)
+        float tv[kQrPerThread], gv[kQrPerThread];
+#pragma unroll
+        for (int k = 0; k < kQrPerThread; ++k) {
+            const int a = min(ea[k], n - 1), c = ec[k];
+            tv[k] = T[a][c];
+            gv[k] = G[a][c];
         }
-        __syncthreads();
-        if (tid == 0) T[j][j] = beta;                            // exact value of the diagonal (the update rounds)
-        for (int e = tid; e < n * n; e += 256) {
-            const int a = e / n, c = e % n;
-            if (a >= j && c >= j) G[a][c] -= T[j][a] * T[j][c];
+#pragma unroll
+        for (int k = 0; k < kQrPerThread; ++k) {
+            const int a = ea[k], c = ec[k];
+            if (a >= j && a < n) {
+                T[a][c] = a == j ? r[c] : tv[k] - tau * v[a] * w[c];
+                if (c >= j) G[a][c] = gv[k] - r[a] * r[c];
+            }
         }
         __syncthreads();
     }
@@ -60,8 +82,16 @@ __global__ void __launch_bounds__(256) qr_gram_kernel(const float* __restrict__ 
     if (tid < n) {
         const int c = tid;
         for (int i = n - 1; i >= 0; --i) {
-            float acc = i == c ? 1.f : 0.f;
-            for (int k = i + 1; k <= c; ++k) acc -= T[i][k] * Ri[k][c];
+            // (eight independent partial sums: the loads of a group are issued together — one LDS round trip per 8 terms
+            // instead of one per term; this serial tail was ~50 us of the kernel)
+            float pa[8] = {i == c ? 1.f : 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            int k = i + 1;
+            for (; k + 8 <= c + 1; k += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) pa[u] -= T[i][k + u] * Ri[k + u][c];
+            }
+            for (; k <= c; ++k) pa[0] -= T[i][k] * Ri[k][c];
+            const float acc = ((pa[0] + pa[1]) + (pa[2] + pa[3])) + ((pa[4] + pa[5]) + (pa[6] + pa[7]));
             Ri[i][c] = i <= c ? acc / T[i][i] : 0.f;
         }
     }
@@ -99,6 +129,13 @@ __global__ void __launch_bounds__(256) qr_refine_kernel(const float* __restrict_
         }
         __syncthreads();
     }
+    int ea[kQrPerThread], ec[kQrPerThread];
+#pragma unroll
+    for (int k = 0; k < kQrPerThread; ++k) {
+        const int e = tid + 256 * k;
+        ea[k] = e < n * n ? e / n : n;
+        ec[k] = e < n * n ? e % n : 0;
+    }
     // right-looking upper Cholesky: row j of R = G[j][j:] / sqrt(G[j][j]); trailing block -= r r^T
     for (int j = 0; j < n; ++j) {
         const float piv = G[j][j];
@@ -107,9 +144,16 @@ __global__ void __launch_bounds__(256) qr_refine_kernel(const float* __restrict_
         __syncthreads();
         if (tid >= j && tid < n) G[j][tid] *= inv;              // (G[j][j] becomes sqrt(piv))
         __syncthreads();
-        for (int e = tid; e < (n - j - 1) * (n - j - 1); e += 256) {
-            const int a = j + 1 + e / (n - j - 1), c = j + 1 + e % (n - j - 1);
-            if (c >= a) G[a][c] -= G[j][a] * G[j][c];
+        float gv[kQrPerThread];                                // (fixed elements per thread; reads first, then writes: see qr_gram_kernel)
+#pragma unroll
+        for (int k = 0; k < kQrPerThread; ++k) {
+            const int a = min(ea[k], n - 1), c = ec[k];
+            gv[k] = G[a][c] - G[j][a] * G[j][c];
+        }
+#pragma unroll
+        for (int k = 0; k < kQrPerThread; ++k) {
+            const int a = ea[k], c = ec[k];
+            if (a > j && a < n && c >= a) G[a][c] = gv[k];
         }
         __syncthreads();
     }
@@ -121,8 +165,14 @@ __global__ void __launch_bounds__(256) qr_refine_kernel(const float* __restrict_
     if (tid < n) {
         const int c = tid;
         for (int i = n - 1; i >= 0; --i) {
-            float acc = i == c ? 1.f : 0.f;
-            for (int k = i + 1; k <= c; ++k) acc -= G[i][k] * Ri[k][c];
+            float pa[8] = {i == c ? 1.f : 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            int k = i + 1;
+            for (; k + 8 <= c + 1; k += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) pa[u] -= G[i][k + u] * Ri[k + u][c];
+            }
+            for (; k <= c; ++k) pa[0] -= G[i][k] * Ri[k][c];
+            const float acc = ((pa[0] + pa[1]) + (pa[2] + pa[3])) + ((pa[4] + pa[5]) + (pa[6] + pa[7]));
             Ri[i][c] = i <= c ? acc / G[i][i] : 0.f;
         }
     }
