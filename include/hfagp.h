@@ -394,7 +394,8 @@ int hfagp_pointwise_bwd(const HfagpPointwiseBwdArgs* a, void* stream);
 
 /* MipRayMarcher2's depth clamp (EG3D: `torch.clamp(depth, min(sample depths), max(sample depths))` over the WHOLE batch) in one
  * launch: depth [n] is clamped in place to [min_i tminmax[i][0], max_i tminmax[i][1]] (tminmax as hfagp_raymarch_fwd writes it).
- * One workgroup: meant for small batches (n <= 65536 rays; -2 above that — the caller then uses its framework's reductions). */
+ * Up to 16 workgroups, each reducing all of tminmax itself and clamping its slice: meant for small batches (n <= 65536 rays; -2
+ * above that — the caller then uses its framework's reductions). */
 int hfagp_depth_clamp(float* depth, const float* tminmax, int64_t n, void* stream);
 
 /* adjoint of hfagp_upfir_epilogue_fwd's FIR: g_y [B][2H][2W][C] -> four parity images of the y_t gradient,
