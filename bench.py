@@ -391,6 +391,7 @@ def train_legs(args, cfg_name, dev, rank, world, dist):
         ms, phases = timed(tr, fa, max(2, args.train_steps // 2), B)
         leg["tuned"][B] = {"step_ms": ms, "phases_ms": phases}
         leg["shared_grad_bytes_tuned"] = 4 * tr.flat_grads().numel
+        leg["kernel_events_tuned"] = kernel_events(tr, fa, B)
         out[mode] = leg
         del tr
         torch.cuda.empty_cache()
@@ -990,6 +991,7 @@ def main():
                 (profiles/traffic_train.json, written by profiles/train_pmc.sh), only if batch and mode match."""
                 try:
                     t = json.load(open(os.path.join(ROOT, "profiles", "traffic_train.json")))
+                    t = t.get("regimes", {}).get(mode_, t)       # {"regimes": {"3dmm": {...}, "rgb": {...}, "3dmm_tuned": {...}, ...}}
                     if t.get("batch") != train_B or t.get("mode") != mode_:
                         return None
                     for k, v in t.items():
@@ -1025,6 +1027,24 @@ def main():
                     res_["bwd_data_gemms"] = {"bound": "mfma", "achieved": tot_fl / (tot_ms * 1e-3) / 1e12, "peak": peak_g,
                                               "unit": "TFLOP/s", "frac": tot_fl / (tot_ms * 1e-3) / 1e12 / peak_g,
                                               "ms_per_step": tot_ms, "share_of_step": tot_ms / step_ms}
+                # generator being tuned: the weight-gradient GEMM family (wgrad_bf16_kernel<...> / wgrad_kernel<...> + their split-K
+                # reducers; K = positions), algorithmic 2 * positions * Cin * Cout * taps against the same 833 TF (bf16x3)
+                wg_ms = wg_fl = 0.0
+                for key, name in (("wgrad", "3x3 weight gradient (wgrad_bf16_kernel<7,7> + wgrad_reduce_tiled_kernel)"),
+                                  ("wgrad_up", "weight gradient of the up-sampling conv (parity images of the y_t gradient) + reducer"),
+                                  ("wgrad_1x1", "96-channel toRGB weight gradient (wgrad_kernel<1,*>, exact fp32 MFMA) + reducer")):
+                    if key in ev:
+                        ms, fl, n = ev[key]
+                        wg_ms, wg_fl = wg_ms + ms, wg_fl + fl
+                        res_[key] = {"kernel": name, "ms_per_step": ms, "launches_per_step": n,
+                                     "achieved": fl / (ms * 1e-3) / 1e12, "frac": fl / (ms * 1e-3) / 1e12 / peak_g,
+                                     "traffic": train_traffic({"wgrad": "wgrad_bf16_kernel<7, 7", "wgrad_up": "wgrad_up_bf16_kernel",
+                                                               "wgrad_1x1": "wgrad_kernel<1"}[key], mode_)}
+                if wg_ms > 0:
+                    res_["wgrad_gemms"] = {"bound": "mfma", "achieved": wg_fl / (wg_ms * 1e-3) / 1e12, "peak": peak_g,
+                                           "unit": "TFLOP/s", "frac": wg_fl / (wg_ms * 1e-3) / 1e12 / peak_g,
+                                           "ms_per_step": wg_ms, "share_of_step": wg_ms / step_ms,
+                                           "algorithmic_gflop_per_step": wg_fl / 1e9}
                 if "pointwise_bwd" in ev:
                     ms, by, n = ev["pointwise_bwd"]
                     gbs = by / (ms * 1e-3) / 1e9
@@ -1052,7 +1072,12 @@ def main():
                     res_["conv_fwd_ms_per_step"] = fwd
                 return res_
             out["roofline_train"] = {"rgb": roofline_train(trgb["kernel_events"], trgb["frozen"][train_B]["step_ms"], "rgb"),
-                                     "3dmm": roofline_train(t3["kernel_events"], t3["frozen"][train_B]["step_ms"], "3dmm")}
+                                     "3dmm": roofline_train(t3["kernel_events"], t3["frozen"][train_B]["step_ms"], "3dmm"),
+                                     # the reference's regime after tune_iter (750 000 of its 800 000 default iterations,
+                                     # train_rgb.py:132-134,162,193; trainer_rgb.py:69-71): all generator parameters get gradients
+                                     "tuned": {"rgb": roofline_train(trgb["kernel_events_tuned"], trgb["tuned"][train_B]["step_ms"], "rgb_tuned"),
+                                               "3dmm": roofline_train(t3["kernel_events_tuned"], t3["tuned"][train_B]["step_ms"], "3dmm_tuned")}}
+            out["train_phases_ms_3dmm_generator_tuned"] = t3["tuned"][train_B]["phases_ms"]
         if fit is not None:
             out["fit_rgb"] = fit
         if fit3 is not None:

@@ -14,7 +14,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # (HFAGP_LIB_PATH: developer override, used by the ablation builds of tools/dev/ — the product loads the in-tree library)
 LIB_PATH = os.environ.get("HFAGP_LIB_PATH") or os.path.join(_HERE, "libhfagp_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 c_float_p = C.c_void_p  # device pointers travel as integers
 
@@ -166,6 +166,7 @@ SYMBOLS = {
     "hfagp_style_bwd": (C.c_int, [C.POINTER(StyleBwdArgs), C.c_void_p]),
     "hfagp_style_batch_bwd": (C.c_int, [C.POINTER(StyleBwdItem), C.c_int32, C.c_void_p]),
     "hfagp_raymarch_bwd": (C.c_int, [C.POINTER(RaymarchBwdArgs), C.c_void_p]),
+    "hfagp_wgrad_ksplit": (C.c_int32, [C.POINTER(WgradArgs)]),
     "hfagp_wgrad_workspace_bytes": (C.c_size_t, [C.POINTER(WgradArgs)]),
     "hfagp_conv_wgrad": (C.c_int, [C.POINTER(WgradArgs), C.c_void_p]),
     "hfagp_affine_grad": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 4 + [C.c_void_p]),

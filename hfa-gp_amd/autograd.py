@@ -59,6 +59,16 @@ class _Backward:
                                             if kw.get(k) is not None))
         return self.gen._timed("pointwise_bwd", nbytes, ops.pointwise_bwd, x, **kw)
 
+    def wgrad(self, x: torch.Tensor, styles, g: torch.Tensor, weight: torch.Tensor, mode: int, **kw) -> torch.Tensor:
+        """Weight-gradient GEMM of one layer (generator being tuned); timing keys "wgrad" (3x3), "wgrad_up" (the four parity
+        images of the up-sampling conv), "wgrad_1x1" (96-channel toRGB): algorithmic flops 2 * positions * Cin * Cout * taps,
+        the split-K reducer that follows the GEMM included."""
+        if self.gen.timing is None:
+            return ops.conv_wgrad(x, styles, g, weight, mode, **kw)
+        flops = 2.0 * x.shape[0] * x.shape[1] * x.shape[2] * weight.numel()
+        key = {ops.CONV3X3: "wgrad", ops.CONVT3X3_UP2: "wgrad_up", ops.CONV1X1: "wgrad_1x1"}[mode]
+        return self.gen._timed(key, flops, ops.conv_wgrad, x, styles, g, weight, mode, **kw)
+
     def _acc(self, param: torch.Tensor, g: torch.Tensor):
         key = id(param)
         self.grads[key] = g if key not in self.grads else self.grads[key] + g
@@ -175,7 +185,7 @@ class _Backward:
                 db = torch.zeros_like(tr.bias)
                 ops.channel_sum(g_y.permute(0, 2, 3, 1).contiguous(), db)
             else:
-                self._acc(tr.weight, ops.conv_wgrad(x1, rgb["styles"], g_y, tr.weight, ops.CONV1X1))
+                self._acc(tr.weight, self.wgrad(x1, rgb["styles"], g_y, tr.weight, ops.CONV1X1))
                 db = torch.zeros_like(tr.bias)
                 ops.channel_sum(g_y, db)
             self._acc(tr.bias, db)
@@ -216,8 +226,8 @@ class _Backward:
         # gradient GEMMs follow the generator's precision class: exact fp32 MFMA when conv_precision is "fp32", else
         # split-bf16 (the 3x3 layers with 64-multiple channels; bf16 parts keep a gradient's exponent range)
         wprec = "fp32" if self.gen.conv_precision == "fp32" else "bf16x3"
-        self._acc(layer.weight, ops.conv_wgrad(x, rec["styles"], g, layer.weight, mode, dd=rec["dd"].contiguous(),
-                                               dcoef=rec["dcoef"], precision=wprec))
+        self._acc(layer.weight, self.wgrad(x, rec["styles"], g, layer.weight, mode, dd=rec["dd"].contiguous(),
+                                           dcoef=rec["dcoef"], precision=wprec))
         self._acc(layer.bias, sums_out[:, 4].sum(0))
         if rec["producer"]["noise"] is not None:
             self._acc(layer.noise_strength, sums_out[:, 5].sum())

@@ -346,6 +346,22 @@ static int run_wgrad(WgradParams& p, const HfagpWgradArgs* a, hipStream_t s, boo
 
 extern "C" {
 
+// split-K policy (ABI 11; the host used to carry a copy of it): one resident block per CU for the split-bf16 kernel (measured 5 %
+// better than two rounds: half the slabs to write and reduce), two rounds for the fp32 one; never more slabs than position tiles
+int32_t hfagp_wgrad_ksplit(const HfagpWgradArgs* a) {
+    if (!a || a->B <= 0 || a->H <= 0 || a->W <= 0 || a->Cin <= 0 || a->Cout <= 0) return 1;
+    const bool up = a->mode == HFAGP_CONVT3X3_UP2;
+    const bool split16 = a->precision == HFAGP_PREC_BF16X3 && (a->mode == HFAGP_CONV3X3 || up) && a->Cin % 64 == 0 && a->Cout % 64 == 0;
+    const int rows = split16 ? 4 : 2;                  // position tile of the kernel that will run: rows x 16
+    const long long units = (long long)a->B * ((a->H + rows - 1) / rows) * ((a->W + 15) / 16);
+    long long tiles = (long long)((a->Cin + 63) / 64) * ((a->Cout + 63) / 64);
+    const long long want = (split16 ? 256 : 512) / (tiles > 0 ? tiles : 1);
+    long long k = want < 1 ? 1 : want;
+    if (k > units) k = units;
+    if (k > 256) k = 256;
+    return (int32_t)(k < 1 ? 1 : k);
+}
+
 size_t hfagp_wgrad_workspace_bytes(const HfagpWgradArgs* a) {
     if (!a || a->ksplit <= 0) return 0;
     // (up-sampling mode: the four parity launches write disjoint regions — 4 + 2 + 2 + 1 taps — and ONE reducer finishes them)

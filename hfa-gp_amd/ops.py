@@ -881,7 +881,7 @@ def _style_bwd_each(items, d_ws):
 
 def conv_wgrad(x: torch.Tensor, styles: Optional[torch.Tensor], g: torch.Tensor, weight: torch.Tensor, mode: int,
                dd: Optional[torch.Tensor] = None, dcoef: Optional[torch.Tensor] = None,
-               precision: str = "fp32") -> torch.Tensor:
+               precision: str = "fp32", ksplit: Optional[int] = None) -> torch.Tensor:
     """Weight gradient of a modulated conv (see include/hfagp.h): returns dweight like `weight`.  precision 'bf16x3':
     the 3x3 and up-sampling modes with Cin, Cout multiples of 64 run on the split-bf16 MFMA kernel (the 1x1 mode and
     other shapes stay fp32)."""
@@ -891,18 +891,11 @@ def conv_wgrad(x: torch.Tensor, styles: Optional[torch.Tensor], g: torch.Tensor,
     cout = weight.shape[0]
     a = L.WgradArgs()
     dweight = torch.empty_like(weight)
-    split16 = precision == "bf16x3" and mode in (CONV3X3, CONVT3X3_UP2) and cin % 64 == 0 and cout % 64 == 0
-    rows = 4 if split16 else 2                         # position tile of the kernel that will run: rows x 16
-    units = b * ((h + rows - 1) // rows) * ((w + 15) // 16)
-    tiles = ((cin + 63) // 64) * ((cout + 63) // 64)
-    # one resident block per CU (117 KB of LDS): aim at a whole number of rounds over the 256 CUs
-    # split-K so that the grid is one round of the 256 CUs for the split-bf16 kernel (one workgroup per CU; measured
-    # 5 % better than two rounds: half the slabs to write and reduce) and two rounds for the fp32 one
-    ksplit = max(1, min(units, max((256 if split16 else 512) // tiles, 1), 256))
     a.x, a.styles, a.g = _ptr(x), _ptr(styles), _ptr(g)
     a.weight, a.dd, a.dcoef, a.dweight = _ptr(_chk(weight.detach(), "weight")), _ptr(dd), _ptr(dcoef), _ptr(dweight)
-    a.B, a.H, a.W, a.Cin, a.Cout, a.mode, a.ksplit = b, h, w, cin, cout, mode, ksplit
+    a.B, a.H, a.W, a.Cin, a.Cout, a.mode = b, h, w, cin, cout, mode
     a.precision = PREC_BF16X3 if precision == "bf16x3" else PREC_F32
+    a.ksplit = L.lib().hfagp_wgrad_ksplit(C.byref(a)) if ksplit is None else ksplit      # (the library's split-K policy)
     ws = torch.empty(L.lib().hfagp_wgrad_workspace_bytes(C.byref(a)) // 4, device=x.device, dtype=torch.float32)
     a.workspace = _ptr(ws)
     L.check(L.lib().hfagp_conv_wgrad(C.byref(a), _stream()), "conv_wgrad")

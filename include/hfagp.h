@@ -61,7 +61,7 @@
 extern "C" {
 #endif
 
-#define HFAGP_ABI_VERSION 10
+#define HFAGP_ABI_VERSION 11
 
 enum { HFAGP_OK = 0, HFAGP_EBADARG = -1, HFAGP_EUNSUPPORTED = -2, HFAGP_ELAUNCH = -3 };
 
@@ -489,6 +489,9 @@ typedef struct {
                               /* multiples of 64 then run on the split-bf16 MFMA kernel, every other case stays fp32   */
 } HfagpWgradArgs;
 
+/* ABI 11: the library's split-K choice for this layer (everything but `ksplit` / `workspace` filled in): one block per CU for the
+ * kernel that will run (64 x 64 (ci, co) tiles), never more slabs than position tiles */
+int32_t hfagp_wgrad_ksplit(const HfagpWgradArgs* a);
 size_t hfagp_wgrad_workspace_bytes(const HfagpWgradArgs* a);
 int hfagp_conv_wgrad(const HfagpWgradArgs* a, void* stream);
 

@@ -1,0 +1,126 @@
+"""Round-5 parity cases: the GENERATOR-TUNED optimisation step at BASELINE's own size.
+
+The reference trains the generator from iteration `tune_iter` = 50 000 of its default 800 000 on
+(/root/reference/code/train_rgb.py:132-134,162,193 -> trainer_rgb.py:69-71 `tune_generator`): 94 % of its iterations
+back-propagate into all 30.7 M generator parameters.  `test_full_size_parameter_gradients_three_way` checks `synthesis`'
+gradients for a white-noise cotangent; this file checks the TRAINER's composed step in that regime — driver net -> QR basis ->
+HIP generator -> fused pool + MSE -> backward with the weight-gradient GEMMs, the decoder-gradient pass and the bucketed
+gradient sink of the multi-GPU path active (1-rank RCCL group, small buckets) — against the identical step through the CPU
+oracle under autograd.  Needs an MI355X:  python -m pytest tests -m gpu"""
+import os
+
+import pytest
+import torch
+
+from tests.test_gpu_round4 import OwnSizeArgs, _free_port, _own_size_inputs, rel_l2
+from tests.util import perturb_state
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("the -m gpu tests need an MI355X")
+    from hfa_gp_amd import _lib
+    _lib.lib()
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("mode", ["3dmm", "rgb"])
+def test_tuned_gen_update_at_own_size_matches_oracle_step(dev, mode):
+    """`ffhq512_128`, B = 2, K = 50, L2 at 256^2, `tune_generator()` called on both sides.  The HIP side runs with the
+    bucketed all-reduce sink ACTIVE (force_collective in a 1-rank "nccl" = RCCL group, 4 MB buckets: the generator's gradients
+    are released block by block from inside SynthesisFn.backward into the flat buffer while collectives of finished buckets are
+    in flight).  Compared: loss, pooled image, bases / delta / every driver gradient (bar 2e-4 as in the frozen test) and EVERY
+    generator parameter's .grad after the step: tensor-valued ones by rel-L2 (bar 2e-3: split-bf16 weight-gradient GEMMs,
+    2^-16 per product, K up to 524 288 positions; the three-way fp64 test prices the oracle's own fp32 distance from the truth
+    at 1.0-1.2e-3 for a white-noise cotangent, the smooth loss gradient here is better conditioned), scalars (noise strengths:
+    one number, near-total cancellation) against the cancellation scale the oracle's own fp32 run reaches."""
+    import torch.distributed as dist
+    from hfa_gp_amd import headnerf
+    from hfa_gp_amd.trainer import FlatGrads, Trainer
+    from tests.test_trainer_cpu import OracleGenerator
+    cls = headnerf.HeadNeRF_final if mode == "rgb" else headnerf.HeadNeRF_3DMM
+
+    def build(device, oracle):
+        torch.manual_seed(0)
+        gen = cls(OwnSizeArgs(), OwnSizeArgs.size, device, 512, OwnSizeArgs.latent_dim_shape)
+        perturb_state(gen.generator)
+        if oracle:
+            OracleGenerator.adopt(gen.generator)
+        tr = Trainer(OwnSizeArgs(), device, mode=mode, gen=gen, lpips="none")
+        tr.optimizer = torch.optim.SGD(tr.gen.parameters(), lr=0.0)        # compare gradients, not Adam's first step
+        tr.tune_generator()
+        return tr
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(_free_port())
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        gpu = build(dev, False)
+        gpu.force_collective = True
+        gpu._flat = FlatGrads(gpu.shared_parameters(), bucket_bytes=4 << 20)
+        gpu._bucketer = None
+        cfg = gpu.gen.generator.cfg
+        real, params, label, us, ui = _own_size_inputs(cfg, 2)
+        out = gpu.gen_update(real.to(dev), label.clone().to(dev), None if mode == "rgb" else params.to(dev),
+                             u_strat=us.to(dev), u_imp=ui.to(dev))
+        torch.cuda.synchronize()
+        order = gpu._bucketer.last_order
+        assert len(order) == len(gpu._flat.buckets) > 8 and order == list(range(len(order))), order
+        assert gpu._bucketer.launched_early == len(order), (gpu._bucketer.launched_early, len(order))
+        l2_gpu, img_gpu = (out[0], out[2]) if mode == "rgb" else (out[1], out[3])
+        got = {n: p.grad.detach().cpu() for n, p in gpu.gen.named_parameters() if p.grad is not None and p.requires_grad}
+        l2_gpu, img_gpu = float(l2_gpu), img_gpu.cpu()
+        del gpu
+        torch.cuda.empty_cache()
+    finally:
+        dist.destroy_process_group()
+
+    cpu = build("cpu", True)
+    out = cpu.gen_update(real, label.clone(), None if mode == "rgb" else params, u_strat=us, u_imp=ui)
+    l2_cpu, img_cpu = (out[0], out[2]) if mode == "rgb" else (out[1], out[3])
+    want = {n: p.grad.detach() for n, p in cpu.gen.named_parameters() if p.grad is not None and p.requires_grad}
+    l2_cpu = float(l2_cpu)
+    assert abs(l2_gpu - l2_cpu) <= 1e-5 * max(1.0, abs(l2_cpu))
+    assert (img_gpu - img_cpu).abs().max().item() <= 2e-5
+
+    # ---- driver side: as in the frozen test
+    drivers = sorted(n for n in want if not n.startswith(("generator.", "encoder.pose.")))
+    assert "bases" in drivers and "delta" in drivers and set(drivers) <= set(got)
+    d_errs = {n: rel_l2(got[n], want[n]) for n in drivers}
+    assert all(e <= 2e-4 for e in d_errs.values()), {n: e for n, e in d_errs.items() if e > 2e-4}
+
+    # ---- generator side: every parameter on the synthesis path (the mapping network is not: HFA-GP never calls it)
+    gens = sorted(n for n in want if n.startswith("generator.") and float(want[n].abs().max()) > 0)
+    assert len(gens) >= 100, len(gens)                       # 14 + 6 synthesis layers x (weight, bias, affine.*, noise) + toRGBs + decoder
+    missing = [n for n in gens if n not in got]
+    assert not missing, missing
+    kinds = {"weight": 0, "affine": 0, "bias": 0, "noise_strength": 0, "const": 0, "decoder": 0}
+    t_errs, s_errs = {}, {}
+    for n in gens:
+        for k in kinds:
+            if k in n:
+                kinds[k] += 1
+        if want[n].numel() == 1:
+            s_errs[n] = abs(float(got[n]) - float(want[n]))
+        else:
+            t_errs[n] = rel_l2(got[n], want[n])
+    assert all(v > 0 for v in kinds.values()), kinds
+    worst = max(t_errs, key=t_errs.get)
+    conv_w = {n: e for n, e in t_errs.items() if n.endswith(("conv0.weight", "conv1.weight"))}
+    worst_w = max(conv_w, key=conv_w.get)
+    print(f"own-size TUNED {mode} step: l2 hip {l2_gpu:.8f} oracle {l2_cpu:.8f}; drivers worst {max(d_errs.values()):.2e}; "
+          f"{len(t_errs)} generator tensors: worst {worst} {t_errs[worst]:.2e}, worst conv weight {worst_w} {conv_w[worst_w]:.2e}; "
+          f"{len(s_errs)} scalars")
+    bad = {n: e for n, e in t_errs.items() if not (e <= 2e-3)}
+    assert not bad, bad
+    # scalars (noise strengths): |error| against the size of the LARGEST tensor-valued noise-free quantity is meaningless; use the
+    # scalar's own magnitude with a floor at the scale at which the oracle's fp32 sum itself is uncertain (sum over R^2 positions
+    # x Cout channels of products g * noise of magnitude |g|_rms: eps_fp32 * sqrt(N) * rms — a few 1e-4 of the rms product sum)
+    top = max(abs(float(want[n])) for n in s_errs)
+    print("scalars (got, want):", {n.replace("generator.", ""): (round(float(got[n]), 7), round(float(want[n]), 7)) for n in s_errs})
+    for n, e in s_errs.items():
+        ref = abs(float(want[n]))
+        assert e <= 5e-2 * ref + 5e-3 * top, (n, float(got[n]), float(want[n]))

@@ -19,6 +19,8 @@ def main():
     torch.manual_seed(0)
     mode = sys.argv[3] if len(sys.argv) > 3 else "3dmm"
     tr = Trainer(Args(), dev, mode=mode, lpips="none")
+    if len(sys.argv) > 4 and sys.argv[4] == "tuned":      # the reference's regime after tune_iter (trainer_rgb.py:69-71)
+        tr.tune_generator()
     g = torch.Generator().manual_seed(1)
     real = (0.5 * torch.randn(B, 3, 256, 256, generator=g)).clamp(-1, 1).to(dev)
     params = torch.randn(B, 76, generator=g).to(dev)
