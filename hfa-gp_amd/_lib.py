@@ -118,7 +118,7 @@ class StyleBwdArgs(C.Structure):
 
 class WgradArgs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("x", "styles", "g", "weight", "dd", "dcoef", "dweight", "workspace")] + \
-        [(n, C.c_int32) for n in ("B", "H", "W", "Cin", "Cout", "mode", "ksplit", "precision")]
+        [(n, C.c_int32) for n in ("B", "H", "W", "Cin", "Cout", "mode", "ksplit", "precision", "accumulate")]
 
 
 class StyleBwdItem(C.Structure):

@@ -34,7 +34,12 @@ class _Backward:
         self.gen, self.tape, self.d_ws, self.ws, self.pg = gen, tape, d_ws, ws, param_grads
         self.grads = {}            # id(parameter) -> gradient (only when the generator is being tuned)
         self.by_id = {}            # id(parameter) -> parameter
-        self.released = set()      # ids already handed to the gradient sink
+        self.released = set()      # ids already handed to the gradient sink / accumulated in place
+        # in-place mode (set by the trainer's step scope): this pass ADDS every generator gradient into the parameter's
+        # existing .grad (a slice of the trainer's flat buffer) itself — the conv weight gradients straight from the reducer
+        # kernel, everything else in one multi-tensor add per release — and autograd receives None for them (round 5: the
+        # tuned step spent ~140 launches of 2-3 us + 370 MB of traffic on AccumulateGrad's per-tensor adds)
+        self.inplace = bool(getattr(gen, "_grad_inplace", False))
         self.pending = []          # style gradients of the whole pass: (item for ops.style_bwd_batch, affine module)
 
     # bench.py's roofline_train: HIP events around the three kernel families that carry the backward pass (gen.timing keys
@@ -59,15 +64,26 @@ class _Backward:
                                             if kw.get(k) is not None))
         return self.gen._timed("pointwise_bwd", nbytes, ops.pointwise_bwd, x, **kw)
 
-    def wgrad(self, x: torch.Tensor, styles, g: torch.Tensor, weight: torch.Tensor, mode: int, **kw) -> torch.Tensor:
-        """Weight-gradient GEMM of one layer (generator being tuned); timing keys "wgrad" (3x3), "wgrad_up" (the four parity
-        images of the up-sampling conv), "wgrad_1x1" (96-channel toRGB): algorithmic flops 2 * positions * Cin * Cout * taps,
-        the split-K reducer that follows the GEMM included."""
+    def wgrad(self, x: torch.Tensor, styles, g: torch.Tensor, weight: torch.Tensor, mode: int, **kw) -> None:
+        """Weight-gradient GEMM of one layer (generator being tuned) into the layer's gradient; timing keys "wgrad" (3x3),
+        "wgrad_up" (the four parity images of the up-sampling conv), "wgrad_1x1" (96-channel toRGB): algorithmic flops
+        2 * positions * Cin * Cout * taps, the split-K reducer that follows the GEMM included."""
+        direct = self.inplace and weight.requires_grad and weight.grad is not None and id(weight) not in self.grads
+        if direct:
+            kw["out"] = weight.grad            # the reducer accumulates into the flat-buffer slice
         if self.gen.timing is None:
-            return ops.conv_wgrad(x, styles, g, weight, mode, **kw)
-        flops = 2.0 * x.shape[0] * x.shape[1] * x.shape[2] * weight.numel()
-        key = {ops.CONV3X3: "wgrad", ops.CONVT3X3_UP2: "wgrad_up", ops.CONV1X1: "wgrad_1x1"}[mode]
-        return self.gen._timed(key, flops, ops.conv_wgrad, x, styles, g, weight, mode, **kw)
+            dw = ops.conv_wgrad(x, styles, g, weight.detach(), mode, **kw)
+        else:
+            flops = 2.0 * x.shape[0] * x.shape[1] * x.shape[2] * weight.numel()
+            key = {ops.CONV3X3: "wgrad", ops.CONVT3X3_UP2: "wgrad_up", ops.CONV1X1: "wgrad_1x1"}[mode]
+            dw = self.gen._timed(key, flops, ops.conv_wgrad, x, styles, g, weight.detach(), mode, **kw)
+        if direct:
+            self.released.add(id(weight))
+            sink = getattr(self.gen, "_grad_sink", None)
+            if sink is not None:
+                sink(weight, None)             # (already accumulated: only counted as ready)
+        else:
+            self._acc(weight, dw)
 
     def _acc(self, param: torch.Tensor, g: torch.Tensor):
         key = id(param)
@@ -81,6 +97,16 @@ class _Backward:
         the collective of a finished bucket while the rest of the backward pass is still being enqueued; released
         parameters get None from autograd.  Without a sink nothing happens and autograd receives every gradient."""
         sink = getattr(self.gen, "_grad_sink", None)
+        if self.inplace:
+            ready = [k for k in self.grads if self.by_id[k].requires_grad and self.by_id[k].grad is not None]
+            if ready:
+                prms = [self.by_id[k] for k in ready]
+                torch._foreach_add_([p.grad for p in prms], [self.grads.pop(k).view_as(p.grad) for k, p in zip(ready, prms)])
+                self.released.update(ready)
+                if sink is not None:
+                    for p in prms:
+                        sink(p, None)
+            return
         if sink is None:
             return
         for key in list(self.grads):
@@ -185,7 +211,7 @@ class _Backward:
                 db = torch.zeros_like(tr.bias)
                 ops.channel_sum(g_y.permute(0, 2, 3, 1).contiguous(), db)
             else:
-                self._acc(tr.weight, self.wgrad(x1, rgb["styles"], g_y, tr.weight, ops.CONV1X1))
+                self.wgrad(x1, rgb["styles"], g_y, tr.weight, ops.CONV1X1)
                 db = torch.zeros_like(tr.bias)
                 ops.channel_sum(g_y, db)
             self._acc(tr.bias, db)
@@ -226,8 +252,7 @@ class _Backward:
         # gradient GEMMs follow the generator's precision class: exact fp32 MFMA when conv_precision is "fp32", else
         # split-bf16 (the 3x3 layers with 64-multiple channels; bf16 parts keep a gradient's exponent range)
         wprec = "fp32" if self.gen.conv_precision == "fp32" else "bf16x3"
-        self._acc(layer.weight, self.wgrad(x, rec["styles"], g, layer.weight, mode, dd=rec["dd"].contiguous(),
-                                           dcoef=rec["dcoef"], precision=wprec))
+        self.wgrad(x, rec["styles"], g, layer.weight, mode, dd=rec["dd"].contiguous(), dcoef=rec["dcoef"], precision=wprec)
         self._acc(layer.bias, sums_out[:, 4].sum(0))
         if rec["producer"]["noise"] is not None:
             self._acc(layer.noise_strength, sums_out[:, 5].sum())

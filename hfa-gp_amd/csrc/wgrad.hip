@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
                                                            const float* __restrict__ dd, const float* __restrict__ dcoef,
                                                            const float* __restrict__ styles, float* __restrict__ dW,
                                                            int ksplit, int ntaps, int Cin, int Cout, int B, int wtaps,
-                                                           const WTaps9 taps) {
+                                                           const WTaps9 taps, int accumulate) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // over Cin * Cout, co fastest
     if (idx >= Cin * Cout) return;
     const int t = blockIdx.y;
@@ -200,7 +200,8 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
     for (; k < ksplit; ++k) part[0] += src[(size_t)k * kstride];
     const float acc = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
     const size_t wi = ((size_t)co * Cin + ci) * wtaps + taps.t[t].widx;
-    dW[wi] = acc - weight[wi] * dem;
+    const float v = acc - weight[wi] * dem;
+    dW[wi] = accumulate ? dW[wi] + v : v;
 }
 
 // Tiled reducer (round 4): the reducer above stores dW[(co * Cin + ci) * wtaps + tap] from threads that are consecutive in co —
@@ -212,31 +213,42 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
 struct RedTap { long long base; long long kstride; int widx; };     // slab of split k at slabs + base + k * kstride + ci * Cout + co
 struct RedTaps { RedTap t[9]; };
 
+// V = floats per thread along co (round 5: 4 where Cout % 128 == 0 — 16-byte slab reads, a block owns 8 ci x 128 co; the 4-byte
+// version moved 2 TB/s out of L2 / the memory-side cache, one 128-byte row per wave-load).
+template <int V>
 __global__ void __launch_bounds__(256) wgrad_reduce_tiled_kernel(const float* __restrict__ slabs, const float* __restrict__ weight,
                                                                  const float* __restrict__ dd, const float* __restrict__ dcoef,
                                                                  const float* __restrict__ styles, float* __restrict__ dW,
                                                                  int ksplit, int ntaps, int Cin, int Cout, int B, int wtaps,
-                                                                 const RedTaps taps) {
-    __shared__ float tile[32][8 * 9 + 1];                       // [co][ci * ntaps + tap slot]
+                                                                 const RedTaps taps, int accumulate) {
+    constexpr int CW = 32 * V;
+    __shared__ float tile[CW][8 * 9 + 1];                       // [co][ci * ntaps + tap slot]
+    typedef float vec __attribute__((ext_vector_type(V)));
     const int tid = threadIdx.x, col = tid & 31, row = tid >> 5;
-    const int ci0 = blockIdx.x * 8, co0 = blockIdx.y * 32;
-    const int ci = ci0 + row, co = co0 + col;
+    const int ci0 = blockIdx.x * 8, co0 = blockIdx.y * CW;
+    const int ci = ci0 + row, co = co0 + V * col;
     for (int t = 0; t < ntaps; ++t) {
         const float* src = slabs + taps.t[t].base + (size_t)ci * Cout + co;
         const long long ks = taps.t[t].kstride;
-        float part[4] = {0.f, 0.f, 0.f, 0.f};
+        vec part[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) part[u] = vec(0.f);
         int k = 0;
         for (; k + 4 <= ksplit; k += 4) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) part[u] += src[(size_t)(k + u) * ks];
+            for (int u = 0; u < 4; ++u) part[u] += *reinterpret_cast<const vec*>(src + (size_t)(k + u) * ks);
         }
-        for (; k < ksplit; ++k) part[0] += src[(size_t)k * ks];
-        tile[col][row * ntaps + t] = (part[0] + part[1]) + (part[2] + part[3]);
+        for (; k < ksplit; ++k) part[0] += *reinterpret_cast<const vec*>(src + (size_t)k * ks);
+        const vec sum = (part[0] + part[1]) + (part[2] + part[3]);
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            tile[V * col + v][row * ntaps + t] = sum[v];
+        }
     }
     __syncthreads();
     // out: for each co a run of 8 ci x ntaps values; consecutive threads -> consecutive (ci, tap slot) of one co
     const int per_co = 8 * ntaps;
-    for (int e = tid; e < 32 * per_co; e += 256) {
+    for (int e = tid; e < CW * per_co; e += 256) {
         const int c = e / per_co, rem = e - c * per_co;
         const int r = rem / ntaps, t = rem - r * ntaps;
         const size_t wi = ((size_t)(co0 + c) * Cin + ci0 + r) * wtaps + taps.t[t].widx;
@@ -249,15 +261,19 @@ __global__ void __launch_bounds__(256) wgrad_reduce_tiled_kernel(const float* __
             }
             v -= weight[wi] * dem;
         }
-        dW[wi] = v;
+        dW[wi] = accumulate ? dW[wi] + v : v;        // (accumulate: dweight is the parameter's .grad slice — ABI 11)
     }
 }
 
 // reduce `ntaps` taps described by `taps` (tap slots in widx order give contiguous stores); falls back to the per-element reducer
 // for shapes the tiles do not divide
 static int launch_wgrad_reduce(const HfagpWgradArgs* a, const RedTaps& rt, int ntaps, int wtaps, hipStream_t s) {
-    wgrad_reduce_tiled_kernel<<<dim3((unsigned)(a->Cin / 8), (unsigned)(a->Cout / 32)), 256, 0, s>>>(
-        a->workspace, a->weight, a->dd, a->dcoef, a->styles, a->dweight, a->ksplit, ntaps, a->Cin, a->Cout, a->B, wtaps, rt);
+    if (a->Cout % 128 == 0)
+        wgrad_reduce_tiled_kernel<4><<<dim3((unsigned)(a->Cin / 8), (unsigned)(a->Cout / 128)), 256, 0, s>>>(
+            a->workspace, a->weight, a->dd, a->dcoef, a->styles, a->dweight, a->ksplit, ntaps, a->Cin, a->Cout, a->B, wtaps, rt, a->accumulate);
+    else
+        wgrad_reduce_tiled_kernel<1><<<dim3((unsigned)(a->Cin / 8), (unsigned)(a->Cout / 32)), 256, 0, s>>>(
+            a->workspace, a->weight, a->dd, a->dcoef, a->styles, a->dweight, a->ksplit, ntaps, a->Cin, a->Cout, a->B, wtaps, rt, a->accumulate);
     return check_launch("conv_wgrad/reduce");
 }
 
@@ -278,32 +294,41 @@ __global__ void __launch_bounds__(256) affine_grad_kernel(const float* __restric
     if (k == 0) db[i] += sb;
 }
 
-// per-channel sums over all pixels of a channels-last tensor: out[c] += sum_{b,pix} g[b][pix][c] (deterministic 2-stage)
+// per-channel sums over all pixels of a channels-last tensor: out[c] += sum_{b,pix} g[b][pix][c] (deterministic 2-stage).
+// Round 5: the tensor is walked as a FLAT array with consecutive threads on consecutive floats (the first version gave a thread
+// one channel of 256 / C pixel lanes — for the 3-channel image gradient 3 active lanes per block and a final pass of 3 threads
+// summing 512 partials each: 118 us); the grid stride is a multiple of C, so a thread's channel never changes; four
+// independent partial sums per thread; fixed order everywhere.
 __global__ void __launch_bounds__(256) channel_sum_kernel(const float* __restrict__ g, float* __restrict__ partial,
-                                                          long long npix, int C) {
-    // block handles a slice of pixels; thread = (pixel lane, channel)
+                                                          long long n_elems, int C) {
     __shared__ float red[256];
-    const int c = threadIdx.x % C, pl = threadIdx.x / C, npl = 256 / C;
-    float acc = 0.f;
-    if (pl < npl)
-        for (long long px = (long long)blockIdx.x * npl + pl; px < npix; px += (long long)gridDim.x * npl)
-            acc += g[px * C + c];
-    red[threadIdx.x] = pl < npl ? acc : 0.f;
+    const long long stride = (long long)gridDim.x * 256;                 // multiple of C (checked by the host entry point)
+    const long long i0 = (long long)blockIdx.x * 256 + threadIdx.x;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    long long i = i0;
+    for (; i + 3 * stride < n_elems; i += 4 * stride) {
+        a0 += g[i]; a1 += g[i + stride]; a2 += g[i + 2 * stride]; a3 += g[i + 3 * stride];
+    }
+    for (; i < n_elems; i += stride) a0 += g[i];
+    red[threadIdx.x] = (a0 + a1) + (a2 + a3);
     __syncthreads();
     if (threadIdx.x < C) {
+        const int first = (int)(((long long)blockIdx.x * 256) % C);      // channel of thread 0
         float s = 0.f;
-        for (int q = 0; q < npl; ++q) s += red[q * C + threadIdx.x];
+        for (int j = (threadIdx.x - first + C) % C; j < 256; j += C) s += red[j];
         partial[(size_t)blockIdx.x * C + threadIdx.x] = s;
     }
 }
 
-__global__ void __launch_bounds__(256) channel_sum_final_kernel(const float* __restrict__ partial, float* __restrict__ out,
-                                                                int nblocks, int C, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// one wave per channel: lane j sums the partials j, j + 64, ..., then a fixed butterfly
+__global__ void __launch_bounds__(64) channel_sum_final_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                               int nblocks, int C, int accumulate) {
+    const int c = blockIdx.x;
     float s = 0.f;
-    for (int q = 0; q < nblocks; ++q) s += partial[(size_t)q * C + c];
-    out[c] = accumulate ? out[c] + s : s;
+    for (int q = threadIdx.x; q < nblocks; q += 64) s += partial[(size_t)q * C + c];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+    if (threadIdx.x == 0) out[c] = accumulate ? out[c] + s : s;
 }
 
 }  // namespace hfagp
@@ -340,7 +365,7 @@ static int run_wgrad(WgradParams& p, const HfagpWgradArgs* a, hipStream_t s, boo
     for (int t = 0; t < 9; ++t) taps.t[t] = p.tap[t];
     const dim3 rgrid((unsigned)((a->Cin * a->Cout + 255) / 256), (unsigned)NT);
     wgrad_reduce_kernel<<<rgrid, 256, 0, s>>>(p.slabs, a->weight, a->dd, a->dcoef, a->styles, a->dweight, a->ksplit, NT,
-                                              a->Cin, a->Cout, a->B, wtaps, taps);
+                                              a->Cin, a->Cout, a->B, wtaps, taps, a->accumulate);
     return check_launch("conv_wgrad/reduce");
 }
 
@@ -431,7 +456,7 @@ int hfagp_conv_wgrad(const HfagpWgradArgs* a, void* stream) {
                 for (int t = 0; t < 9; ++t) taps.t[t] = p.tap[t];
                 const dim3 rgrid((unsigned)((a->Cin * a->Cout + 255) / 256), (unsigned)ntaps_of[ph]);
                 wgrad_reduce_kernel<<<rgrid, 256, 0, s>>>(a->workspace, a->weight, a->dd, a->dcoef, a->styles, a->dweight,
-                                                          a->ksplit, ntaps_of[ph], a->Cin, a->Cout, a->B, 9, taps);
+                                                          a->ksplit, ntaps_of[ph], a->Cin, a->Cout, a->B, 9, taps, a->accumulate);
                 rc = check_launch("conv_wgrad/reduce");
                 if (rc != HFAGP_OK) return rc;
                 continue;
@@ -460,9 +485,11 @@ int hfagp_channel_sum(const float* g, float* partial, float* out, int64_t npix, 
                       int32_t accumulate, void* stream) {
     HFAGP_REQUIRE(g && partial && out, HFAGP_EBADARG, "channel_sum: null pointer");
     HFAGP_REQUIRE(C >= 1 && C <= 256 && nblocks >= 1, HFAGP_EUNSUPPORTED, "channel_sum: C=%d (max 256)", C);
+    HFAGP_REQUIRE(((long long)nblocks * 256) % C == 0, HFAGP_EBADARG,
+                  "channel_sum: nblocks * 256 must be a multiple of C (nblocks=%d, C=%d): a thread keeps one channel", nblocks, C);
     hipStream_t s = (hipStream_t)stream;
-    channel_sum_kernel<<<nblocks, 256, 0, s>>>(g, partial, npix, C);
-    channel_sum_final_kernel<<<(C + 255) / 256, 256, 0, s>>>(partial, out, nblocks, C, accumulate);
+    channel_sum_kernel<<<nblocks, 256, 0, s>>>(g, partial, (long long)npix * C, C);
+    channel_sum_final_kernel<<<C, 64, 0, s>>>(partial, out, nblocks, C, accumulate);
     return check_launch("channel_sum");
 }
 

@@ -881,16 +881,21 @@ def _style_bwd_each(items, d_ws):
 
 def conv_wgrad(x: torch.Tensor, styles: Optional[torch.Tensor], g: torch.Tensor, weight: torch.Tensor, mode: int,
                dd: Optional[torch.Tensor] = None, dcoef: Optional[torch.Tensor] = None,
-               precision: str = "fp32", ksplit: Optional[int] = None) -> torch.Tensor:
+               precision: str = "fp32", ksplit: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Weight gradient of a modulated conv (see include/hfagp.h): returns dweight like `weight`.  precision 'bf16x3':
     the 3x3 and up-sampling modes with Cin, Cout multiples of 64 run on the split-bf16 MFMA kernel (the 1x1 mode and
-    other shapes stay fp32)."""
+    other shapes stay fp32).  `out`: ACCUMULATE into this tensor (the parameter's .grad slice of the trainer's flat buffer)
+    instead of returning a new one."""
     _chk(x, "x")
     _chk(g, "g")
     b, h, w, cin = x.shape
     cout = weight.shape[0]
     a = L.WgradArgs()
-    dweight = torch.empty_like(weight)
+    if out is not None:
+        if out.shape != weight.shape or out.dtype != torch.float32 or not out.is_contiguous():
+            raise RuntimeError("conv_wgrad: `out` must be a contiguous fp32 tensor of the weight's shape")
+        a.accumulate = 1
+    dweight = torch.empty_like(weight) if out is None else out
     a.x, a.styles, a.g = _ptr(x), _ptr(styles), _ptr(g)
     a.weight, a.dd, a.dcoef, a.dweight = _ptr(_chk(weight.detach(), "weight")), _ptr(dd), _ptr(dcoef), _ptr(dweight)
     a.B, a.H, a.W, a.Cin, a.Cout, a.mode = b, h, w, cin, cout, mode
@@ -914,7 +919,10 @@ def channel_sum(g: torch.Tensor, out: torch.Tensor, accumulate: bool = True) -> 
     _chk(g, "g")
     c = g.shape[-1]
     npix = g.numel() // c
-    nblocks = int(max(1, min(512, npix // 256)))
+    # the kernel walks the tensor as a flat array with a grid stride that is a multiple of C (a thread keeps one channel):
+    # nblocks = a multiple of C / gcd(C, 256), about one block per 4096 floats, at most ~1024
+    unit = c // math.gcd(c, 256)
+    nblocks = unit * int(max(1, min(1024 // unit, g.numel() // (4096 * unit))))
     partial = torch.empty(nblocks, c, device=g.device, dtype=torch.float32)
     L.check(L.lib().hfagp_channel_sum(_ptr(g), _ptr(partial), _ptr(out), npix, c, nblocks, int(accumulate), _stream()),
             "channel_sum")

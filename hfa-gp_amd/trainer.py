@@ -252,14 +252,16 @@ class BucketedAllReduce:
         self._advance()
 
     def sink(self, p: torch.Tensor, g: torch.Tensor):
-        """generator._grad_sink: accumulate into the flat slice, then count the parameter as ready."""
+        """generator._grad_sink: accumulate into the flat slice (g None: the backward pass already did, in place), then count
+        the parameter as ready."""
         b = self.bucket_of.get(id(p))
         if self.active and b is not None and self.works[b] is not None:
             raise RuntimeError("BucketedAllReduce: a generator gradient arrived for a parameter whose bucket is already being "
                                "all-reduced (the parameter was declared absent, or its gradient is produced twice in one "
                                "step — e.g. two synthesis calls in one graph); sum the losses into ONE backward pass and "
                                "do not list used parameters as absent")
-        p.grad.add_(g.view_as(p.grad))
+        if g is not None:
+            p.grad.add_(g.view_as(p.grad))
         self.on_grad(p)
 
     def finish(self):
@@ -368,6 +370,9 @@ class _StepScope:
         self.b, self.gens, self.absent = bucketer, [g for g in generators if g is not None], absent
 
     def __enter__(self):
+        for g in self.gens:
+            # SynthesisFn.backward adds the generator's gradients into their .grad slices itself (HFAGP_GRAD_INPLACE=0: autograd does)
+            g._grad_inplace = os.environ.get("HFAGP_GRAD_INPLACE", "1") != "0"
         if self.b is not None:
             if not self.b.generator_ids:
                 self.b.generator_ids = {id(p) for g in self.gens for p in g.parameters()}
@@ -377,6 +382,8 @@ class _StepScope:
         return self.b
 
     def __exit__(self, exc_type, exc, tb):
+        for g in self.gens:
+            g._grad_inplace = False
         if self.b is not None:
             for g in self.gens:
                 g._grad_sink = None

@@ -487,6 +487,7 @@ typedef struct {
     int32_t ksplit;           /* number of split-K slabs over (b, position tiles); >= 1 */
     int32_t precision;        /* HFAGP_PREC_F32 (exact fp32 MFMA) or HFAGP_PREC_BF16X3: modes 0 and 1 with Cin, Cout    */
                               /* multiples of 64 then run on the split-bf16 MFMA kernel, every other case stays fp32   */
+    int32_t accumulate;       /* ABI 11: 1 = dweight += (the parameter's .grad slice: no separate add pass), 0 = overwrite */
 } HfagpWgradArgs;
 
 /* ABI 11: the library's split-K choice for this layer (everything but `ksplit` / `workspace` filled in): one block per CU for the
@@ -499,7 +500,8 @@ int hfagp_conv_wgrad(const HfagpWgradArgs* a, void* stream);
 int hfagp_affine_grad(const float* dstot, const float* w, float* dA, float* db, int32_t B, int32_t Cin, int32_t w_dim,
                       int32_t w_stride, void* stream);
 
-/* out[c] (+)= sum over npix rows of a [npix][C] channels-last tensor (C <= 256); partial: [nblocks][C] workspace */
+/* out[c] (+)= sum over npix rows of a [npix][C] channels-last tensor (C <= 256); partial: [nblocks][C] workspace;
+ * ABI 11: nblocks * 256 must be a multiple of C (the tensor is walked as a flat array and a thread keeps its channel) */
 int hfagp_channel_sum(const float* g, float* partial, float* out, int64_t npix, int32_t C, int32_t nblocks,
                       int32_t accumulate, void* stream);
 

@@ -124,3 +124,22 @@ def test_tuned_gen_update_at_own_size_matches_oracle_step(dev, mode):
     for n, e in s_errs.items():
         ref = abs(float(want[n]))
         assert e <= 5e-2 * ref + 5e-3 * top, (n, float(got[n]), float(want[n]))
+
+
+@pytest.mark.parametrize("shape", [(2, 512, 512, 3), (2, 64, 64, 96), (3, 37, 5, 96), (1, 9, 7, 40), (2, 16, 16, 128), (1, 1, 1, 3)])
+def test_channel_sum_flat_walk(dev, shape):
+    """hfagp_channel_sum (round 5: flat walk with a grid stride that is a multiple of C; the toRGB bias gradients of the tuned step)
+    against torch.sum in fp64, accumulate on and off, ragged sizes; bit-repeatable."""
+    from hfa_gp_amd import ops
+    g = torch.randn(*shape, generator=torch.Generator().manual_seed(5)).to(dev)
+    want = g.double().sum(dim=(0, 1, 2))
+    out = torch.full((shape[-1],), 3.0, device=dev)
+    ops.channel_sum(g, out, accumulate=True)
+    out2 = torch.full((shape[-1],), 3.0, device=dev)
+    ops.channel_sum(g, out2, accumulate=False)
+    again = torch.empty_like(out2)
+    ops.channel_sum(g, again, accumulate=False)
+    tol = 1e-5 * (g.abs().double().sum(dim=(0, 1, 2)) + 1.0)
+    assert bool(((out.double() - 3.0 - want).abs() <= tol).all()), (out.double() - 3.0 - want).abs().max()
+    assert bool(((out2.double() - want).abs() <= tol).all())
+    assert torch.equal(out2, again)

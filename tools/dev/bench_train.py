@@ -29,13 +29,17 @@ def main():
     for _ in range(2):
         step()
     torch.cuda.synchronize()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(iters + 1)]
     t = time.perf_counter()
-    for _ in range(iters):
+    evs[0].record()
+    for i in range(iters):
         l2 = step()[-3]
+        evs[i + 1].record()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t) / iters
-    print(f"train step B={B}: {dt*1e3:.2f} ms/step ({dt/B*1e3:.2f} ms/frame), l2={float(l2):.4f}, "
-          f"mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB")
+    per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(iters))
+    print(f"train step B={B}: {dt*1e3:.2f} ms/step ({dt/B*1e3:.2f} ms/frame), per-step HIP events median {per[len(per)//2]:.2f} "
+          f"min {per[0]:.2f} max {per[-1]:.2f} ms, l2={float(l2):.4f}, mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB")
 
 
 if __name__ == "__main__":

@@ -1,0 +1,6 @@
+cd $GRAFT_REPO_ROOT
+python -m pytest tests/test_gpu_backward.py tests/test_gpu_round2.py -x -q -k "weight_gradient or generator_parameter or bucketed or tuned_step" 2>&1 | tail -3
+python -m pytest tests/test_gpu_round5.py -x -q -s -k "tuned_gen_update and 3dmm" 2>&1 | tail -8
+python tools/dev/bench_train.py 2 10 3dmm tuned 2>&1 | tail -1
+python tools/dev/bench_train.py 2 10 rgb tuned 2>&1 | tail -1
+python tools/dev/bench_train.py 2 10 3dmm 2>&1 | tail -1
