@@ -335,7 +335,7 @@ __global__ void __launch_bounds__(64) channel_sum_final_kernel(const float* __re
 
 namespace hfagp {      // wgrad_bf16.hip
 int launch_wgrad3x3_bf16(const HfagpWgradArgs* a, hipStream_t s);
-int launch_wgrad_parity_bf16(const HfagpWgradArgs* a, const float* g_par, int parity, float* slabs, hipStream_t s);
+int launch_wgrad_up_bf16(const HfagpWgradArgs* a, hipStream_t s);
 }
 
 using namespace hfagp;
@@ -432,8 +432,17 @@ int hfagp_conv_wgrad(const HfagpWgradArgs* a, void* stream) {
         const long long img = (long long)a->B * p.gH * p.gW * a->Cout;
         static const int taps_of[4][4] = {{0, 2, 6, 8}, {1, 7, -1, -1}, {3, 5, -1, -1}, {4, -1, -1, -1}};
         static const int ntaps_of[4] = {4, 2, 2, 1};
-        const bool split16 = a->precision == HFAGP_PREC_BF16X3 && a->Cin % 64 == 0 && a->Cout % 64 == 0;
-        // one reducer for the four parity launches when the tiles divide the layer: parity ph writes its own slab region
+        if (a->precision == HFAGP_PREC_BF16X3 && a->Cin % 64 == 0 && a->Cout % 64 == 0) {
+            // split-bf16 MFMA kernel: all nine taps in ONE launch (slab slot = tap index 3 ky + kx), then the shared reducer
+            int rc = launch_wgrad_up_bf16(a, s);
+            if (rc != HFAGP_OK) return rc;
+            RedTaps rt9;
+            const long long plane9 = (long long)a->Cin * a->Cout;
+            for (int t = 0; t < 9; ++t) rt9.t[t] = RedTap{t * plane9, 9 * plane9, t};
+            return launch_wgrad_reduce(a, rt9, 9, 9, s);
+        }
+        // exact fp32: one launch per parity image; one reducer for the four when the tiles divide the layer (parity ph writes its
+        // own slab region)
         const bool one_reduce = a->Cin % 8 == 0 && a->Cout % 32 == 0;
         const long long plane = (long long)a->Cin * a->Cout;
         static const int first_tap[4] = {0, 4, 6, 8};             // slab planes in front of parity ph, per split
@@ -447,19 +456,6 @@ int hfagp_conv_wgrad(const HfagpWgradArgs* a, void* stream) {
             for (int k = 0; k < ntaps_of[ph]; ++k) {
                 const int t = taps_of[ph][k], ti = t / 3, tj = t % 3;
                 p.tap[k] = WTap{0, 0, (signed char)(ti >> 1), (signed char)(tj >> 1), (signed char)t};
-            }
-            if (split16) {      // split-bf16 MFMA kernel (tap slots in the order of taps_of[ph]), then the shared reducer
-                int rc = launch_wgrad_parity_bf16(a, p.g, ph, p.slabs, s);
-                if (rc != HFAGP_OK) return rc;
-                if (one_reduce) continue;
-                WTaps9 taps;
-                for (int t = 0; t < 9; ++t) taps.t[t] = p.tap[t];
-                const dim3 rgrid((unsigned)((a->Cin * a->Cout + 255) / 256), (unsigned)ntaps_of[ph]);
-                wgrad_reduce_kernel<<<rgrid, 256, 0, s>>>(a->workspace, a->weight, a->dd, a->dcoef, a->styles, a->dweight,
-                                                          a->ksplit, ntaps_of[ph], a->Cin, a->Cout, a->B, 9, taps, a->accumulate);
-                rc = check_launch("conv_wgrad/reduce");
-                if (rc != HFAGP_OK) return rc;
-                continue;
             }
             const int rc = ntaps_of[ph] == 4 ? run_wgrad<4, 2>(p, a, s, one_reduce) : ntaps_of[ph] == 2 ? run_wgrad<2, 2>(p, a, s, one_reduce)
                                                                                                       : run_wgrad<1, 2>(p, a, s, one_reduce);

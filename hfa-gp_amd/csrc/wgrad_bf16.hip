@@ -347,6 +347,265 @@ __global__ void __launch_bounds__(256, 1) wgrad_bf16_kernel(const Wg16Params p) 
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Weight gradient of the UP-SAMPLING conv in one kernel (round 5; before: four launches of the kernel above, one per parity image
+// of the y_t gradient, each staging the x tile again — 1.3 ms of the generator-tuned step at 0.11-0.16 of the MFMA ceiling).
+//   dW[ky][kx][ci][co] = sum_{b,i,j} (x s)[b][i][j][ci] * g_t[b][2i + ky][2j + kx][co]
+//                      = sum_{b,m,n} (x s)[b][m - sy][n - sx][ci] * g_par[p][q][b][m][n][co],   ky = p + 2 sy, kx = q + 2 sx
+// on the (H+1) x (W+1) grid of a parity image: the SHIFTED operand is x (shifts -1 / 0: halo on top and on the left, staged
+// ONCE per position tile), the plain operand is the tile of ONE parity image, and a tile is four PHASES — parity (1,1): 1 tap,
+// (0,1) and (1,0): 2 taps, (0,0): 4 taps — that share the nine accumulators of the 3x3 kernel (tap slot = 3 ky + kx).
+// Same pipeline as above, per phase instead of per tile: the gradient tile of phase f+2 is loaded while phase f runs (two
+// register sets) and converted inside the K loop of phase f+1 (4 pieces); the x patch of tile u+1 is loaded at the start of
+// tile u and converted inside its last two phases (the 2- and 4-tap ones: 4 pieces each).  The loop body (one tile = four
+// phases) has no branch; phases past the block's range load zeros.
+struct WgUpParams {
+    const float* x; const float* g; const float* styles;      // g = [2][2][B][H+1][W+1][Cout]
+    float* slabs;                                             // [ksplit][9][Cin][Cout]
+    int B, H, W, Cin, Cout, tiles_h, tiles_w, ksplit;
+};
+constexpr int UBX = 2 * XPART, UBG = 2 * GPART;               // one x stage (hi, lo), one g stage
+
+__global__ void __launch_bounds__(256, 1) wgrad_up_bf16_kernel(const WgUpParams p) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];     // [x stage 0][x stage 1][g stage 0][g stage 1]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int ci0 = blockIdx.x * CT, co0 = blockIdx.y * CT, ks = blockIdx.z;
+    const int gH = p.H + 1, gW = p.W + 1;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int units = p.B * p.tiles_h * p.tiles_w;
+    const int u_begin = (int)(((long long)units * ks) / p.ksplit), u_end = (int)(((long long)units * (ks + 1)) / p.ksplit);
+
+    float4 rx[2][4], sx[2], rg[2][4];                          // x: one register set (two units); g: [set][column]
+    const int ux0 = tid, ux1 = min(tid + 256, XR * 5 * 16 - 1);
+    const int xq0 = ux0 & 15, xcg0 = (ux0 >> 4) % 5, xrow0 = (ux0 >> 4) / 5;
+    const int xq1 = ux1 & 15, xcg1 = (ux1 >> 4) % 5, xrow1 = (ux1 >> 4) / 5;
+    const int gq = tid & 15, gcg = (tid >> 4) & 3, grow = tid >> 6;
+    auto x_offsets = [&](int row, int cg, int q, int& oa, int& ob0, int& ob1) {      // (as in the 3x3 kernel)
+        const int base = q * XPITCH;
+        oa = base + (cg <= 3 ? row * XROW + 8 * cg : 2 * XCOPY);
+        ob0 = base + (cg >= 1 ? XCOPY + row * XROW + 4 * (2 * cg - 1) : 2 * XCOPY + 8);
+        ob1 = base + (cg <= 3 ? XCOPY + row * XROW + 8 * cg : 2 * XCOPY + 12);
+    };
+    int oa0, ob00, ob10, oa1, ob01, ob11;
+    x_offsets(xrow0, xcg0, xq0, oa0, ob00, ob10);
+    x_offsets(xrow1, xcg1, xq1, oa1, ob01, ob11);
+    const int og = gq * GPITCH + (grow * QW + 4 * gcg) * 2;
+
+    const int xoff0 = ((xrow0 * p.W + 4 * xcg0) * p.Cin + 4 * xq0) * 4, xoff1 = ((xrow1 * p.W + 4 * xcg1) * p.Cin + 4 * xq1) * 4;
+    const int goff = ((grow * gW + 4 * gcg) * p.Cout + 4 * gq) * 4;
+    const unsigned xbytes = (unsigned)(p.H * p.W * p.Cin) * 4u, gbytes = (unsigned)(gH * gW * p.Cout) * 4u;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.styles ? p.styles : p.x), 0, p.styles ? (unsigned)(p.B * p.Cin) * 4u : 0u, 0x00020000);
+    const float one = p.styles ? 0.f : 1.f;
+    constexpr unsigned OOB = 0xfffffff0u;
+    const size_t par_stride = (size_t)p.B * gH * gW * p.Cout;        // floats between parity images
+
+    auto tile_origin = [&](int u, int& b, int& m0, int& n0) __attribute__((always_inline)) {
+        const int tw = u % p.tiles_w, th = (u / p.tiles_w) % p.tiles_h;
+        b = u / (p.tiles_w * p.tiles_h); m0 = th * QH; n0 = tw * QW;
+    };
+    // x patch of tile u: rows m0-1 .. m0+4, columns n0-1 .. n0+18 (5 column groups of 4)
+    auto fetch_x = [&](int u) __attribute__((always_inline)) {
+        const bool live = u < u_end;
+        int b, m0, n0;
+        tile_origin(live ? u : u_end - 1, b, m0, n0);
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.x + (size_t)b * p.H * p.W * p.Cin + ci0), 0, live ? xbytes - 4u * ci0 : 0u, 0x00020000);
+        const int base_t = (((m0 - 1) * p.W + n0 - 1) * p.Cin) * 4;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int row = k ? xrow1 : xrow0, cg = k ? xcg1 : xcg0, q = k ? xq1 : xq0;
+            const bool rowok = (unsigned)(m0 - 1 + row) < (unsigned)p.H && row < XR - 1;      // (shifts -1 / 0: five patch rows)
+            const float4 v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)((b * p.Cin + ci0 + 4 * q) * 4), 0, 0));
+            sx[k] = make_float4(v.x + one, v.y + one, v.z + one, v.w + one);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const bool ok = rowok && (unsigned)(n0 - 1 + 4 * cg + c) < (unsigned)p.W;
+                const unsigned off = (unsigned)(base_t + c * p.Cin * 4 + (k ? xoff1 : xoff0));
+                rx[k][c] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ra, ok ? off : OOB, 0, 0));
+            }
+        }
+    };
+    // gradient tile of (tile u, parity PAR) into register set S
+    auto fetch_g = [&](int u, auto par_tag, auto set_tag) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(par_tag)::value, S = decltype(set_tag)::value;
+        const bool live = u < u_end;
+        int b, m0, n0;
+        tile_origin(live ? u : u_end - 1, b, m0, n0);
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.g + PAR * par_stride + (size_t)b * gH * gW * p.Cout + co0), 0, live ? gbytes - 4u * co0 : 0u, 0x00020000);
+        const int base_t = ((m0 * gW + n0) * p.Cout) * 4;
+        const bool rowok = m0 + grow < gH;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const bool ok = rowok && n0 + 4 * gcg + c < gW;
+            const unsigned off = (unsigned)(base_t + c * p.Cout * 4 + goff);
+            rg[S][c] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rb, ok ? off : OOB, 0, 0));
+        }
+    };
+    // conversion pieces: x piece P = 0..7 (unit P >> 2, channel P & 3) into x stage `xs`; g piece e of set S into g stage `gs`
+    auto x_piece = [&](int xs, auto piece_tag) __attribute__((always_inline)) {
+        constexpr int P = decltype(piece_tag)::value, e = P & 3, k = P >> 2;
+        const float* f0 = &rx[k][0].x; const float* f1 = &rx[k][1].x; const float* f2 = &rx[k][2].x; const float* f3 = &rx[k][3].x;
+        const float sv = e == 0 ? sx[k].x : e == 1 ? sx[k].y : e == 2 ? sx[k].z : sx[k].w;
+        uint2 hi, lo;
+        split_run(f0[e] * sv, f1[e] * sv, f2[e] * sv, f3[e] * sv, hi, lo);
+        char* row = lds + xs * UBX + 16 * e * XPITCH;
+        *reinterpret_cast<uint2*>(row + (k ? oa1 : oa0)) = hi;
+        *reinterpret_cast<uint2*>(row + (k ? oa1 : oa0) + XPART) = lo;
+        *reinterpret_cast<unsigned*>(row + (k ? ob01 : ob00)) = hi.x;
+        *reinterpret_cast<unsigned*>(row + (k ? ob11 : ob10)) = hi.y;
+        *reinterpret_cast<unsigned*>(row + (k ? ob01 : ob00) + XPART) = lo.x;
+        *reinterpret_cast<unsigned*>(row + (k ? ob11 : ob10) + XPART) = lo.y;
+    };
+    auto g_piece = [&](int gs, auto set_tag, auto e_tag) __attribute__((always_inline)) {
+        constexpr int S = decltype(set_tag)::value, e = decltype(e_tag)::value;
+        const float* f0 = &rg[S][0].x; const float* f1 = &rg[S][1].x; const float* f2 = &rg[S][2].x; const float* f3 = &rg[S][3].x;
+        uint2 hi, lo;
+        split_run(f0[e], f1[e], f2[e], f3[e], hi, lo);
+        char* dst = lds + 2 * UBX + gs * UBG + og + 16 * e * GPITCH;
+        *reinterpret_cast<uint2*>(dst) = hi;
+        *reinterpret_cast<uint2*>(dst + GPART) = lo;
+    };
+
+    const int abase = (32 * wi + l31) * XPITCH + 8 * h * 2;
+    const int bbase = (32 * wj + l31) * GPITCH + 8 * h * 2;
+    struct Raw { u32x4 ha, hb, la, lb; };
+    auto read_a = [&](const char* st, int prow) __attribute__((always_inline)) {
+        const char* ar = st + abase + prow * XROW;
+        Raw r;
+        r.ha = *reinterpret_cast<const u32x4*>(ar);
+        r.hb = *reinterpret_cast<const u32x4*>(ar + XCOPY);
+        r.la = *reinterpret_cast<const u32x4*>(ar + XPART);
+        r.lb = *reinterpret_cast<const u32x4*>(ar + XPART + XCOPY);
+        return r;
+    };
+
+    // one phase: K loop of (x stage xs, g stage J & 1) for parity PAR = (PP, PQ); riding along: the four g pieces of the NEXT
+    // phase (register set (J + 1) & 1 -> g stage (J + 1) & 1) and, in the last two phases of a tile, four x pieces of the next tile
+    auto phase = [&](int xs, auto j_tag) __attribute__((always_inline)) {
+        constexpr int J = decltype(j_tag)::value;                      // phase of the tile: parities in the order 3, 1, 2, 0
+        constexpr int PAR = J == 0 ? 3 : J == 1 ? 1 : J == 2 ? 2 : 0, PP = PAR >> 1, PQ = PAR & 1;
+        constexpr int DYM = PP ? 2 : 3, DXM = PQ ? 2 : 3, NDY = popc3(DYM), NG = QH * NDY;
+        constexpr int NP = J >= 2 ? 8 : 4;                             // pieces that ride in this phase
+        const char* xst = lds + xs * UBX;
+        const char* gst = lds + 2 * UBX + (J & 1) * UBG;
+        Raw cur_a = read_a(xst, nth3(DYM, 0));
+        u32x4 bh = *reinterpret_cast<const u32x4*>(gst + bbase);
+        u32x4 bl = *reinterpret_cast<const u32x4*>(gst + bbase + GPART);
+        auto piece = [&](auto k_tag) __attribute__((always_inline)) {
+            constexpr int K = decltype(k_tag)::value;
+            if constexpr (K < 4) g_piece((J + 1) & 1, std::integral_constant<int, (J + 1) & 1>{}, std::integral_constant<int, (K < 4 ? K : 0)>{});
+            else x_piece(xs ^ 1, std::integral_constant<int, (J == 3 ? 4 : 0) + (K >= 4 ? K - 4 : 0)>{});
+        };
+        auto step = [&](auto g_tag) __attribute__((always_inline)) {
+            constexpr int G = decltype(g_tag)::value;
+            constexpr int kr = G / NDY, dy = nth3(DYM, G % NDY);
+            constexpr int G1 = G + 1, kr1 = G1 / NDY, dy1 = nth3(DYM, G1 % NDY);
+            Raw nxt = cur_a;
+            u32x4 nbh = bh, nbl = bl;
+            if constexpr (G1 < NG) {
+                nxt = read_a(xst, kr1 + dy1);
+                if constexpr (kr1 != kr) {
+                    nbh = *reinterpret_cast<const u32x4*>(gst + bbase + kr1 * QW * 2);
+                    nbl = *reinterpret_cast<const u32x4*>(gst + bbase + GPART + kr1 * QW * 2);
+                }
+            }
+            {
+                u32x4 ah[2], al[2];                                    // windows dx = 0 (shift -1: copy A) and dx = 1 (shift 0)
+                ah[0] = cur_a.ha; al[0] = cur_a.la;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    ah[1][e] = __builtin_amdgcn_alignbit(cur_a.hb[e], cur_a.ha[e], 16);
+                    al[1][e] = __builtin_amdgcn_alignbit(cur_a.lb[e], cur_a.la[e], 16);
+                }
+                constexpr int ky = PP + 2 * (1 - dy);                   // dy = 1: shift 0 -> sy = 0; dy = 0: shift -1 -> sy = 1
+#pragma unroll
+                for (int pr = 0; pr < 3; ++pr)                          // products hi.hi, lo.hi, hi.lo
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx)
+                        if ((DXM >> dx) & 1) {
+                            const int t = 3 * ky + PQ + 2 * (1 - dx);
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pr == 1 ? al[dx] : ah[dx]),
+                                                                             __builtin_bit_cast(bf16x8, pr == 2 ? bl : bh), acc[t], 0, 0, 0);
+                        }
+            }
+            if constexpr (G < NP) piece(std::integral_constant<int, (G < NP ? G : 0)>{});
+            if constexpr (G + NG < NP) piece(std::integral_constant<int, (G + NG < NP ? G + NG : 0)>{});
+            __builtin_amdgcn_sched_barrier(0);
+            cur_a = nxt; bh = nbh; bl = nbl;
+        };
+        step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{});
+        step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 3>{});
+        if constexpr (NG > 4) {
+            step(std::integral_constant<int, (NG > 4 ? 4 : 0)>{}); step(std::integral_constant<int, (NG > 4 ? 5 : 0)>{});
+            step(std::integral_constant<int, (NG > 4 ? 6 : 0)>{}); step(std::integral_constant<int, (NG > 4 ? 7 : 0)>{});
+        }
+        __syncthreads();
+    };
+
+    // prologue: x of the first tile and the gradient tiles of its first two phases; first x patch and first g tile converted
+    fetch_x(u_begin);
+    fetch_g(u_begin, std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{});
+    fetch_g(u_begin, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+    x_piece(0, std::integral_constant<int, 0>{}); x_piece(0, std::integral_constant<int, 1>{});
+    x_piece(0, std::integral_constant<int, 2>{}); x_piece(0, std::integral_constant<int, 3>{});
+    x_piece(0, std::integral_constant<int, 4>{}); x_piece(0, std::integral_constant<int, 5>{});
+    x_piece(0, std::integral_constant<int, 6>{}); x_piece(0, std::integral_constant<int, 7>{});
+    g_piece(0, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    g_piece(0, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+    g_piece(0, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+    g_piece(0, std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{});
+    __syncthreads();
+    int xs = 0;
+    for (int u = u_begin; u < u_end; ++u) {
+        // phase 0 (parity 3) runs; loads: x of tile u+1, gradient of phase 2 (parity 2) of this tile -> set 0
+        fetch_x(u + 1);
+        fetch_g(u, std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{});
+        phase(xs, std::integral_constant<int, 0>{});
+        fetch_g(u, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});         // phase 3 (parity 0) -> set 1
+        phase(xs, std::integral_constant<int, 1>{});
+        fetch_g(u + 1, std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{});     // next tile, phase 0 -> set 0
+        phase(xs, std::integral_constant<int, 2>{});
+        fetch_g(u + 1, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});     // next tile, phase 1 -> set 1
+        phase(xs, std::integral_constant<int, 3>{});
+        xs ^= 1;
+    }
+    float* slab = p.slabs + (size_t)ks * 9 * p.Cin * p.Cout;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int ci = ci0 + 4 * (rr & 15) + 2 * wi + (rr >> 4), co = co0 + 4 * (l31 & 15) + 2 * wj + (l31 >> 4);
+            slab[((size_t)t * p.Cin + ci) * p.Cout + co] = acc[t][r];
+        }
+}
+
+// host side: all nine taps of the up-sampling conv in one launch; slabs [ksplit][9][Cin][Cout], slot = 3 ky + kx
+int launch_wgrad_up_bf16(const HfagpWgradArgs* a, hipStream_t s) {
+    WgUpParams p{};
+    p.x = a->x; p.g = a->g; p.styles = a->styles; p.slabs = a->workspace;
+    p.B = a->B; p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.Cout = a->Cout; p.ksplit = a->ksplit;
+    p.tiles_h = (a->H + 1 + QH - 1) / QH; p.tiles_w = (a->W + 1 + QW - 1) / QW;
+    const size_t lds = 2 * UBX + 2 * UBG;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_up_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    wgrad_up_bf16_kernel<<<dim3(a->Cin / CT, a->Cout / CT, a->ksplit), 256, lds, s>>>(p);
+    return check_launch("conv_wgrad (up-sampling conv, split bf16)");
+}
+
 template <int DYM, int DXM, bool SWAP>
 static int launch_wg16(const Wg16Params& p, dim3 grid, hipStream_t s) {
     const size_t lds = 2 * BUF;
@@ -368,23 +627,6 @@ int launch_wgrad3x3_bf16(const HfagpWgradArgs* a, hipStream_t s) {
     p.Cin = a->Cin; p.Cout = a->Cout; p.ksplit = a->ksplit;
     p.tiles_h = (a->H + QH - 1) / QH; p.tiles_w = (a->W + QW - 1) / QW;
     return launch_wg16<7, 7, false>(p, dim3(a->Cin / CT, a->Cout / CT, a->ksplit), s);
-}
-
-// ... and one parity image of the y_t gradient of the up-conv: g_par [B][H+1][W+1][Cout], taps = shifts
-// {0, +1} x {0, +1} (parity 0), {0, +1} x {0} (1), {0} x {0, +1} (2), {0} x {0} (3); slabs [ksplit][ntaps][Cin][Cout]
-int launch_wgrad_parity_bf16(const HfagpWgradArgs* a, const float* g_par, int parity, float* slabs, hipStream_t s) {
-    Wg16Params p{};
-    p.a = g_par; p.b = a->x; p.styles = a->styles; p.slabs = slabs;       // (slabs: this parity's region of the workspace)
-    p.B = a->B; p.aH = a->H + 1; p.aW = a->W + 1; p.aC = a->Cout; p.bH = a->H; p.bW = a->W; p.bC = a->Cin;
-    p.Cin = a->Cin; p.Cout = a->Cout; p.ksplit = a->ksplit;
-    p.tiles_h = (a->H + QH - 1) / QH; p.tiles_w = (a->W + QW - 1) / QW;
-    const dim3 grid(a->Cout / CT, a->Cin / CT, a->ksplit);
-    switch (parity) {
-        case 0: return launch_wg16<6, 6, true>(p, grid, s);
-        case 1: return launch_wg16<6, 2, true>(p, grid, s);
-        case 2: return launch_wg16<2, 6, true>(p, grid, s);
-        default: return launch_wg16<2, 2, true>(p, grid, s);
-    }
 }
 
 }  // namespace hfagp
