@@ -213,8 +213,9 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
 struct RedTap { long long base; long long kstride; int widx; };     // slab of split k at slabs + base + k * kstride + ci * Cout + co
 struct RedTaps { RedTap t[9]; };
 
-// V = floats per thread along co (round 5: 4 where Cout % 128 == 0 — 16-byte slab reads, a block owns 8 ci x 128 co; the 4-byte
-// version moved 2 TB/s out of L2 / the memory-side cache, one 128-byte row per wave-load).
+// V = floats per thread along co.  (Round 5 measured V = 4 — 16-byte reads, 8 ci x 128 co per block — at 92 us against 28: a
+// quarter of the blocks, and the output phase with its per-element demodulation loads is latency-bound.  The split-bf16
+// kernels no longer use this reducer: wgrad_sum_final_kernel below.)
 template <int V>
 __global__ void __launch_bounds__(256) wgrad_reduce_tiled_kernel(const float* __restrict__ slabs, const float* __restrict__ weight,
                                                                  const float* __restrict__ dd, const float* __restrict__ dcoef,
@@ -265,15 +266,68 @@ __global__ void __launch_bounds__(256) wgrad_reduce_tiled_kernel(const float* __
     }
 }
 
+// Reducer of the split-bf16 kernels (round 5): their slabs already have the parameter layout [Cout][Cin][9], so the reduction is
+// an elementwise sum of `ksplit` arrays (16-byte loads, eight in flight per thread) minus the demodulation term.
+__global__ void __launch_bounds__(256) wgrad_sum_final_kernel(const float* __restrict__ slabs, const float* __restrict__ weight,
+                                                              const float* __restrict__ dd, const float* __restrict__ dcoef,
+                                                              const float* __restrict__ styles, float* __restrict__ dW,
+                                                              int ksplit, int Cin, int Cout, int B, int accumulate) {
+    const size_t n4 = (size_t)Cin * Cout * 9 / 4;            // (Cin, Cout multiples of 64)
+    const size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i4 >= n4) return;
+    const float4* src = reinterpret_cast<const float4*>(slabs) + i4;
+    float4 part[4] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+    int k = 0;
+    for (; k + 8 <= ksplit; k += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(k + u) * n4];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            part[u & 3].x += v[u].x; part[u & 3].y += v[u].y; part[u & 3].z += v[u].z; part[u & 3].w += v[u].w;
+        }
+    }
+    for (; k < ksplit; ++k) {
+        const float4 v = src[(size_t)k * n4];
+        part[0].x += v.x; part[0].y += v.y; part[0].z += v.z; part[0].w += v.w;
+    }
+    float out[4] = {(part[0].x + part[1].x) + (part[2].x + part[3].x), (part[0].y + part[1].y) + (part[2].y + part[3].y),
+                    (part[0].z + part[1].z) + (part[2].z + part[3].z), (part[0].w + part[1].w) + (part[2].w + part[3].w)};
+    float4* dst = reinterpret_cast<float4*>(dW) + i4;
+    if (dd) {
+        const float4 w4 = reinterpret_cast<const float4*>(weight)[i4];
+        const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const size_t pair = (i4 * 4 + j) / 9;            // co * Cin + ci
+            const int co = (int)(pair / Cin), ci = (int)(pair - (size_t)co * Cin);
+            float dem = 0.f;
+            for (int b = 0; b < B; ++b) {
+                const float d = dcoef[(size_t)b * Cout + co], sv = styles[(size_t)b * Cin + ci];
+                dem += dd[(size_t)b * Cout + co] * d * d * d * sv * sv;
+            }
+            out[j] -= wv[j] * dem;
+        }
+    }
+    if (accumulate) {
+        const float4 o = *dst;
+        out[0] += o.x; out[1] += o.y; out[2] += o.z; out[3] += o.w;
+    }
+    *dst = make_float4(out[0], out[1], out[2], out[3]);
+}
+
+static int launch_wgrad_sum_final(const HfagpWgradArgs* a, hipStream_t s) {
+    const size_t n4 = (size_t)a->Cin * a->Cout * 9 / 4;
+    wgrad_sum_final_kernel<<<(unsigned)((n4 + 255) / 256), 256, 0, s>>>(a->workspace, a->weight, a->dd, a->dcoef, a->styles, a->dweight,
+                                                                        a->ksplit, a->Cin, a->Cout, a->B, a->accumulate);
+    return check_launch("conv_wgrad/sum");
+}
+
 // reduce `ntaps` taps described by `taps` (tap slots in widx order give contiguous stores); falls back to the per-element reducer
 // for shapes the tiles do not divide
 static int launch_wgrad_reduce(const HfagpWgradArgs* a, const RedTaps& rt, int ntaps, int wtaps, hipStream_t s) {
-    if (a->Cout % 128 == 0)
-        wgrad_reduce_tiled_kernel<4><<<dim3((unsigned)(a->Cin / 8), (unsigned)(a->Cout / 128)), 256, 0, s>>>(
-            a->workspace, a->weight, a->dd, a->dcoef, a->styles, a->dweight, a->ksplit, ntaps, a->Cin, a->Cout, a->B, wtaps, rt, a->accumulate);
-    else
-        wgrad_reduce_tiled_kernel<1><<<dim3((unsigned)(a->Cin / 8), (unsigned)(a->Cout / 32)), 256, 0, s>>>(
-            a->workspace, a->weight, a->dd, a->dcoef, a->styles, a->dweight, a->ksplit, ntaps, a->Cin, a->Cout, a->B, wtaps, rt, a->accumulate);
+    wgrad_reduce_tiled_kernel<1><<<dim3((unsigned)(a->Cin / 8), (unsigned)(a->Cout / 32)), 256, 0, s>>>(
+        a->workspace, a->weight, a->dd, a->dcoef, a->styles, a->dweight, a->ksplit, ntaps, a->Cin, a->Cout, a->B, wtaps, rt, a->accumulate);
     return check_launch("conv_wgrad/reduce");
 }
 
@@ -408,13 +462,10 @@ int hfagp_conv_wgrad(const HfagpWgradArgs* a, void* stream) {
         p.gH = a->H; p.gW = a->W;
         for (int t = 0; t < 9; ++t) p.tap[t] = WTap{(signed char)(t / 3 - 1), (signed char)(t % 3 - 1), 0, 0, (signed char)t};
         if (a->precision == HFAGP_PREC_BF16X3 && a->Cin % 64 == 0 && a->Cout % 64 == 0) {
-            // split-bf16 MFMA kernel (slab t = tap t, like the taps above), then the shared reducer
+            // split-bf16 MFMA kernel (slabs in the parameter layout), then the elementwise reducer
             int rc = launch_wgrad3x3_bf16(a, s);
             if (rc != HFAGP_OK) return rc;
-            RedTaps rt;
-            const long long plane = (long long)a->Cin * a->Cout;
-            for (int t = 0; t < 9; ++t) rt.t[t] = RedTap{t * plane, 9 * plane, t};
-            return launch_wgrad_reduce(a, rt, 9, 9, s);
+            return launch_wgrad_sum_final(a, s);
         }
         HFAGP_REQUIRE(a->precision == HFAGP_PREC_F32 || a->precision == HFAGP_PREC_BF16X3, HFAGP_EBADARG,
                       "conv_wgrad: precision %d (F32 or BF16X3)", a->precision);
@@ -433,13 +484,10 @@ int hfagp_conv_wgrad(const HfagpWgradArgs* a, void* stream) {
         static const int taps_of[4][4] = {{0, 2, 6, 8}, {1, 7, -1, -1}, {3, 5, -1, -1}, {4, -1, -1, -1}};
         static const int ntaps_of[4] = {4, 2, 2, 1};
         if (a->precision == HFAGP_PREC_BF16X3 && a->Cin % 64 == 0 && a->Cout % 64 == 0) {
-            // split-bf16 MFMA kernel: all nine taps in ONE launch (slab slot = tap index 3 ky + kx), then the shared reducer
+            // split-bf16 MFMA kernel: all nine taps in ONE launch (slabs in the parameter layout), then the elementwise reducer
             int rc = launch_wgrad_up_bf16(a, s);
             if (rc != HFAGP_OK) return rc;
-            RedTaps rt9;
-            const long long plane9 = (long long)a->Cin * a->Cout;
-            for (int t = 0; t < 9; ++t) rt9.t[t] = RedTap{t * plane9, 9 * plane9, t};
-            return launch_wgrad_reduce(a, rt9, 9, 9, s);
+            return launch_wgrad_sum_final(a, s);
         }
         // exact fp32: one launch per parity image; one reducer for the four when the tiles divide the layer (parity ph writes its
         // own slab region)

@@ -36,7 +36,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // Parity launches of the up-conv (SWAP): a = the parity image of the y_t gradient (shift 0 / +1), b = x*s.
 struct Wg16Params {
     const float* a; const float* b; const float* styles;       // styles [B][channels of x] or null
-    float* slabs;                       // [ksplit][ntaps][Cin][Cout], tap slot = row-major index over the (dy, dx) used
+    float* slabs;                       // [ksplit][Cout][Cin][9]: the parameter layout (tap = 3 (dy) + dx)
     int B, aH, aW, aC, bH, bW, bC;      // image extents / channel counts of the two operands (bH x bW = position grid)
     int Cin, Cout, tiles_h, tiles_w, ksplit;
 };
@@ -69,6 +69,36 @@ constexpr int nth3(int m, int j) {                                          // p
     int seen = 0;
     for (int i = 0; i < 3; ++i) if ((m >> i) & 1) { if (seen == j) return i; ++seen; }
     return 0;
+}
+
+// Epilogue of both kernels (round 5): the block's nine 64 x 64 accumulator tiles leave in the PARAMETER layout
+// slab[co][ci][tap] — through LDS (the staging buffers are free by then): lane (co, rows ci) writes [co][ci * 9 + tap] with a
+// row pitch of 64 * 9 + 1 floats (consecutive co -> consecutive banks), the block reads each co row back as 576 consecutive
+// floats and stores them as one contiguous run.  The split-K reducer is then a plain sum of identical layouts (the slabs used to
+// be [tap][ci][co] and the reducer a transposing gather: 28 us for 38-47 MB, launch after launch).
+constexpr int EPI_PITCH = CT * 9 + 1;
+constexpr int EPI_BYTES = CT * EPI_PITCH * 4;            // 147 712
+__device__ __forceinline__ void store_slab_final(const f32x16 (&acc)[9], char* lds, float* slab, int Cin, int ci0, int co0,
+                                                 int wi, int wj, int h, int l31, int tid) {
+    float* t32 = reinterpret_cast<float*>(lds);
+    __syncthreads();                                         // every wave is done with the staging buffers
+    const int cb = 4 * (l31 & 15) + 2 * wj + (l31 >> 4);     // MFMA column -> co of the tile (row permutation of the staging)
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int ca = 4 * (rr & 15) + 2 * wi + (rr >> 4);               // MFMA row -> ci of the tile
+            t32[cb * EPI_PITCH + ca * 9 + t] = acc[t][r];
+        }
+    __syncthreads();
+    for (int c = 0; c < CT; ++c) {
+        float* dst = slab + ((size_t)(co0 + c) * Cin + ci0) * 9;
+        const float* src = t32 + c * EPI_PITCH;
+        dst[tid] = src[tid];
+        dst[tid + 256] = src[tid + 256];
+        if (tid < CT * 9 - 512) dst[tid + 512] = src[tid + 512];
+    }
 }
 
 // DYM / DXM: bit i set = patch-row / window offset i is used (shift i - 1).  3x3: 7, 7 (nine taps).  Parity images of the
@@ -333,18 +363,10 @@ __global__ void __launch_bounds__(256, 1) wgrad_bf16_kernel(const Wg16Params p) 
         phase(u, std::integral_constant<int, 0>{});
         phase(u + 1, std::integral_constant<int, 1>{});
     }
-    // ---- slab [tap slot][Cin][Cout]: C/D layout row = (r&3) + 8*(r>>2) + 4*h (operand-a channel), col = lane&31
-    // (operand-b channel); SWAP: a = Cout side, b = Cin side
-    float* slab = p.slabs + (size_t)ks * NT * p.Cin * p.Cout;
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;                       // MFMA row -> channel (row permutation)
-            const int ca = ci0 + 4 * (rr & 15) + 2 * wi + (rr >> 4), cb = co0 + 4 * (l31 & 15) + 2 * wj + (l31 >> 4);
-            const int ci = SWAP ? cb : ca, co = SWAP ? ca : cb;
-            slab[((size_t)t * p.Cin + ci) * p.Cout + co] = acc[t][r];
-        }
+    // ---- slab [Cout][Cin][9] (the parameter layout): C/D layout row = (r&3) + 8*(r>>2) + 4*h (operand-a channel = ci),
+    // col = lane&31 (operand-b channel = co)
+    static_assert(NT == 9 && !SWAP, "the final-layout epilogue is written for the nine-tap, un-swapped kernel");
+    store_slab_final(acc, lds, p.slabs + (size_t)ks * 9 * p.Cin * p.Cout, p.Cin, ci0, co0, wi, wj, h, l31, tid);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -361,7 +383,7 @@ __global__ void __launch_bounds__(256, 1) wgrad_bf16_kernel(const Wg16Params p) 
 // phases) has no branch; phases past the block's range load zeros.
 struct WgUpParams {
     const float* x; const float* g; const float* styles;      // g = [2][2][B][H+1][W+1][Cout]
-    float* slabs;                                             // [ksplit][9][Cin][Cout]
+    float* slabs;                                             // [ksplit][Cout][Cin][9]
     int B, H, W, Cin, Cout, tiles_h, tiles_w, ksplit;
 };
 constexpr int UBX = 2 * XPART, UBG = 2 * GPART;               // one x stage (hi, lo), one g stage
@@ -579,24 +601,16 @@ __global__ void __launch_bounds__(256, 1) wgrad_up_bf16_kernel(const WgUpParams 
         phase(xs, std::integral_constant<int, 3>{});
         xs ^= 1;
     }
-    float* slab = p.slabs + (size_t)ks * 9 * p.Cin * p.Cout;
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
-            const int ci = ci0 + 4 * (rr & 15) + 2 * wi + (rr >> 4), co = co0 + 4 * (l31 & 15) + 2 * wj + (l31 >> 4);
-            slab[((size_t)t * p.Cin + ci) * p.Cout + co] = acc[t][r];
-        }
+    store_slab_final(acc, lds, p.slabs + (size_t)ks * 9 * p.Cin * p.Cout, p.Cin, ci0, co0, wi, wj, h, l31, tid);
 }
 
-// host side: all nine taps of the up-sampling conv in one launch; slabs [ksplit][9][Cin][Cout], slot = 3 ky + kx
+// host side: all nine taps of the up-sampling conv in one launch; slabs [ksplit][Cout][Cin][9], tap = 3 ky + kx
 int launch_wgrad_up_bf16(const HfagpWgradArgs* a, hipStream_t s) {
     WgUpParams p{};
     p.x = a->x; p.g = a->g; p.styles = a->styles; p.slabs = a->workspace;
     p.B = a->B; p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.Cout = a->Cout; p.ksplit = a->ksplit;
     p.tiles_h = (a->H + 1 + QH - 1) / QH; p.tiles_w = (a->W + 1 + QW - 1) / QW;
-    const size_t lds = 2 * UBX + 2 * UBG;
+    const size_t lds = (2 * UBX + 2 * UBG) > EPI_BYTES ? (size_t)(2 * UBX + 2 * UBG) : (size_t)EPI_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_up_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -608,7 +622,7 @@ int launch_wgrad_up_bf16(const HfagpWgradArgs* a, hipStream_t s) {
 
 template <int DYM, int DXM, bool SWAP>
 static int launch_wg16(const Wg16Params& p, dim3 grid, hipStream_t s) {
-    const size_t lds = 2 * BUF;
+    const size_t lds = 2 * BUF > EPI_BYTES ? (size_t)(2 * BUF) : (size_t)EPI_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_kernel<DYM, DXM, SWAP>),
