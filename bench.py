@@ -100,6 +100,31 @@ def launcher_command(n: int, argv, port: int):
             "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py")] + list(argv)
 
 
+def rccl_choices(log_path, n_ranks):
+    """{payload bytes: {"algo", "proto", "time_us"}} from RCCL's TUNING lines of this rank's NCCL_DEBUG_FILE
+    ("AllReduce: N Bytes -> Algo a proto p time t"; enum names of nccl.h since 2.19), or a note saying why there are none —
+    with ONE rank RCCL copies in place and never runs its tuning model."""
+    import re
+    algos = {0: "Tree", 1: "Ring", 2: "CollNetDirect", 3: "CollNetChain", 4: "NVLS", 5: "NVLSTree"}
+    protos = {0: "LL", 1: "LL128", 2: "Simple"}
+    if not log_path or not os.path.exists(log_path):
+        return {"note": f"no RCCL log ({log_path}): NCCL_DEBUG / NCCL_DEBUG_FILE were set by the caller, or the backend is not nccl"}
+    found, version = {}, None
+    pat = re.compile(r"AllReduce: (\d+) Bytes -> Algo (\d+) proto (\d+) time ([0-9.eE+-]+)")
+    with open(log_path, errors="replace") as f:
+        for line in f:
+            m = pat.search(line)
+            if m:
+                found[m.group(1)] = {"algo": algos.get(int(m.group(2)), m.group(2)), "proto": protos.get(int(m.group(3)), m.group(3)),
+                                     "model_time_us": float(m.group(4))}
+            elif "RCCL version" in line or "NCCL version" in line:
+                version = line.strip().split("INFO")[-1].strip()
+    if found:
+        return {"by_payload_bytes": found, "rccl": version, "log": log_path}
+    return {"note": ("one rank: RCCL short-circuits the collective (in-place copy), its tuning model never runs" if n_ranks == 1 else
+                     "no 'Bytes -> Algo' line in the log (RCCL built without the TUNING trace?)"), "rccl": version, "log": log_path}
+
+
 def cpu_model() -> str:
     try:
         for line in open("/proc/cpuinfo"):
@@ -587,7 +612,14 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(_free_port()))
-        os.environ.setdefault("NCCL_DEBUG", "WARN")          # RCCL's own warnings on stderr (fd 1 points there too, see above)
+        # RCCL's log of THIS run goes to a per-rank file (fd 1 / 2 stay readable): INFO level with the INIT and TUNING subsystems, so
+        # that the line can say which algorithm / protocol RCCL picked for each all-reduce payload (`allreduce_us.algo`: the
+        # 1.46 MB / 6.98 MB / 92 MB / 123 MB buffers are latency- resp. bandwidth-bound on 7 x 153 GB/s xGMI links — ring is 14 hops,
+        # SURVEY section 5.8).  A caller's own NCCL_DEBUG* settings win.
+        if args.backend == "nccl":
+            os.environ.setdefault("NCCL_DEBUG", "INFO")
+            os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,TUNING")
+            os.environ.setdefault("NCCL_DEBUG_FILE", f"/tmp/hfagp_rccl_rank{rank}_{os.getpid()}.log")
         import datetime
         # a rank that dies (or never starts) must end the job with a message, not hang its peers for the default 10 - 30 min
         tmo = datetime.timedelta(seconds=args.dist_timeout)
@@ -976,6 +1008,7 @@ def main():
                                    "rgb_generator_tuned": 1e3 * trgb["tuned"][train_B]["phases_ms"].get("allreduce", 0.0),
                                    "bytes": {"rgb": trgb["shared_grad_bytes"], "3dmm": t3["shared_grad_bytes"],
                                              "rgb_generator_tuned": trgb["shared_grad_bytes_tuned"]}}
+            out["allreduce_us"]["algo"] = rccl_choices(os.environ.get("NCCL_DEBUG_FILE"), n_ranks) if dist is not None else None
             out["train_config"] = {"workload": "latent-basis fitting step (fwd + bwd + Adam), K=50, generator frozen, L2 at "
                                                "256^2, synthetic frames; train_step_ms = RGB-driven (Encoder(256) in the "
                                                "step, trainer_rgb.py:73-98), train_step_ms_3dmm = 3DMM-driven "

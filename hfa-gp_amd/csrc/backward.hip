@@ -17,6 +17,10 @@ namespace hfagp {
 // 6..9 sum_pix g_rgb_small[c] * x   (weight gradient rows of the small toRGB, before the style factor)
 constexpr int kRed = 10;
 
+// SMALL: the small (1 .. 4-channel) toRGB's adjoint is part of the pass; PG: parameter-gradient reductions (rows 4 .. 9).
+// Round 5: compile-time variants — the generic kernel carried all ten reduction rows (40 registers) and the small-toRGB operands
+// through every launch: 181 registers, two waves per SIMD; the common (frozen generator, 96-channel toRGB) instance needs three rows.
+template <bool SMALL, bool PG>
 __global__ void __launch_bounds__(256) pointwise_bwd_kernel(const HfagpPointwiseBwdArgs a, int rows_per_block) {
     // block = (chunk of pixel rows, sample b); thread = (pixel lane, 4-channel group)
     extern __shared__ __attribute__((aligned(16))) float red[];      // [256/C4][kRed][C]
@@ -34,7 +38,7 @@ __global__ void __launch_bounds__(256) pointwise_bwd_kernel(const HfagpPointwise
     if (a.bias_p) b_p = reinterpret_cast<const float4*>(a.bias_p)[c4];
     float4 wsm[4];                       // small toRGB: w[c][i] * s_small[b][i]
     float4 s_sm = make_float4(0, 0, 0, 0);
-    if (a.g_rgb_small) {
+    if constexpr (SMALL) {
         s_sm = reinterpret_cast<const float4*>(a.s_small + (size_t)b * a.C)[c4];
 #pragma unroll
         for (int c = 0; c < 4; ++c)
@@ -68,7 +72,7 @@ __global__ void __launch_bounds__(256) pointwise_bwd_kernel(const HfagpPointwise
 #pragma unroll
             for (int k = 0; k < 4; ++k) { gx[k] += gv[k] * sv[k]; acc[1][k] += gv[k] * xv[k]; }
         }
-        if (a.g_rgb_small) {
+        if constexpr (SMALL) {
             float t[4] = {0, 0, 0, 0};
             const float gsm[4] = {gs0, gs1, gs2, gs3};
 #pragma unroll
@@ -76,7 +80,7 @@ __global__ void __launch_bounds__(256) pointwise_bwd_kernel(const HfagpPointwise
                 if (c < a.Co) {
                     const float g = gsm[c];
                     t[0] += g * wsm[c].x; t[1] += g * wsm[c].y; t[2] += g * wsm[c].z; t[3] += g * wsm[c].w;
-                    if (a.param_grads) {
+                    if constexpr (PG) {
 #pragma unroll
                         for (int k = 0; k < 4; ++k) acc[6 + c][k] += g * xv[k];
                     }
@@ -106,7 +110,7 @@ __global__ void __launch_bounds__(256) pointwise_bwd_kernel(const HfagpPointwise
                 float pre = xv[k] * rgain;
                 if (a.act_p == HFAGP_ACT_LRELU && !(xv[k] > 0.f)) { g *= a.alpha; pre *= ralpha; }   // (alpha at 0, as ATen / EG3D)
                 acc[3][k] += g * (pre - bv[k] - nz) * rdv[k];
-                if (a.param_grads) { acc[4][k] += g; acc[5][k] += g * nraw; }
+                if constexpr (PG) { acc[4][k] += g; acc[5][k] += g * nraw; }
                 g *= dv[k];
             }
             go[k] = g;
@@ -122,7 +126,7 @@ __global__ void __launch_bounds__(256) pointwise_bwd_kernel(const HfagpPointwise
         // (the small toRGB's clamp mask [|y| < clamp] applied here when the caller hands over y: three framework kernels less)
         const bool mask_small = a.y_rgb_small != nullptr && a.clamp_rgb_small >= 0.f;
         auto small = [&](int p, int c) {
-            if (!(a.g_rgb_small && c < a.Co)) return 0.f;
+            if (!(SMALL && c < a.Co)) return 0.f;
             const size_t q = ((size_t)b * a.Co + c) * HW + p;
             const float g = a.g_rgb_small[q];
             return (mask_small && !(fabsf(a.y_rgb_small[q]) < a.clamp_rgb_small)) ? 0.f : g;
@@ -194,7 +198,8 @@ __global__ void __launch_bounds__(256) reduce_partials_kernel(const float* __res
     }
 }
 
-// depth[i] = clamp(depth[i], min_j t[j].x, max_j t[j].y) for the whole batch, one workgroup (hfagp_depth_clamp)
+// depth[i] = clamp(depth[i], min_j t[j].x, max_j t[j].y) for the whole batch in one launch (hfagp_depth_clamp): every block
+// reduces ALL min / max pairs itself (they stay in L2: 256 KB at two frames, 4 MB at 32) and clamps its own slice
 __global__ void __launch_bounds__(1024) depth_clamp_kernel(float* __restrict__ depth, const float2* __restrict__ t, int n) {
     __shared__ float smin[16], smax[16];
     float lo = INFINITY, hi = -INFINITY;
@@ -210,7 +215,6 @@ __global__ void __launch_bounds__(1024) depth_clamp_kernel(float* __restrict__ d
     lo = smin[0]; hi = smax[0];
 #pragma unroll
     for (int w = 1; w < 16; ++w) { lo = fminf(lo, smin[w]); hi = fmaxf(hi, smax[w]); }
-    // every block has reduced ALL sample depths itself (256 KB at two frames: L2-resident) and clamps its own slice of the rays:
     // no second launch, no grid barrier (one block alone took 21 us at two frames)
     for (int i = blockIdx.x * 1024 + threadIdx.x; i < n; i += gridDim.x * 1024) depth[i] = fminf(fmaxf(depth[i], lo), hi);
 }
@@ -466,7 +470,14 @@ int hfagp_pointwise_bwd(const HfagpPointwiseBwdArgs* a, void* stream) {
     const size_t lds = (size_t)npl * kRed * a->C * sizeof(float);
     HFAGP_REQUIRE(lds <= 64 * 1024, HFAGP_EUNSUPPORTED, "pointwise_bwd: LDS %zu", lds);
     hipStream_t s = (hipStream_t)stream;
-    pointwise_bwd_kernel<<<dim3(a->nchunks, a->B), 256, lds, s>>>(*a, rows);
+    const dim3 grid(a->nchunks, a->B);
+    if (a->g_rgb_small) {
+        if (a->param_grads) pointwise_bwd_kernel<true, true><<<grid, 256, lds, s>>>(*a, rows);
+        else pointwise_bwd_kernel<true, false><<<grid, 256, lds, s>>>(*a, rows);
+    } else {
+        if (a->param_grads) pointwise_bwd_kernel<false, true><<<grid, 256, lds, s>>>(*a, rows);
+        else pointwise_bwd_kernel<false, false><<<grid, 256, lds, s>>>(*a, rows);
+    }
     const int n = kRed * a->C;
     reduce_partials_kernel<<<dim3((n + 15) / 16, a->B), 256, 0, s>>>(a->partial, a->sums, a->B, a->nchunks, n);
     return check_launch("pointwise_bwd");
@@ -474,8 +485,10 @@ int hfagp_pointwise_bwd(const HfagpPointwiseBwdArgs* a, void* stream) {
 
 int hfagp_depth_clamp(float* depth, const float* tminmax, int64_t n, void* stream) {
     HFAGP_REQUIRE(depth && tminmax && n > 0, HFAGP_EBADARG, "depth_clamp: null pointer / n <= 0");
-    HFAGP_REQUIRE(n <= 65536, HFAGP_EUNSUPPORTED, "depth_clamp: n=%lld > 65536 rays (one-workgroup kernel: small batches only)", (long long)n);
-    const unsigned blocks = (unsigned)std::min<long long>(16, (n + 4095) / 4096);
+    HFAGP_REQUIRE(n <= (1ll << 30), HFAGP_EUNSUPPORTED, "depth_clamp: n=%lld rays", (long long)n);
+    // (round 5: any batch — the cap of 65 536 rays left ten framework launches behind the ray march at B = 32; up to 64 blocks,
+    // each re-reading the n pairs from L2: 64 x 4 MB at 32 frames)
+    const unsigned blocks = (unsigned)std::min<long long>(64, (n + 4095) / 4096);
     depth_clamp_kernel<<<blocks, 1024, 0, (hipStream_t)stream>>>(depth, reinterpret_cast<const float2*>(tminmax), (int)n);
     return check_launch("depth_clamp");
 }

@@ -11,9 +11,11 @@ namespace hfagp {
 
 typedef int (*AllReduceFn)(const void*, void*, size_t, int, int, void*, hipStream_t);
 typedef int (*GetVersionFn)(int*);
+typedef int (*CommCountFn)(void*, int*);
 
 struct Rccl {
     AllReduceFn allreduce = nullptr;
+    CommCountFn count = nullptr;      // ncclCommCount: the mean by hand when ncclAvg cannot be relied upon
     int version = 0;                  // ncclGetVersion: major * 10000 + minor * 100 + patch (0: the entry point is absent)
     char why[256] = "no dlerror";     // the loader's message at the moment the lookup failed
 };
@@ -36,9 +38,14 @@ static const Rccl& rccl() {
         }
         GetVersionFn gv = reinterpret_cast<GetVersionFn>(h ? dlsym(h, "ncclGetVersion") : dlsym(RTLD_DEFAULT, "ncclGetVersion"));
         if (gv && gv(&x.version) != 0) x.version = 0;
+        x.count = reinterpret_cast<CommCountFn>(h ? dlsym(h, "ncclCommCount") : dlsym(RTLD_DEFAULT, "ncclCommCount"));
         return x;
     }();
     return r;
+}
+
+__global__ void __launch_bounds__(256) scale_kernel(float* __restrict__ buf, size_t n, float f) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) buf[i] *= f;
 }
 
 }  // namespace hfagp
@@ -52,12 +59,24 @@ extern "C" int hfagp_allreduce_f32(void* buf, size_t n, void* comm, int32_t aver
     const Rccl& lib = rccl();
     HFAGP_REQUIRE(lib.allreduce, HFAGP_EUNSUPPORTED, "allreduce_f32: ncclAllReduce not found (load librccl.so in the host process "
                                                      "or put it on the loader path): %s", lib.why);
-    // the enum values below are those of rccl.h since NCCL 2.10 (ncclAvg appeared there); an older or unidentifiable library
-    // is refused rather than called with a reduction op it may number differently
-    HFAGP_REQUIRE(lib.version >= 21000, HFAGP_EUNSUPPORTED, "allreduce_f32: RCCL reports version %d (need >= 2.10.0 for ncclAvg)",
-                  lib.version);
+    // ncclSum = 0 and ncclFloat32 = 7 in every NCCL / RCCL; ncclAvg = 4 exists since 2.10.  A library that is older — or whose
+    // ncclGetVersion entry point is missing, so that its version is unknown (that used to be refused outright although
+    // ncclAllReduce had been found) — gets ncclSum and the division by ncclCommCount on the same stream.
     constexpr int kFloat32 = 7, kSum = 0, kAvg = 4;                     // rccl.h: ncclFloat32, ncclSum, ncclAvg
-    const int rc = lib.allreduce(buf, buf, n, kFloat32, average ? kAvg : kSum, comm, (hipStream_t)stream);
+    const bool native_avg = lib.version >= 21000;
+    HFAGP_REQUIRE(!average || native_avg || lib.count, HFAGP_EUNSUPPORTED,
+                  "allreduce_f32: RCCL version %d has no ncclAvg and ncclCommCount was not found for the mean by hand", lib.version);
+    int rc = lib.allreduce(buf, buf, n, kFloat32, (average && native_avg) ? kAvg : kSum, comm, (hipStream_t)stream);
+    if (rc == 0 && average && !native_avg) {
+        int world = 0;
+        rc = lib.count(comm, &world);
+        if (rc == 0 && world > 1) {
+            scale_kernel<<<(unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024), 256, 0, (hipStream_t)stream>>>(
+                static_cast<float*>(buf), n, 1.0f / (float)world);
+            const int lrc = check_launch("allreduce_f32 (mean by hand)");
+            if (lrc != HFAGP_OK) return lrc;
+        }
+    }
     int dev = -1;
     (void)hipGetDevice(&dev);
     HFAGP_REQUIRE(rc == 0, HFAGP_ELAUNCH, "allreduce_f32: ncclAllReduce returned %d (device %d, %zu floats, RCCL %d)", rc, dev, n,

@@ -196,7 +196,8 @@ static inline int validate(const HfagpModconvArgs* a, int ck) {
 // modconv_bf16.hip
 int launch_modconv_bf16(const HfagpModconvArgs* a, Plan& pl, hipStream_t s);
 
-// smallconv.hip: the small-image kernel (whole K range per block, epilogue in the same launch, no workspace).  Taken for the
+// smallconv.hip: the small-image kernel (lean 32 x 32 blocks without staging; K sliced over blocks through the workspace and the
+// split-K reducer like the staged kernel, smallconv_ksplit).  Taken for the
 // 3x3 conv, its data adjoint (images of at most 256 positions: 4^2 ... 16^2) and the 1x1 conv (at most 1024: ... 32^2) on 16-bit
 // weight images when the caller did not ask for a particular split (ksplit <= 0).
 int launch_smallconv(const HfagpModconvArgs* a, Plan& pl, hipStream_t s);

@@ -18,7 +18,8 @@
 //   * a layer is 16 (4^2) ... 128 (16^2) blocks per sample of 8 waves: the whole K loop of a wave is 36 steps.
 // Same operand arithmetic as modconv_bf16_kernel (operand kinds, fp16 range guard, product order); the K summation order differs
 // (per-wave partial sums), i.e. fp32 rounding noise.  Taken by hfagp_modconv_fwd for modes 0 / 2 / 3 on 16-bit weight images when
-// H * W <= 256 (modconv_plan.h smallconv_takes); hfagp_modconv_workspace_bytes is then 0.
+// H * W <= 256 (the 1x1: <= 1024; modconv_plan.h smallconv_takes); the K slices go through the caller's workspace like the
+// staged kernel's (hfagp_modconv_workspace_bytes: smallconv_ksplit slabs, 0 when one block takes the whole K range).
 #include "conv16_common.h"
 
 namespace hfagp {

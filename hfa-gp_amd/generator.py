@@ -371,8 +371,11 @@ class TriPlaneGenerator(nn.Module):
         # which kernel bench.py times
         key = ("modconv" if wt.dtype == torch.float32 else
                "modconv_f16" if wt.dtype == torch.float16 and wt.shape[0] == 1 else "modconv_split")
-        if layer.up != 2 and wt.dtype != torch.float32 and x.shape[1] * x.shape[2] <= 256:
-            key = "modconv_small"          # the library runs these on smallconv_kernel (csrc/smallconv.hip): not the roofline kernel
+        if (layer.up != 2 and wt.dtype != torch.float32 and x.shape[1] * x.shape[2] <= 256 and x.shape[3] % 16 == 0
+                and x.shape[3] <= 512 and cout % 32 == 0 and not half and rgb is None):
+            # the library runs these on smallconv_kernel (csrc/smallconv.hip, modconv_plan.h `smallconv_takes` — same predicate:
+            # fp16-storage, Cin > 512 and fused-toRGB layers stay on the staged kernel): not the roofline kernel
+            key = "modconv_small"
         fuse = self.fuse_up_fir
         # (fp16 STORAGE halves the stand-alone FIR kernel's traffic: there the two-kernel form measured 0.6 % ahead)
         fuse = fuse in (True, "1") or (fuse == "auto" and x.shape[3] <= 64 and not half)
@@ -530,8 +533,10 @@ class TriPlaneGenerator(nn.Module):
             prev = am[2 * k + 1] if track else None
             idx += n_conv
         side = self._side_streams.get(ws.device.index if ws.device.index is not None else torch.cuda.current_device())
-        if side is not None:
-            torch.cuda.current_stream(ws.device).wait_stream(side)     # (join of the image side chain, whatever block ended it)
+        if side is not None and not torch.cuda.is_current_stream_capturing():
+            # join of the image side chain, whatever block ended it (not inside a HIP-graph capture: side_stream() declines there,
+            # and waiting on a stream outside the capture would invalidate it — ADVICE r4)
+            torch.cuda.current_stream(ws.device).wait_stream(side)
         return img
 
     def f16_range_report(self) -> Optional[Dict[str, float]]:

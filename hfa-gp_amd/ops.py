@@ -289,6 +289,8 @@ def modconv(x: torch.Tensor, wt: torch.Tensor, cout: int, mode: int, styles: Opt
     else:
         y = torch.empty(b, h, w, cout, device=x.device, dtype=ydt)
     a.y = y.data_ptr() if y is not None else None
+    if rgb_w is not None:
+        a.rgb_w = _ptr(_chk(rgb_w, "rgb_w"))   # set BEFORE the workspace query: the kernel choice (small-image vs staged) reads it
     nbytes = L.lib().hfagp_modconv_workspace_bytes(C.byref(a))
     ws = None
     if nbytes:
@@ -570,12 +572,10 @@ def raymarch(planes: torch.Tensor, cam2world: torch.Tensor, intrinsics: torch.Te
 
 def depth_clamp_(depth: torch.Tensor, tminmax: torch.Tensor) -> torch.Tensor:
     """In place: depth.clamp_(tminmax[..., 0].min(), tminmax[..., 1].max()) — MipRayMarcher2's batch-global depth clamp — as ONE
-    launch for up to 65536 rays (hfagp_depth_clamp); above that, the same with the framework's reductions."""
+    launch (hfagp_depth_clamp)."""
     _chk(depth, "depth")
     _chk(tminmax, "tminmax")
     n = depth.numel()
-    if n > 65536:
-        return depth.clamp_(tminmax[..., 0].min(), tminmax[..., 1].max())
     L.check(L.lib().hfagp_depth_clamp(_ptr(depth), _ptr(tminmax), n, _stream()), "depth_clamp")
     return depth
 

@@ -40,3 +40,21 @@ def test_world_size_mismatch_is_refused():
     run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"],
                          env=_env(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=600)
     assert run.returncode != 0 and "--gpus 4 but WORLD_SIZE=2" in run.stderr
+
+
+def test_rccl_choice_parser(tmp_path):
+    """bench.py `allreduce_us.algo`: RCCL's TUNING lines -> {payload bytes: algorithm, protocol}; a one-rank log has none and says why."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    log = tmp_path / "rccl.log"
+    log.write_text("h:1:2 [0] NCCL INFO RCCL version 2.26.6-HEAD\n"
+                   "h:1:2 [0] NCCL INFO AllReduce: 1464320 Bytes -> Algo 1 proto 0 time 23.5\n"
+                   "h:1:2 [0] NCCL INFO AllReduce: 96468992 Bytes -> Algo 0 proto 2 time 1440.0\n")
+    got = bench.rccl_choices(str(log), 8)
+    assert got["by_payload_bytes"]["1464320"] == {"algo": "Ring", "proto": "LL", "model_time_us": 23.5}
+    assert got["by_payload_bytes"]["96468992"]["algo"] == "Tree" and got["by_payload_bytes"]["96468992"]["proto"] == "Simple"
+    log.write_text("h:1:2 [0] NCCL INFO RCCL version 2.26.6-HEAD\n")
+    assert "one rank" in bench.rccl_choices(str(log), 1)["note"]
+    assert "no RCCL log" in bench.rccl_choices(str(tmp_path / "absent.log"), 2)["note"]

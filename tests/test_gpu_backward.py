@@ -412,12 +412,15 @@ def test_generator_parameter_gradients_vs_oracle_autograd(dev, preset, batch, pr
         assert got is not None, n
         scale = max(ref.abs().max().item(), 1e-12)
         err = (got.cpu() - ref).abs().max().item()
-        # (a noise_strength gradient is ONE number with near-total cancellation: its bar is relative to the cancellation
-        #  scale measured above, not to its own magnitude — round 3 had loosened it to 15 % of |sum|, which no longer caught a
-        #  regression of that reduction)
+        # (a noise_strength gradient is ONE number with near-total cancellation — sum |g * noise| is ~1e3 x |sum|.  Its bar is
+        #  relative to that cancellation scale, but with a constant that still means something for the VALUE (5e-4 k of the
+        #  cancellation scale was 50 % of the value in fp32 and passed a sign flip at bf16x3): 1e-4 k of the cancellation scale, i.e.
+        #  ~10 % of the value at fp32 — the oracle's own fp32 run sits 2-3 % from the fp64 truth (three-way test) — and a sign flip,
+        #  an error of 2 |sum| = 2e-3 of the scale, fails at every k.)
         tol = 5e-4 * k
         if n in cancel:
-            scale = max(cancel[n], 1e-12)      # a scalar noise strength: relative to its cancellation scale, same bar as a tensor
+            scale = max(cancel[n], 1e-12)
+            tol = 1e-4 * k
         if not err <= tol * scale + 1e-7:
             bad.append((n, err, scale))
     assert not bad, bad[:8]

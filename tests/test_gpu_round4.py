@@ -262,8 +262,8 @@ def test_raymarch_backward_two_kernel_form_equals_the_fused_kernel(dev):
 @pytest.mark.parametrize("b,h,w,cin,cout", [(1, 4, 4, 512, 512), (2, 8, 8, 512, 512), (3, 16, 16, 256, 512), (2, 5, 7, 64, 96),
                                             (1, 16, 16, 512, 96), (2, 13, 3, 32, 64)])
 def test_small_image_conv_kernel_vs_reference_conv(dev, prec, b, h, w, cin, cout):
-    """hfagp_modconv_fwd on images of at most 256 positions takes `smallconv_kernel` (whole K range per block, epilogue in
-    the same launch, no workspace) for the 3x3 conv, its data adjoint and the 1x1 conv: against torch's conv2d of the
+    """hfagp_modconv_fwd on images of at most 256 positions (1024 for the 1x1) takes `smallconv_kernel` (lean blocks without
+    staging, K sliced over blocks through the workspace and the shared reducer) for the 3x3 conv, its data adjoint and the 1x1 conv: against torch's conv2d of the
     modulated input in fp64, with the full epilogue (demodulation, noise, bias, leaky ReLU, clamp), ragged tiles (5 x 7,
     13 x 3), Cout = 96 (the toRGB) and a broadcast input (the learned constant); and against the 128 x 128-tile kernel with a
     forced split (`ksplit=2`), which the small kernel must agree with to the fp32 summation order."""

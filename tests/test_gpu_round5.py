@@ -143,3 +143,27 @@ def test_channel_sum_flat_walk(dev, shape):
     assert bool(((out.double() - 3.0 - want).abs() <= tol).all()), (out.double() - 3.0 - want).abs().max()
     assert bool(((out2.double() - want).abs() <= tol).all())
     assert torch.equal(out2, again)
+
+
+def test_bench_with_a_forced_one_rank_rccl_group_reports_its_algorithm_field():
+    """First-contact hardening: `HFAGP_BENCH_FORCE_DIST=1 python bench.py` drives every collective call of the
+    N > 1 path through a ONE-rank RCCL group on this box — init with device_id, the probe all-reduce, the trainers' bucketed
+    all-reduces, barriers, the MAX reduction of the timing — with RCCL's INFO log (INIT + TUNING) captured per rank; the line must
+    carry `allreduce_us.algo`: the algorithm / protocol per payload on a multi-GPU node, here the note that one rank never runs
+    RCCL's tuning model, plus the RCCL version read from the log (proof that the log was written and parsed)."""
+    import json
+    import subprocess
+    import sys
+    from tests.util import ROOT
+    env = dict(os.environ, HFAGP_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("NCCL_DEBUG", "NCCL_DEBUG_SUBSYS", "NCCL_DEBUG_FILE", "RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "2", "--no-cpu-baseline",
+                          "--no-sweep", "--audio-frames", "0", "--fit-frames", "0", "--fit3dmm-frames-per-rank", "0", "--no-lpips",
+                          "--no-fp32-leg", "--no-f16-leg", "--train-steps", "2"], capture_output=True, text=True, timeout=900, env=env)
+    assert run.returncode == 0, run.stderr[-3000:]
+    line = json.loads(run.stdout.strip().splitlines()[-1])
+    algo = line["allreduce_us"]["algo"]
+    assert algo is not None and ("by_payload_bytes" in algo or "note" in algo), algo
+    assert algo.get("rccl") and "version" in algo["rccl"].lower(), algo      # the per-rank RCCL log exists and was read
+    assert line["n_gpus"] == 1 and line["train_step_ms_generator_tuned"] > 0

@@ -71,9 +71,9 @@ def test_torgb_skip_is_built_without_packed_fp32_fma(tmp_path):
     top of that file; tests/test_gpu_round2.py repeats the kernel 20 times bit for bit).  Guard both the build script and
     the instruction stream it produces; and no spills / at least 3 waves per SIMD (the kernel hides HBM latency with waves)."""
     build = open(os.path.join(ROOT, "hfa-gp_amd", "csrc", "build.sh")).read()
-    assert re.search(r"^FLAGS=\(.*-fno-slp-vectorize.*\)", build, re.M), "build.sh lost -fno-slp-vectorize (now applied to every unit)"
+    assert re.search(r"^FLAGS=\(.*-fno-slp-vectorize.*-fno-vectorize.*\)", build, re.M), "build.sh lost -fno-slp-vectorize / -fno-vectorize"
     asm = tmp_path / "t.s"
-    out = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-S",
+    out = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-fno-vectorize", "-S",
                           "--cuda-device-only", os.path.join(ROOT, "hfa-gp_amd", "csrc", "torgb_skip.hip"), "-o", str(asm),
                           "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -91,3 +91,32 @@ def test_torgb_skip_is_built_without_packed_fp32_fma(tmp_path):
             assert not m or int(m.group(1)) == 0, f"{name} spills"
             m = re.search(r"Occupancy \[waves/SIMD\]: (\d+)", line)
             assert not m or int(m.group(1)) >= 3, f"{name}: occupancy {m.group(1)}"
+
+
+UNITS = ["elementwise", "modconv", "modconv_bf16", "smallconv", "upconv_fir", "torgb_skip", "raymarch", "backward", "raymarch_bwd",
+         "wgrad", "wgrad_bf16", "qr", "loss", "collective"]
+
+
+@pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="hipcc not available")
+def test_no_unit_contains_packed_fp32_arithmetic(tmp_path):
+    """the lanes-48-63 bug (build.sh's comment; reproducer tests/micro/lanes48/, result profiles/r05_lanes48_repro.txt)
+    is a lost low-half result of a packed fp32 op while a vector-memory return is in flight — not an MFMA hazard, not a miscounted
+    wait — so there is no source-level fence: the instruction class stays out of the library.  EVERY unit, compiled with build.sh's
+    flags, must contain no v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 (round 4 checked torgb_skip.hip only; the loop vectoriser had
+    left 5 in qr_refine_kernel and 2 in bias_act_bwd_kernel).  The unit list must be build.sh's."""
+    from concurrent.futures import ThreadPoolExecutor
+    build = open(os.path.join(ROOT, "hfa-gp_amd", "csrc", "build.sh")).read()
+    listed = re.search(r"^for src in ([a-z0-9_ ]+); do", build, re.M).group(1).split()
+    assert sorted(listed) == sorted(UNITS), (listed, UNITS)
+    flags = re.search(r"^FLAGS=\((.*)\)", build, re.M).group(1).split()
+
+    def count(unit):
+        asm = tmp_path / f"{unit}.s"
+        run = subprocess.run([HIPCC, *flags, "-S", "--cuda-device-only", os.path.join(ROOT, "hfa-gp_amd", "csrc", unit + ".hip"), "-o", str(asm)],
+                             capture_output=True, text=True, timeout=900)
+        assert run.returncode == 0, run.stderr[-2000:]
+        return unit, len(re.findall(r"\bv_pk_(?:fma|mul|add)_f32\b", asm.read_text()))
+
+    with ThreadPoolExecutor(max_workers=6) as pool:
+        found = dict(pool.map(count, UNITS))
+    assert all(n == 0 for n in found.values()), {u: n for u, n in found.items() if n}
