@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the fitting-step legs (train_step_ms ...)")
     ap.add_argument("--train-batch", type=int, default=2, help="frames per fitting step per GPU")
-    ap.add_argument("--train-steps", type=int, default=6)
+    ap.add_argument("--train-steps", type=int, default=10)
     ap.add_argument("--fit-frames", type=int, default=500,
                     help="frames of the synthetic RGB-driven fit (BASELINE config 3; 0 = skip): one pass over them")
     ap.add_argument("--fit3dmm-frames-per-rank", type=int, default=250,
@@ -359,16 +359,32 @@ def train_legs(args, cfg_name, dev, rank, world, dist):
         real, params, label = inputs(fa, B, torch.Generator().manual_seed(40 + rank))
         call = (lambda: tr.gen_update(real, label.clone())) if tr.mode == "rgb" else \
                (lambda: tr.gen_update(real, label.clone(), params))
-        for _ in range(2):
+        # settle: untimed steps until two consecutive ones agree to 2 % (at least 2, at most 10) — a new trainer's first steps grow the
+        # caching allocator, build weight images and (RGB) run the Encoder's first-use paths; round 5's first line timed the RGB step
+        # at 16.9 ms with a 8.3 ms forward phase after two warm-up steps, 12.6 - 12.8 ms in every longer run (fit_rgb, dev scripts)
+        prev = None
+        for i in range(10):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
             call()
+            e1.record()
+            torch.cuda.synchronize()
+            cur = e0.elapsed_time(e1)
+            if i >= 1 and prev is not None and abs(cur - prev) <= 0.02 * prev:
+                break
+            prev = cur
+        gc.collect()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         tr.timing = {}
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        evs[0].record()
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for i in range(steps):
             res = call()
+            evs[i + 1].record()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -381,6 +397,9 @@ def train_legs(args, cfg_name, dev, rank, world, dist):
             dt = float(t.item())
         assert torch.isfinite(res[-3]), "fitting step produced a non-finite loss"
         phases = {k: sum(a.elapsed_time(b) for a, b in v) / max(len(v), 1) for k, v in spans.items()}
+        per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(steps))
+        phases["step_events_median"] = per[len(per) // 2]        # per-step HIP event pairs on the launch stream (this rank)
+        phases["step_events_max"] = per[-1]
         return dt / steps * 1e3, phases
 
     def kernel_events(tr, fa, B, steps=3):
@@ -663,7 +682,9 @@ def main():
     ws, c, us, ui = ws.to(dev), c.to(dev), us.to(dev), ui.to(dev)
 
     def step():
-        return gen.synthesis(ws, c, noise_mode="const", u_strat=us, u_imp=ui)["image"]
+        # the renderer's stratified / importance uniforms are DRAWN INSIDE the timed call, as EG3D's ImportanceRenderer does on every
+        # synthesis (torch.rand on the device: 50 M floats at B = 32); the parity legs hand over fixed ones
+        return gen.synthesis(ws, c, noise_mode="const")["image"]
 
     def render_leg(precision, sr_precision=None, events=True, sr_storage="f32"):
         """W warm-up + K timed steps with the conv GEMMs in ``precision`` (super-resolution blocks: ``sr_precision``
@@ -871,7 +892,9 @@ def main():
                                                f"v_mfma_f32_32x32x16_{SPLIT_ELEM[prec]} per fp32 product)",
                     "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
                     "traffic": profiled_traffic(f"modconv_bf16_kernel<{kd}, 2, 9"), "avg_launch_ms": ms / max(n, 1),
-                    "launches": n, "mfma_16bit_tflops": tf * SPLIT_MFMAS[prec]}
+                    "launches": n, "mfma_16bit_tflops": tf * SPLIT_MFMAS[prec],
+                    "traffic_source": "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of THIS command taken on the "
+                                      "GPU box when the kernels last changed (profiles/run_profile.sh), not measured during this run"}
             if n_up:
                 tf_up = flops_up / (ms_up * 1e-3) / 1e12
                 tf_all = (flops + flops_up) / ((ms + ms_up) * 1e-3) / 1e12
@@ -925,6 +948,7 @@ def main():
                                                   f"MFMAs per product" + (": 22 mantissa bits, fp32-class results)"
                                                                           if prec == "f16x3" else ")"),
             "data": "synthetic",
+            "renderer_uniforms": "drawn inside the timed call (torch.rand on the device per synthesis, as EG3D's ImportanceRenderer does)",
             "config": {"workload": f"{cfg.name}: synthesis(ws[B,14,512], c[B,25]) forward, 512x512 out, 128^2 rays x "
                                    f"(48+48) samples, random-init weights, random latents+cameras",
                        "frames_per_step_per_gpu": B, "parallelism": f"frame-parallel x{n_ranks}"},

@@ -1,44 +1,54 @@
 #!/usr/bin/env bash
-# Run ON THE GPU BOX (via gpurun):  bash profiles/train_pmc.sh <tag> [B] [mode]
-# HBM traffic of the BACKWARD kernel families of one fitting step (VERDICT r3 #1d): FETCH_SIZE and WRITE_SIZE in separate
-# rocprofv3 --pmc passes (kernel-trace only, as the guide prescribes) over tools/dev/bench_train.py; bytes per launch =
-# 2 * FETCH_SIZE + WRITE_SIZE (KiB -> bytes; the guide's gfx950 correction for 16-byte-per-lane reads), averaged over the
-# launches of the steady-state steps.  Writes gpurun_out/prof_<tag>/traffic_train.json (copy it to profiles/).
+# Run ON THE GPU BOX (via gpurun):  bash profiles/train_pmc.sh <tag> [B] ["3dmm rgb 3dmm_tuned rgb_tuned"]
+# HBM traffic of the BACKWARD kernel families of one fitting step, per regime (driver x generator frozen / tuned): FETCH_SIZE and
+# WRITE_SIZE in separate rocprofv3 --pmc passes (kernel-trace only, as the guide prescribes) over tools/dev/bench_train.py; bytes
+# per launch = 2 * FETCH_SIZE + WRITE_SIZE (KiB -> bytes; the guide's gfx950 correction for 16-byte-per-lane reads), averaged over
+# all launches of the run.  Writes gpurun_out/prof_<tag>/traffic_train.json = {"regimes": {name: {...}}} (copy it to profiles/).
 set -uo pipefail
 R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
-tag="${1:-r04}"; B="${2:-2}"; mode="${3:-3dmm}"
+tag="${1:-r05}"; B="${2:-2}"; regimes="${3:-3dmm rgb 3dmm_tuned rgb_tuned}"
 keep="$R/gpurun_out/prof_$tag"; out="/tmp/prof_train_$tag"
 rm -rf "$out"; mkdir -p "$out" "$keep"
 cd /tmp && export TMPDIR=/tmp
-for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$out/$c" -o t -- python "$R/tools/dev/bench_train.py" "$B" 6 "$mode" > "$out/$c.log" 2>&1
+for reg in $regimes; do
+  mode="${reg%%_*}"; tun=""; [[ "$reg" == *_tuned ]] && tun="tuned"
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$out/$reg/$c" -o t -- python "$R/tools/dev/bench_train.py" "$B" 6 "$mode" $tun > "$out/${reg}_$c.log" 2>&1
+  done
 done
-python - "$out" "$tag" "$B" "$mode" > "$keep/traffic_train.json" <<'PY'
+python - "$out" "$tag" "$B" "$regimes" > "$keep/traffic_train.json" <<'PY'
 import csv, glob, json, sys
 from collections import defaultdict
-out, tag, B, mode = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+out, tag, B, regimes = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4].split()
 fam = {"pointwise_bwd_kernel": "pointwise_bwd_kernel", "raymarch_bwd_cols_kernel": "raymarch_bwd_cols_kernel",
+       "raymarch_bwd_tiles_kernel": "raymarch_bwd_tiles_kernel (decoder gradients)",
        "modconv_bf16_kernel<2, 2, 9": "modconv_bf16_kernel<2, 2, 9, 0> (3x3 bwd-data)",
        "modconv_bf16_kernel<2, 2, 0": "modconv_bf16_kernel<2, 2, 0, 0> (merged adjoint of the up-conv)",
        "modconv_bf16_kernel<2, 2, 1": "modconv_bf16_kernel<2, 2, 1, 0> (toRGB adjoint)",
+       "wgrad_bf16_kernel<7, 7": "wgrad_bf16_kernel<7, 7, false> (3x3 weight gradient)",
+       "wgrad_up_bf16_kernel": "wgrad_up_bf16_kernel (weight gradient of the up-sampling conv)",
+       "wgrad_sum_final_kernel": "wgrad_sum_final_kernel (split-K reducer of the weight gradients)",
+       "wgrad_kernel<1": "wgrad_kernel<1, *> (toRGB weight gradient, exact fp32)",
        "upfir_bwd_kernel": "upfir_bwd_kernel", "raymarch_kernel<3, 3, true": "raymarch_kernel<GRADS> (compositing adjoint)"}
-acc = {c: defaultdict(lambda: [0, 0.0]) for c in ("FETCH_SIZE", "WRITE_SIZE")}
-for c in acc:
-    for f in glob.glob(f"{out}/{c}/**/*counter_collection.csv", recursive=True):
-        for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] != c:
-                continue
-            for key, name in fam.items():
-                if key in r["Kernel_Name"]:
-                    a = acc[c][name]; a[0] += 1; a[1] += float(r["Counter_Value"])
-res = {"tag": tag, "batch": B, "mode": mode,
-       "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/dev/bench_train.py; per launch, all launches of the "
-               "run (8 steps) averaged; hbm_bytes = 2 * FETCH_SIZE + WRITE_SIZE, KiB -> bytes"}
-for name in fam.values():
-    if acc["FETCH_SIZE"][name][0] and acc["WRITE_SIZE"][name][0]:
-        nf, vf = acc["FETCH_SIZE"][name]; nw, vw = acc["WRITE_SIZE"][name]
-        fr, wr = vf / nf * 1024.0, vw / nw * 1024.0
-        res[name] = {"launches": nf, "fetch_raw": fr, "write": wr, "hbm_bytes": 2 * fr + wr}
+res = {"tag": tag, "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/dev/bench_train.py; per launch, all launches of the "
+                           "run (8 steps) averaged; hbm_bytes = 2 * FETCH_SIZE + WRITE_SIZE, KiB -> bytes", "regimes": {}}
+for reg in regimes:
+    acc = {c: defaultdict(lambda: [0, 0.0]) for c in ("FETCH_SIZE", "WRITE_SIZE")}
+    for c in acc:
+        for f in glob.glob(f"{out}/{reg}/{c}/**/*counter_collection.csv", recursive=True):
+            for r in csv.DictReader(open(f)):
+                if r["Counter_Name"] != c:
+                    continue
+                for key, name in fam.items():
+                    if key in r["Kernel_Name"]:
+                        a = acc[c][name]; a[0] += 1; a[1] += float(r["Counter_Value"])
+    one = {"batch": B, "mode": reg}
+    for name in fam.values():
+        if acc["FETCH_SIZE"][name][0] and acc["WRITE_SIZE"][name][0]:
+            nf, vf = acc["FETCH_SIZE"][name]; nw, vw = acc["WRITE_SIZE"][name]
+            fr, wr = vf / nf * 1024.0, vw / nw * 1024.0
+            one[name] = {"launches": nf, "fetch_raw": fr, "write": wr, "hbm_bytes": 2 * fr + wr}
+    res["regimes"][reg] = one
 print(json.dumps(res, indent=1))
 PY
-cat "$keep/traffic_train.json" | head -60
+head -c 1500 "$keep/traffic_train.json"
