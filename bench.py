@@ -373,7 +373,11 @@ def train_legs(args, cfg_name, dev, rank, world, dist):
             if i >= 1 and prev is not None and abs(cur - prev) <= 0.02 * prev:
                 break
             prev = cur
+        # the few timed steps run with the cyclic collector off, like the render leg (a generation-2 collection is ~50 ms of host
+        # time: in a 10-step region it is 3 - 5 ms per step of noise); the 250-step fitting legs below keep it ON
         gc.collect()
+        gc_was = gc.isenabled()
+        gc.disable()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -386,6 +390,8 @@ def train_legs(args, cfg_name, dev, rank, world, dist):
             res = call()
             evs[i + 1].record()
         torch.cuda.synchronize()
+        if gc_was:
+            gc.enable()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()

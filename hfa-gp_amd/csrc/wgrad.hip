@@ -430,7 +430,8 @@ extern "C" {
 int32_t hfagp_wgrad_ksplit(const HfagpWgradArgs* a) {
     if (!a || a->B <= 0 || a->H <= 0 || a->W <= 0 || a->Cin <= 0 || a->Cout <= 0) return 1;
     const bool up = a->mode == HFAGP_CONVT3X3_UP2;
-    const bool split16 = a->precision == HFAGP_PREC_BF16X3 && (a->mode == HFAGP_CONV3X3 || up) && a->Cin % 64 == 0 && a->Cout % 64 == 0;
+    const bool split16 = a->precision == HFAGP_PREC_BF16X3 && (a->mode == HFAGP_CONV3X3 || up) && a->Cout % 64 == 0 &&
+                         (a->Cin % 64 == 0 || (up && a->Cin == 32));
     const int rows = split16 ? 4 : 2;                  // position tile of the kernel that will run: rows x 16
     const long long units = (long long)a->B * ((a->H + rows - 1) / rows) * ((a->W + 15) / 16);
     long long tiles = (long long)((a->Cin + 63) / 64) * ((a->Cout + 63) / 64);
@@ -483,7 +484,7 @@ int hfagp_conv_wgrad(const HfagpWgradArgs* a, void* stream) {
         const long long img = (long long)a->B * p.gH * p.gW * a->Cout;
         static const int taps_of[4][4] = {{0, 2, 6, 8}, {1, 7, -1, -1}, {3, 5, -1, -1}, {4, -1, -1, -1}};
         static const int ntaps_of[4] = {4, 2, 2, 1};
-        if (a->precision == HFAGP_PREC_BF16X3 && a->Cin % 64 == 0 && a->Cout % 64 == 0) {
+        if (a->precision == HFAGP_PREC_BF16X3 && (a->Cin % 64 == 0 || a->Cin == 32) && a->Cout % 64 == 0) {
             // split-bf16 MFMA kernel: all nine taps in ONE launch (slabs in the parameter layout), then the elementwise reducer
             int rc = launch_wgrad_up_bf16(a, s);
             if (rc != HFAGP_OK) return rc;

@@ -80,6 +80,7 @@ constexpr int EPI_PITCH = CT * 9 + 1;
 constexpr int EPI_BYTES = CT * EPI_PITCH * 4;            // 147 712
 __device__ __forceinline__ void store_slab_final(const f32x16 (&acc)[9], char* lds, float* slab, int Cin, int ci0, int co0,
                                                  int wi, int wj, int h, int l31, int tid) {
+    const int run = min(CT, Cin - ci0) * 9;                  // floats per co row (a partial ci tile: Cin = 32 of the first SR layer)
     float* t32 = reinterpret_cast<float*>(lds);
     __syncthreads();                                         // every wave is done with the staging buffers
     const int cb = 4 * (l31 & 15) + 2 * wj + (l31 >> 4);     // MFMA column -> co of the tile (row permutation of the staging)
@@ -95,9 +96,9 @@ __device__ __forceinline__ void store_slab_final(const f32x16 (&acc)[9], char* l
     for (int c = 0; c < CT; ++c) {
         float* dst = slab + ((size_t)(co0 + c) * Cin + ci0) * 9;
         const float* src = t32 + c * EPI_PITCH;
-        dst[tid] = src[tid];
-        dst[tid + 256] = src[tid + 256];
-        if (tid < CT * 9 - 512) dst[tid + 512] = src[tid + 512];
+        if (tid < run) dst[tid] = src[tid];
+        if (tid + 256 < run) dst[tid + 256] = src[tid + 256];
+        if (tid + 512 < run) dst[tid + 512] = src[tid + 512];
     }
 }
 
@@ -445,7 +446,8 @@ __global__ void __launch_bounds__(256, 1) wgrad_up_bf16_kernel(const WgUpParams 
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int row = k ? xrow1 : xrow0, cg = k ? xcg1 : xcg0, q = k ? xq1 : xq0;
-            const bool rowok = (unsigned)(m0 - 1 + row) < (unsigned)p.H && row < XR - 1;      // (shifts -1 / 0: five patch rows)
+            // (shifts -1 / 0: five patch rows; a partial ci tile — Cin = 32 — loads zeros for the channels it does not have)
+            const bool rowok = (unsigned)(m0 - 1 + row) < (unsigned)p.H && row < XR - 1 && ci0 + 4 * q < p.Cin;
             const float4 v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)((b * p.Cin + ci0 + 4 * q) * 4), 0, 0));
             sx[k] = make_float4(v.x + one, v.y + one, v.z + one, v.w + one);
 #pragma unroll
@@ -616,7 +618,7 @@ int launch_wgrad_up_bf16(const HfagpWgradArgs* a, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_up_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    wgrad_up_bf16_kernel<<<dim3(a->Cin / CT, a->Cout / CT, a->ksplit), 256, lds, s>>>(p);
+    wgrad_up_bf16_kernel<<<dim3((a->Cin + CT - 1) / CT, a->Cout / CT, a->ksplit), 256, lds, s>>>(p);
     return check_launch("conv_wgrad (up-sampling conv, split bf16)");
 }
 

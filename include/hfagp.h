@@ -486,7 +486,7 @@ typedef struct {
     int32_t B, H, W, Cin, Cout, mode;
     int32_t ksplit;           /* number of split-K slabs over (b, position tiles); >= 1 */
     int32_t precision;        /* HFAGP_PREC_F32 (exact fp32 MFMA) or HFAGP_PREC_BF16X3: modes 0 and 1 with Cin, Cout    */
-                              /* multiples of 64 then run on the split-bf16 MFMA kernel, every other case stays fp32   */
+                              /* multiples of 64 (mode 1 also Cin = 32) then run on the split-bf16 MFMA kernels, the rest fp32 */
     int32_t accumulate;       /* ABI 11: 1 = dweight += (the parameter's .grad slice: no separate add pass), 0 = overwrite */
 } HfagpWgradArgs;
 

@@ -337,10 +337,12 @@ def test_conv_weight_gradient_split_bf16(dev, b, h, w_, cin, cout):
     assert not torch.equal(dw, exact), "the split kernel did not run"
 
 
-@pytest.mark.parametrize("b,h,w_,cin,cout", [(2, 11, 11, 64, 128), (1, 8, 21, 128, 64), (3, 3, 5, 64, 64), (1, 32, 16, 128, 128)])
+@pytest.mark.parametrize("b,h,w_,cin,cout", [(2, 11, 11, 64, 128), (1, 8, 21, 128, 64), (3, 3, 5, 64, 64), (1, 32, 16, 128, 128),
+                                             (2, 20, 33, 32, 128), (1, 15, 16, 192, 64)])
 def test_upconv_weight_gradient_split_bf16(dev, b, h, w_, cin, cout):
-    """The weight gradient of the up-sampling conv on the split-bf16 MFMA kernel (four parity launches, the shifted
-    operand is the gradient image) vs autograd through the oracle's transposed conv + FIR."""
+    """The weight gradient of the up-sampling conv on the split-bf16 MFMA kernel (round 5: ONE launch, x staged once per position
+    tile of the parity grid, four parity phases into the nine accumulators; Cin = 32 — the first super-resolution layer — as a
+    partial channel tile) vs autograd through the oracle's transposed conv + FIR; ragged tiles, W + 1 a multiple of 16 + 1."""
     from hfa_gp_amd import ops
     from oracle import eg3d_oracle as O
     g = torch.Generator().manual_seed(19)
