@@ -157,18 +157,9 @@ class TriPlaneGenerator(nn.Module):
         # 256- and 512-channel layers.  "auto" (default): fused for Cin <= 64 where the launch fills the chip; "1": wherever the
         # library supports it; "0": never.
         self.fuse_up_fir = os.environ.get("HFAGP_FUSE_UP_FIR", "auto")
-        # The image side chain of the backbone — toRGB + skip of block k — depends on conv1 of block k and on the image of block
-        # k - 1 only; conv0 / conv1 of block k + 1 never read it.  At small batch every kernel of the 4^2 ... 64^2 blocks is a
-        # latency-sized launch on a mostly empty chip, so for batches up to `side_stream_max_batch` the side chain (and, in the
-        # backward pass, the whole image-gradient chain: upsample2d adjoint + toRGB adjoint of every block) is enqueued on a
-        # SECOND HIP stream and joined where its result is consumed (the tri-planes before the ray march; `dxs_rgb` before the
-        # fused pointwise pass of its block).  Same kernels, same arithmetic, same bits.  At large batch the chip is full and two
-        # streams measured slower (profiles/r02d_two_streams_experiment.txt).
-        # OFF by default (0).  Measured, round 4: one forward-only frame 1.93 -> 1.91 ms (1 %), the 6-step fitting-step timing
-        # unchanged — and a 250-step RGB fitting pass 13.5 -> 31.8 ms per step (tensors handed between the streams carry
-        # `record_stream` marks, and in a sustained loop the caching allocator then defers / re-allocates blocks every step), after
-        # the first version had aliased a collective's pool stream (2-rank RGB step 49 -> 2982 ms).  Two pathologies for one per
-        # cent: the code path stays for single-frame inference (`HFAGP_SIDE_STREAM_MAX_BATCH=1`), nothing enables it by itself.
+        # Image side chain (toRGB + skip of block k, and its adjoints) on a SECOND HIP stream for batches up to this value: same bits,
+        # +1 % on one forward frame, two pathologies in fitting loops (allocator churn from record_stream marks; pool-stream aliasing
+        # with collectives) — OFF by default (0); DESIGN.md section 8, round 4.
         self.side_stream_max_batch = int(os.environ.get("HFAGP_SIDE_STREAM_MAX_BATCH", "0"))
         self._side_streams: Dict[int, "torch.cuda.Stream"] = {}
         self._styles: Dict[int, tuple] = {}      # id(layer) -> (styles, dcoef) of the pass in flight
