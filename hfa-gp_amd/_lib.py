@@ -107,7 +107,8 @@ class PointwiseBwdArgs(C.Structure):
         "dcoef_p", "bias_p", "noise_p", "g_out", "partial", "sums")] + \
         [(n, C.c_int32) for n in ("B", "H", "W", "C", "Co", "nchunks", "has_producer", "act_p", "param_grads")] + \
         [(n, C.c_float) for n in ("noise_strength_p", "alpha", "gain", "clamp")] + \
-        [(n, C.c_void_p) for n in ("y_rgb_small", "g_nchw3_a", "g_nchw3_b")] + [("clamp_rgb_small", C.c_float)]
+        [(n, C.c_void_p) for n in ("y_rgb_small", "g_nchw3_a", "g_nchw3_b")] + [("clamp_rgb_small", C.c_float)] + \
+        [("noise_strength_dev", C.c_void_p)]
 
 
 class StyleBwdArgs(C.Structure):
@@ -119,6 +120,11 @@ class StyleBwdArgs(C.Structure):
 class WgradArgs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("x", "styles", "g", "weight", "dd", "dcoef", "dweight", "workspace")] + \
         [(n, C.c_int32) for n in ("B", "H", "W", "Cin", "Cout", "mode", "ksplit", "precision", "accumulate")]
+
+
+class WeightPrepItem(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("weight", "image", "image_t", "wsq")] + \
+        [(n, C.c_int32) for n in ("Cout", "Cin", "taps", "precision", "precision_t")]
 
 
 class StyleBwdItem(C.Structure):
@@ -166,6 +172,7 @@ SYMBOLS = {
     "hfagp_style_bwd": (C.c_int, [C.POINTER(StyleBwdArgs), C.c_void_p]),
     "hfagp_style_batch_bwd": (C.c_int, [C.POINTER(StyleBwdItem), C.c_int32, C.c_void_p]),
     "hfagp_raymarch_bwd": (C.c_int, [C.POINTER(RaymarchBwdArgs), C.c_void_p]),
+    "hfagp_weight_prep_batch": (C.c_int, [C.POINTER(WeightPrepItem), C.c_int32, C.c_void_p]),
     "hfagp_wgrad_ksplit": (C.c_int32, [C.POINTER(WgradArgs)]),
     "hfagp_wgrad_workspace_bytes": (C.c_size_t, [C.POINTER(WgradArgs)]),
     "hfagp_conv_wgrad": (C.c_int, [C.POINTER(WgradArgs), C.c_void_p]),

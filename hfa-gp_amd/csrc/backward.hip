@@ -51,6 +51,7 @@ __global__ void __launch_bounds__(256) pointwise_bwd_kernel(const HfagpPointwise
         for (int k = 0; k < 4; ++k) acc[r][k] = 0.f;
 
     const bool pvalid = pl < npl;        // 256 % C4 != 0 leaves idle threads
+    const float nstr = a.noise_strength_dev ? *a.noise_strength_dev : a.noise_strength_p;      // (tuned generator: device value)
     // reciprocals once per thread instead of three IEEE divisions per element (~40 instructions each 4-channel group)
     const float rgain = 1.f / a.gain, ralpha = 1.f / a.alpha;
     const float dv[4] = {d_p.x, d_p.y, d_p.z, d_p.w}, bv[4] = {b_p.x, b_p.y, b_p.z, b_p.w};
@@ -99,7 +100,7 @@ __global__ void __launch_bounds__(256) pointwise_bwd_kernel(const HfagpPointwise
             }
         }
         // producer layer P: through clamp / gain / leaky-ReLU, then the demodulation
-        const float nz = nraw * a.noise_strength_p;
+        const float nz = nraw * nstr;
         float go[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {

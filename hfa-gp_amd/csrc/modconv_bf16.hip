@@ -840,6 +840,81 @@ __global__ void __launch_bounds__(256) weight_prep_split_kernel(const float* __r
     }
 }
 
+// Batched weight preparation (round 5; ABI 11): while the generator is being TUNED its weights change every step, and every step
+// needs, per conv layer, the forward B-operand image, the image of the Cin/Cout TRANSPOSE for the bwd-data GEMM and wsq for the
+// demodulation — 47 weight_prep_split launches + 23 weight_prep launches (which also wrote an fp32 image nobody read) = 1.2 ms of a
+// 15 ms step.  Here ONE launch serves all layers: a block stages a 32 (co) x 32 (ci) x taps tile of one weight in LDS with coalesced
+// reads and emits the three outputs from it — the weight is read once, every output leaves in 512-byte runs.
+constexpr int kWPMax = 48;
+struct WPItem { const float* w; uint4* img; uint4* img_t; float* wsq; int Cout, Cin, taps, kd, kd_t, tile0; };
+struct WPBatch { WPItem it[kWPMax]; int n; };
+
+__device__ __forceinline__ void wp_emit(const float (&r)[8], uint4* dst, long long n_img, long long idx, int kd) {
+    if (kd == 5) kd = 4;
+    if (kd == 1 || kd == 4) {
+        unsigned u[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) u[e] = pack_f16(r[2 * e], r[2 * e + 1]);
+        dst[idx] = make_uint4(u[0], u[1], u[2], u[3]);
+        if (kd == 4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) u[e] = pack_f16(r[2 * e] - f16_lo_back(u[e]), r[2 * e + 1] - f16_hi_back(u[e]));
+            dst[n_img + idx] = make_uint4(u[0], u[1], u[2], u[3]);
+        }
+        return;
+    }
+    float t[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = r[e];
+    for (int q = 0; q < kd; ++q) {
+        unsigned u[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            u[e] = pack_bf16(t[2 * e], t[2 * e + 1]);
+            t[2 * e] -= __builtin_bit_cast(float, u[e] << 16);
+            t[2 * e + 1] -= __builtin_bit_cast(float, u[e] & 0xffff0000u);
+        }
+        dst[q * n_img + idx] = make_uint4(u[0], u[1], u[2], u[3]);
+    }
+}
+
+__global__ void __launch_bounds__(256) weight_prep_batch_kernel(const WPBatch b) {
+    __shared__ float tile[32][32 * 9 + 1];                     // [co][ci * taps + t]
+    int i = 0;
+    while (i + 1 < b.n && (int)blockIdx.x >= b.it[i + 1].tile0) ++i;
+    const WPItem& a = b.it[i];
+    const int tci_n = a.Cin >> 5;
+    const int tl = blockIdx.x - a.tile0, co0 = (tl / tci_n) * 32, ci0 = (tl % tci_n) * 32;
+    const int taps = a.taps, row = 32 * taps;
+    for (int e = threadIdx.x; e < 32 * row; e += 256) {
+        const int co = e / row, r = e - co * row;
+        tile[co][r] = a.w[((size_t)(co0 + co) * a.Cin + ci0) * taps + r];
+    }
+    __syncthreads();
+    const long long n_f = (long long)taps * (a.Cin >> 3) * a.Cout, n_t = (long long)taps * (a.Cout >> 3) * a.Cin;
+    for (int e = threadIdx.x; e < taps * 4 * 32; e += 256) {
+        const int c = e & 31, g = (e >> 5) & 3, t = e >> 7;
+        float r[8];
+        if (a.img) {                                           // forward image: 8 consecutive ci of (tap t, co c)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) r[k] = tile[c][(8 * g + k) * taps + t];
+            wp_emit(r, a.img, n_f, ((long long)t * (a.Cin >> 3) + (ci0 >> 3) + g) * a.Cout + co0 + c, a.kd);
+        }
+        if (a.img_t) {                                         // image of the transpose: 8 consecutive co of (tap t, ci c)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) r[k] = tile[8 * g + k][c * taps + t];
+            wp_emit(r, a.img_t, n_t, ((long long)t * (a.Cout >> 3) + (co0 >> 3) + g) * a.Cin + ci0 + c, a.kd_t);
+        }
+    }
+    if (a.wsq)
+        for (int e = threadIdx.x; e < 32 * 32; e += 256) {
+            const int ci = e & 31, co = e >> 5;
+            float sq = 0.f;
+            for (int t = 0; t < taps; ++t) { const float v = tile[co][ci * taps + t]; sq += v * v; }
+            a.wsq[(size_t)(co0 + co) * a.Cin + ci0 + ci] = sq;
+        }
+}
+
 }  // namespace hfagp
 
 using namespace hfagp;
@@ -865,4 +940,25 @@ extern "C" int hfagp_weight_prep_prec(const float* weight, void* wb, int32_t Cou
     const int kd = kind_of(precision);
     HFAGP_REQUIRE(kd != 0, HFAGP_EBADARG, "weight_prep_prec: precision %d has no 16-bit weight image", precision);
     return weight_prep_kind(weight, wb, Cout, Cin, taps, kd, stream);
+}
+
+extern "C" int hfagp_weight_prep_batch(const HfagpWeightPrepItem* items, int32_t n, void* stream) {
+    HFAGP_REQUIRE(items && n >= 1 && n <= kWPMax, HFAGP_EBADARG, "weight_prep_batch: 1..%d items", kWPMax);
+    WPBatch b;
+    int tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        const HfagpWeightPrepItem& a = items[i];
+        HFAGP_REQUIRE(a.weight && (a.image || a.image_t || a.wsq), HFAGP_EBADARG, "weight_prep_batch: null pointer (item %d)", i);
+        HFAGP_REQUIRE(a.Cout % 32 == 0 && a.Cin % 32 == 0 && (a.taps == 1 || a.taps == 9), HFAGP_EUNSUPPORTED,
+                      "weight_prep_batch: item %d: Cout=%d, Cin=%d must be multiples of 32, taps=%d in {1,9}", i, a.Cout, a.Cin, a.taps);
+        const int kd = a.image ? kind_of(a.precision) : 0, kd_t = a.image_t ? kind_of(a.precision_t) : 0;
+        HFAGP_REQUIRE((!a.image || kd != 0) && (!a.image_t || kd_t != 0), HFAGP_EBADARG,
+                      "weight_prep_batch: item %d: precision without a 16-bit weight image", i);
+        b.it[i] = WPItem{a.weight, reinterpret_cast<uint4*>(a.image), reinterpret_cast<uint4*>(a.image_t), a.wsq, a.Cout, a.Cin, a.taps,
+                         kd, kd_t, tiles};
+        tiles += (a.Cout / 32) * (a.Cin / 32);
+    }
+    b.n = n;
+    weight_prep_batch_kernel<<<(unsigned)tiles, 256, 0, (hipStream_t)stream>>>(b);
+    return check_launch("weight_prep_batch");
 }

@@ -221,6 +221,71 @@ class TriPlaneGenerator(nn.Module):
         self._scalars = {}
         self._const_nhwc = None
         self._styles = {}
+        self._plist = None
+        self._conv_weights = None
+        self._noise_layers = None
+        self._scaled_noise = {}
+
+    def _refresh_tuned(self) -> None:
+        """Start of every forward pass while ANY parameter requires grad (the generator is being tuned, trainer_rgb.py:69-71): drop the
+        weight images / wsq / NHWC constant and re-read the 0-d parameters.  The caches are keyed by the parameters' `_version`, and an
+        optimiser's in-place update does not reliably advance it: `torch.optim.Adam(fused=True)` — what the trainers build — moves
+        every weight by lr per step and leaves `_version` at 0 (measured, round 5: rounds 2-4 ran the tuned step on the weight
+        images of step 0, and timed it without the per-step image rebuild).  While the generator is frozen nothing here runs.
+        The host copies of the noise strengths are refreshed in ONE device-to-host copy per step."""
+        plist = getattr(self, "_plist", None)
+        if plist is None:
+            plist = self._plist = [p for n, p in self.named_parameters() if not n.startswith("backbone.mapping.")]
+            self._scalar_params = [p for p in plist if p.dim() == 0]
+        if not any(p.requires_grad for p in plist):
+            self._scaled_noise = {}
+            return
+        self._prep = {}
+        self._const_nhwc = None
+        # noise strengths: NO host copy while tuned (a device-to-host read per step stalls the launch queue: +1.1 ms per step measured).
+        # The forward kernels take noise_const * strength as their noise image with strength 1 (one gather + multiply over the 830 k
+        # noise values of all layers), the fused backward pass reads the strength from device memory (noise_strength_dev).
+        nl = getattr(self, "_noise_layers", None)
+        if nl is None:
+            nl = self._noise_layers = [m for m in self.modules() if isinstance(m, _SynthesisLayer) and getattr(m, "noise_const", None) is not None]
+            if nl:
+                self._noise_flat = torch.cat([m.noise_const.detach().reshape(-1) for m in nl])
+                self._noise_idx = torch.cat([torch.full((m.noise_const.numel(),), i, dtype=torch.long, device=self._noise_flat.device)
+                                             for i, m in enumerate(nl)])
+        self._scaled_noise = {}
+        if nl:
+            strengths = torch.stack([m.noise_strength.detach() for m in nl])
+            scaled = self._noise_flat * strengths[self._noise_idx]
+            off = 0
+            for m in nl:
+                n = m.noise_const.numel()
+                self._scaled_noise[id(m)] = scaled[off: off + n].view_as(m.noise_const)
+                off += n
+        # ... and everything the step needs of the conv weights in ONE launch (ops.weight_prep_batch): forward image, image of the
+        # transpose (when a backward pass can follow) and wsq; per-layer launches were 1.2 ms of a 15 ms step
+        convs = getattr(self, "_conv_weights", None)
+        if convs is None:
+            convs = self._conv_weights = [(p, n.endswith((".conv0.weight", ".conv1.weight"))) for n, p in self.named_parameters()
+                                          if n.endswith((".conv0.weight", ".conv1.weight", ".torgb.weight")) and p.dim() == 4]
+        want_t = torch.is_grad_enabled()
+        items, owners = [], []
+        for w, is_layer in convs:
+            if not (w.is_cuda and ops.weight_prep_batch_supported(w)):
+                continue
+            prec, prec_t = self._precision_of(w), self._precision_of(w, True)
+            prec = "f16x3" if prec == "f16x2" else prec
+            prec_t = "f16x3" if prec_t == "f16x2" else prec_t
+            if prec == "fp32":
+                continue
+            items.append((w.detach(), prec, prec_t if (want_t and prec_t != "fp32") else None, is_layer))
+            owners.append((w, prec, prec_t))
+        if items:
+            for (w, prec, prec_t), (img, img_t, wsq) in zip(owners, ops.weight_prep_batch(items)):
+                self._prep[("G", prec, False, id(w))] = (w._version, w.data_ptr(), img, None)
+                if img_t is not None:
+                    self._prep[("G", prec_t, True, id(w))] = (w._version, w.data_ptr(), img_t, None)
+                if wsq is not None:
+                    self._prep[("Q", id(w))] = (w._version, w.data_ptr(), None, wsq)
 
     def _apply(self, fn, *args, **kwargs):
         out = super()._apply(fn, *args, **kwargs)
@@ -348,8 +413,14 @@ class TriPlaneGenerator(nn.Module):
         styles, dcoef = pre if pre is not None else ops.styles_demod(w, layer.affine.weight, layer.affine.bias, wsq,
                                                                      1.0, cfg.demod_eps)
         noise, ns = None, 0.0
+        noise_raw, ns_dev = None, None
         if noise_mode == "const":
-            noise, ns = layer.noise_const, self._scalar(layer.noise_strength)
+            scaled = getattr(self, "_scaled_noise", {}).get(id(layer))
+            if scaled is not None:       # generator being tuned (_refresh_tuned): pre-scaled noise image, strength stays on the device
+                noise, ns, noise_raw, ns_dev = scaled, 1.0, layer.noise_const, layer.noise_strength.detach()
+            else:
+                noise, ns = layer.noise_const, self._scalar(layer.noise_strength)
+                noise_raw = noise
         elif noise_mode != "none":
             raise NotImplementedError("noise_mode must be 'const' or 'none' (HFA-GP passes 'const', headnerf.py:112)")
         cout = layer.weight.shape[0]
@@ -401,8 +472,8 @@ class TriPlaneGenerator(nn.Module):
         rec = None
         if tape is not None:
             rec = dict(layer=layer, x=x, styles=styles, dcoef=dcoef, out=out, row=row, up=layer.up, wsq=wsq,
-                       producer=dict(dcoef=dcoef, bias=layer.bias, noise=noise, noise_strength=ns, act="lrelu",
-                                     alpha=cfg.lrelu_alpha, gain=gain, clamp=conv_clamp))
+                       producer=dict(dcoef=dcoef, bias=layer.bias, noise=noise_raw, noise_strength=ns if ns_dev is None else 0.0,
+                                     noise_strength_dev=ns_dev, act="lrelu", alpha=cfg.lrelu_alpha, gain=gain, clamp=conv_clamp))
         return out, rec
 
     def _block(self, x, img, blk: _SynthesisBlock, ws, rows, batch, noise_mode, conv_clamp, small_rgb, last, tape,
@@ -442,7 +513,7 @@ class TriPlaneGenerator(nn.Module):
                 img = ops.torgb_small(x.float() if half else x, tr.weight.detach().reshape(tr.weight.shape[0], cin),
                                       styles, tr.bias, img, conv_clamp, y_pre)
         else:
-            wt, _ = self._prepared(tr.weight)
+            wt = self._gemm_image(tr.weight)          # (no demodulation: no wsq)
             side = self.side_stream(batch, x.device)
             main = torch.cuda.current_stream(x.device) if side is not None else None
             if side is not None:
@@ -626,6 +697,7 @@ class TriPlaneGenerator(nn.Module):
         cfg = self.cfg
         b = ws.shape[0]
         res = cfg.neural_rendering_resolution
+        self._refresh_tuned()
         bb_tape = [] if tape is not None else None
         sr_tape = [] if tape is not None else None
         planes = self.backbone_planes(ws, bb_tape)

@@ -97,6 +97,62 @@ def weight_prep_prec(weight: torch.Tensor, precision: str) -> torch.Tensor:
     return wb
 
 
+def weight_prep_batch_supported(weight: torch.Tensor) -> bool:
+    co, ci, kh, kw = weight.shape
+    return co % 32 == 0 and ci % 32 == 0 and kh == kw and kh in (1, 3)
+
+
+def weight_prep_batch(items):
+    """items: [(weight [Cout,Cin,k,k], precision | None, precision_t | None, want_wsq)] -> [(image | None, image_t | None, wsq | None)]
+    in ONE launch per 48 weights (hfagp_weight_prep_batch): the forward image, the image of the Cin/Cout transpose and wsq of every
+    weight from a single read of it.  All outputs of a call live in three flat buffers (one allocation each)."""
+    metas, n16 = [], {torch.float16: 0, torch.bfloat16: 0}
+    nsq = 0
+    for w, prec, prec_t, want_wsq in items:
+        _chk(w, "weight")
+        co, ci, kh, kw = w.shape
+        sizes = []
+        for pr in (prec, prec_t):
+            if pr is None:
+                sizes.append(None)
+            else:
+                dt = _IMAGE_DTYPE[pr]
+                numel = NPARTS[pr] * kh * kw * ci * co            # (same element count for the transpose)
+                sizes.append((dt, n16[dt], numel))
+                n16[dt] += (numel + 256 + 7) // 8 * 8            # + the 512-byte readable pad behind an image (see weight_prep_prec)
+        metas.append((sizes, nsq if want_wsq else None))
+        if want_wsq:
+            nsq += co * ci
+    dev = items[0][0].device
+    flat = {dt: torch.empty(n, device=dev, dtype=dt) for dt, n in n16.items() if n}
+    sq = torch.empty(nsq, device=dev, dtype=torch.float32) if nsq else None
+    out, arr = [], (L.WeightPrepItem * len(items))()
+    for k, ((w, prec, prec_t, want_wsq), (sizes, sq_off)) in enumerate(zip(items, metas)):
+        co, ci, kh, kw = w.shape
+        views = []
+        for pr, sz, shape in ((prec, sizes[0], (kh * kw, ci // 8, co, 8)), (prec_t, sizes[1], (kh * kw, co // 8, ci, 8))):
+            if sz is None:
+                views.append(None)
+            else:
+                dt, off, numel = sz
+                views.append(flat[dt][off: off + numel].view(NPARTS[pr], *shape))
+        wsq = sq[sq_off: sq_off + co * ci].view(co, ci) if want_wsq else None
+        a = arr[k]
+        a.weight = _ptr(w)
+        a.image = views[0].data_ptr() if views[0] is not None else None
+        a.image_t = views[1].data_ptr() if views[1] is not None else None
+        a.wsq = _ptr(wsq)
+        a.Cout, a.Cin, a.taps = co, ci, kh * kw
+        a.precision = PRECISIONS[prec] if prec is not None else 0
+        a.precision_t = PRECISIONS[prec_t] if prec_t is not None else 0
+        out.append((views[0], views[1], wsq))
+    for k0 in range(0, len(items), 48):
+        n = min(48, len(items) - k0)
+        sub = (L.WeightPrepItem * n).from_buffer(arr, k0 * C.sizeof(L.WeightPrepItem))
+        L.check(L.lib().hfagp_weight_prep_batch(sub, n, _stream()), "weight_prep_batch")
+    return out
+
+
 def weight_prep_split(weight: torch.Tensor, nparts: int) -> torch.Tensor:
     """`weight_prep_prec` by part count: 1 = 'f16', 2 = 'bf16x3', 3 = 'bf16x6'."""
     return weight_prep_prec(weight, {1: "f16", 2: "bf16x3", 3: "bf16x6"}[nparts])
@@ -777,6 +833,7 @@ def pointwise_bwd(x: torch.Tensor, dxs_conv=None, s_conv=None, dxs_rgb=None, s_r
         a.has_producer = 1
         a.dcoef_p, a.bias_p, a.noise_p = _ptr(producer.get("dcoef")), _ptr(producer.get("bias")), _ptr(producer.get("noise"))
         a.noise_strength_p = producer.get("noise_strength", 0.0)
+        a.noise_strength_dev = _ptr(producer.get("noise_strength_dev"))     # (0-d device tensor: wins over the host value)
         a.act_p = _ACT[producer.get("act", "lrelu")]
         a.alpha, a.gain = producer.get("alpha", 0.2), producer.get("gain", math.sqrt(2.0))
         clamp = producer.get("clamp")

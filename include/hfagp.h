@@ -165,6 +165,20 @@ int hfagp_weight_prep_split(const float* weight, void* wb, int32_t Cout, int32_t
 int hfagp_weight_prep_prec(const float* weight, void* wb, int32_t Cout, int32_t Cin, int32_t taps,
                            int32_t precision, void* stream);
 
+/* ABI 11: everything a step needs of a set of conv weights in ONE launch — for each item the forward image (layout of
+ * hfagp_weight_prep_prec, `precision`), the image of the Cin/Cout TRANSPOSE (`precision_t`; the bwd-data GEMM's operand) and
+ * wsq[Cout][Cin] = sum over taps of w^2; any of the three outputs may be NULL.  Cout, Cin multiples of 32; at most 48 items.
+ * For a generator that is being tuned: its weights change every step (trainer_rgb.py:69-71), its images with them. */
+typedef struct {
+    const float* weight;      /* [Cout][Cin][taps] */
+    void*        image;       /* [parts][taps][Cin/8][Cout][8] or NULL */
+    void*        image_t;     /* [parts][taps][Cout/8][Cin][8] or NULL */
+    float*       wsq;         /* [Cout][Cin] or NULL */
+    int32_t Cout, Cin, taps;
+    int32_t precision, precision_t;
+} HfagpWeightPrepItem;
+int hfagp_weight_prep_batch(const HfagpWeightPrepItem* items, int32_t n, void* stream);
+
 /* ------------------------------------------------------------------ modulated conv
  * Implicit-GEMM on v_mfma_f32_32x32x2_f32 (exact fp32).  Input is scaled by
  * styles on the way into LDS; demodulation, noise, bias, leaky-ReLU, gain and
@@ -388,14 +402,16 @@ typedef struct {
     const float* g_nchw3_a;   /* NCHW [B][3][H][W] gradients added to channels 0..2 of gX (image_raw = first three channels of  */
     const float* g_nchw3_b;   /* the feature image: the super-resolution skip path and the caller's d image_raw), or NULL          */
     float clamp_rgb_small;
+    /* ABI 11 (optional): the producer's noise strength read from DEVICE memory (one float) instead of `noise_strength_p` — a generator
+     * that is being tuned changes it every step, and a host copy would cost a device-to-host synchronisation per step */
+    const float* noise_strength_dev;
 } HfagpPointwiseBwdArgs;
 
 int hfagp_pointwise_bwd(const HfagpPointwiseBwdArgs* a, void* stream);
 
 /* MipRayMarcher2's depth clamp (EG3D: `torch.clamp(depth, min(sample depths), max(sample depths))` over the WHOLE batch) in one
  * launch: depth [n] is clamped in place to [min_i tminmax[i][0], max_i tminmax[i][1]] (tminmax as hfagp_raymarch_fwd writes it).
- * Up to 16 workgroups, each reducing all of tminmax itself and clamping its slice: meant for small batches (n <= 65536 rays; -2
- * above that — the caller then uses its framework's reductions). */
+ * Up to 64 workgroups, each reducing all of tminmax itself (L2-resident) and clamping its slice; any batch since ABI 11. */
 int hfagp_depth_clamp(float* depth, const float* tminmax, int64_t n, void* stream);
 
 /* adjoint of hfagp_upfir_epilogue_fwd's FIR: g_y [B][2H][2W][C] -> four parity images of the y_t gradient,

@@ -167,3 +167,72 @@ def test_bench_with_a_forced_one_rank_rccl_group_reports_its_algorithm_field():
     assert algo is not None and ("by_payload_bytes" in algo or "note" in algo), algo
     assert algo.get("rccl") and "version" in algo["rccl"].lower(), algo      # the per-rank RCCL log exists and was read
     assert line["n_gpus"] == 1 and line["train_step_ms_generator_tuned"] > 0
+
+
+def test_tuned_generator_forward_uses_the_updated_weights(dev):
+    """Round-5 find: `torch.optim.Adam(fused=True)` (what the trainers build) updates parameters WITHOUT advancing `_version`, the key
+    of the generator's weight-image / wsq / scalar caches — rounds 2-4 ran the generator-tuned step on the weight images of step 0.
+    After real Adam steps with the generator being tuned, `synthesis` must equal the synthesis of a FRESH (frozen) generator loaded
+    with the updated state_dict — same kernels and weight images; the tuned path adds the noise as a pre-scaled image (noise x strength
+    rounded once more than the frozen path's fused multiply-add, so 1e-6-level differences, not bits) — and the weights must indeed
+    have moved.  With the stale images of rounds 2-4 the two differ at the 1e-3 level after three steps of lr 2e-3."""
+    from hfa_gp_amd.generator import TriPlaneGenerator
+    from hfa_gp_amd.trainer import Trainer
+    from tests.test_gpu_round4 import RankArgs, _rank_frames
+    torch.manual_seed(3)
+    tr = Trainer(RankArgs(), dev, mode="3dmm", lpips="none")
+    tr.tune_generator()
+    gen = tr.gen.generator
+    cfg = gen.cfg
+    before = {n: p.detach().clone() for n, p in gen.named_parameters()}
+    real, params, label, us, ui = (t.to(dev) for t in _rank_frames(2, cfg))
+    sf = ui.shape[-1]
+    for _ in range(3):
+        tr.gen_update(real, label.clone(), params, u_strat=us, u_imp=ui.reshape(-1, sf).contiguous())
+    moved = [n for n, p in gen.named_parameters() if not torch.equal(p.detach(), before[n])]
+    assert any(n.endswith("conv1.weight") for n in moved) and any(n.endswith("noise_strength") for n in moved), moved[:5]
+    ws = torch.randn(2, cfg.num_ws, 512, generator=torch.Generator().manual_seed(9)).to(dev)
+    with torch.no_grad():
+        got = gen.synthesis(ws, label.clone(), noise_mode="const", u_strat=us, u_imp=ui.reshape(-1, sf).contiguous())["image"]
+        fresh = TriPlaneGenerator(cfg, seed=0).to(dev)
+        fresh.load_state_dict(gen.state_dict())
+        fresh.requires_grad_(False)
+        want = fresh.synthesis(ws, label.clone(), noise_mode="const", u_strat=us, u_imp=ui.reshape(-1, sf).contiguous())["image"]
+    err, scale = (got - want).abs().max().item(), want.abs().max().item()
+    assert err <= 2e-5 * scale, (err, scale)
+    # ... and the step-0 weights give a visibly different image (the test would be vacuous otherwise)
+    stale = TriPlaneGenerator(cfg, seed=0).to(dev)
+    stale.load_state_dict({n: (before[n[len(""):]] if n in before else v) for n, v in gen.state_dict().items()})
+    stale.requires_grad_(False)
+    with torch.no_grad():
+        old = stale.synthesis(ws, label.clone(), noise_mode="const", u_strat=us, u_imp=ui.reshape(-1, sf).contiguous())["image"]
+    assert (old - want).abs().max().item() > 50 * max(err, 1e-7), ((old - want).abs().max().item(), err)
+
+
+@pytest.mark.parametrize("cout,cin,k", [(128, 64, 3), (96, 256, 1), (512, 512, 3), (32, 32, 3)])
+def test_weight_prep_batch_equals_the_per_layer_calls(dev, cout, cin, k):
+    """hfagp_weight_prep_batch (one launch: forward image, image of the Cin/Cout transpose, wsq, from one read of the weight through
+    LDS) is BIT-IDENTICAL to hfagp_weight_prep_prec of the weight, of its transpose, and to hfagp_weight_prep's wsq, for every pair
+    of operand kinds the generator uses; several items in one call."""
+    from hfa_gp_amd import ops
+    g = torch.Generator().manual_seed(cout + cin + k)
+    w1 = (torch.randn(cout, cin, k, k, generator=g) * 3.0).to(dev)
+    w2 = torch.randn(cin, cout, k, k, generator=g).to(dev)
+    items = [(w1, "f16x3", "bf16x3", True), (w2, "bf16x3", None, False), (w1, "f16", "bf16x6", True), (w2, None, "bf16x3", True)]
+    outs = ops.weight_prep_batch(items)
+    for (w, prec, prec_t, want_wsq), (img, img_t, wsq) in zip(items, outs):
+        if prec is not None:
+            assert torch.equal(img, ops.weight_prep_prec(w, prec)), prec
+        else:
+            assert img is None
+        if prec_t is not None:
+            assert torch.equal(img_t, ops.weight_prep_prec(w.transpose(0, 1).contiguous(), prec_t)), prec_t
+        else:
+            assert img_t is None
+        if want_wsq:
+            ref = (w.double() ** 2).sum(dim=(2, 3)).float()
+            assert torch.allclose(wsq, ref, rtol=1e-6, atol=0)
+            if k == 3:
+                assert torch.equal(wsq, ops.weight_prep(w)[1])
+        else:
+            assert wsq is None
