@@ -226,7 +226,7 @@ class TriPlaneGenerator(nn.Module):
         self._noise_layers = None
         self._scaled_noise = {}
 
-    def _refresh_tuned(self) -> None:
+    def _refresh_tuned(self, backward_follows: bool = True) -> None:
         """Start of every forward pass while ANY parameter requires grad (the generator is being tuned, trainer_rgb.py:69-71): drop the
         weight images / wsq / NHWC constant and re-read the 0-d parameters.  The caches are keyed by the parameters' `_version`, and an
         optimiser's in-place update does not reliably advance it: `torch.optim.Adam(fused=True)` — what the trainers build — moves
@@ -267,7 +267,7 @@ class TriPlaneGenerator(nn.Module):
         if convs is None:
             convs = self._conv_weights = [(p, n.endswith((".conv0.weight", ".conv1.weight"))) for n, p in self.named_parameters()
                                           if n.endswith((".conv0.weight", ".conv1.weight", ".torgb.weight")) and p.dim() == 4]
-        want_t = torch.is_grad_enabled()
+        want_t = backward_follows        # (a call that records a tape: the bwd-data GEMMs will ask for the transposed images)
         items, owners = [], []
         for w, is_layer in convs:
             if not (w.is_cuda and ops.weight_prep_batch_supported(w)):
@@ -697,7 +697,7 @@ class TriPlaneGenerator(nn.Module):
         cfg = self.cfg
         b = ws.shape[0]
         res = cfg.neural_rendering_resolution
-        self._refresh_tuned()
+        self._refresh_tuned(tape is not None)
         bb_tape = [] if tape is not None else None
         sr_tape = [] if tape is not None else None
         planes = self.backbone_planes(ws, bb_tape)
