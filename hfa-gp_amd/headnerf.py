@@ -116,13 +116,18 @@ class _LatentBasis(nn.Module):
         return self.bases, self.delta
 
     def _orthonormal(self, bases: torch.Tensor) -> torch.Tensor:
-        if not (bases.requires_grad and torch.is_grad_enabled()):
+        if not bases.requires_grad:
+            # a FROZEN basis (reenactment loops): Q is cached.  A trainable one is never cached, also under no_grad (`Trainer.sample`
+            # between steps): the key is the parameter's `_version`, which torch's fused Adam does not advance (round 5, see
+            # TriPlaneGenerator._refresh_tuned) — the cached Q would be the basis of the first sample call for ever.
             key = (id(bases), bases._version, bases.data_ptr())
             if self._q_cache is not None and self._q_cache[0] == key:
                 return self._q_cache[1]
             q = self._qr((bases.detach() + 1e-8).T)
             self._q_cache = (key, q)
             return q
+        if not torch.is_grad_enabled():
+            return self._qr((bases.detach() + 1e-8).T)
         return self._qr((bases + 1e-8).T)
 
     def _qr(self, a: torch.Tensor) -> torch.Tensor:

@@ -636,3 +636,26 @@ def test_bucketer_overlap_state_and_absent_parameters():
         assert gw.abs().max() > 0
     finally:
         dist.destroy_process_group()
+
+
+def test_trainable_basis_is_never_served_from_the_q_cache():
+    """Round-5 find (GPU): torch's fused Adam updates parameters without advancing `_version`, the key of the Q cache — so for a
+    TRAINABLE basis the cache would serve the first `sample()` call's Q for ever.  A basis that requires grad is re-factorised on
+    every call, also under no_grad; a frozen one is cached.  (The version-less update is emulated with a `.data` write.)"""
+    torch.manual_seed(5)
+    gen = headnerf.HeadNeRF_3DMM(Args(), Args.size, "cpu", 512, Args.latent_dim_shape)
+    OracleGenerator.adopt(gen.generator)
+    with torch.no_grad():
+        q0 = gen._orthonormal(gen.bases).clone()
+        v0 = gen.bases._version
+        gen.bases.data.add_(0.05 * torch.randn_like(gen.bases))           # what fused Adam does: new values, same _version
+        assert gen.bases._version == v0
+        q1 = gen._orthonormal(gen.bases)
+    assert (q1 - q0).abs().max().item() > 1e-4                           # the new basis, not the cached factor
+    want = torch.linalg.qr((gen.bases.detach() + 1e-8).T, mode="reduced")[0]
+    assert torch.allclose(q1, want, atol=1e-5)
+    gen.bases.requires_grad_(False)                                      # frozen (reenactment): cached
+    with torch.no_grad():
+        a = gen._orthonormal(gen.bases)
+        b = gen._orthonormal(gen.bases)
+    assert a is b
