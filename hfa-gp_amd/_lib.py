@@ -172,6 +172,8 @@ SYMBOLS = {
     "hfagp_style_bwd": (C.c_int, [C.POINTER(StyleBwdArgs), C.c_void_p]),
     "hfagp_style_batch_bwd": (C.c_int, [C.POINTER(StyleBwdItem), C.c_int32, C.c_void_p]),
     "hfagp_raymarch_bwd": (C.c_int, [C.POINTER(RaymarchBwdArgs), C.c_void_p]),
+    "hfagp_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p]),
+    "hfagp_adam_chunk": (C.c_int32, []),
     "hfagp_weight_prep_batch": (C.c_int, [C.POINTER(WeightPrepItem), C.c_int32, C.c_void_p]),
     "hfagp_wgrad_ksplit": (C.c_int32, [C.POINTER(WgradArgs)]),
     "hfagp_wgrad_workspace_bytes": (C.c_size_t, [C.POINTER(WgradArgs)]),

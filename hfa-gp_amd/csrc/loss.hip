@@ -71,6 +71,59 @@ __global__ void __launch_bounds__(256) pool_mse_bwd_kernel(const float* __restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Adam over MANY parameter tensors in one launch (round 5; torch.optim.Adam's update rule, trainer_rgb.py:58: lr 3e-4, betas
+// (0.9, 0.999), eps 1e-8, no weight decay / amsgrad).  When the generator is tuned the step updates 30.7 M + the driver net's
+// parameters: 28 bytes of traffic per parameter, i.e. HBM-bound; PyTorch's fused multi-tensor Adam moved 1.9 TB/s here (19 launches,
+// 0.55 ms per step).  Tables live in device memory (built once per parameter set by the host): per tensor {p, g, m, v, step, numel}
+// as six 64-bit words, per block {tensor, first element}.  `step` (one float per tensor, torch's state layout) is advanced by
+// adam_advance_kernel first; the bias corrections are formed in double like torch's.
+constexpr int kAdamChunk = 16384;       // elements per block: 4 x 16 B per thread and stream, 4 passes
+
+__global__ void __launch_bounds__(256) adam_advance_kernel(const long long* __restrict__ tensors, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) *reinterpret_cast<float*>(tensors[6 * i + 4]) += 1.f;
+}
+
+__global__ void __launch_bounds__(256) adam_update_kernel(const long long* __restrict__ tensors, const int2* __restrict__ chunks,
+                                                          double lr, double beta1d, double beta2d, float eps) {
+    __shared__ float bc[2];
+    const int2 ch = chunks[blockIdx.x];
+    const long long* t = tensors + 6 * (long long)ch.x;
+    float* p = reinterpret_cast<float*>(t[0]);
+    const float* g = reinterpret_cast<const float*>(t[1]);
+    float* m = reinterpret_cast<float*>(t[2]);
+    float* v = reinterpret_cast<float*>(t[3]);
+    const long long numel = t[5];
+    if (threadIdx.x == 0) {
+        const double step = (double)*reinterpret_cast<const float*>(t[4]);
+        bc[0] = (float)(lr / (1.0 - pow(beta1d, step)));                  // lr / bias_correction1
+        bc[1] = (float)(1.0 / sqrt(1.0 - pow(beta2d, step)));             // 1 / sqrt(bias_correction2)
+    }
+    __syncthreads();
+    // (1 - beta in DOUBLE, then rounded: 1.f - 0.999f is 1.3e-5 off the factor torch multiplies with)
+    const float step_size = bc[0], rs2 = bc[1], omb1 = (float)(1.0 - beta1d), omb2 = (float)(1.0 - beta2d), beta2 = (float)beta2d;
+    const long long e0 = (long long)ch.y, e1 = min(numel, e0 + kAdamChunk);
+    auto one = [&](float& pp, float gg, float& mm, float& vv) {
+        mm = mm + (gg - mm) * omb1;
+        vv = vv * beta2 + gg * gg * omb2;
+        pp -= step_size * mm / (sqrtf(vv) * rs2 + eps);
+    };
+    const bool vec = (((unsigned long long)t[0] | (unsigned long long)t[1] | (unsigned long long)t[2] | (unsigned long long)t[3]) & 15ull) == 0 && (e0 & 3) == 0;
+    if (vec) {
+        const long long ev = e0 + ((e1 - e0) & ~3ll);            // end of the whole float4s
+        for (long long i = e0 + 4 * threadIdx.x; i < ev; i += 1024) {
+            float4 pp = *reinterpret_cast<float4*>(p + i), mm = *reinterpret_cast<float4*>(m + i), vv = *reinterpret_cast<float4*>(v + i);
+            const float4 gg = *reinterpret_cast<const float4*>(g + i);
+            one(pp.x, gg.x, mm.x, vv.x); one(pp.y, gg.y, mm.y, vv.y); one(pp.z, gg.z, mm.z, vv.z); one(pp.w, gg.w, mm.w, vv.w);
+            *reinterpret_cast<float4*>(p + i) = pp; *reinterpret_cast<float4*>(m + i) = mm; *reinterpret_cast<float4*>(v + i) = vv;
+        }
+        if (ev + threadIdx.x < e1) { const long long i = ev + threadIdx.x; one(p[i], g[i], m[i], v[i]); }     // ragged tail: <= 3 elements
+    } else {
+        for (long long i = e0 + threadIdx.x; i < e1; i += 256) one(p[i], g[i], m[i], v[i]);
+    }
+}
+
 }  // namespace hfagp
 
 using namespace hfagp;
@@ -103,3 +156,17 @@ int hfagp_pool_mse_bwd(const float* pooled, const float* real, const float* g_lo
 }
 
 }  // extern "C"
+
+extern "C" int hfagp_adam_step(const void* tensor_table, const void* chunk_table, int32_t ntensors, int32_t nchunks, double lr,
+                               double beta1, double beta2, double eps, void* stream) {
+    HFAGP_REQUIRE(tensor_table && chunk_table && ntensors >= 1 && nchunks >= 1, HFAGP_EBADARG, "adam_step: empty tables");
+    HFAGP_REQUIRE(lr == lr && beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0 && eps >= 0.0, HFAGP_EBADARG,
+                  "adam_step: lr=%g betas=(%g, %g) eps=%g", lr, beta1, beta2, eps);
+    hipStream_t s = (hipStream_t)stream;
+    adam_advance_kernel<<<(ntensors + 255) / 256, 256, 0, s>>>(static_cast<const long long*>(tensor_table), ntensors);
+    adam_update_kernel<<<(unsigned)nchunks, 256, 0, s>>>(static_cast<const long long*>(tensor_table), static_cast<const int2*>(chunk_table),
+                                                         lr, beta1, beta2, (float)eps);
+    return check_launch("adam_step");
+}
+
+extern "C" int32_t hfagp_adam_chunk(void) { return kAdamChunk; }

@@ -1068,3 +1068,29 @@ class PoolMSE(torch.autograd.Function):
 def pool_mse(img: torch.Tensor, real: torch.Tensor):
     """→ (l2 loss scalar, pooled image [B,C,h,w])."""
     return PoolMSE.apply(img, real)
+
+
+# ----------------------------------------------------------------------------- optimiser of the fitting step
+class AdamTables:
+    """Device tables of hfagp_adam_step for one set of (param, grad, exp_avg, exp_avg_sq, step) tensors; built once per set."""
+
+    def __init__(self, params, grads, exp_avgs, exp_avg_sqs, steps):
+        chunk = L.lib().hfagp_adam_chunk()
+        rows, chunks = [], []
+        for k, (p, g, m, v, st) in enumerate(zip(params, grads, exp_avgs, exp_avg_sqs, steps)):
+            for t in (p, g, m, v):
+                if t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda:
+                    raise RuntimeError("adam_step: fp32 contiguous CUDA tensors only")
+            n = p.numel()
+            rows.append([p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), st.data_ptr(), n])
+            chunks.extend([k, e] for e in range(0, n, chunk))
+        dev = params[0].device
+        self.tensors = torch.tensor(rows, dtype=torch.int64).to(dev)
+        self.chunks = torch.tensor(chunks, dtype=torch.int32).to(dev)
+        self.n, self.nchunks = len(rows), len(chunks)
+        self.keep = (list(params), list(grads), list(exp_avgs), list(exp_avg_sqs), list(steps))     # (the pointers stay valid)
+
+
+def adam_step(tables: AdamTables, lr: float, beta1: float, beta2: float, eps: float) -> None:
+    L.check(L.lib().hfagp_adam_step(_ptr(tables.tensors), _ptr(tables.chunks), tables.n, tables.nchunks, lr, beta1, beta2, eps,
+                                    _stream()), "adam_step")

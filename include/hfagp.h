@@ -528,6 +528,14 @@ int hfagp_channel_sum(const float* g, float* partial, float* out, int64_t npix, 
  * and its adjoint  d_img = g_loss * 2 (pooled - real) / (BC*h*w * f^2)  (every element of d_img is written).
  * workspace: hfagp_pool_mse_workspace_bytes() bytes; loss, g_loss: one float on the device.              */
 size_t hfagp_pool_mse_workspace_bytes(void);
+
+/* ABI 11: torch.optim.Adam's update (trainer_rgb.py:58; no weight decay, no amsgrad) of MANY tensors in one call.
+ *   tensor_table: device memory, ntensors x 6 64-bit words {param*, grad*, exp_avg*, exp_avg_sq*, step* (ONE float, advanced by
+ *                 this call), numel};   chunk_table: device memory, nchunks x {int32 tensor index, int32 first element}, one entry
+ *                 per hfagp_adam_chunk() elements of every tensor.  All tensors fp32, contiguous. */
+int hfagp_adam_step(const void* tensor_table, const void* chunk_table, int32_t ntensors, int32_t nchunks, double lr, double beta1,
+                    double beta2, double eps, void* stream);      /* (doubles: torch forms 1 - beta and the bias corrections in double) */
+int32_t hfagp_adam_chunk(void);
 int hfagp_pool_mse_fwd(const float* img, const float* real, float* pooled, float* loss, float* workspace,
                        int32_t BC, int32_t h, int32_t w, int32_t f, void* stream);
 int hfagp_pool_mse_bwd(const float* pooled, const float* real, const float* g_loss, float* d_img,

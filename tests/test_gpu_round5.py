@@ -236,3 +236,39 @@ def test_weight_prep_batch_equals_the_per_layer_calls(dev, cout, cin, k):
                 assert torch.equal(wsq, ops.weight_prep(w)[1])
         else:
             assert wsq is None
+
+
+def test_multi_tensor_adam_matches_torch_adam(dev):
+    """trainer.MultiTensorAdam (hfagp_adam_step: one launch over device-resident pointer tables) against torch.optim.Adam's reference
+    (non-fused) implementation: ragged sizes (1, 3, 4257, one chunk + 5, several chunks), a parameter without a gradient (skipped: no
+    moment decay, no step advance), three steps with changing gradients, then a state_dict round trip into torch's own Adam."""
+    from hfa_gp_amd.trainer import MultiTensorAdam
+    g = torch.Generator().manual_seed(12)
+    shapes = [(), (3,), (33, 129), (16384 + 5,), (512, 512, 3, 3), (7, 11)]
+    mine = [torch.nn.Parameter(torch.randn(s, generator=g).to(dev)) for s in shapes]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in mine]
+    o1 = MultiTensorAdam(mine, lr=3e-4)
+    o2 = torch.optim.Adam(ref, lr=3e-4, foreach=False, fused=False)
+    for step in range(3):
+        for k, (a, b) in enumerate(zip(mine, ref)):
+            if k == len(shapes) - 1 and step != 1:
+                a.grad = b.grad = None                      # absent in steps 0 and 2
+                continue
+            gr = (torch.randn(tuple(a.shape), generator=g) * (10.0 ** (step - 1))).to(dev)
+            a.grad, b.grad = gr.clone(), gr.clone()
+        o1.step()
+        o2.step()
+    for a, b, s in zip(mine, ref, shapes):
+        assert torch.allclose(a, b, rtol=2e-6, atol=2e-7), (s, (a - b).abs().max().item())
+        assert torch.allclose(o1.state[a]["exp_avg"], o2.state[b]["exp_avg"], rtol=2e-6, atol=1e-9), s
+        assert torch.allclose(o1.state[a]["exp_avg_sq"], o2.state[b]["exp_avg_sq"], rtol=2e-6, atol=1e-12), s
+        assert float(o1.state[a]["step"]) == float(o2.state[b]["step"]), s
+    assert float(o1.state[mine[-1]]["step"]) == 1.0
+    o3 = torch.optim.Adam([torch.nn.Parameter(p.detach().clone()) for p in mine], lr=3e-4)
+    o3.load_state_dict(o1.state_dict())                     # same layout as torch's
+    o1b = MultiTensorAdam([torch.nn.Parameter(p.detach().clone()) for p in mine], lr=3e-4)
+    o1b.load_state_dict(o2.state_dict())                    # ... and torch's (host-side `step`) loads into ours
+    for p in o1b.param_groups[0]["params"]:
+        p.grad = torch.ones_like(p)
+    o1b.step()
+    assert float(o1b.state[o1b.param_groups[0]["params"][0]]["step"]) == 4.0
