@@ -378,9 +378,9 @@ __global__ void __launch_bounds__(256, 1) wgrad_bf16_kernel(const Wg16Params p) 
 // on the (H+1) x (W+1) grid of a parity image: the SHIFTED operand is x (shifts -1 / 0: halo on top and on the left, staged
 // ONCE per position tile), the plain operand is the tile of ONE parity image, and a tile is four PHASES — parity (1,1): 1 tap,
 // (0,1) and (1,0): 2 taps, (0,0): 4 taps — that share the nine accumulators of the 3x3 kernel (tap slot = 3 ky + kx).
-// Same pipeline as above, per phase instead of per tile: the gradient tile of phase f+2 is loaded while phase f runs (two
-// register sets) and converted inside the K loop of phase f+1 (4 pieces); the x patch of tile u+1 is loaded at the start of
-// tile u and converted inside its last two phases (the 2- and 4-tap ones: 4 pieces each).  The loop body (one tile = four
+// Same pipeline as above, per phase instead of per tile: the gradient tile of (tile u+1, phase f) is loaded at the start of (tile u,
+// phase f) (four register sets: a whole tile of latency) and converted inside the K loop of the phase before its own (4 pieces); the
+// x patch of tile u+1 is loaded at the start of tile u and converted inside its last, 4-tap phase (8 pieces).  The loop body (one tile = four
 // phases) has no branch; phases past the block's range load zeros.
 struct WgUpParams {
     const float* x; const float* g; const float* styles;      // g = [2][2][B][H+1][W+1][Cout]
@@ -406,7 +406,7 @@ __global__ void __launch_bounds__(256, 1) wgrad_up_bf16_kernel(const WgUpParams 
     const int units = p.B * p.tiles_h * p.tiles_w;
     const int u_begin = (int)(((long long)units * ks) / p.ksplit), u_end = (int)(((long long)units * (ks + 1)) / p.ksplit);
 
-    float4 rx[2][4], sx[2], rg[2][4];                          // x: one register set (two units); g: [set][column]
+    float4 rx[2][4], sx[2], rg[4][4];                          // x: one register set (two units); g: [set = phase of the tile][column]
     const int ux0 = tid, ux1 = min(tid + 256, XR * 5 * 16 - 1);
     const int xq0 = ux0 & 15, xcg0 = (ux0 >> 4) % 5, xrow0 = (ux0 >> 4) / 5;
     const int xq1 = ux1 & 15, xcg1 = (ux1 >> 4) % 5, xrow1 = (ux1 >> 4) / 5;
@@ -519,7 +519,7 @@ __global__ void __launch_bounds__(256, 1) wgrad_up_bf16_kernel(const WgUpParams 
         constexpr int J = decltype(j_tag)::value;                      // phase of the tile: parities in the order 3, 1, 2, 0
         constexpr int PAR = J == 0 ? 3 : J == 1 ? 1 : J == 2 ? 2 : 0, PP = PAR >> 1, PQ = PAR & 1;
         constexpr int DYM = PP ? 2 : 3, DXM = PQ ? 2 : 3, NDY = popc3(DYM), NG = QH * NDY;
-        constexpr int NP = J >= 2 ? 8 : 4;                             // pieces that ride in this phase
+        constexpr int NP = J == 3 ? 12 : 4;                            // pieces that ride in this phase (the 4-tap phase also converts x)
         const char* xst = lds + xs * UBX;
         const char* gst = lds + 2 * UBX + (J & 1) * UBG;
         Raw cur_a = read_a(xst, nth3(DYM, 0));
@@ -527,8 +527,8 @@ __global__ void __launch_bounds__(256, 1) wgrad_up_bf16_kernel(const WgUpParams 
         u32x4 bl = *reinterpret_cast<const u32x4*>(gst + bbase + GPART);
         auto piece = [&](auto k_tag) __attribute__((always_inline)) {
             constexpr int K = decltype(k_tag)::value;
-            if constexpr (K < 4) g_piece((J + 1) & 1, std::integral_constant<int, (J + 1) & 1>{}, std::integral_constant<int, (K < 4 ? K : 0)>{});
-            else x_piece(xs ^ 1, std::integral_constant<int, (J == 3 ? 4 : 0) + (K >= 4 ? K - 4 : 0)>{});
+            if constexpr (K < 4) g_piece((J + 1) & 1, std::integral_constant<int, (J + 1) & 3>{}, std::integral_constant<int, (K < 4 ? K : 0)>{});
+            else x_piece(xs ^ 1, std::integral_constant<int, (K >= 4 ? K - 4 : 0)>{});
         };
         auto step = [&](auto g_tag) __attribute__((always_inline)) {
             constexpr int G = decltype(g_tag)::value;
@@ -576,10 +576,15 @@ __global__ void __launch_bounds__(256, 1) wgrad_up_bf16_kernel(const WgUpParams 
         __syncthreads();
     };
 
-    // prologue: x of the first tile and the gradient tiles of its first two phases; first x patch and first g tile converted
+    // prologue: x of the first tile and the gradient tiles of its four phases (register set = phase); first x patch and first g tile
+    // converted.  In the loop the gradient tile of (tile u+1, phase J) is loaded at the start of (tile u, phase J) — a whole tile
+    // ahead: with two sets / two phases ahead (first version) a phase of 12 - 24 MFMAs was over before its successor's loads had
+    // landed, SQ_WAIT_ANY 43 % of the wave cycles, MFMA pipe 0.27 busy — and converted inside the phase before its own.
     fetch_x(u_begin);
     fetch_g(u_begin, std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{});
     fetch_g(u_begin, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+    fetch_g(u_begin, std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
+    fetch_g(u_begin, std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{});
     x_piece(0, std::integral_constant<int, 0>{}); x_piece(0, std::integral_constant<int, 1>{});
     x_piece(0, std::integral_constant<int, 2>{}); x_piece(0, std::integral_constant<int, 3>{});
     x_piece(0, std::integral_constant<int, 4>{}); x_piece(0, std::integral_constant<int, 5>{});
@@ -591,15 +596,15 @@ __global__ void __launch_bounds__(256, 1) wgrad_up_bf16_kernel(const WgUpParams 
     __syncthreads();
     int xs = 0;
     for (int u = u_begin; u < u_end; ++u) {
-        // phase 0 (parity 3) runs; loads: x of tile u+1, gradient of phase 2 (parity 2) of this tile -> set 0
-        fetch_x(u + 1);
-        fetch_g(u, std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{});
+        // (set J held tile u's phase-J tile, converted during phase J - 1: free when phase J starts)
+        fetch_x(u + 1);                                                                          // converted inside phase 3
+        fetch_g(u + 1, std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{});
         phase(xs, std::integral_constant<int, 0>{});
-        fetch_g(u, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});         // phase 3 (parity 0) -> set 1
+        fetch_g(u + 1, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
         phase(xs, std::integral_constant<int, 1>{});
-        fetch_g(u + 1, std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{});     // next tile, phase 0 -> set 0
+        fetch_g(u + 1, std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
         phase(xs, std::integral_constant<int, 2>{});
-        fetch_g(u + 1, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});     // next tile, phase 1 -> set 1
+        fetch_g(u + 1, std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{});
         phase(xs, std::integral_constant<int, 3>{});
         xs ^= 1;
     }
