@@ -14,7 +14,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # (HFAGP_LIB_PATH: developer override, used by the ablation builds of tools/dev/ — the product loads the in-tree library)
 LIB_PATH = os.environ.get("HFAGP_LIB_PATH") or os.path.join(_HERE, "libhfagp_hip.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 c_float_p = C.c_void_p  # device pointers travel as integers
 
@@ -136,7 +136,7 @@ class StyleBwdItem(C.Structure):
 class RaymarchBwdArgs(C.Structure):
     _fields_ = [("fwd", RaymarchArgs), ("g_feat", C.c_void_p), ("d_planes", C.c_void_p), ("rec", C.c_void_p),
                 ("d_dec_w0", C.c_void_p), ("d_dec_b0", C.c_void_p), ("d_dec_w1", C.c_void_p), ("d_dec_b1", C.c_void_p),
-                ("df_scratch", C.c_void_p)]
+                ("df_scratch", C.c_void_p), ("rows_scratch", C.c_void_p), ("rows_scratch_bytes", C.c_uint64)]
 
 
 # every symbol include/hfagp.h declares: name -> (restype, argtypes)
@@ -172,6 +172,7 @@ SYMBOLS = {
     "hfagp_style_bwd": (C.c_int, [C.POINTER(StyleBwdArgs), C.c_void_p]),
     "hfagp_style_batch_bwd": (C.c_int, [C.POINTER(StyleBwdItem), C.c_int32, C.c_void_p]),
     "hfagp_raymarch_bwd": (C.c_int, [C.POINTER(RaymarchBwdArgs), C.c_void_p]),
+    "hfagp_raymarch_bwd_rows_bytes": (C.c_size_t, [C.POINTER(RaymarchArgs)]),
     "hfagp_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p]),
     "hfagp_adam_chunk": (C.c_int32, []),
     "hfagp_weight_prep_batch": (C.c_int, [C.POINTER(WeightPrepItem), C.c_int32, C.c_void_p]),

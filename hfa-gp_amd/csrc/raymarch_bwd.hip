@@ -46,12 +46,12 @@ template <bool PG> struct BwdWaves { static constexpr int value = PG ? 4 : 6; };
 // global atomics take 3.2 ms for; what is left here is gather + decoder forward / backward + the weight-gradient MFMAs).
 // (the decoder-gradient-only variant with 8 waves per CU — the LDS would allow it without the scatter tables — measured
 // 2.2 ms against 1.9 ms: 256 registers per wave instead of 512 spill)
-template <bool PG, bool SCATTER> struct TileWaves { static constexpr int value = BwdWaves<PG>::value; };
+template <bool PG, bool SCATTER> struct TileWaves { static constexpr int value = SCATTER ? BwdWaves<PG>::value : 4; };
 
 template <int S, bool PG, bool MIRROR, bool DEC16, bool SCATTER = true>
 __global__ void __launch_bounds__((TileWaves<PG, SCATTER>::value * 64), (PG ? 1 : 2))
-raymarch_bwd_tiles_kernel(const RayParams p, float* __restrict__ d_planes, const DecGrads dg) {
-    static_assert(SCATTER || PG, "without the scatter only the decoder gradients are left");
+raymarch_bwd_tiles_kernel(const RayParams p, float* __restrict__ d_planes, const DecGrads dg, const RowsOut ro) {
+    // (SCATTER = false, PG = false: dL/dF to the sorted slots alone — the generator-frozen pass of the sort + gather form)
     constexpr int NWB = TileWaves<PG, SCATTER>::value, NTHB = NWB * 64;
     __shared__ TileLds lds_all[SCATTER ? NWB : 1];
     // (sized 1 float instead of one GradLds when the decoder gradients are off: 13 KB less -> 3 workgroups per CU)
@@ -120,12 +120,13 @@ raymarch_bwd_tiles_kernel(const RayParams p, float* __restrict__ d_planes, const
     // the saved depths of tile i+2 and the 24 texel loads of tile i+1 are in flight while tile i runs its decoder and its 64
     // weight-gradient MFMAs.  Without it the wave walked  rec load -> taps -> gather -> decoder -> MFMAs  strictly in sequence,
     // alone on its SIMD: 5.7 us per tile, 1.1 ms per 2 frames for 0.16 ms of matrix work.
-    constexpr bool PIPE = PG && !SCATTER;
-    struct RecPre { int b, ray; float o3[3], d3[3]; float4 rec; float zq; float4 gf[2]; };
+    constexpr bool PIPE = !SCATTER;
+    struct RecPre { int b, ray, tt; float o3[3], d3[3]; float4 rec; float zq; float4 gf[2]; DfSlots slots; };
     struct GatPre { float w[3][4]; float4 v0[3][4], v1[3][4]; };
     auto issue_rec = [&](long long tile) __attribute__((always_inline)) {
         RecPre r;
         const int tt = __builtin_amdgcn_readfirstlane((int)(tile % NT));
+        r.tt = tt;
         int pi, pj;
         ray_of(__builtin_amdgcn_readfirstlane((int)(tile / NT)), a.res, r.b, pi, pj);
         r.ray = __builtin_amdgcn_readfirstlane(r.b * R + pi * a.res + pj);
@@ -134,6 +135,7 @@ raymarch_bwd_tiles_kernel(const RayParams p, float* __restrict__ d_planes, const
         r.zq = p.rec[((size_t)r.ray * S + 16 * tt + (lane >> 2)) * 4];
 #pragma unroll
         for (int ot = 0; ot < 2; ++ot) r.gf[ot] = *reinterpret_cast<const float4*>(p.g_feat + (size_t)r.ray * 32 + 16 * ot + 4 * g);
+        if (ro.dfs) r.slots = load_df_slots(ro, (size_t)r.ray * S + 16 * tt + j);
         return r;
     };
     auto issue_gather = [&](const RecPre& r) __attribute__((always_inline)) {
@@ -189,7 +191,8 @@ raymarch_bwd_tiles_kernel(const RayParams p, float* __restrict__ d_planes, const
         float f[8];
         float4 gfeat[2];
         PlaneTaps taps[3];
-        int b = 0, ray = 0;
+        int b = 0, ray = 0, tt = 0;
+        DfSlots slots;
         if constexpr (PIPE) {
             // tile i+1: its depths have landed -> taps -> its 24 texel loads go out; tile i+2: its depths go out; THEN tile i
             // (past the wave's last tile the pipeline re-loads that tile: no branch, nothing is used twice)
@@ -197,13 +200,14 @@ raymarch_bwd_tiles_kernel(const RayParams p, float* __restrict__ d_planes, const
             const RecPre r_nn = issue_rec(min(tile + 2 * sch.stride, last_tile));
             __builtin_amdgcn_sched_barrier(0);
             rec = r_cur.rec; gfeat[0] = r_cur.gf[0]; gfeat[1] = r_cur.gf[1];
+            ray = r_cur.ray; tt = r_cur.tt; slots = r_cur.slots;
             finish_gather(g_cur, f);
             const int src = 4 * j + g;
 #pragma unroll
             for (int c = 0; c < 8; ++c) f[c] = __shfl(f[c], src);
             r_cur = r_nxt; r_nxt = r_nn; g_cur = g_nxt;
         } else {
-        const int tt = __builtin_amdgcn_readfirstlane((int)(tile % NT));        // wave-uniform -> scalar registers
+        tt = __builtin_amdgcn_readfirstlane((int)(tile % NT));        // wave-uniform -> scalar registers
         int pi, pj;
         ray_of(__builtin_amdgcn_readfirstlane((int)(tile / NT)), a.res, b, pi, pj);
         ray = __builtin_amdgcn_readfirstlane(b * R + pi * a.res + pj);
@@ -277,6 +281,9 @@ raymarch_bwd_tiles_kernel(const RayParams p, float* __restrict__ d_planes, const
             if constexpr (SCATTER)
                 *reinterpret_cast<float4*>(&lds.df[j * 32 + 16 * ft + 4 * g]) =
                     make_float4(dF[ft][0], dF[ft][1], dF[ft][2], dF[ft][3]);
+        }
+        if constexpr (!SCATTER) {           // sort + gather form of d planes (raymarch_rows.hip): dL/dF to the sample's slots
+            if (ro.dfs) store_df_sorted(ro, slots, g, dF);
         }
         if constexpr (PG) {
             // operand images for the weight-gradient products + running bias / sigma-row sums
@@ -752,9 +759,9 @@ raymarch_bwd_cols_kernel(const RayParams p, float* __restrict__ d_planes, const 
 // The scratch round trip is 0.4 GB per frame of streaming traffic; taken when the caller provides HfagpRaymarchBwdArgs::df_scratch.
 constexpr int kDfWaves = 4;      // two workgroups per CU (254 VGPRs: two waves per SIMD, as the forward kernel)
 
-template <int S, bool DEC16>
+template <int S, bool DEC16, bool SORTED>
 __global__ void __launch_bounds__(kDfWaves * 64, 2)
-raymarch_bwd_df_kernel(const RayParams p, float* __restrict__ df_out) {
+raymarch_bwd_df_kernel(const RayParams p, float* __restrict__ df_out, const RowsOut ro) {
     __shared__ float w1t[4 * 8 * 64];
     __shared__ float w0t[2 * 16 * 64];
     __shared__ float wfwd[kDecLdsRows * 64];
@@ -798,6 +805,8 @@ raymarch_bwd_df_kernel(const RayParams p, float* __restrict__ df_out) {
         ray_setup(a, b, pi, pj, o3, d3);
         const int s = 16 * tt + j;
         const float4 rec = *reinterpret_cast<const float4*>(p.rec + ((size_t)ray * S + s) * 4);   // depth, omega, dsigma
+        DfSlots slots;
+        if constexpr (SORTED) slots = load_df_slots(ro, (size_t)ray * S + s);      // lands while the tile runs its decoder
         float f[8];
         {
             PlaneTaps tq[3];
@@ -843,20 +852,19 @@ raymarch_bwd_df_kernel(const RayParams p, float* __restrict__ df_out) {
         float* dst = df_out + ((size_t)ray * S + s) * 32 + 4 * g;
 #pragma unroll
         for (int ft = 0; ft < 2; ++ft) {
-            f32x4 dF = f32x4{0.f, 0.f, 0.f, 0.f};
-            if constexpr (DEC16) {
-                dF = dF2[ft];
-            } else {
+            if constexpr (!DEC16) {
+                dF2[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float wA = w0t[(ft * 16 + mt * 4 + r) * 64 + lane];
-                        dF = __builtin_amdgcn_mfma_f32_16x16x4f32(wA, dH[mt][r], dF, 0, 0, 0);
+                        dF2[ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(wA, dH[mt][r], dF2[ft], 0, 0, 0);
                     }
             }
-            *reinterpret_cast<float4*>(dst + 16 * ft) = make_float4(dF[0], dF[1], dF[2], dF[3]);
+            if constexpr (!SORTED) *reinterpret_cast<float4*>(dst + 16 * ft) = make_float4(dF2[ft][0], dF2[ft][1], dF2[ft][2], dF2[ft][3]);
         }
+        if constexpr (SORTED) store_df_sorted(ro, slots, g, dF2);                     // sort + gather form: raymarch_rows.hip
     }
 }
 
@@ -1058,21 +1066,40 @@ template <int S, bool DEC16>
 static void launch_tiles2(bool pg, bool mirror, unsigned blocks, const RayParams& p, float* d_planes, const DecGrads& dg,
                           hipStream_t s) {
     if (pg) {
-        if (mirror) raymarch_bwd_tiles_kernel<S, true, true, DEC16><<<blocks, BwdWaves<true>::value * 64, 0, s>>>(p, d_planes, dg);
-        else raymarch_bwd_tiles_kernel<S, true, false, DEC16><<<blocks, BwdWaves<true>::value * 64, 0, s>>>(p, d_planes, dg);
+        if (mirror) raymarch_bwd_tiles_kernel<S, true, true, DEC16><<<blocks, BwdWaves<true>::value * 64, 0, s>>>(p, d_planes, dg, RowsOut{});
+        else raymarch_bwd_tiles_kernel<S, true, false, DEC16><<<blocks, BwdWaves<true>::value * 64, 0, s>>>(p, d_planes, dg, RowsOut{});
     } else {
-        if (mirror) raymarch_bwd_tiles_kernel<S, false, true, DEC16><<<blocks, BwdWaves<false>::value * 64, 0, s>>>(p, d_planes, dg);
-        else raymarch_bwd_tiles_kernel<S, false, false, DEC16><<<blocks, BwdWaves<false>::value * 64, 0, s>>>(p, d_planes, dg);
+        if (mirror) raymarch_bwd_tiles_kernel<S, false, true, DEC16><<<blocks, BwdWaves<false>::value * 64, 0, s>>>(p, d_planes, dg, RowsOut{});
+        else raymarch_bwd_tiles_kernel<S, false, false, DEC16><<<blocks, BwdWaves<false>::value * 64, 0, s>>>(p, d_planes, dg, RowsOut{});
     }
 }
 
 // decoder-parameter gradients only (d planes is the column kernel's job)
 template <int S>
-static void launch_decoder_grads(unsigned blocks, const RayParams& p, float* d_planes, const DecGrads& dg, hipStream_t s) {
+static void launch_decoder_grads(unsigned blocks, const RayParams& p, float* d_planes, const DecGrads& dg, const RowsOut& ro,
+                                 hipStream_t s) {
     if (p.a.planes_absmax)
-        raymarch_bwd_tiles_kernel<S, true, true, true, false><<<blocks, TileWaves<true, false>::value * 64, 0, s>>>(p, d_planes, dg);
+        raymarch_bwd_tiles_kernel<S, true, true, true, false><<<blocks, TileWaves<true, false>::value * 64, 0, s>>>(p, d_planes, dg, ro);
     else
-        raymarch_bwd_tiles_kernel<S, true, true, false, false><<<blocks, TileWaves<true, false>::value * 64, 0, s>>>(p, d_planes, dg);
+        raymarch_bwd_tiles_kernel<S, true, true, false, false><<<blocks, TileWaves<true, false>::value * 64, 0, s>>>(p, d_planes, dg, ro);
+}
+
+// sort + gather form: dL/dF of every sample to its slots (generator frozen: no decoder gradients)
+template <int S>
+static void launch_df_sorted(const RayParams& p, const RowsOut& ro, hipStream_t s) {
+    const long long ntiles = (long long)p.total_rays * (S / 16);
+    static const bool piped = getenv("HFAGP_DEV_DF_PIPE") != nullptr;        // developer switch: A/B timing
+    if (piped) {
+        const unsigned blocks = (unsigned)std::min<long long>((ntiles + 3) / 4, (long long)kNumCU * 2);
+        if (p.a.planes_absmax)
+            raymarch_bwd_tiles_kernel<S, false, true, true, false><<<blocks, 256, 0, s>>>(p, nullptr, DecGrads{}, ro);
+        else
+            raymarch_bwd_tiles_kernel<S, false, true, false, false><<<blocks, 256, 0, s>>>(p, nullptr, DecGrads{}, ro);
+        return;
+    }
+    const unsigned dblocks = (unsigned)std::min<long long>((ntiles + kDfWaves - 1) / kDfWaves, (long long)kNumCU * 2 * 8);
+    if (p.a.planes_absmax) raymarch_bwd_df_kernel<S, true, true><<<dblocks, kDfWaves * 64, 0, s>>>(p, nullptr, ro);
+    else raymarch_bwd_df_kernel<S, false, true><<<dblocks, kDfWaves * 64, 0, s>>>(p, nullptr, ro);
 }
 
 template <int S>
@@ -1111,8 +1138,8 @@ static int launch_df_scatter(const RayParams& p, float* df, float* d_planes, uns
                              hipStream_t s) {
     const long long ntiles = (long long)p.total_rays * (S / 16);
     const unsigned dblocks = (unsigned)std::min<long long>((ntiles + kDfWaves - 1) / kDfWaves, (long long)kNumCU * 2 * 8);
-    if (p.a.planes_absmax) raymarch_bwd_df_kernel<S, true><<<dblocks, kDfWaves * 64, 0, s>>>(p, df);
-    else raymarch_bwd_df_kernel<S, false><<<dblocks, kDfWaves * 64, 0, s>>>(p, df);
+    if (p.a.planes_absmax) raymarch_bwd_df_kernel<S, true, false><<<dblocks, kDfWaves * 64, 0, s>>>(p, df, RowsOut{});
+    else raymarch_bwd_df_kernel<S, false, false><<<dblocks, kDfWaves * 64, 0, s>>>(p, df, RowsOut{});
     const size_t lds = scatter_lds_bytes();
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&raymarch_bwd_scatter_kernel<S>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1159,6 +1186,28 @@ extern "C" int hfagp_raymarch_bwd(const HfagpRaymarchBwdArgs* a, void* stream) {
                   "raymarch_bwd: decoder gradients need all four buffers");
     // planes 1 and 2 mirror each other for EG3D's original axes on square planes: scatter plane 1 only
     const bool mirror = a->fwd.plane_axes == 0 && a->fwd.H == a->fwd.W;
+    // sort + gather form (raymarch_rows.hip): the caller provided its scratch buffer
+    if (a->rows_scratch) {
+        RowsOut ro;
+        rc = rows_prepare(p, a->rows_scratch, a->rows_scratch_bytes, ro, s);
+        if (rc != HFAGP_OK) return rc;
+        if (pg) {
+            // decoder MLP gradients + dL/dF in one pass (one wave per SIMD: the pass that was the decoder gradients alone)
+            const unsigned gblocks = (unsigned)std::min<long long>((ntiles + 3) / 4, (long long)kNumCU);
+            if (S == 96) launch_decoder_grads<96>(gblocks, p, a->d_planes, dg, ro, s);
+            else if (S == 64) launch_decoder_grads<64>(gblocks, p, a->d_planes, dg, ro, s);
+            else launch_decoder_grads<32>(gblocks, p, a->d_planes, dg, ro, s);
+        } else if (S == 96) launch_df_sorted<96>(p, ro, s);
+        else if (S == 64) launch_df_sorted<64>(p, ro, s);
+        else launch_df_sorted<32>(p, ro, s);
+        rc = rows_gather(p, a->rows_scratch, a->d_planes, s);
+        if (rc != HFAGP_OK) return rc;
+        if (mirror) {
+            const long long n = (long long)a->fwd.B * a->fwd.H * a->fwd.W * 8;
+            mirror_plane_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(a->d_planes, a->fwd.B, a->fwd.H);
+        }
+        return check_launch("raymarch_bwd/rows");
+    }
     // frozen generator + mirrored square planes up to 256^2: the column variant (LDS line cache for plane (x,z))
     static const bool no_cols = getenv("HFAGP_DEV_NO_COLS") != nullptr;      // developer switch: A/B timing
     if (mirror && a->fwd.H <= kColMaxRows && !no_cols) {
@@ -1180,9 +1229,9 @@ extern "C" int hfagp_raymarch_bwd(const HfagpRaymarchBwdArgs* a, void* stream) {
             // one resident workgroup per CU (109 KB of LDS); every wave ends with ~4.3 k atomics on the SAME gradient
             // buffers, so the grid is the chip, not a multiple of it (x16: 1.90 ms, x1: 1.09 ms per B = 2 call)
             const unsigned gblocks = (unsigned)std::min<long long>((ntiles + 3) / 4, (long long)kNumCU);
-            if (S == 96) launch_decoder_grads<96>(gblocks, p, a->d_planes, dg, s);
-            else if (S == 64) launch_decoder_grads<64>(gblocks, p, a->d_planes, dg, s);
-            else launch_decoder_grads<32>(gblocks, p, a->d_planes, dg, s);
+            if (S == 96) launch_decoder_grads<96>(gblocks, p, a->d_planes, dg, RowsOut{}, s);
+            else if (S == 64) launch_decoder_grads<64>(gblocks, p, a->d_planes, dg, RowsOut{}, s);
+            else launch_decoder_grads<32>(gblocks, p, a->d_planes, dg, RowsOut{}, s);
         }
     } else if (S == 96) launch_tiles<96>(pg, mirror, (unsigned)blocks, p, a->d_planes, dg, s);
     else if (S == 64) launch_tiles<64>(pg, mirror, (unsigned)blocks, p, a->d_planes, dg, s);

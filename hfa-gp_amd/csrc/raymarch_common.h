@@ -42,6 +42,16 @@ inline int fill_ray_params(const HfagpRaymarchArgs* a, RayParams& p, const char*
 
 int launch_raymarch(const RayParams& p, bool grads, hipStream_t s);   // raymarch.hip
 
+// sort + gather form of the backward pass 2 (raymarch_rows.hip): where the dL/dF producers write a sample's line
+struct RowsOut {
+    const int2* pos;     // [samples][P] (slot, slot of the second entry or -1)
+    unsigned* dfs;       // [slots][32] bf16 hi << 16 | bf16 lo
+    int P;               // planes scattered (2: planes 1 and 2 mirror each other)
+};
+size_t rows_scratch_bytes(const HfagpRaymarchArgs& a);                                         // 0: variant does not apply
+int rows_prepare(const RayParams& p, void* scratch, size_t bytes, RowsOut& out, hipStream_t s);    // S1, scan, S2
+int rows_gather(const RayParams& p, void* scratch, float* d_planes, hipStream_t s);               // G
+
 // XCD-local ray schedule (MI355X: 8 XCDs, each with its own 4 MB L2; block b runs on XCD b % 8).  The planes of a frame
 // are 25 MB — no L2 holds them — and with rays dealt round-robin over the blocks every XCD walks every region of every
 // frame's planes: measured 2.07 GB of L2 fills per 8-frame launch against 0.22 GB compulsory.  Here
@@ -158,10 +168,15 @@ struct PlaneTaps {            // the 4 bilinear taps of one plane: texel index (
 
 // F.grid_sample(bilinear, zeros, align_corners=False) as ATen's CPU kernel computes it:
 // pixel = (g + 1) * (size / 2) - 0.5;  weights nw = (1-fy)(1-fx), ne = (1-fy)fx, sw = fy(1-fx), se = fy fx
+__device__ __forceinline__ void plane_pixel(const HfagpRaymarchArgs& a, float gx, float gy, float& ix, float& iy) {
+    ix = __fsub_rn(__fmul_rn(__fadd_rn(gx, 1.f), (float)a.W * 0.5f), 0.5f);
+    iy = __fsub_rn(__fmul_rn(__fadd_rn(gy, 1.f), (float)a.H * 0.5f), 0.5f);
+}
+
 __device__ __forceinline__ void plane_taps(const HfagpRaymarchArgs& a, float gx, float gy, PlaneTaps& t) {
     const float fW = (float)a.W, fH = (float)a.H;
-    const float ix = __fsub_rn(__fmul_rn(__fadd_rn(gx, 1.f), fW * 0.5f), 0.5f);
-    const float iy = __fsub_rn(__fmul_rn(__fadd_rn(gy, 1.f), fH * 0.5f), 0.5f);
+    float ix, iy;
+    plane_pixel(a, gx, gy, ix, iy);
     const float fx0 = floorf(ix), fy0 = floorf(iy);
     const float we = __fsub_rn(ix, fx0), ww = __fsub_rn(1.f, we);
     const float ws_ = __fsub_rn(iy, fy0), wn = __fsub_rn(1.f, ws_);
@@ -181,11 +196,20 @@ __device__ __forceinline__ void plane_taps(const HfagpRaymarchArgs& a, float gx,
 }
 
 // sample position -> the three plane projections: (x,y), (x,z), (z,x) [eg3d original] or (z,y) [fixed]
+__device__ __forceinline__ void sample_point(const RayParams& p, const float o3[3], const float d3[3], float tz, float q[3]) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) q[k] = __fmul_rn(p.coord_scale, __fadd_rn(o3[k], __fmul_rn(tz, d3[k])));
+}
+// grid coordinates (gx, gy) of plane pl for the normalised sample point q
+__device__ __forceinline__ void plane_coords(const HfagpRaymarchArgs& a, const float q[3], int pl, float& gx, float& gy) {
+    gx = pl == 2 ? q[2] : q[0];
+    gy = pl == 0 ? q[1] : pl == 1 ? q[2] : (a.plane_axes == 0 ? q[0] : q[1]);
+}
+
 __device__ __forceinline__ void sample_taps(const RayParams& p, const float o3[3], const float d3[3], float tz,
                                             PlaneTaps taps[3]) {
     float q[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) q[k] = __fmul_rn(p.coord_scale, __fadd_rn(o3[k], __fmul_rn(tz, d3[k])));
+    sample_point(p, o3, d3, tz, q);
     plane_taps(p.a, q[0], q[1], taps[0]);
     plane_taps(p.a, q[0], q[2], taps[1]);
     plane_taps(p.a, q[2], p.a.plane_axes == 0 ? q[0] : q[1], taps[2]);
@@ -345,6 +369,45 @@ __device__ __forceinline__ f32x4 mfma3_bf16(u32x4r ah, u32x4r al, u32x4r bh, u32
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8r, al), __builtin_bit_cast(bf16x8r, bh), c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8r, ah), __builtin_bit_cast(bf16x8r, bl), c, 0, 0, 0);
     return c;
+}
+
+// dL/dF of sample j, lane (j, g): channels 16 ft + 4 g .. + 3 -> the sample's slots, split into bf16 hi << 16 | bf16 lo
+struct DfSlots { int2 sl[3]; };
+__device__ __forceinline__ DfSlots load_df_slots(const RowsOut& ro, size_t sample) {        // early: the stores depend on it
+    DfSlots d;
+    const int2* ps = ro.pos + sample * ro.P;
+    d.sl[0] = ps[0]; d.sl[1] = ps[1];
+    d.sl[2] = ro.P > 2 ? ps[2] : make_int2(-1, -1);
+    return d;
+}
+__device__ __forceinline__ void store_df_sorted(const RowsOut& ro, const DfSlots& ds, int g, const f32x4 dF[2]) {
+    uint4 w[2];
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft) {
+        unsigned o[4];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const f32x2r x = {dF[ft][2 * q], dF[ft][2 * q + 1]};
+            const unsigned hh = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2r));
+            const f32x2r r = {x[0] - __builtin_bit_cast(float, hh << 16), x[1] - __builtin_bit_cast(float, hh & 0xffff0000u)};
+            const unsigned ll = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2r));
+            o[2 * q] = (hh << 16) | (ll & 0xffffu);
+            o[2 * q + 1] = (hh & 0xffff0000u) | (ll >> 16);
+        }
+        w[ft] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+        const int2 sl = ds.sl[pl];
+        if (sl.x >= 0) {
+            uint4* d = reinterpret_cast<uint4*>(ro.dfs + (size_t)sl.x * 32 + 4 * g);
+            d[0] = w[0]; d[4] = w[1];
+        }
+        if (sl.y >= 0) {
+            uint4* d = reinterpret_cast<uint4*>(ro.dfs + (size_t)sl.y * 32 + 4 * g);
+            d[0] = w[0]; d[4] = w[1];
+        }
+    }
 }
 
 // wave-wide max of a non-negative value (all 64 lanes)

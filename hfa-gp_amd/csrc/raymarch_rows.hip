@@ -1,0 +1,347 @@
+// Ray-march backward, pass 2 as SORT + GATHER (gfx950): d planes without the per-sample scatter.
+//
+// The scatter forms (raymarch_bwd.hip) push every sample's dL/dF line into 8-12 texel lines of d_planes: ~10 M fp32 line
+// atomics per 2 frames (fabric transactions: 1.1 GB of write traffic for a 50 MB output) or a walk through an LDS line cache.
+// Here the samples are SORTED by where they land and every output row is produced by dense matrix products:
+//
+//   bin    = (frame, plane, 32-texel column strip xb, texel row y0 = floor(iy))        P * ceil(W/32) * (H+1) bins per frame
+//            a sample of bin (xb, y0) touches rows y0 (weight 1 - wy) and y0 + 1 (weight wy) of the strip, at the columns
+//            floor(ix), floor(ix) + 1 (a sample whose column pair straddles two strips is entered in both);
+//   S1     raymarch_bwd_bins_kernel<false>: per 32-ray column chunk an LDS histogram of the bins, added to the global counts;
+//   scan   raymarch_bwd_scan_kernel: bin -> slot offset (bins padded to 16 slots), and the list of units = bin chunks of
+//          <= 1024 slots;
+//   S2     raymarch_bwd_bins_kernel<true>: reserves the chunk's range of every bin with ONE global atomic per bin, ranks its
+//          samples inside with LDS atomics, writes (ix, wy) to the slot and the slot number to pos[sample][plane];
+//   dF     raymarch_bwd_df_kernel / raymarch_bwd_tiles_kernel<PG> (raymarch_bwd.hip) write dL/dF of a sample, split into
+//          bf16 hi | lo, straight to its slots: the gather below then STREAMS contiguous memory;
+//   G      raymarch_bwd_rows_kernel: one wave per unit;  per batch of 16 slots
+//              A[m][k] = hat(ix_k - x_m) * rowweight_k / 3     32 texels x 16 samples, built in registers, split bf16 hi + lo
+//              B[k][c] = dL/dF[k][c]                            16 samples x 32 channels, v_perm of the packed words
+//              acc_row(y0), acc_row(y0+1) += A . B              2 x 3 v_mfma_f32_32x32x16_bf16
+//          hat(t) = max(0, 1 - |t|) IS the bilinear weight of grid_sample (bit for bit: ix - x0 and ix - (x0 + 1) are exact),
+//          and a texel outside the plane simply is no row / column of any strip (zeros padding).
+//          At the end the two 32 x 32 row tiles are added to d_planes: two addends per output element and bin chunk
+//          (~0.7 M line atomics per 2 frames instead of ~10 M), nothing per sample.
+#include <algorithm>
+#include <cstdlib>
+#include "raymarch_common.h"
+
+namespace hfagp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kRowsStrip = 32;          // texel columns per strip = M of the MFMA
+constexpr int kRowsUnit = 1024;         // slots per unit (a multiple of 16)
+constexpr int kRowsMaxBins = 8192;      // bins per frame the two LDS tables of S2 hold (64 KB)
+constexpr int kRowsRays = 32;           // rays of a column chunk (S1 / S2 block)
+
+struct RowsDev {
+    unsigned* cnt;       // [NB]      entries per bin
+    unsigned* off;       // [NB + 1]  first slot of the bin (bins padded to 16 slots)
+    unsigned* cursor;    // [NB]      S2: next free slot of the bin
+    unsigned* meta;      // [4]       number of units, number of slots
+    int4* units;         // [max_units] (bin, first slot, end slot, -)
+    int2* pos;           // [samples][P] slot of the sample in plane p (and of its second entry), -1 = none
+    float* ix;           // [cap] column coordinate of the slot's sample
+    float* wy;           // [cap] row fraction
+    unsigned* dfs;       // [cap][32] dL/dF, bf16 hi << 16 | bf16 lo
+    int P, XB, H1, NBF, NB, max_units, unit;
+    unsigned cap;
+};
+
+static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// carve the scratch buffer; returns the bytes needed (base may be null), 0 when the variant does not apply
+static size_t rows_layout(const HfagpRaymarchArgs& a, unsigned char* base, RowsDev& d) {
+    const bool mirror = a.plane_axes == 0 && a.H == a.W;
+    d.P = mirror ? 2 : 3;
+    d.XB = (a.W + kRowsStrip - 1) / kRowsStrip;
+    d.H1 = a.H + 1;
+    const long long nbf = (long long)d.P * d.XB * d.H1;
+    if (nbf > kRowsMaxBins) return 0;
+    d.NBF = (int)nbf;
+    const long long nb = nbf * a.B;
+    const long long samples = (long long)a.B * a.res * a.res * (a.Sc + a.Sf);
+    const long long cap = 2ll * d.P * samples + 16ll * nb;
+    if (nb > (1ll << 24) || cap >= (1ll << 31)) return 0;
+    d.NB = (int)nb;
+    d.cap = (unsigned)cap;
+    static const int unit_env = getenv("HFAGP_DEV_ROWS_UNIT") ? atoi(getenv("HFAGP_DEV_ROWS_UNIT")) : 0;      // developer: A/B timing
+    d.unit = unit_env >= 16 ? unit_env & ~15 : kRowsUnit;
+    d.max_units = (int)(cap / d.unit + nb);
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o = align256(o + bytes); return base ? base + at : nullptr; };
+    d.cnt = reinterpret_cast<unsigned*>(take((size_t)nb * 4));
+    d.meta = reinterpret_cast<unsigned*>(take(16));
+    d.off = reinterpret_cast<unsigned*>(take((size_t)(nb + 1) * 4));
+    d.cursor = reinterpret_cast<unsigned*>(take((size_t)nb * 4));
+    d.units = reinterpret_cast<int4*>(take((size_t)d.max_units * 16));
+    d.pos = reinterpret_cast<int2*>(take((size_t)samples * d.P * 8));
+    d.ix = reinterpret_cast<float*>(take((size_t)cap * 4));
+    d.wy = reinterpret_cast<float*>(take((size_t)cap * 4));
+    d.dfs = reinterpret_cast<unsigned*>(take((size_t)cap * 128));
+    return o;
+}
+
+struct RowsKey { int key, dup; float ix, wy; };       // bin of the frame (-1: the sample has no texel in this plane)
+
+__device__ __forceinline__ RowsKey rows_key(const HfagpRaymarchArgs& a, const RowsDev& r, const float q[3], int pl) {
+    float gx, gy, ix, iy;
+    plane_coords(a, q, pl, gx, gy);
+    plane_pixel(a, gx, gy, ix, iy);
+    const float fx0 = floorf(ix), fy0 = floorf(iy);
+    const int x0 = (int)fminf(fmaxf(fx0, -2.f), (float)a.W + 1.f), y0 = (int)fminf(fmaxf(fy0, -2.f), (float)a.H + 1.f);
+    RowsKey k;
+    k.key = -1; k.dup = -1; k.ix = ix; k.wy = __fsub_rn(iy, fy0);
+    if (x0 >= -1 && x0 < a.W && y0 >= -1 && y0 < a.H) {
+        const int xb = max(x0, 0) >> 5;
+        k.key = (pl * r.XB + xb) * r.H1 + y0 + 1;
+        if (x0 >= 0 && (x0 & 31) == 31 && x0 + 1 < a.W) k.dup = k.key + r.H1;       // columns x0 | x0 + 1 in two strips
+    }
+    return k;
+}
+
+// S1 (PLACE = false) / S2 (PLACE = true): a workgroup = 32 rays of one image column (their samples fall into few bins:
+// one or two strips of every plane), thread = (ray, every 8th sample)
+template <int S, bool PLACE>
+__global__ void __launch_bounds__(256)
+raymarch_bwd_bins_kernel(const RayParams p, const RowsDev r, const int chunks_per_col) {
+    extern __shared__ unsigned rows_smem[];
+    unsigned* hist = rows_smem;                    // [NBF]
+    unsigned* base = rows_smem + r.NBF;            // [NBF], PLACE only
+    const HfagpRaymarchArgs& a = p.a;
+    const int chunk = blockIdx.x;
+    const int col_id = chunk / chunks_per_col, piece = chunk % chunks_per_col;
+    const int b = col_id / a.res, pj = col_id % a.res;
+    const int pi = piece * kRowsRays + (threadIdx.x >> 3), sub = threadIdx.x & 7;
+    const bool active = pi < a.res;
+    for (int i = threadIdx.x; i < r.NBF; i += 256) hist[i] = 0;
+    if constexpr (PLACE) {
+        // the padding slots of the bins (zeros: no weight, no gradient), dealt over the workgroups
+        for (int bin = blockIdx.x; bin < r.NB; bin += gridDim.x) {
+            const unsigned o = r.off[bin] + r.cnt[bin], e = r.off[bin + 1];
+            for (unsigned i = threadIdx.x; i < (e - o) * 32; i += 256) r.dfs[(size_t)o * 32 + i] = 0u;
+            if (threadIdx.x < e - o) { r.ix[o + threadIdx.x] = 3e38f; r.wy[o + threadIdx.x] = 0.f; }
+        }
+    }
+    __syncthreads();
+    float o3[3], d3[3];
+    ray_setup(a, b, min(pi, a.res - 1), pj, o3, d3);
+    const size_t ray = (size_t)b * a.res * a.res + (size_t)min(pi, a.res - 1) * a.res + pj;
+    const float* depth = p.rec + ray * S * 4;
+    if (active) {
+#pragma unroll 2
+        for (int s = sub; s < S; s += 8) {
+            float q[3];
+            sample_point(p, o3, d3, depth[s * 4], q);
+            for (int pl = 0; pl < r.P; ++pl) {
+                const RowsKey k = rows_key(a, r, q, pl);
+                if (k.key >= 0) atomicAdd(&hist[k.key], 1u);
+                if (k.dup >= 0) atomicAdd(&hist[k.dup], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    if constexpr (!PLACE) {
+        for (int i = threadIdx.x; i < r.NBF; i += 256) {
+            const unsigned c = hist[i];
+            if (c) atomicAdd(&r.cnt[(size_t)b * r.NBF + i], c);
+        }
+    } else {
+        for (int i = threadIdx.x; i < r.NBF; i += 256) {
+            const unsigned c = hist[i];
+            if (c) base[i] = atomicAdd(&r.cursor[(size_t)b * r.NBF + i], c);
+            hist[i] = 0;
+        }
+        __syncthreads();
+        if (active) {
+#pragma unroll 2
+            for (int s = sub; s < S; s += 8) {
+                float q[3];
+                sample_point(p, o3, d3, depth[s * 4], q);
+                for (int pl = 0; pl < r.P; ++pl) {
+                    const RowsKey k = rows_key(a, r, q, pl);
+                    int2 sl = make_int2(-1, -1);
+                    if (k.key >= 0) {
+                        sl.x = (int)(base[k.key] + atomicAdd(&hist[k.key], 1u));
+                        r.ix[sl.x] = k.ix; r.wy[sl.x] = k.wy;
+                    }
+                    if (k.dup >= 0) {
+                        sl.y = (int)(base[k.dup] + atomicAdd(&hist[k.dup], 1u));
+                        r.ix[sl.y] = k.ix; r.wy[sl.y] = k.wy;
+                    }
+                    r.pos[(ray * S + s) * r.P + pl] = sl;
+                }
+            }
+        }
+    }
+}
+
+// counts -> slot offsets (bins padded to 16 slots) + the unit list; one workgroup
+__global__ void __launch_bounds__(1024) raymarch_bwd_scan_kernel(const RowsDev r) {
+    __shared__ unsigned ssl[1024], ssu[1024];
+    const int t = threadIdx.x;
+    const int seg = (r.NB + 1023) / 1024;
+    const int i0 = min(r.NB, t * seg), i1 = min(r.NB, i0 + seg);
+    unsigned sl = 0, su = 0;
+    for (int i = i0; i < i1; ++i) {
+        const unsigned c16 = (r.cnt[i] + 15u) & ~15u;
+        sl += c16;
+        su += (c16 + r.unit - 1) / r.unit;
+    }
+    ssl[t] = sl; ssu[t] = su;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const unsigned vl = t >= o ? ssl[t - o] : 0u, vu = t >= o ? ssu[t - o] : 0u;
+        __syncthreads();
+        ssl[t] += vl; ssu[t] += vu;
+        __syncthreads();
+    }
+    unsigned ol = ssl[t] - sl, ou = ssu[t] - su;
+    for (int i = i0; i < i1; ++i) {
+        const unsigned c16 = (r.cnt[i] + 15u) & ~15u;
+        r.off[i] = ol; r.cursor[i] = ol;
+        for (unsigned k = 0; k * r.unit < c16; ++k)
+            r.units[ou++] = make_int4(i, (int)(ol + k * r.unit), (int)(ol + min(c16, (k + 1) * r.unit)), 0);
+        ol += c16;
+    }
+    if (t == 1023) { r.off[r.NB] = ssl[t]; r.meta[0] = ssu[t]; r.meta[1] = ssl[t]; }
+}
+
+// G: one wave per unit
+__global__ void __launch_bounds__(256, 2)
+raymarch_bwd_rows_kernel(const RowsDev r, float* __restrict__ d_planes, const int H, const int W) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned unit = blockIdx.x * 4 + wave;
+    if (unit >= r.meta[0]) return;
+    const int4 u = r.units[unit];
+    const int bin = __builtin_amdgcn_readfirstlane(u.x);
+    const unsigned e0 = __builtin_amdgcn_readfirstlane(u.y), e1 = __builtin_amdgcn_readfirstlane(u.z);
+    const int y0 = bin % r.H1 - 1, strip = bin / r.H1, xb = strip % r.XB, bp = strip / r.XB;
+    const int n = lane & 31, h = lane >> 5;
+    const float xm = (float)(xb * kRowsStrip + n);
+    // lane (n, h): A row m = n (texel column), B column n (channel), K = samples 8h .. 8h + 7 of the batch
+    const float* ixp = r.ix + 8 * h;
+    const float* wyp = r.wy + 8 * h;
+    const unsigned* dfp = r.dfs + (size_t)(8 * h) * 32 + n;
+    struct Batch { float4 i0, i1, w0, w1; unsigned pk[8]; };
+    auto fetch = [&](unsigned e) __attribute__((always_inline)) {
+        Batch b;
+        b.i0 = *reinterpret_cast<const float4*>(ixp + e); b.i1 = *reinterpret_cast<const float4*>(ixp + e + 4);
+        b.w0 = *reinterpret_cast<const float4*>(wyp + e); b.w1 = *reinterpret_cast<const float4*>(wyp + e + 4);
+        const unsigned* d = dfp + (size_t)e * 32;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) b.pk[t] = d[t * 32];
+        return b;
+    };
+    f32x16 acc_u, acc_l;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc_u[i] = 0.f; acc_l[i] = 0.f; }
+    Batch cur = fetch(e0);
+    for (unsigned e = e0; e < e1; e += 16) {
+        const Batch nxt = fetch(min(e + 16, e1 - 16));          // (the last batch once more: no branch around the loads)
+        const float ixs[8] = {cur.i0.x, cur.i0.y, cur.i0.z, cur.i0.w, cur.i1.x, cur.i1.y, cur.i1.z, cur.i1.w};
+        const float wys[8] = {cur.w0.x, cur.w0.y, cur.w0.z, cur.w0.w, cur.w1.x, cur.w1.y, cur.w1.z, cur.w1.w};
+        float au[8], al[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const float hx = fmaxf(1.f - fabsf(ixs[t] - xm), 0.f);
+            au[t] = (1.f - wys[t]) * hx * 0.3333333333333333f;
+            al[t] = wys[t] * hx * 0.3333333333333333f;
+        }
+        u32x4r auh, aul, alh, all_, bh, bl;
+        split8_bf16(au, auh, aul);
+        split8_bf16(al, alh, all_);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bh[q] = __builtin_amdgcn_perm(cur.pk[2 * q + 1], cur.pk[2 * q], 0x07060302u);
+            bl[q] = __builtin_amdgcn_perm(cur.pk[2 * q + 1], cur.pk[2 * q], 0x05040100u);
+        }
+        const bf16x8r vbh = __builtin_bit_cast(bf16x8r, bh), vbl = __builtin_bit_cast(bf16x8r, bl);
+        acc_u = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8r, auh), vbh, acc_u, 0, 0, 0);
+        acc_l = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8r, alh), vbh, acc_l, 0, 0, 0);
+        acc_u = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8r, aul), vbh, acc_u, 0, 0, 0);
+        acc_l = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8r, all_), vbh, acc_l, 0, 0, 0);
+        acc_u = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8r, auh), vbl, acc_u, 0, 0, 0);
+        acc_l = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8r, alh), vbl, acc_l, 0, 0, 0);
+        cur = nxt;
+    }
+    // C layout: lane (n, h), register i -> texel column 8 (i / 4) + 4 h + i % 4, channel n: two full 128-byte lines per store
+    const int b = bp / r.P, pl = bp % r.P;
+    float* plane = d_planes + ((size_t)(b * 3 + pl) * H * W) * 32 + n;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int row = y0 + half;
+        if (row < 0 || row >= H) continue;
+        float* dst = plane + ((size_t)row * W + xb * kRowsStrip) * 32;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int m = 8 * (i >> 2) + 4 * h + (i & 3);
+            if (xb * kRowsStrip + m < W) unsafeAtomicAdd(dst + m * 32, half ? acc_l[i] : acc_u[i]);
+        }
+    }
+}
+
+size_t rows_scratch_bytes(const HfagpRaymarchArgs& a) {
+    RowsDev d;
+    return rows_layout(a, nullptr, d);
+}
+
+template <int S>
+static void launch_bins(const RayParams& p, const RowsDev& d, int nchunks, int chunks_per_col, hipStream_t s) {
+    raymarch_bwd_bins_kernel<S, false><<<nchunks, 256, (size_t)d.NBF * 4, s>>>(p, d, chunks_per_col);
+    raymarch_bwd_scan_kernel<<<1, 1024, 0, s>>>(d);
+    raymarch_bwd_bins_kernel<S, true><<<nchunks, 256, (size_t)d.NBF * 8, s>>>(p, d, chunks_per_col);
+}
+
+int rows_prepare(const RayParams& p, void* scratch, size_t bytes, RowsOut& out, hipStream_t s) {
+    RowsDev d;
+    const size_t need = rows_layout(p.a, reinterpret_cast<unsigned char*>(scratch), d);
+    HFAGP_REQUIRE(need != 0 && bytes >= need, HFAGP_EBADARG, "raymarch_bwd: rows_scratch of %zu bytes, %zu needed", bytes, need);
+    static bool raised = false;
+    if (!raised) {
+        const int lds = kRowsMaxBins * 8;
+        hipError_t e = hipSuccess;
+        const void* fns[] = {reinterpret_cast<const void*>(&raymarch_bwd_bins_kernel<96, true>),
+                             reinterpret_cast<const void*>(&raymarch_bwd_bins_kernel<64, true>),
+                             reinterpret_cast<const void*>(&raymarch_bwd_bins_kernel<32, true>)};
+        for (const void* f : fns)
+            if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) {
+            set_error("raymarch_bwd: cannot raise dynamic LDS to %d bytes: %s", lds, hipGetErrorString(e));
+            return HFAGP_ELAUNCH;
+        }
+        raised = true;
+    }
+    hipError_t e = hipMemsetAsync(d.cnt, 0, (size_t)d.NB * 4, s);
+    if (e != hipSuccess) {
+        set_error("raymarch_bwd: hipMemsetAsync: %s", hipGetErrorString(e));
+        return HFAGP_ELAUNCH;
+    }
+    const int S = p.a.Sc + p.a.Sf;
+    const int chunks_per_col = (p.a.res + kRowsRays - 1) / kRowsRays;
+    const int nchunks = p.a.B * p.a.res * chunks_per_col;
+    if (S == 96) launch_bins<96>(p, d, nchunks, chunks_per_col, s);
+    else if (S == 64) launch_bins<64>(p, d, nchunks, chunks_per_col, s);
+    else launch_bins<32>(p, d, nchunks, chunks_per_col, s);
+    out.pos = d.pos;
+    out.dfs = d.dfs;
+    out.P = d.P;
+    return check_launch("raymarch_bwd/bins");
+}
+
+int rows_gather(const RayParams& p, void* scratch, float* d_planes, hipStream_t s) {
+    RowsDev d;
+    rows_layout(p.a, reinterpret_cast<unsigned char*>(scratch), d);
+    raymarch_bwd_rows_kernel<<<(unsigned)((d.max_units + 3) / 4), 256, 0, s>>>(d, d_planes, p.a.H, p.a.W);
+    return check_launch("raymarch_bwd/rows");
+}
+
+}  // namespace hfagp
+
+using namespace hfagp;
+
+extern "C" size_t hfagp_raymarch_bwd_rows_bytes(const HfagpRaymarchArgs* fwd) {
+    if (!fwd || fwd->B <= 0 || fwd->H <= 1 || fwd->W <= 1 || fwd->res <= 0) return 0;
+    return rows_scratch_bytes(*fwd);
+}

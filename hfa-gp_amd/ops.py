@@ -990,9 +990,11 @@ def raymarch_bwd(g_feat: torch.Tensor, planes: torch.Tensor, cam2world, intrinsi
                  decoder_lr_mul: float = 1.0, plane_axes: int = 0, white_back: bool = False,
                  return_rec: bool = False, decoder_grads: bool = False, decoder_precision: str = "f16x3",
                  planes_absmax: Optional[torch.Tensor] = None, state: Optional[torch.Tensor] = None,
-                 two_kernel: bool = False):
-    """g_feat [B,R,32] → d planes [B,3,H,W,32] (fp32 atomics into a zero-initialised buffer).  ``state``: what the forward
-    call of this step left behind (`raymarch(..., state=)`): the compositing adjoint reads it instead of recomputing."""
+                 two_kernel: bool = False, rows: Optional[bool] = None):
+    """g_feat [B,R,32] → d planes [B,3,H,W,32].  ``state``: what the forward call of this step left behind
+    (`raymarch(..., state=)`): the compositing adjoint reads it instead of recomputing.  ``rows``: pass 2 as sort + gather
+    (hfagp.h `rows_scratch`, csrc/raymarch_rows.hip) — None = whenever it applies and its scratch stays under 16 GiB
+    (HFAGP_RAYBWD_ROWS=0 turns the default off: A/B timing), False = the scatter kernels."""
     _chk(planes, "planes")
     _chk(g_feat, "g_feat")
     b, _, h, w, _ = planes.shape
@@ -1018,7 +1020,15 @@ def raymarch_bwd(g_feat: torch.Tensor, planes: torch.Tensor, cam2world, intrinsi
     # variant applies; 201 MB per frame at 128^2 rays x 96 samples.  OFF by default: measured SLOWER than the fused kernel
     # (B = 2: dL/dF 0.51 ms + scatter 1.41 ms against 1.58 ms fused — the scatter alone is the bound, the arithmetic already
     # hides under it; profiles/r04_raybwd_split.txt).  Kept as the vehicle for work on the scatter.
-    if two_kernel and plane_axes == 0 and h == w and h <= 256 and b * r * (sc + sf) * 128 <= (4 << 30):
+    if rows is None:
+        rows = os.environ.get("HFAGP_RAYBWD_ROWS", "1") != "0" and not two_kernel
+    scratch = None
+    if rows:
+        need = int(L.lib().hfagp_raymarch_bwd_rows_bytes(C.byref(f)))
+        if 0 < need <= (16 << 30):
+            scratch = torch.empty(need, device=planes.device, dtype=torch.uint8)
+            a.rows_scratch, a.rows_scratch_bytes = _ptr(scratch), need
+    if scratch is None and two_kernel and plane_axes == 0 and h == w and h <= 256 and b * r * (sc + sf) * 128 <= (4 << 30):
         df = torch.empty(b, r, sc + sf, 32, device=planes.device, dtype=torch.float32)
         a.df_scratch = _ptr(df)
     dec = None

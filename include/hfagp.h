@@ -61,7 +61,7 @@
 extern "C" {
 #endif
 
-#define HFAGP_ABI_VERSION 11
+#define HFAGP_ABI_VERSION 12
 
 enum { HFAGP_OK = 0, HFAGP_EBADARG = -1, HFAGP_EUNSUPPORTED = -2, HFAGP_ELAUNCH = -3 };
 
@@ -478,9 +478,21 @@ typedef struct {
      * up to 256^2), pass 2 runs as two kernels — dL/dF of every sample into the scratch buffer, then the scatter alone — instead
      * of one whose waves alternate between the two in lock step; same arithmetic, the atomic order differs as it does run to run. */
     float*       df_scratch;
+    /* optional (ABI 12): scratch of hfagp_raymarch_bwd_rows_bytes(&fwd) bytes.  Given, pass 2 runs as SORT + GATHER instead of
+     * a per-sample scatter: the samples are counting-sorted by (frame, plane, 32-texel column strip, texel row), dL/dF of every
+     * sample goes to its sorted slot, and every output row tile is a dense product  W[32 texels x 16 samples] . dL/dF[16 x 32]
+     * on the 16-bit matrix pipe (split bf16 operands), W being grid_sample's bilinear weights.  d_planes receives two adds per
+     * element and bin chunk instead of ~12 atomics per sample; takes precedence over df_scratch.  Decoder gradients (d_dec_*)
+     * come from the same pass as dL/dF.  The buffer's contents are undefined before and after the call.                       */
+    void*        rows_scratch;
+    uint64_t     rows_scratch_bytes;
 } HfagpRaymarchBwdArgs;
 
 int hfagp_raymarch_bwd(const HfagpRaymarchBwdArgs* a, void* stream);
+/* bytes of HfagpRaymarchBwdArgs::rows_scratch for this forward configuration (B, H, W, res, Sc, Sf, plane_axes are read);
+ * 0 = the sort + gather form does not apply (more than 8192 bins per frame: planes beyond ~256 x 341 texels, or more than
+ * 2^31 slots): leave rows_scratch NULL.  At 2 frames x 128^2 rays x 96 samples on mirrored 256^2 planes: 1.8 GB.            */
+size_t hfagp_raymarch_bwd_rows_bytes(const HfagpRaymarchArgs* fwd);
 
 /* ------------------------------------------------------------------ gradients w.r.t. the generator weights
  * (needed once HFA-GP calls tune_generator(), trainer_rgb.py:69-71)                                       */

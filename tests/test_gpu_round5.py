@@ -272,3 +272,69 @@ def test_multi_tensor_adam_matches_torch_adam(dev):
         p.grad = torch.ones_like(p)
     o1b.step()
     assert float(o1b.state[o1b.param_groups[0]["params"][0]]["step"]) == 4.0
+
+
+# ----------------------------------------------------------------------------- ray-march backward as sort + gather (ABI 12)
+def _raybwd_case(dev, cfg, b, seed, h=None, w=None, **override):
+    from hfa_gp_amd.generator import TriPlaneGenerator
+    from tests.util import make_inputs
+    gen = perturb_state(TriPlaneGenerator(cfg, seed=0)).requires_grad_(False).to(dev)
+    ws, c, us, ui = (t.to(dev) for t in make_inputs(cfg, b, seed=seed))
+    gdev = torch.Generator(device=dev).manual_seed(seed)
+    with torch.no_grad():
+        if h is None:
+            planes = gen.backbone_planes(ws)
+            pam = gen._planes_absmax
+        else:
+            planes = torch.randn(b, 3, h, w, 32, device=dev, generator=gdev)
+            pam = None
+        u_s, u_i = gen._uniforms(b, dev, us, ui)
+        g = torch.randn(b, cfg.neural_rendering_resolution ** 2, 32, device=dev, generator=gdev)
+    kw = dict(gen._render_args(c), u_strat=u_s, u_imp=u_i, planes_absmax=pam)
+    kw.update(override)
+    return g, planes, kw
+
+
+@pytest.mark.parametrize("dec", [False, True])
+def test_raymarch_backward_sort_gather_equals_the_scatter_kernels(dev, dec):
+    """`HfagpRaymarchBwdArgs::rows_scratch` (csrc/raymarch_rows.hip) at BASELINE's size (2 frames x 128^2 rays x 96 samples, mirrored
+    256^2 planes): the samples are counting-sorted by (plane, column strip, texel row), dL/dF goes to the sorted slots and every
+    output row tile is W . dL/dF on the 16-bit matrix pipe (split bf16: 2^-16 per product) — against the column kernel's per-sample
+    scatter with fp32 weights.  With `dec` the decoder-MLP gradients come out of the same pass that writes dL/dF."""
+    from hfa_gp_amd import ops
+    from hfa_gp_amd.config import ffhq512_128
+    g, planes, kw = _raybwd_case(dev, ffhq512_128(), 2, 12)
+    with torch.no_grad():
+        ref = ops.raymarch_bwd(g, planes, rows=False, decoder_grads=dec, **kw)
+        out = ops.raymarch_bwd(g, planes, rows=True, decoder_grads=dec, **kw)
+        again = ops.raymarch_bwd(g, planes, rows=True, decoder_grads=dec, **kw)
+    dref, dout, dagain = (ref[0], out[0], again[0]) if dec else (ref, out, again)
+    scale = dref.abs().max().item()
+    assert scale > 0 and torch.isfinite(dout).all()
+    assert (dout - dref).abs().max().item() <= 2e-5 * scale
+    assert rel_l2(dout, dref) <= 2e-5
+    # a second call reuses nothing of the first (the scratch buffer's contents are undefined between calls)
+    assert (dagain - dout).abs().max().item() <= 1e-5 * scale
+    if dec:
+        for x, y in zip(out[1], ref[1]):
+            assert (x - y).abs().max().item() <= 2e-5 * y.abs().max().item()
+
+
+@pytest.mark.parametrize("h,w,axes,box_warp", [(40, 72, "eg3d_original", 1.0), (33, 33, "eg3d_fixed", 1.0), (64, 64, "eg3d_original", 0.45),
+                                               (20, 100, "eg3d_fixed", 0.6)])
+def test_raymarch_backward_sort_gather_ragged_planes_and_rays_leaving_the_box(dev, h, w, axes, box_warp):
+    """Planes that are not a multiple of the 32-texel strip, non-square planes and the fixed axes (three planes sorted instead of
+    two + the mirror), and a box so small that most samples have taps outside the planes (zeros padding: they are in no bin or
+    contribute to one row / column only): sort + gather against the per-sample scatter of `raymarch_bwd_tiles_kernel`."""
+    import dataclasses
+    from hfa_gp_amd import ops
+    from hfa_gp_amd.config import PRESETS
+    cfg = dataclasses.replace(PRESETS["small128"](), neural_rendering_resolution=24, img_resolution=96, plane_axes=axes)
+    g, planes, kw = _raybwd_case(dev, cfg, 3, 5, h=h, w=w, box_warp=box_warp)
+    with torch.no_grad():
+        ref = ops.raymarch_bwd(g, planes, rows=False, **kw)
+        out = ops.raymarch_bwd(g, planes, rows=True, **kw)
+    scale = ref.abs().max().item()
+    assert scale > 0 and torch.isfinite(out).all()
+    assert (out - ref).abs().max().item() <= 2e-5 * scale
+    assert rel_l2(out, ref) <= 2e-5

@@ -93,7 +93,7 @@ def test_torgb_skip_is_built_without_packed_fp32_fma(tmp_path):
             assert not m or int(m.group(1)) >= 3, f"{name}: occupancy {m.group(1)}"
 
 
-UNITS = ["elementwise", "modconv", "modconv_bf16", "smallconv", "upconv_fir", "torgb_skip", "raymarch", "backward", "raymarch_bwd",
+UNITS = ["elementwise", "modconv", "modconv_bf16", "smallconv", "upconv_fir", "torgb_skip", "raymarch", "backward", "raymarch_bwd", "raymarch_rows",
          "wgrad", "wgrad_bf16", "qr", "loss", "collective"]
 
 
