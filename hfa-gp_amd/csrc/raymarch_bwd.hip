@@ -795,22 +795,33 @@ raymarch_bwd_df_kernel(const RayParams p, float* __restrict__ df_out, const Rows
         }
     }
     __syncthreads();
-    const RaySchedule sch = ray_schedule((long long)p.total_rays * NT, wave, kDfWaves);
-    for (long long tile = sch.begin; tile < sch.end; tile += sch.stride) {
-        const int tt = __builtin_amdgcn_readfirstlane((int)(tile % NT));
+    // a wave walks the tiles of ONE ray in sequence: ray generation (six divisions and a square root), the position -> pixel
+    // arithmetic and the ray's dL/dfeat once per ray instead of once per tile (~100 of ~800 vector instructions of a tile)
+    const RaySchedule sch = ray_schedule((long long)p.total_rays, wave, kDfWaves);
+    for (long long rp = sch.begin; rp < sch.end; rp += sch.stride) {
         int b, pi, pj;
-        ray_of(__builtin_amdgcn_readfirstlane((int)(tile / NT)), a.res, b, pi, pj);
+        ray_of(__builtin_amdgcn_readfirstlane((int)rp), a.res, b, pi, pj);
         const int ray = __builtin_amdgcn_readfirstlane(b * R + pi * a.res + pj);
         float o3[3], d3[3];
         ray_setup(a, b, pi, pj, o3, d3);
+        float4 gfeat[2];
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot) gfeat[ot] = *reinterpret_cast<const float4*>(p.g_feat + (size_t)ray * 32 + 16 * ot + 4 * g);
+        // the depth the gather of a tile hangs on is loaded a tile ahead (the chain  depth -> taps -> 24 texel loads -> decoder
+        // is what a wave waits on: two waves per SIMD hide one of its two memory round trips, not both)
+        float zq = p.rec[((size_t)ray * S + (lane >> 2)) * 4];
+#pragma unroll 1
+        for (int tt = 0; tt < NT; ++tt) {
         const int s = 16 * tt + j;
+        const float zq_cur = zq;
+        zq = p.rec[((size_t)ray * S + 16 * min(tt + 1, NT - 1) + (lane >> 2)) * 4];
         const float4 rec = *reinterpret_cast<const float4*>(p.rec + ((size_t)ray * S + s) * 4);   // depth, omega, dsigma
         DfSlots slots;
         if constexpr (SORTED) slots = load_df_slots(ro, (size_t)ray * S + s);      // lands while the tile runs its decoder
         float f[8];
         {
             PlaneTaps tq[3];
-            sample_taps(p, o3, d3, p.rec[((size_t)ray * S + 16 * tt + (lane >> 2)) * 4], tq);
+            sample_taps(p, o3, d3, zq_cur, tq);
             gather8(a, b, lane & 3, tq, f);
             const int src = 4 * j + g;
 #pragma unroll
@@ -823,7 +834,7 @@ raymarch_bwd_df_kernel(const RayParams p, float* __restrict__ df_out, const Rows
         f32x4 dO[2];
 #pragma unroll
         for (int ot = 0; ot < 2; ++ot) {
-            const float4 gf = *reinterpret_cast<const float4*>(p.g_feat + (size_t)ray * 32 + 16 * ot + 4 * g);
+            const float4 gf = gfeat[ot];
             const float gv[4] = {gf.x, gf.y, gf.z, gf.w};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -865,6 +876,7 @@ raymarch_bwd_df_kernel(const RayParams p, float* __restrict__ df_out, const Rows
             if constexpr (!SORTED) *reinterpret_cast<float4*>(dst + 16 * ft) = make_float4(dF2[ft][0], dF2[ft][1], dF2[ft][2], dF2[ft][3]);
         }
         if constexpr (SORTED) store_df_sorted(ro, slots, g, dF2);                     // sort + gather form: raymarch_rows.hip
+        }
     }
 }
 
@@ -1097,7 +1109,8 @@ static void launch_df_sorted(const RayParams& p, const RowsOut& ro, hipStream_t 
             raymarch_bwd_tiles_kernel<S, false, true, false, false><<<blocks, 256, 0, s>>>(p, nullptr, DecGrads{}, ro);
         return;
     }
-    const unsigned dblocks = (unsigned)std::min<long long>((ntiles + kDfWaves - 1) / kDfWaves, (long long)kNumCU * 2 * 8);
+    static const int per_cu = getenv("HFAGP_DEV_DF_BLOCKS") ? atoi(getenv("HFAGP_DEV_DF_BLOCKS")) : 4;      // developer: A/B timing
+    const unsigned dblocks = (unsigned)std::min<long long>((ntiles + kDfWaves - 1) / kDfWaves, (long long)kNumCU * per_cu);
     if (p.a.planes_absmax) raymarch_bwd_df_kernel<S, true, true><<<dblocks, kDfWaves * 64, 0, s>>>(p, nullptr, ro);
     else raymarch_bwd_df_kernel<S, false, true><<<dblocks, kDfWaves * 64, 0, s>>>(p, nullptr, ro);
 }

@@ -381,7 +381,7 @@ __device__ __forceinline__ DfSlots load_df_slots(const RowsOut& ro, size_t sampl
     return d;
 }
 __device__ __forceinline__ void store_df_sorted(const RowsOut& ro, const DfSlots& ds, int g, const f32x4 dF[2]) {
-    uint4 w[2];
+    u32x4r w[2];
 #pragma unroll
     for (int ft = 0; ft < 2; ++ft) {
         unsigned o[4];
@@ -394,18 +394,19 @@ __device__ __forceinline__ void store_df_sorted(const RowsOut& ro, const DfSlots
             o[2 * q] = (hh << 16) | (ll & 0xffffu);
             o[2 * q + 1] = (hh & 0xffff0000u) | (ll >> 16);
         }
-        w[ft] = make_uint4(o[0], o[1], o[2], o[3]);
+        w[ft] = u32x4r{o[0], o[1], o[2], o[3]};
     }
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) {
         const int2 sl = ds.sl[pl];
+        // (streaming stores: 0.8 GB per 2 frames must not push the plane bands the gather lives on out of the L2s)
         if (sl.x >= 0) {
-            uint4* d = reinterpret_cast<uint4*>(ro.dfs + (size_t)sl.x * 32 + 4 * g);
-            d[0] = w[0]; d[4] = w[1];
+            u32x4r* d = reinterpret_cast<u32x4r*>(ro.dfs + (size_t)sl.x * 32 + 4 * g);
+            __builtin_nontemporal_store(w[0], d); __builtin_nontemporal_store(w[1], d + 4);
         }
         if (sl.y >= 0) {
-            uint4* d = reinterpret_cast<uint4*>(ro.dfs + (size_t)sl.y * 32 + 4 * g);
-            d[0] = w[0]; d[4] = w[1];
+            u32x4r* d = reinterpret_cast<u32x4r*>(ro.dfs + (size_t)sl.y * 32 + 4 * g);
+            __builtin_nontemporal_store(w[0], d); __builtin_nontemporal_store(w[1], d + 4);
         }
     }
 }

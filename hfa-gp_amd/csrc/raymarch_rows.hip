@@ -40,10 +40,9 @@ struct RowsDev {
     unsigned* off;       // [NB + 1]  first slot of the bin (bins padded to 16 slots)
     unsigned* cursor;    // [NB]      S2: next free slot of the bin
     unsigned* meta;      // [4]       number of units, number of slots
-    int4* units;         // [max_units] (bin, first slot, end slot, -)
+    int4* units;         // [max_units] (bin, first slot, end slot (a multiple of 16 slots from the first), end of the bin's entries)
     int2* pos;           // [samples][P] slot of the sample in plane p (and of its second entry), -1 = none
-    float* ix;           // [cap] column coordinate of the slot's sample
-    float* wy;           // [cap] row fraction
+    float2* ent;         // [cap] (column coordinate ix, row fraction wy) of the slot's sample
     unsigned* dfs;       // [cap][32] dL/dF, bf16 hi << 16 | bf16 lo
     int P, XB, H1, NBF, NB, max_units, unit;
     unsigned cap;
@@ -77,8 +76,7 @@ static size_t rows_layout(const HfagpRaymarchArgs& a, unsigned char* base, RowsD
     d.cursor = reinterpret_cast<unsigned*>(take((size_t)nb * 4));
     d.units = reinterpret_cast<int4*>(take((size_t)d.max_units * 16));
     d.pos = reinterpret_cast<int2*>(take((size_t)samples * d.P * 8));
-    d.ix = reinterpret_cast<float*>(take((size_t)cap * 4));
-    d.wy = reinterpret_cast<float*>(take((size_t)cap * 4));
+    d.ent = reinterpret_cast<float2*>(take((size_t)cap * 8));
     d.dfs = reinterpret_cast<unsigned*>(take((size_t)cap * 128));
     return o;
 }
@@ -116,14 +114,6 @@ raymarch_bwd_bins_kernel(const RayParams p, const RowsDev r, const int chunks_pe
     const int pi = piece * kRowsRays + (threadIdx.x >> 3), sub = threadIdx.x & 7;
     const bool active = pi < a.res;
     for (int i = threadIdx.x; i < r.NBF; i += 256) hist[i] = 0;
-    if constexpr (PLACE) {
-        // the padding slots of the bins (zeros: no weight, no gradient), dealt over the workgroups
-        for (int bin = blockIdx.x; bin < r.NB; bin += gridDim.x) {
-            const unsigned o = r.off[bin] + r.cnt[bin], e = r.off[bin + 1];
-            for (unsigned i = threadIdx.x; i < (e - o) * 32; i += 256) r.dfs[(size_t)o * 32 + i] = 0u;
-            if (threadIdx.x < e - o) { r.ix[o + threadIdx.x] = 3e38f; r.wy[o + threadIdx.x] = 0.f; }
-        }
-    }
     __syncthreads();
     float o3[3], d3[3];
     ray_setup(a, b, min(pi, a.res - 1), pj, o3, d3);
@@ -148,10 +138,17 @@ raymarch_bwd_bins_kernel(const RayParams p, const RowsDev r, const int chunks_pe
             if (c) atomicAdd(&r.cnt[(size_t)b * r.NBF + i], c);
         }
     } else {
-        for (int i = threadIdx.x; i < r.NBF; i += 256) {
-            const unsigned c = hist[i];
-            if (c) base[i] = atomicAdd(&r.cursor[(size_t)b * r.NBF + i], c);
-            hist[i] = 0;
+        // one RETURNING global atomic per bin the chunk touches (~600 of them): four in flight per thread — one at a time the
+        // loop waited out 16 atomic round trips in sequence (S2 76 us, half of it here)
+        for (int i0 = threadIdx.x; i0 < r.NBF; i0 += 256 * 4) {
+            unsigned c[4], got[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) c[k] = i0 + 256 * k < r.NBF ? hist[i0 + 256 * k] : 0u;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) got[k] = c[k] ? atomicAdd(&r.cursor[(size_t)b * r.NBF + i0 + 256 * k], c[k]) : 0u;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (i0 + 256 * k < r.NBF) { base[i0 + 256 * k] = got[k]; hist[i0 + 256 * k] = 0; }
         }
         __syncthreads();
         if (active) {
@@ -164,11 +161,11 @@ raymarch_bwd_bins_kernel(const RayParams p, const RowsDev r, const int chunks_pe
                     int2 sl = make_int2(-1, -1);
                     if (k.key >= 0) {
                         sl.x = (int)(base[k.key] + atomicAdd(&hist[k.key], 1u));
-                        r.ix[sl.x] = k.ix; r.wy[sl.x] = k.wy;
+                        r.ent[sl.x] = make_float2(k.ix, k.wy);
                     }
                     if (k.dup >= 0) {
                         sl.y = (int)(base[k.dup] + atomicAdd(&hist[k.dup], 1u));
-                        r.ix[sl.y] = k.ix; r.wy[sl.y] = k.wy;
+                        r.ent[sl.y] = make_float2(k.ix, k.wy);
                     }
                     r.pos[(ray * S + s) * r.P + pl] = sl;
                 }
@@ -199,55 +196,70 @@ __global__ void __launch_bounds__(1024) raymarch_bwd_scan_kernel(const RowsDev r
     }
     unsigned ol = ssl[t] - sl, ou = ssu[t] - su;
     for (int i = i0; i < i1; ++i) {
-        const unsigned c16 = (r.cnt[i] + 15u) & ~15u;
+        const unsigned c = r.cnt[i], c16 = (c + 15u) & ~15u;
         r.off[i] = ol; r.cursor[i] = ol;
         for (unsigned k = 0; k * r.unit < c16; ++k)
-            r.units[ou++] = make_int4(i, (int)(ol + k * r.unit), (int)(ol + min(c16, (k + 1) * r.unit)), 0);
+            r.units[ou++] = make_int4(i, (int)(ol + k * r.unit), (int)(ol + min(c16, (k + 1) * r.unit)), (int)(ol + c));
         ol += c16;
     }
     if (t == 1023) { r.off[r.NB] = ssl[t]; r.meta[0] = ssu[t]; r.meta[1] = ssl[t]; }
 }
 
-// G: one wave per unit
+// G: one wave per unit.  The stream of a unit is contiguous: per batch of 16 slots 128 bytes of (ix, wy) + 2 KB of dL/dF; a
+// wave keeps kRowsDepth batches in flight (9 registers each: the 16 (ix, wy) pairs travel as ONE dword per lane and are
+// re-distributed through 128 bytes of LDS when the batch is consumed) — with one batch in flight per wave the kernel ran at the
+// memory LATENCY (3.9 us per batch and wave, 3.4 TB/s).
+constexpr int kRowsDepth = 4;
+
 __global__ void __launch_bounds__(256, 2)
 raymarch_bwd_rows_kernel(const RowsDev r, float* __restrict__ d_planes, const int H, const int W) {
+    __shared__ __attribute__((aligned(16))) float stage_all[4][32];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned unit = blockIdx.x * 4 + wave;
     if (unit >= r.meta[0]) return;
+    float* stage = stage_all[wave];
     const int4 u = r.units[unit];
     const int bin = __builtin_amdgcn_readfirstlane(u.x);
     const unsigned e0 = __builtin_amdgcn_readfirstlane(u.y), e1 = __builtin_amdgcn_readfirstlane(u.z);
+    const unsigned ev = __builtin_amdgcn_readfirstlane(u.w);             // slots >= ev are the bin's padding: never written
     const int y0 = bin % r.H1 - 1, strip = bin / r.H1, xb = strip % r.XB, bp = strip / r.XB;
     const int n = lane & 31, h = lane >> 5;
     const float xm = (float)(xb * kRowsStrip + n);
     // lane (n, h): A row m = n (texel column), B column n (channel), K = samples 8h .. 8h + 7 of the batch
-    const float* ixp = r.ix + 8 * h;
-    const float* wyp = r.wy + 8 * h;
+    const float* entp = reinterpret_cast<const float*>(r.ent) + n;
     const unsigned* dfp = r.dfs + (size_t)(8 * h) * 32 + n;
-    struct Batch { float4 i0, i1, w0, w1; unsigned pk[8]; };
+    struct Batch { float m; unsigned pk[8]; };
     auto fetch = [&](unsigned e) __attribute__((always_inline)) {
         Batch b;
-        b.i0 = *reinterpret_cast<const float4*>(ixp + e); b.i1 = *reinterpret_cast<const float4*>(ixp + e + 4);
-        b.w0 = *reinterpret_cast<const float4*>(wyp + e); b.w1 = *reinterpret_cast<const float4*>(wyp + e + 4);
+        b.m = __builtin_nontemporal_load(entp + (size_t)e * 2);
         const unsigned* d = dfp + (size_t)e * 32;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) b.pk[t] = d[t * 32];
+        for (int t = 0; t < 8; ++t) b.pk[t] = __builtin_nontemporal_load(d + t * 32);
         return b;
     };
     f32x16 acc_u, acc_l;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc_u[i] = 0.f; acc_l[i] = 0.f; }
-    Batch cur = fetch(e0);
-    for (unsigned e = e0; e < e1; e += 16) {
-        const Batch nxt = fetch(min(e + 16, e1 - 16));          // (the last batch once more: no branch around the loads)
-        const float ixs[8] = {cur.i0.x, cur.i0.y, cur.i0.z, cur.i0.w, cur.i1.x, cur.i1.y, cur.i1.z, cur.i1.w};
-        const float wys[8] = {cur.w0.x, cur.w0.y, cur.w0.z, cur.w0.w, cur.w1.x, cur.w1.y, cur.w1.z, cur.w1.w};
+    auto consume = [&](Batch cur, unsigned ec) __attribute__((always_inline)) {
+        stage[n] = cur.m;
+        WAVE_SYNC();
+        float4 pr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pr[i] = *reinterpret_cast<const float4*>(stage + 16 * h + 4 * i);
+        WAVE_SYNC();
+        const float ixs[8] = {pr[0].x, pr[0].z, pr[1].x, pr[1].z, pr[2].x, pr[2].z, pr[3].x, pr[3].z};
+        const float wys[8] = {pr[0].y, pr[0].w, pr[1].y, pr[1].w, pr[2].y, pr[2].w, pr[3].y, pr[3].w};
         float au[8], al[8];
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             const float hx = fmaxf(1.f - fabsf(ixs[t] - xm), 0.f);
             au[t] = (1.f - wys[t]) * hx * 0.3333333333333333f;
             al[t] = wys[t] * hx * 0.3333333333333333f;
+        }
+        if (ec + 16 > ev) {                          // the bin's last batch: its padding slots hold whatever the buffer held
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+                if (ec + 8 * h + t >= ev) { au[t] = 0.f; al[t] = 0.f; cur.pk[t] = 0u; }
         }
         u32x4r auh, aul, alh, all_, bh, bl;
         split8_bf16(au, auh, aul);
@@ -264,7 +276,17 @@ raymarch_bwd_rows_kernel(const RowsDev r, float* __restrict__ d_planes, const in
         acc_l = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8r, all_), vbh, acc_l, 0, 0, 0);
         acc_u = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8r, auh), vbl, acc_u, 0, 0, 0);
         acc_l = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8r, alh), vbl, acc_l, 0, 0, 0);
-        cur = nxt;
+    };
+    Batch q[kRowsDepth];
+#pragma unroll
+    for (int i = 0; i < kRowsDepth; ++i) q[i] = fetch(min(e0 + 16u * i, e1 - 16));
+    for (unsigned e = e0; e < e1; e += 16 * kRowsDepth) {
+#pragma unroll
+        for (int i = 0; i < kRowsDepth; ++i) {
+            const unsigned ec = e + 16 * i;
+            if (ec < e1) consume(q[i], ec);                                    // (wave-uniform; no load inside the branch)
+            q[i] = fetch(min(ec + 16 * kRowsDepth, e1 - 16));             // past the end: the last batch once more
+        }
     }
     // C layout: lane (n, h), register i -> texel column 8 (i / 4) + 4 h + i % 4, channel n: two full 128-byte lines per store
     const int b = bp / r.P, pl = bp % r.P;
