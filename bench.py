@@ -1070,9 +1070,9 @@ def main():
                   bwd-data GEMMs: algorithmic flops 2 M N K of the adjoint conv (gradients run in bf16x3: 3 MFMAs per product ->
                     2.5 PF / 3 = 833 TF ceiling); the figure includes the split-K reducer launches that follow a GEMM;
                   pointwise_bwd: bytes of the full-size tensors it reads + writes against HBM;
-                  ray-march backward (both passes + the zero fill of d planes): against a floor of re-gather + scatter through L2
-                    (2 x the forward's 12-line gather per sample / 34.5 TB/s) + decoder recompute and adjoint (2 x the forward
-                    decoder flops at the split-operand rate)."""
+                  ray-march backward (both passes + the zero fill of d planes): against a floor of the re-gather through L2 (the
+                    forward's 12-line gather per sample / 34.5 TB/s) + decoder recompute and adjoint (2 x the forward decoder flops
+                    at the split-operand rate) + the sorted dL/dF stream once out and once back through HBM."""
                 res_ = {"batch": train_B, "step_ms": step_ms}
                 peak_g = MFMA_BF16_PEAK_TFLOPS / 3
                 tot_ms = tot_fl = 0.0
@@ -1121,13 +1121,20 @@ def main():
                     ms, fr, n = ev["raymarch_bwd"]
                     gb = fr * r * s_tot * 3 * 4 * 32 * 4
                     fl = fr * r * s_tot * 2.0 * (32 * 64 + 64 * 33)
-                    floor = (2.0 * gb / (L2_PEAK_GBS * 1e9) + 2.0 * fl / (MFMA_BF16_PEAK_TFLOPS / 3 * 1e12)) * 1e3
-                    res_["raymarch_bwd"] = {"bound": "l2+mfma", "kernel": "raymarch_kernel<GRADS> (compositing adjoint from the saved "
-                                                                          "state) + raymarch_bwd_cols_kernel + zero fill of d planes",
+                    # round 5: pass 2 is sort + gather (csrc/raymarch_rows.hip) — the re-gather through L2 and the decoder recompute +
+                    # adjoint stay; the scatter is a stream: dL/dF (128 B) + (ix, wy) of every sample written to its sorted slot in
+                    # two planes (the third is the mirror) and read back once, through HBM
+                    stream = fr * r * s_tot * 2 * (128 + 8) * 2.0
+                    floor = (gb / (L2_PEAK_GBS * 1e9) + 2.0 * fl / (MFMA_BF16_PEAK_TFLOPS / 3 * 1e12) + stream / (HBM_PEAK_GBS * 1e9)) * 1e3
+                    tr = [train_traffic(k, mode_) for k in ("raymarch_bwd_df_kernel", "raymarch_bwd_rows_kernel", "raymarch_bwd_bins_kernel")]
+                    res_["raymarch_bwd"] = {"bound": "l2+mfma+hbm",
+                                            "kernel": "raymarch_kernel<GRADS> (compositing adjoint from the saved state) + sort (bins, scan, "
+                                                      "place) + raymarch_bwd_df_kernel (dL/dF to sorted slots; tuned: the decoder-gradient "
+                                                      "pass) + raymarch_bwd_rows_kernel (row tiles on the bf16 matrix pipe) + zero fill",
                                             "ms_per_step": ms, "ms_per_frame": ms / max(fr, 1), "floor_ms_per_step": floor,
                                             "frac": floor / ms, "share_of_step": ms / step_ms,
-                                            "scatter_updates_per_frame": r * s_tot * 12,
-                                            "traffic": train_traffic("raymarch_bwd_cols_kernel", mode_)}
+                                            "sorted_entries_per_frame": r * s_tot * 2, "stream_bytes_per_step": stream,
+                                            "traffic": sum(tr) if all(t is not None for t in tr) else None}
                 if "raymarch" in ev:
                     res_["raymarch_fwd_ms_per_step"] = ev["raymarch"][0]
                 fwd = sum(ev[k][0] for k in ev if k.startswith("modconv"))

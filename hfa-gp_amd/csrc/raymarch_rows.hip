@@ -118,12 +118,16 @@ raymarch_bwd_bins_kernel(const RayParams p, const RowsDev r, const int chunks_pe
     float o3[3], d3[3];
     ray_setup(a, b, min(pi, a.res - 1), pj, o3, d3);
     const size_t ray = (size_t)b * a.res * a.res + (size_t)min(pi, a.res - 1) * a.res + pj;
-    const float* depth = p.rec + ray * S * 4;
+    // the thread's S / 8 depths: all loads go out together and stay in registers for the second pass of S2
+    const float* depth = p.rec + (ray * S + sub) * 4;
+    float dep[S / 8];
+#pragma unroll
+    for (int i = 0; i < S / 8; ++i) dep[i] = depth[i * 32];
     if (active) {
 #pragma unroll 2
-        for (int s = sub; s < S; s += 8) {
+        for (int i = 0; i < S / 8; ++i) {
             float q[3];
-            sample_point(p, o3, d3, depth[s * 4], q);
+            sample_point(p, o3, d3, dep[i], q);
             for (int pl = 0; pl < r.P; ++pl) {
                 const RowsKey k = rows_key(a, r, q, pl);
                 if (k.key >= 0) atomicAdd(&hist[k.key], 1u);
@@ -153,9 +157,10 @@ raymarch_bwd_bins_kernel(const RayParams p, const RowsDev r, const int chunks_pe
         __syncthreads();
         if (active) {
 #pragma unroll 2
-            for (int s = sub; s < S; s += 8) {
+            for (int i = 0; i < S / 8; ++i) {
+                const int s = sub + 8 * i;
                 float q[3];
-                sample_point(p, o3, d3, depth[s * 4], q);
+                sample_point(p, o3, d3, dep[i], q);
                 for (int pl = 0; pl < r.P; ++pl) {
                     const RowsKey k = rows_key(a, r, q, pl);
                     int2 sl = make_int2(-1, -1);
@@ -174,35 +179,60 @@ raymarch_bwd_bins_kernel(const RayParams p, const RowsDev r, const int chunks_pe
     }
 }
 
-// counts -> slot offsets (bins padded to 16 slots) + the unit list; one workgroup
+// counts -> slot offsets (bins padded to 16 slots) + the unit list; one workgroup.  Tiles of 12288 bins go through LDS: coalesced
+// loads / stores, the per-thread segments (12 consecutive bins) are walked in LDS.
+constexpr int kScanTile = 12288;      // 12 bins per thread: 2 frames of mirrored 256^2 planes (8224 bins) are one tile
 __global__ void __launch_bounds__(1024) raymarch_bwd_scan_kernel(const RowsDev r) {
-    __shared__ unsigned ssl[1024], ssu[1024];
+    __shared__ unsigned sc[kScanTile], ssl[16], ssu[16];
     const int t = threadIdx.x;
-    const int seg = (r.NB + 1023) / 1024;
-    const int i0 = min(r.NB, t * seg), i1 = min(r.NB, i0 + seg);
-    unsigned sl = 0, su = 0;
-    for (int i = i0; i < i1; ++i) {
-        const unsigned c16 = (r.cnt[i] + 15u) & ~15u;
-        sl += c16;
-        su += (c16 + r.unit - 1) / r.unit;
-    }
-    ssl[t] = sl; ssu[t] = su;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        const unsigned vl = t >= o ? ssl[t - o] : 0u, vu = t >= o ? ssu[t - o] : 0u;
+    unsigned carry_l = 0, carry_u = 0;
+    for (int t0 = 0; t0 < r.NB; t0 += kScanTile) {
+        const int nt = min(kScanTile, r.NB - t0);
+#pragma unroll
+        for (int i = 0; i < kScanTile / 1024; ++i) sc[t + 1024 * i] = t + 1024 * i < nt ? r.cnt[t0 + t + 1024 * i] : 0u;
         __syncthreads();
-        ssl[t] += vl; ssu[t] += vu;
+        constexpr int PT = kScanTile / 1024;
+        unsigned c[PT], sl = 0, su = 0;
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+            c[i] = sc[PT * t + i];
+            const unsigned c16 = (c[i] + 15u) & ~15u;
+            sl += c16;
+            su += (c16 + r.unit - 1) / r.unit;
+        }
+        // block scan: inside the wave with shuffles, then over the 16 wave totals (a 10-step scan in LDS costs 20 barriers of
+        // 16 waves: 12 of the kernel's 17 us)
+        unsigned il = sl, iu = su;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned vl = __shfl_up(il, o), vu = __shfl_up(iu, o);
+            if ((t & 63) >= o) { il += vl; iu += vu; }
+        }
+        if ((t & 63) == 63) { ssl[t >> 6] = il; ssu[t >> 6] = iu; }
+        __syncthreads();
+        unsigned wl = 0, wu = 0, tl = 0, tu = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            if (w < (t >> 6)) { wl += ssl[w]; wu += ssu[w]; }
+            tl += ssl[w]; tu += ssu[w];
+        }
+        unsigned ol = carry_l + wl + il - sl, ou = carry_u + wu + iu - su;
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+            const unsigned c16 = (c[i] + 15u) & ~15u;
+            sc[PT * t + i] = ol;
+            for (unsigned k = 0; k * r.unit < c16; ++k)
+                r.units[ou++] = make_int4(t0 + PT * t + i, (int)(ol + k * r.unit), (int)(ol + min(c16, (k + 1) * r.unit)), (int)(ol + c[i]));
+            ol += c16;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < kScanTile / 1024; ++i)
+            if (t + 1024 * i < nt) { r.off[t0 + t + 1024 * i] = sc[t + 1024 * i]; r.cursor[t0 + t + 1024 * i] = sc[t + 1024 * i]; }
+        carry_l += tl; carry_u += tu;
         __syncthreads();
     }
-    unsigned ol = ssl[t] - sl, ou = ssu[t] - su;
-    for (int i = i0; i < i1; ++i) {
-        const unsigned c = r.cnt[i], c16 = (c + 15u) & ~15u;
-        r.off[i] = ol; r.cursor[i] = ol;
-        for (unsigned k = 0; k * r.unit < c16; ++k)
-            r.units[ou++] = make_int4(i, (int)(ol + k * r.unit), (int)(ol + min(c16, (k + 1) * r.unit)), (int)(ol + c));
-        ol += c16;
-    }
-    if (t == 1023) { r.off[r.NB] = ssl[t]; r.meta[0] = ssu[t]; r.meta[1] = ssl[t]; }
+    if (t == 0) { r.off[r.NB] = carry_l; r.meta[0] = carry_u; r.meta[1] = carry_l; }
 }
 
 // G: one wave per unit.  The stream of a unit is contiguous: per batch of 16 slots 128 bytes of (ix, wy) + 2 KB of dL/dF; a

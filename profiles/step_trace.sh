@@ -20,7 +20,7 @@ print(f"# fitting step, {mode}-driven, generator {tun}, B = {B}: rocprofv3 --ker
 print("# " + open(out + "/log.txt").read().strip().splitlines()[-1])
 f = glob.glob(out + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-marks = [i for i, r in enumerate(rows) if "raymarch_bwd_cols_kernel" in r["Kernel_Name"] or "raymarch_bwd_gather" in r["Kernel_Name"]
+marks = [i for i, r in enumerate(rows) if "raymarch_bwd_cols_kernel" in r["Kernel_Name"] or "raymarch_bwd_rows_kernel" in r["Kernel_Name"]
          or ("raymarch_bwd_tiles_kernel" in r["Kernel_Name"] and "false>" not in r["Kernel_Name"].split("(")[0][-8:])]
 # one mark per step: the d-planes scatter / gather of the ray-march backward
 steps = []

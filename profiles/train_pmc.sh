@@ -21,7 +21,10 @@ import csv, glob, json, sys
 from collections import defaultdict
 out, tag, B, regimes = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4].split()
 fam = {"pointwise_bwd_kernel": "pointwise_bwd_kernel", "raymarch_bwd_cols_kernel": "raymarch_bwd_cols_kernel",
-       "raymarch_bwd_tiles_kernel": "raymarch_bwd_tiles_kernel (decoder gradients)",
+       "raymarch_bwd_df_kernel": "raymarch_bwd_df_kernel (dL/dF to the sorted slots)",
+       "raymarch_bwd_rows_kernel": "raymarch_bwd_rows_kernel (row tiles of d planes from the sorted slots)",
+       "raymarch_bwd_bins_kernel": "raymarch_bwd_bins_kernel (count + place)",
+       "raymarch_bwd_tiles_kernel": "raymarch_bwd_tiles_kernel (decoder gradients; with the sort + gather form also dL/dF)",
        "modconv_bf16_kernel<2, 2, 9": "modconv_bf16_kernel<2, 2, 9, 0> (3x3 bwd-data)",
        "modconv_bf16_kernel<2, 2, 0": "modconv_bf16_kernel<2, 2, 0, 0> (merged adjoint of the up-conv)",
        "modconv_bf16_kernel<2, 2, 1": "modconv_bf16_kernel<2, 2, 1, 0> (toRGB adjoint)",
