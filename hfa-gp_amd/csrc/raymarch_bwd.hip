@@ -760,7 +760,7 @@ raymarch_bwd_cols_kernel(const RayParams p, float* __restrict__ d_planes, const 
 constexpr int kDfWaves = 4;      // two workgroups per CU (254 VGPRs: two waves per SIMD, as the forward kernel)
 
 template <int S, bool DEC16, bool SORTED>
-__global__ void __launch_bounds__(kDfWaves * 64, 2)
+__global__ void __launch_bounds__(kDfWaves * 64, SORTED ? 3 : 2)
 raymarch_bwd_df_kernel(const RayParams p, float* __restrict__ df_out, const RowsOut ro) {
     __shared__ float w1t[4 * 8 * 64];
     __shared__ float w0t[2 * 16 * 64];
@@ -813,6 +813,8 @@ raymarch_bwd_df_kernel(const RayParams p, float* __restrict__ df_out, const Rows
 #pragma unroll 1
         for (int tt = 0; tt < NT; ++tt) {
         const int s = 16 * tt + j;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));       // the weight images are READ per tile (not hoisted into ~170 registers): 3 waves per SIMD
         const float zq_cur = zq;
         zq = p.rec[((size_t)ray * S + 16 * min(tt + 1, NT - 1) + (lane >> 2)) * 4];
         const float4 rec = *reinterpret_cast<const float4*>(p.rec + ((size_t)ray * S + s) * 4);   // depth, omega, dsigma
@@ -829,7 +831,7 @@ raymarch_bwd_df_kernel(const RayParams p, float* __restrict__ df_out, const Rows
         }
         f32x4 hp[4], h[4], o[2];
         float sigma;
-        if constexpr (DEC16) decoder_fwd16_lds<true>(wfwd, lane, f, hp, h, sigma, o);
+        if constexpr (DEC16) decoder_fwd16_lds<true>(wfwd, ln, f, hp, h, sigma, o);
         else decoder_fwd_lds<true>(wfwd, lane, f, hp, h, sigma, o);
         f32x4 dO[2];
 #pragma unroll
@@ -844,7 +846,7 @@ raymarch_bwd_df_kernel(const RayParams p, float* __restrict__ df_out, const Rows
         }
         f32x4 dH[4];
         f32x4 dF2[2];
-        if constexpr (DEC16) decoder_bwd16_lds(wfwd, w1t, w0t, lane, dO, rec.z, hp, dH, dF2);
+        if constexpr (DEC16) decoder_bwd16_lds(wfwd, w1t, w0t, ln, dO, rec.z, hp, dH, dF2);
 #pragma unroll
         for (int mt = 0; mt < (DEC16 ? 0 : 4); ++mt) {
             const float* ws_ = wfwd + (48 + mt * 4) * 64 + lane;
@@ -1109,7 +1111,7 @@ static void launch_df_sorted(const RayParams& p, const RowsOut& ro, hipStream_t 
             raymarch_bwd_tiles_kernel<S, false, true, false, false><<<blocks, 256, 0, s>>>(p, nullptr, DecGrads{}, ro);
         return;
     }
-    static const int per_cu = getenv("HFAGP_DEV_DF_BLOCKS") ? atoi(getenv("HFAGP_DEV_DF_BLOCKS")) : 4;      // developer: A/B timing
+    static const int per_cu = getenv("HFAGP_DEV_DF_BLOCKS") ? atoi(getenv("HFAGP_DEV_DF_BLOCKS")) : 6;      // developer: A/B timing
     const unsigned dblocks = (unsigned)std::min<long long>((ntiles + kDfWaves - 1) / kDfWaves, (long long)kNumCU * per_cu);
     if (p.a.planes_absmax) raymarch_bwd_df_kernel<S, true, true><<<dblocks, kDfWaves * 64, 0, s>>>(p, nullptr, ro);
     else raymarch_bwd_df_kernel<S, false, true><<<dblocks, kDfWaves * 64, 0, s>>>(p, nullptr, ro);
