@@ -46,13 +46,17 @@ template <bool PG> struct BwdWaves { static constexpr int value = PG ? 4 : 6; };
 // global atomics take 3.2 ms for; what is left here is gather + decoder forward / backward + the weight-gradient MFMAs).
 // (the decoder-gradient-only variant with 8 waves per CU — the LDS would allow it without the scatter tables — measured
 // 2.2 ms against 1.9 ms: 256 registers per wave instead of 512 spill)
-template <bool PG, bool SCATTER> struct TileWaves { static constexpr int value = SCATTER ? BwdWaves<PG>::value : 4; };
+// WIDE (PG, no scatter): eight waves per workgroup = two per SIMD at 256 registers, the weight images read from LDS per tile
+// (a laundered lane offset keeps hipcc from hoisting ~170 registers of them out of the loop) and no software pipeline — against
+// one wave per SIMD with 512 registers and the pipeline.
+template <bool PG, bool SCATTER, bool WIDE = false> struct TileWaves { static constexpr int value = SCATTER ? BwdWaves<PG>::value : WIDE ? 8 : 4; };
 
-template <int S, bool PG, bool MIRROR, bool DEC16, bool SCATTER = true>
-__global__ void __launch_bounds__((TileWaves<PG, SCATTER>::value * 64), (PG ? 1 : 2))
+template <int S, bool PG, bool MIRROR, bool DEC16, bool SCATTER = true, bool WIDE = false>
+__global__ void __launch_bounds__((TileWaves<PG, SCATTER, WIDE>::value * 64), (PG ? 1 : 2))
 raymarch_bwd_tiles_kernel(const RayParams p, float* __restrict__ d_planes, const DecGrads dg, const RowsOut ro) {
     // (SCATTER = false, PG = false: dL/dF to the sorted slots alone — the generator-frozen pass of the sort + gather form)
-    constexpr int NWB = TileWaves<PG, SCATTER>::value, NTHB = NWB * 64;
+    static_assert(!WIDE || (PG && !SCATTER), "the wide form is the decoder-gradient pass");
+    constexpr int NWB = TileWaves<PG, SCATTER, WIDE>::value, NTHB = NWB * 64;
     __shared__ TileLds lds_all[SCATTER ? NWB : 1];
     // (sized 1 float instead of one GradLds when the decoder gradients are off: 13 KB less -> 3 workgroups per CU)
     __shared__ __attribute__((aligned(16))) float glds_raw[PG ? NWB * sizeof(GradLds) / sizeof(float) : 1];
@@ -115,12 +119,14 @@ raymarch_bwd_tiles_kernel(const RayParams p, float* __restrict__ d_planes, const
     }
 
     // XCD-local schedule over (ray in column-strip order, tile of the ray): raymarch_common.h ray_schedule
-    const RaySchedule sch = ray_schedule((long long)p.total_rays * NT, wave, NWB);
+    // (WIDE: the schedule runs over RAYS and a wave walks the tiles of its ray in sequence — ray generation and the ray's dL/dfeat
+    // once per ray, the depths a tile's gather hangs on loaded a tile ahead — as raymarch_bwd_df_kernel does)
+    const RaySchedule sch = ray_schedule((long long)p.total_rays * (WIDE ? 1 : NT), wave, NWB);
     // PIPE (the decoder-gradient-only variant, one wave per SIMD with 512 registers; round 5): software pipeline over the tiles —
     // the saved depths of tile i+2 and the 24 texel loads of tile i+1 are in flight while tile i runs its decoder and its 64
     // weight-gradient MFMAs.  Without it the wave walked  rec load -> taps -> gather -> decoder -> MFMAs  strictly in sequence,
     // alone on its SIMD: 5.7 us per tile, 1.1 ms per 2 frames for 0.16 ms of matrix work.
-    constexpr bool PIPE = !SCATTER;
+    constexpr bool PIPE = !SCATTER && !WIDE;
     struct RecPre { int b, ray, tt; float o3[3], d3[3]; float4 rec; float zq; float4 gf[2]; DfSlots slots; };
     struct GatPre { float w[3][4]; float4 v0[3][4], v1[3][4]; };
     auto issue_rec = [&](long long tile) __attribute__((always_inline)) {
@@ -186,7 +192,13 @@ raymarch_bwd_tiles_kernel(const RayParams p, float* __restrict__ d_planes, const
             r_nxt = issue_rec(min(sch.begin + sch.stride, last_tile));
         }
     }
-    for (long long tile = sch.begin; tile < sch.end; tile += sch.stride) {
+    float o3w[3] = {0.f, 0.f, 0.f}, d3w[3] = {0.f, 0.f, 0.f}, zqw = 0.f;      // WIDE: what a ray's tiles share
+    float4 gfw[2] = {};
+    int bw = 0, rayw = 0;
+    for (long long it = sch.begin; it < sch.end; it += sch.stride) {
+#pragma unroll 1
+    for (int tw = 0; tw < (WIDE ? NT : 1); ++tw) {
+        const long long tile = WIDE ? it * NT + tw : it;
         float4 rec;
         float f[8];
         float4 gfeat[2];
@@ -207,31 +219,43 @@ raymarch_bwd_tiles_kernel(const RayParams p, float* __restrict__ d_planes, const
             for (int c = 0; c < 8; ++c) f[c] = __shfl(f[c], src);
             r_cur = r_nxt; r_nxt = r_nn; g_cur = g_nxt;
         } else {
-        tt = __builtin_amdgcn_readfirstlane((int)(tile % NT));        // wave-uniform -> scalar registers
-        int pi, pj;
-        ray_of(__builtin_amdgcn_readfirstlane((int)(tile / NT)), a.res, b, pi, pj);
-        ray = __builtin_amdgcn_readfirstlane(b * R + pi * a.res + pj);
-        float o3[3], d3[3];
-        ray_setup(a, b, pi, pj, o3, d3);
+        tt = WIDE ? tw : __builtin_amdgcn_readfirstlane((int)(tile % NT));        // wave-uniform -> scalar registers
+        if (!WIDE || tw == 0) {
+            int pi, pj;
+            ray_of(__builtin_amdgcn_readfirstlane((int)(WIDE ? it : tile / NT)), a.res, bw, pi, pj);
+            rayw = __builtin_amdgcn_readfirstlane(bw * R + pi * a.res + pj);
+            ray_setup(a, bw, pi, pj, o3w, d3w);
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot) gfw[ot] = *reinterpret_cast<const float4*>(p.g_feat + (size_t)rayw * 32 + 16 * ot + 4 * g);
+            zqw = p.rec[((size_t)rayw * S + 16 * tt + (lane >> 2)) * 4];
+        }
+        b = bw; ray = rayw;
+        const float* o3 = o3w; const float* d3 = d3w;
         const int s = 16 * tt + j;
         rec = *reinterpret_cast<const float4*>(p.rec + ((size_t)ray * S + s) * 4);   // depth, omega, dsigma
-        sample_taps(p, o3, d3, rec.x, taps);          // taps of sample j: the scatter below publishes them
+        if constexpr (SCATTER) sample_taps(p, o3, d3, rec.x, taps);          // taps of sample j: the scatter below publishes them
         {
             // gather in the quad layout of raymarch_kernel (4 adjacent lanes per texel line), then to the MFMA layout
             PlaneTaps tq[3];
-            sample_taps(p, o3, d3, p.rec[((size_t)ray * S + 16 * tt + (lane >> 2)) * 4], tq);
+            const float zq_cur = zqw;
+            if constexpr (WIDE) zqw = p.rec[((size_t)ray * S + 16 * min(tt + 1, NT - 1) + (lane >> 2)) * 4];
+            sample_taps(p, o3, d3, zq_cur, tq);
             gather8(a, b, lane & 3, tq, f);
             const int src = 4 * j + g;
 #pragma unroll
             for (int c = 0; c < 8; ++c) f[c] = __shfl(f[c], src);
         }
-#pragma unroll
-        for (int ot = 0; ot < 2; ++ot) gfeat[ot] = *reinterpret_cast<const float4*>(p.g_feat + (size_t)ray * 32 + 16 * ot + 4 * g);
+        gfeat[0] = gfw[0]; gfeat[1] = gfw[1];
+        if constexpr (!SCATTER) {
+            if (ro.dfs) slots = load_df_slots(ro, (size_t)ray * S + s);
+        }
         }
         f32x4 hp[4], h[4], o[2];
         float sigma;
-        if constexpr (DEC16) decoder_fwd16_lds<true>(wfwd, lane, f, hp, h, sigma, o);
-        else decoder_fwd_lds<true>(wfwd, lane, f, hp, h, sigma, o);
+        int ln = lane;
+        if constexpr (WIDE) asm volatile("" : "+v"(ln));
+        if constexpr (DEC16) decoder_fwd16_lds<true>(wfwd, ln, f, hp, h, sigma, o);
+        else decoder_fwd_lds<true>(wfwd, ln, f, hp, h, sigma, o);
 
         // dL/do (colour logits) in the C layout: lane (j, g), register r of tile ot -> channel 16ot + 4g + r
         //   colour = sigmoid(o) * 1.002 - 0.001,  dL/dcolour = omega * 2 dL/dfeat
@@ -249,16 +273,16 @@ raymarch_bwd_tiles_kernel(const RayParams p, float* __restrict__ d_planes, const
         // dH^T = W1c^T . dO^T + wsig (x) dsigma:  A[i][k] = W1[1 + c(k)][16mt + i],  c(k) = 16ot + 4g + r
         f32x4 dH[4];
         f32x4 dF[2];
-        if constexpr (DEC16) decoder_bwd16_lds(wfwd, w1t, w0t, lane, dO, rec.z, hp, dH, dF);
+        if constexpr (DEC16) decoder_bwd16_lds(wfwd, w1t, w0t, ln, dO, rec.z, hp, dH, dF);
 #pragma unroll
         for (int mt = 0; mt < (DEC16 ? 0 : 4); ++mt) {
-            const float* ws_ = wfwd + (48 + mt * 4) * 64 + lane;
+            const float* ws_ = wfwd + (48 + mt * 4) * 64 + ln;
             dH[mt] = f32x4{ws_[0] * rec.z, ws_[64] * rec.z, ws_[128] * rec.z, ws_[192] * rec.z};
 #pragma unroll
             for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float wA = w1t[(mt * 8 + ot * 4 + r) * 64 + lane];
+                    const float wA = w1t[(mt * 8 + ot * 4 + r) * 64 + ln];
                     dH[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wA, dO[ot][r], dH[mt], 0, 0, 0);
                 }
 #pragma unroll
@@ -273,7 +297,7 @@ raymarch_bwd_tiles_kernel(const RayParams p, float* __restrict__ d_planes, const
                 for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float wA = w0t[(ft * 16 + mt * 4 + r) * 64 + lane];
+                        const float wA = w0t[(ft * 16 + mt * 4 + r) * 64 + ln];
                         dF[ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(wA, dH[mt][r], dF[ft], 0, 0, 0);
                     }
             }
@@ -395,6 +419,7 @@ raymarch_bwd_tiles_kernel(const RayParams p, float* __restrict__ d_planes, const
         }
         }   // SCATTER
         WAVE_SYNC();
+    }
     }
     if constexpr (PG) {
         // effective weight = parameter * gain  ->  d parameter = d effective * gain
@@ -1092,6 +1117,16 @@ static void launch_tiles2(bool pg, bool mirror, unsigned blocks, const RayParams
 template <int S>
 static void launch_decoder_grads(unsigned blocks, const RayParams& p, float* d_planes, const DecGrads& dg, const RowsOut& ro,
                                  hipStream_t s) {
+    // two waves per SIMD reading the weight images from LDS (WIDE): 1.06 -> 0.93 ms per 2 frames against one 512-register wave
+    // per SIMD with the software pipeline
+    static const bool narrow = getenv("HFAGP_DEV_PG_NARROW") != nullptr;      // developer switch: A/B timing
+    if (!narrow) {
+        if (p.a.planes_absmax)
+            raymarch_bwd_tiles_kernel<S, true, true, true, false, true><<<blocks, 512, 0, s>>>(p, d_planes, dg, ro);
+        else
+            raymarch_bwd_tiles_kernel<S, true, true, false, false, true><<<blocks, 512, 0, s>>>(p, d_planes, dg, ro);
+        return;
+    }
     if (p.a.planes_absmax)
         raymarch_bwd_tiles_kernel<S, true, true, true, false><<<blocks, TileWaves<true, false>::value * 64, 0, s>>>(p, d_planes, dg, ro);
     else
@@ -1102,15 +1137,6 @@ static void launch_decoder_grads(unsigned blocks, const RayParams& p, float* d_p
 template <int S>
 static void launch_df_sorted(const RayParams& p, const RowsOut& ro, hipStream_t s) {
     const long long ntiles = (long long)p.total_rays * (S / 16);
-    static const bool piped = getenv("HFAGP_DEV_DF_PIPE") != nullptr;        // developer switch: A/B timing
-    if (piped) {
-        const unsigned blocks = (unsigned)std::min<long long>((ntiles + 3) / 4, (long long)kNumCU * 2);
-        if (p.a.planes_absmax)
-            raymarch_bwd_tiles_kernel<S, false, true, true, false><<<blocks, 256, 0, s>>>(p, nullptr, DecGrads{}, ro);
-        else
-            raymarch_bwd_tiles_kernel<S, false, true, false, false><<<blocks, 256, 0, s>>>(p, nullptr, DecGrads{}, ro);
-        return;
-    }
     static const int per_cu = getenv("HFAGP_DEV_DF_BLOCKS") ? atoi(getenv("HFAGP_DEV_DF_BLOCKS")) : 6;      // developer: A/B timing
     const unsigned dblocks = (unsigned)std::min<long long>((ntiles + kDfWaves - 1) / kDfWaves, (long long)kNumCU * per_cu);
     if (p.a.planes_absmax) raymarch_bwd_df_kernel<S, true, true><<<dblocks, kDfWaves * 64, 0, s>>>(p, nullptr, ro);
