@@ -23,7 +23,10 @@ constexpr int kRed = 10;
 template <bool SMALL, bool PG>
 __global__ void __launch_bounds__(256) pointwise_bwd_kernel(const HfagpPointwiseBwdArgs a, int rows_per_block) {
     // block = (chunk of pixel rows, sample b); thread = (pixel lane, 4-channel group)
-    extern __shared__ __attribute__((aligned(16))) float red[];      // [256/C4][kRed][C]
+    // rows the variant really accumulates: 0 .. 3 without the parameter gradients (the LDS scratch of all ten rows was 40 KB per
+    // workgroup: four workgroups per CU whatever the register count)
+    constexpr int NR = PG ? kRed : 4;
+    extern __shared__ __attribute__((aligned(16))) float red[];      // [256/C4][NR][C]
     const int C4 = a.C >> 2;
     const int b = blockIdx.y, chunk = blockIdx.x;
     const int c4 = threadIdx.x % C4, pl = threadIdx.x / C4, npl = 256 / C4;
@@ -153,14 +156,15 @@ __global__ void __launch_bounds__(256) pointwise_bwd_kernel(const HfagpPointwise
         }
     }
     // ---- block reduction over the pixel lanes, then one deterministic partial per (b, chunk)
-    float* mine = red + ((size_t)pl * kRed) * a.C + c4 * 4;
+    float* mine = red + ((size_t)pl * NR) * a.C + c4 * 4;
 #pragma unroll
-    for (int r = 0; r < kRed; ++r)
+    for (int r = 0; r < NR; ++r)
         if (pvalid) *reinterpret_cast<float4*>(mine + r * a.C) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
     __syncthreads();
     for (int i = threadIdx.x; i < kRed * a.C; i += 256) {
         float s = 0.f;
-        for (int q = 0; q < npl; ++q) s += red[(size_t)q * kRed * a.C + i];
+        if (i < NR * a.C)
+            for (int q = 0; q < npl; ++q) s += red[(size_t)q * NR * a.C + i];
         a.partial[(((size_t)b * gridDim.x + chunk) * kRed) * a.C + i] = s;
     }
 }
@@ -468,7 +472,7 @@ int hfagp_pointwise_bwd(const HfagpPointwiseBwdArgs* a, void* stream) {
     const int HW = a->H * a->W;
     const int rows = (HW + a->nchunks - 1) / a->nchunks;
     const int npl = 256 / (a->C / 4);
-    const size_t lds = (size_t)npl * kRed * a->C * sizeof(float);
+    const size_t lds = (size_t)npl * (a->param_grads ? kRed : 4) * a->C * sizeof(float);
     HFAGP_REQUIRE(lds <= 64 * 1024, HFAGP_EUNSUPPORTED, "pointwise_bwd: LDS %zu", lds);
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(a->nchunks, a->B);
