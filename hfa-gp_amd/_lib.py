@@ -119,7 +119,15 @@ class StyleBwdArgs(C.Structure):
 
 class WgradArgs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("x", "styles", "g", "weight", "dd", "dcoef", "dweight", "workspace")] + \
-        [(n, C.c_int32) for n in ("B", "H", "W", "Cin", "Cout", "mode", "ksplit", "precision", "accumulate")]
+        [(n, C.c_int32) for n in ("B", "H", "W", "Cin", "Cout", "mode", "ksplit", "precision", "accumulate", "dd_stride")]
+
+
+class AffineGradItem(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("dstot", "w", "dA", "db")] + [(n, C.c_int32) for n in ("B", "Cin", "w_dim", "w_stride")]
+
+
+class BiasNoiseGradItem(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("sums", "dbias", "dnoise")] + [(n, C.c_int32) for n in ("B", "C")]
 
 
 class WeightPrepItem(C.Structure):
@@ -180,6 +188,8 @@ SYMBOLS = {
     "hfagp_wgrad_workspace_bytes": (C.c_size_t, [C.POINTER(WgradArgs)]),
     "hfagp_conv_wgrad": (C.c_int, [C.POINTER(WgradArgs), C.c_void_p]),
     "hfagp_affine_grad": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 4 + [C.c_void_p]),
+    "hfagp_affine_grad_batch": (C.c_int, [C.POINTER(AffineGradItem), C.c_int32, C.c_void_p]),
+    "hfagp_bias_noise_grads": (C.c_int, [C.POINTER(BiasNoiseGradItem), C.c_int32, C.c_void_p]),
     "hfagp_channel_sum": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "hfagp_pool_mse_workspace_bytes": (C.c_size_t, []),
     "hfagp_pool_mse_fwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 4 + [C.c_void_p]),

@@ -41,6 +41,8 @@ class _Backward:
         # tuned step spent ~140 launches of 2-3 us + 370 MB of traffic on AccumulateGrad's per-tensor adds)
         self.inplace = bool(getattr(gen, "_grad_inplace", False))
         self.pending = []          # style gradients of the whole pass: (item for ops.style_bwd_batch, affine module)
+        self.direct_ready = []     # parameters whose .grad a kernel has accumulated into since the last release
+        self.small = []            # in-place mode: (sums, bias.grad, noise_strength.grad) of the block's layers, one launch per block
 
     # bench.py's roofline_train: HIP events around the three kernel families that carry the backward pass (gen.timing keys
     # "bwd_data" [algorithmic flops 2 M N K of the adjoint conv], "pointwise_bwd" [bytes of the full-size tensors read +
@@ -85,6 +87,15 @@ class _Backward:
         else:
             self._acc(weight, dw)
 
+    def _direct(self, param: torch.Tensor) -> bool:
+        """May a kernel accumulate into param.grad itself (the trainer's step scope: .grad is a zeroed slice of the flat buffer)?"""
+        return self.inplace and param.requires_grad and param.grad is not None and param.grad.is_contiguous() \
+            and id(param) not in self.grads and id(param) not in self.released
+
+    def _mark_direct(self, param: torch.Tensor):
+        self.released.add(id(param))
+        self.direct_ready.append(param)
+
     def _acc(self, param: torch.Tensor, g: torch.Tensor):
         key = id(param)
         self.grads[key] = g if key not in self.grads else self.grads[key] + g
@@ -97,6 +108,14 @@ class _Backward:
         the collective of a finished bucket while the rest of the backward pass is still being enqueued; released
         parameters get None from autograd.  Without a sink nothing happens and autograd receives every gradient."""
         sink = getattr(self.gen, "_grad_sink", None)
+        if self.small:
+            ops.bias_noise_grads(self.small)
+            self.small = []
+        if self.direct_ready:
+            if sink is not None:
+                for p in self.direct_ready:
+                    sink(p, None)          # (already accumulated: only counted as ready)
+            self.direct_ready = []
         if self.inplace:
             ready = [k for k in self.grads if self.by_id[k].requires_grad and self.by_id[k].grad is not None]
             if ready:
@@ -208,13 +227,17 @@ class _Backward:
                 co = tr.weight.shape[0]
                 dw = (sums[:, 6:6 + co] * rgb["styles"][:, None, :]).sum(0)          # [Co, C]: tiny host-side glue
                 self._acc(tr.weight, dw.reshape(tr.weight.shape))
-                db = torch.zeros_like(tr.bias)
-                ops.channel_sum(g_y.permute(0, 2, 3, 1).contiguous(), db)
+                g_cl = g_y.permute(0, 2, 3, 1).contiguous()
             else:
                 self.wgrad(x1, rgb["styles"], g_y, tr.weight, ops.CONV1X1)
+                g_cl = g_y
+            if self._direct(tr.bias):                  # straight into the .grad slice (no zero-filled temporary, no add)
+                ops.channel_sum(g_cl, tr.bias.grad)
+                self._mark_direct(tr.bias)
+            else:
                 db = torch.zeros_like(tr.bias)
-                ops.channel_sum(g_y, db)
-            self._acc(tr.bias, db)
+                ops.channel_sum(g_cl, db)
+                self._acc(tr.bias, db)
             self.layer_param_grads(c1, sums, g_conv1)
         # ---- conv1 bwd-data
         c1_cin = c1["layer"].weight.shape[1]
@@ -252,10 +275,19 @@ class _Backward:
         # gradient GEMMs follow the generator's precision class: exact fp32 MFMA when conv_precision is "fp32", else
         # split-bf16 (the 3x3 layers with 64-multiple channels; bf16 parts keep a gradient's exponent range)
         wprec = "fp32" if self.gen.conv_precision == "fp32" else "bf16x3"
-        self.wgrad(x, rec["styles"], g, layer.weight, mode, dd=rec["dd"].contiguous(), dcoef=rec["dcoef"], precision=wprec)
+        self.wgrad(x, rec["styles"], g, layer.weight, mode, dd=rec["dd"], dcoef=rec["dcoef"], precision=wprec)
+        noise = layer.noise_strength if rec["producer"]["noise"] is not None else None
+        if self._direct(layer.bias) and (noise is None or self._direct(noise)):
+            # straight into the .grad slices, all layers of the block in one launch (release_ready): per layer the framework
+            # ran two reductions and the release two adds
+            self.small.append((sums_out, layer.bias.grad, None if noise is None else noise.grad.view(1)))
+            self._mark_direct(layer.bias)
+            if noise is not None:
+                self._mark_direct(noise)
+            return
         self._acc(layer.bias, sums_out[:, 4].sum(0))
-        if rec["producer"]["noise"] is not None:
-            self._acc(layer.noise_strength, sums_out[:, 5].sum())
+        if noise is not None:
+            self._acc(noise, sums_out[:, 5].sum())
 
     def finish_layer(self, rec: dict):
         """ds (from the pass over the layer's input) and dd (from the pass over its output) are both known: queue the
@@ -265,7 +297,16 @@ class _Backward:
 
     def flush_styles(self):
         dstots = ops.style_bwd_batch([it for it, _ in self.pending], self.d_ws)
-        if self.pg:
+        if self.pg and all(self._direct(affine.weight) and self._direct(affine.bias) for _, affine in self.pending) \
+                and len({id(affine) for _, affine in self.pending}) == len(self.pending):
+            # every affine layer of the pass in one launch, straight into the .grad slices (was: a zero-filled staging buffer,
+            # 26 launches, a multi-tensor add)
+            ops.affine_grad_batch([(dstot, self.ws[:, it[6]], affine.weight.grad, affine.bias.grad)
+                                   for (it, affine), dstot in zip(self.pending, dstots)])
+            for _, affine in self.pending:
+                self._mark_direct(affine.weight)
+                self._mark_direct(affine.bias)
+        elif self.pg:
             sizes = [(affine.weight.numel(), affine.bias.numel()) for _, affine in self.pending]
             flat = torch.zeros(sum(a + b for a, b in sizes), device=self.d_ws.device, dtype=torch.float32)
             off = 0
@@ -329,15 +370,21 @@ class SynthesisFn(torch.autograd.Function):
         bw.finish_layer(c0rec0)
         # ---- renderer
         res = cfg.neural_rendering_resolution
+        net = gen.decoder.net
+        dec_prm = (net["0"].weight, net["0"].bias, net["2"].weight, net["2"].bias)
+        dec_direct = ctx.pg and all(bw._direct(p) for p in dec_prm)       # the kernel's atomics land in the .grad slices themselves
         rb = gen._timed("raymarch_bwd", float(b), ops.raymarch_bwd, g_feat.view(b, res * res, 32), tape["planes"],
                         u_strat=tape["u_strat"], u_imp=tape["u_imp"], decoder_grads=ctx.pg,
                         planes_absmax=tape.get("planes_absmax"), state=tape.get("ray_state"),
+                        dec_out=tuple(p.grad for p in dec_prm) if dec_direct else None,
                         **gen._render_args(tape["c"]))
         if ctx.pg:
             d_planes, dec = rb
-            net = gen.decoder.net
-            for prm, g in zip((net["0"].weight, net["0"].bias, net["2"].weight, net["2"].bias), dec):
-                bw._acc(prm, g)
+            for prm, g in zip(dec_prm, dec):
+                if dec_direct:
+                    bw._mark_direct(prm)
+                else:
+                    bw._acc(prm, g)
             bw.release_ready()
         else:
             d_planes = rb

@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
                                                            const float* __restrict__ dd, const float* __restrict__ dcoef,
                                                            const float* __restrict__ styles, float* __restrict__ dW,
                                                            int ksplit, int ntaps, int Cin, int Cout, int B, int wtaps,
-                                                           const WTaps9 taps, int accumulate) {
+                                                           const WTaps9 taps, int accumulate, int dds) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // over Cin * Cout, co fastest
     if (idx >= Cin * Cout) return;
     const int t = blockIdx.y;
@@ -187,7 +187,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
     if (dd)
         for (int b = 0; b < B; ++b) {
             const float d = dcoef[(size_t)b * Cout + co], sv = styles[(size_t)b * Cin + ci];
-            dem += dd[(size_t)b * Cout + co] * d * d * d * sv * sv;
+            dem += dd[(size_t)b * dds + co] * d * d * d * sv * sv;
         }
     const float* src = slabs + ((size_t)t * Cin + ci) * Cout + co;
     const size_t kstride = (size_t)ntaps * Cin * Cout;
@@ -221,7 +221,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce_tiled_kernel(const float* __
                                                                  const float* __restrict__ dd, const float* __restrict__ dcoef,
                                                                  const float* __restrict__ styles, float* __restrict__ dW,
                                                                  int ksplit, int ntaps, int Cin, int Cout, int B, int wtaps,
-                                                                 const RedTaps taps, int accumulate) {
+                                                                 const RedTaps taps, int accumulate, int dds) {
     constexpr int CW = 32 * V;
     __shared__ float tile[CW][8 * 9 + 1];                       // [co][ci * ntaps + tap slot]
     typedef float vec __attribute__((ext_vector_type(V)));
@@ -258,7 +258,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce_tiled_kernel(const float* __
             float dem = 0.f;
             for (int b = 0; b < B; ++b) {
                 const float d = dcoef[(size_t)b * Cout + co0 + c], sv = styles[(size_t)b * Cin + ci0 + r];
-                dem += dd[(size_t)b * Cout + co0 + c] * d * d * d * sv * sv;
+                dem += dd[(size_t)b * dds + co0 + c] * d * d * d * sv * sv;
             }
             v -= weight[wi] * dem;
         }
@@ -271,7 +271,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce_tiled_kernel(const float* __
 __global__ void __launch_bounds__(256) wgrad_sum_final_kernel(const float* __restrict__ slabs, const float* __restrict__ weight,
                                                               const float* __restrict__ dd, const float* __restrict__ dcoef,
                                                               const float* __restrict__ styles, float* __restrict__ dW,
-                                                              int ksplit, int Cin, int Cout, int B, int accumulate) {
+                                                              int ksplit, int Cin, int Cout, int B, int accumulate, int dds) {
     const size_t n4 = (size_t)Cin * Cout * 9 / 4;            // (Cin, Cout multiples of 64)
     const size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i4 >= n4) return;
@@ -304,7 +304,7 @@ __global__ void __launch_bounds__(256) wgrad_sum_final_kernel(const float* __res
             float dem = 0.f;
             for (int b = 0; b < B; ++b) {
                 const float d = dcoef[(size_t)b * Cout + co], sv = styles[(size_t)b * Cin + ci];
-                dem += dd[(size_t)b * Cout + co] * d * d * d * sv * sv;
+                dem += dd[(size_t)b * dds + co] * d * d * d * sv * sv;
             }
             out[j] -= wv[j] * dem;
         }
@@ -319,7 +319,7 @@ __global__ void __launch_bounds__(256) wgrad_sum_final_kernel(const float* __res
 static int launch_wgrad_sum_final(const HfagpWgradArgs* a, hipStream_t s) {
     const size_t n4 = (size_t)a->Cin * a->Cout * 9 / 4;
     wgrad_sum_final_kernel<<<(unsigned)((n4 + 255) / 256), 256, 0, s>>>(a->workspace, a->weight, a->dd, a->dcoef, a->styles, a->dweight,
-                                                                        a->ksplit, a->Cin, a->Cout, a->B, a->accumulate);
+                                                                        a->ksplit, a->Cin, a->Cout, a->B, a->accumulate, a->dd_stride > 0 ? a->dd_stride : a->Cout);
     return check_launch("conv_wgrad/sum");
 }
 
@@ -327,7 +327,8 @@ static int launch_wgrad_sum_final(const HfagpWgradArgs* a, hipStream_t s) {
 // for shapes the tiles do not divide
 static int launch_wgrad_reduce(const HfagpWgradArgs* a, const RedTaps& rt, int ntaps, int wtaps, hipStream_t s) {
     wgrad_reduce_tiled_kernel<1><<<dim3((unsigned)(a->Cin / 8), (unsigned)(a->Cout / 32)), 256, 0, s>>>(
-        a->workspace, a->weight, a->dd, a->dcoef, a->styles, a->dweight, a->ksplit, ntaps, a->Cin, a->Cout, a->B, wtaps, rt, a->accumulate);
+        a->workspace, a->weight, a->dd, a->dcoef, a->styles, a->dweight, a->ksplit, ntaps, a->Cin, a->Cout, a->B, wtaps, rt, a->accumulate,
+        a->dd_stride > 0 ? a->dd_stride : a->Cout);
     return check_launch("conv_wgrad/reduce");
 }
 
@@ -346,6 +347,49 @@ __global__ void __launch_bounds__(256) affine_grad_kernel(const float* __restric
     }
     dA[idx] += acc * wgain;
     if (k == 0) db[i] += sb;
+}
+
+// the same for every affine layer of a backward pass in ONE launch (the tuned step ran 26 of the above: 3 us each and a
+// zero-filled staging buffer; here dA / db are the parameters' .grad slices themselves)
+constexpr int kBatchMax = 32;
+struct AffineGradBatch { HfagpAffineGradItem it[kBatchMax]; };
+__global__ void __launch_bounds__(256) affine_grad_batch_kernel(const AffineGradBatch t) {
+    const HfagpAffineGradItem& a = t.it[blockIdx.y];
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.Cin * a.w_dim) return;
+    const int i = idx / a.w_dim, k = idx % a.w_dim;
+    float acc = 0.f, sb = 0.f;
+    for (int b = 0; b < a.B; ++b) {
+        const float d = a.dstot[(size_t)b * a.Cin + i];
+        acc += d * a.w[(size_t)b * a.w_stride + k];
+        sb += d;
+    }
+    a.dA[idx] += acc * (1.0f / sqrtf((float)a.w_dim));
+    if (k == 0) a.db[i] += sb;
+}
+
+// bias and noise-strength gradients of the synthesis layers of one block from the reductions hfagp_pointwise_bwd left behind
+// (rows 4 and 5 of sums [B][10][C]):  dbias[c] += sum_b sums[b][4][c],  dnoise += sum_{b,c} sums[b][5][c]; fixed order
+struct BiasNoiseBatch { HfagpBiasNoiseGradItem it[kBatchMax]; };
+__global__ void __launch_bounds__(256) bias_noise_grads_kernel(const BiasNoiseBatch t) {
+    __shared__ float red[256];
+    const HfagpBiasNoiseGradItem& a = t.it[blockIdx.x];
+    float n5 = 0.f;
+    for (int c = threadIdx.x; c < a.C; c += 256) {
+        float s4 = 0.f;
+        for (int b = 0; b < a.B; ++b) {
+            s4 += a.sums[((size_t)b * 10 + 4) * a.C + c];
+            n5 += a.sums[((size_t)b * 10 + 5) * a.C + c];
+        }
+        if (a.dbias) a.dbias[c] += s4;
+    }
+    red[threadIdx.x] = n5;
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && a.dnoise) a.dnoise[0] += red[0];
 }
 
 // per-channel sums over all pixels of a channels-last tensor: out[c] += sum_{b,pix} g[b][pix][c] (deterministic 2-stage).
@@ -419,7 +463,8 @@ static int run_wgrad(WgradParams& p, const HfagpWgradArgs* a, hipStream_t s, boo
     for (int t = 0; t < 9; ++t) taps.t[t] = p.tap[t];
     const dim3 rgrid((unsigned)((a->Cin * a->Cout + 255) / 256), (unsigned)NT);
     wgrad_reduce_kernel<<<rgrid, 256, 0, s>>>(p.slabs, a->weight, a->dd, a->dcoef, a->styles, a->dweight, a->ksplit, NT,
-                                              a->Cin, a->Cout, a->B, wtaps, taps, a->accumulate);
+                                              a->Cin, a->Cout, a->B, wtaps, taps, a->accumulate,
+                                              a->dd_stride > 0 ? a->dd_stride : a->Cout);
     return check_launch("conv_wgrad/reduce");
 }
 
@@ -524,6 +569,32 @@ int hfagp_affine_grad(const float* dstot, const float* w, float* dA, float* db, 
     affine_grad_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(dstot, w, dA, db, B, Cin, w_dim, w_stride,
                                                                          1.0f / sqrtf((float)w_dim));
     return check_launch("affine_grad");
+}
+
+int hfagp_affine_grad_batch(const HfagpAffineGradItem* items, int32_t n, void* stream) {
+    HFAGP_REQUIRE(items && n >= 1 && n <= kBatchMax, HFAGP_EBADARG, "affine_grad_batch: 1..%d items", kBatchMax);
+    AffineGradBatch t;
+    int most = 0;
+    for (int i = 0; i < n; ++i) {
+        const HfagpAffineGradItem& a = items[i];
+        HFAGP_REQUIRE(a.dstot && a.w && a.dA && a.db && a.B > 0 && a.Cin > 0 && a.w_dim > 0, HFAGP_EBADARG,
+                      "affine_grad_batch: item %d: null pointer / bad dims", i);
+        t.it[i] = a;
+        most = std::max(most, a.Cin * a.w_dim);
+    }
+    affine_grad_batch_kernel<<<dim3((unsigned)((most + 255) / 256), (unsigned)n), 256, 0, (hipStream_t)stream>>>(t);
+    return check_launch("affine_grad_batch");
+}
+
+int hfagp_bias_noise_grads(const HfagpBiasNoiseGradItem* items, int32_t n, void* stream) {
+    HFAGP_REQUIRE(items && n >= 1 && n <= kBatchMax, HFAGP_EBADARG, "bias_noise_grads: 1..%d items", kBatchMax);
+    BiasNoiseBatch t;
+    for (int i = 0; i < n; ++i) {
+        HFAGP_REQUIRE(items[i].sums && items[i].B > 0 && items[i].C > 0, HFAGP_EBADARG, "bias_noise_grads: item %d", i);
+        t.it[i] = items[i];
+    }
+    bias_noise_grads_kernel<<<(unsigned)n, 256, 0, (hipStream_t)stream>>>(t);
+    return check_launch("bias_noise_grads");
 }
 
 int hfagp_channel_sum(const float* g, float* partial, float* out, int64_t npix, int32_t C, int32_t nblocks,

@@ -105,6 +105,31 @@ class EqualConv2d(nn.Module):
         return F.conv2d(x, self.weight * self.scale, bias=self.bias, stride=self.stride, padding=self.padding)
 
 
+class _EqualLinearFn(torch.autograd.Function):
+    """y = x @ (W * scale)^T + b * lr_mul with the scale folded into the GEMM calls (`alpha`): the plain expression costs two
+    scalar-multiply kernels per layer in the forward pass and two more in autograd's backward — 28 launches of ~3 us per step
+    for the 3DMM driver's seven-layer chain, a third of its kernels."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, scale, lr_mul):
+        ctx.save_for_backward(x, weight)
+        ctx.scale, ctx.lr_mul = scale, lr_mul
+        return torch.addmm(bias if lr_mul == 1 else bias * lr_mul, x, weight.t(), alpha=scale)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g = g.contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.addmm(g.new_empty(x.shape), g, weight, beta=0, alpha=ctx.scale)
+        if ctx.needs_input_grad[1]:
+            gw = torch.addmm(g.new_empty(weight.shape), g.t(), x, beta=0, alpha=ctx.scale)
+        if ctx.needs_input_grad[2]:
+            gb = g.sum(0) if ctx.lr_mul == 1 else g.sum(0) * ctx.lr_mul
+        return gx, gw, gb, None, None
+
+
 class EqualLinear(nn.Module):
     def __init__(self, in_dim, out_dim, bias=True, bias_init=0, lr_mul=1, activation=None):
         super().__init__()
@@ -117,6 +142,8 @@ class EqualLinear(nn.Module):
     def forward(self, x):
         if self.activation:
             return fused_leaky_relu(F.linear(x, self.weight * self.scale), self.bias * self.lr_mul)
+        if x.dim() == 2 and self.bias is not None and x.dtype == self.weight.dtype:
+            return _EqualLinearFn.apply(x, self.weight, self.bias, self.scale, self.lr_mul)
         return F.linear(x, self.weight * self.scale, bias=self.bias * self.lr_mul)
 
 

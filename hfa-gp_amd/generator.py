@@ -615,7 +615,10 @@ class TriPlaneGenerator(nn.Module):
     def _render_args(self, c: torch.Tensor):
         cfg = self.cfg
         net = self.decoder.net
-        return dict(cam2world=c[:, :16].contiguous(), intrinsics=c[:, 16:25].contiguous(),
+        hit = getattr(self, "_cam_cache", None)       # the backward pass of a step asks again with the forward's tensor
+        if hit is None or hit[0] is not c or hit[1] != c._version:
+            hit = self._cam_cache = (c, c._version, c[:, :16].contiguous(), c[:, 16:25].contiguous())
+        return dict(cam2world=hit[2], intrinsics=hit[3],
                     dec_w0=net["0"].weight, dec_b0=net["0"].bias, dec_w1=net["2"].weight, dec_b1=net["2"].bias,
                     res=cfg.neural_rendering_resolution, ray_start=cfg.ray_start, ray_end=cfg.ray_end,
                     box_warp=cfg.box_warp, decoder_lr_mul=cfg.decoder_lr_mul,

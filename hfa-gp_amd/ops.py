@@ -957,6 +957,10 @@ def conv_wgrad(x: torch.Tensor, styles: Optional[torch.Tensor], g: torch.Tensor,
     dweight = torch.empty_like(weight) if out is None else out
     a.x, a.styles, a.g = _ptr(x), _ptr(styles), _ptr(g)
     a.weight, a.dd, a.dcoef, a.dweight = _ptr(_chk(weight.detach(), "weight")), _ptr(dd), _ptr(dcoef), _ptr(dweight)
+    if dd is not None:                  # a row view [B, Cout] of pointwise_bwd's sums is read in place (ABI 12 `dd_stride`)
+        if dd.dim() != 2 or dd.shape[1] != cout or dd.stride(1) != 1 or dd.dtype != torch.float32:
+            raise RuntimeError("conv_wgrad: dd must be [B, Cout] fp32 with unit column stride")
+        a.dd_stride = dd.stride(0)
     a.B, a.H, a.W, a.Cin, a.Cout, a.mode = b, h, w, cin, cout, mode
     a.precision = PREC_BF16X3 if precision == "bf16x3" else PREC_F32
     a.ksplit = L.lib().hfagp_wgrad_ksplit(C.byref(a)) if ksplit is None else ksplit      # (the library's split-K policy)
@@ -971,6 +975,29 @@ def affine_grad(dstot: torch.Tensor, w: torch.Tensor, dA: torch.Tensor, db: torc
     b, cin = dstot.shape
     L.check(L.lib().hfagp_affine_grad(_ptr(dstot), w.data_ptr(), _ptr(dA), _ptr(db), b, cin, w.shape[1], w.stride(0),
                                       _stream()), "affine_grad")
+
+
+def affine_grad_batch(items) -> None:
+    """items: (dstot [B,Cin], w row view [B,w_dim] of ws, dA [Cin,w_dim], db [Cin]) per affine layer; dA / db are accumulated
+    into (the parameters' .grad slices): every affine layer of a backward pass in one launch per 32."""
+    for i0 in range(0, len(items), 32):
+        chunk = items[i0:i0 + 32]
+        arr = (L.AffineGradItem * len(chunk))()
+        for a, (dstot, w, dA, db) in zip(arr, chunk):
+            a.dstot, a.w, a.dA, a.db = _ptr(_chk(dstot, "dstot")), w.data_ptr(), _ptr(_chk(dA, "dA")), _ptr(_chk(db, "db"))
+            a.B, a.Cin, a.w_dim, a.w_stride = dstot.shape[0], dstot.shape[1], w.shape[1], w.stride(0)
+        L.check(L.lib().hfagp_affine_grad_batch(arr, len(chunk), _stream()), "affine_grad_batch")
+
+
+def bias_noise_grads(items) -> None:
+    """items: (sums [B,10,C] of pointwise_bwd(param_grads=True), dbias [C] or None, dnoise [1] or None): accumulated into."""
+    for i0 in range(0, len(items), 32):
+        chunk = items[i0:i0 + 32]
+        arr = (L.BiasNoiseGradItem * len(chunk))()
+        for a, (sums, dbias, dnoise) in zip(arr, chunk):
+            a.sums, a.dbias, a.dnoise = _ptr(_chk(sums, "sums")), _ptr(dbias), _ptr(dnoise)
+            a.B, a.C = sums.shape[0], sums.shape[2]
+        L.check(L.lib().hfagp_bias_noise_grads(arr, len(chunk), _stream()), "bias_noise_grads")
 
 
 def channel_sum(g: torch.Tensor, out: torch.Tensor, accumulate: bool = True) -> None:
@@ -992,7 +1019,7 @@ def raymarch_bwd(g_feat: torch.Tensor, planes: torch.Tensor, cam2world, intrinsi
                  decoder_lr_mul: float = 1.0, plane_axes: int = 0, white_back: bool = False,
                  return_rec: bool = False, decoder_grads: bool = False, decoder_precision: str = "f16x3",
                  planes_absmax: Optional[torch.Tensor] = None, state: Optional[torch.Tensor] = None,
-                 two_kernel: bool = False, rows: Optional[bool] = None):
+                 two_kernel: bool = False, rows: Optional[bool] = None, dec_out=None):
     """g_feat [B,R,32] → d planes [B,3,H,W,32].  ``state``: what the forward call of this step left behind
     (`raymarch(..., state=)`): the compositing adjoint reads it instead of recomputing.  ``rows``: pass 2 as sort + gather
     (hfagp.h `rows_scratch`, csrc/raymarch_rows.hip) — None = whenever it applies and its scratch stays under 16 GiB
@@ -1035,7 +1062,11 @@ def raymarch_bwd(g_feat: torch.Tensor, planes: torch.Tensor, cam2world, intrinsi
         a.df_scratch = _ptr(df)
     dec = None
     if decoder_grads:
-        dec = tuple(torch.zeros_like(t) for t in (dec_w0, dec_b0, dec_w1, dec_b1))
+        # `dec_out`: four tensors the decoder gradients are ACCUMULATED into (the parameters' .grad slices) instead of new ones
+        dec = tuple(dec_out) if dec_out is not None else tuple(torch.zeros_like(t) for t in (dec_w0, dec_b0, dec_w1, dec_b1))
+        for t, like in zip(dec, (dec_w0, dec_b0, dec_w1, dec_b1)):
+            if t.shape != like.shape or t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda:
+                raise RuntimeError("raymarch_bwd: dec_out must be four contiguous fp32 device tensors shaped like the decoder parameters")
         a.d_dec_w0, a.d_dec_b0, a.d_dec_w1, a.d_dec_b1 = (_ptr(t) for t in dec)
     L.check(L.lib().hfagp_raymarch_bwd(C.byref(a), _stream()), "raymarch_bwd")
     if decoder_grads:

@@ -516,6 +516,7 @@ typedef struct {
     int32_t precision;        /* HFAGP_PREC_F32 (exact fp32 MFMA) or HFAGP_PREC_BF16X3: modes 0 and 1 with Cin, Cout    */
                               /* multiples of 64 (mode 1 also Cin = 32) then run on the split-bf16 MFMA kernels, the rest fp32 */
     int32_t accumulate;       /* ABI 11: 1 = dweight += (the parameter's .grad slice: no separate add pass), 0 = overwrite */
+    int32_t dd_stride;        /* ABI 12: row stride of dd in elements (0 = Cout): row 3 of hfagp_pointwise_bwd's sums without a copy */
 } HfagpWgradArgs;
 
 /* ABI 11: the library's split-K choice for this layer (everything but `ksplit` / `workspace` filled in): one block per CU for the
@@ -527,6 +528,27 @@ int hfagp_conv_wgrad(const HfagpWgradArgs* a, void* stream);
 /* affine layer: dA[Cin][w_dim] += dstot^T . w / sqrt(w_dim);  db[Cin] += sum_b dstot   (dstot from hfagp_style_bwd) */
 int hfagp_affine_grad(const float* dstot, const float* w, float* dA, float* db, int32_t B, int32_t Cin, int32_t w_dim,
                       int32_t w_stride, void* stream);
+
+/* ABI 12: the same for up to 32 affine layers in one launch (every dA / db accumulated into: the .grad slices themselves) */
+typedef struct {
+    const float* dstot;       /* [B][Cin] */
+    const float* w;           /* row view [B][w_dim] of ws, row stride w_stride */
+    float*       dA;          /* [Cin][w_dim] += */
+    float*       db;          /* [Cin] += */
+    int32_t B, Cin, w_dim, w_stride;
+} HfagpAffineGradItem;
+int hfagp_affine_grad_batch(const HfagpAffineGradItem* items, int32_t n, void* stream);
+
+/* ABI 12: bias and noise-strength gradients of up to 32 synthesis layers in one launch, from the reductions hfagp_pointwise_bwd
+ * (param_grads = 1) left in sums [B][10][C]:  dbias[c] += sum_b sums[b][4][c],  dnoise[0] += sum_{b,c} sums[b][5][c]
+ * (either pointer may be NULL); fixed summation order.  Replaces two framework reductions + adds per layer.                  */
+typedef struct {
+    const float* sums;
+    float*       dbias;
+    float*       dnoise;
+    int32_t B, C;
+} HfagpBiasNoiseGradItem;
+int hfagp_bias_noise_grads(const HfagpBiasNoiseGradItem* items, int32_t n, void* stream);
 
 /* out[c] (+)= sum over npix rows of a [npix][C] channels-last tensor (C <= 256); partial: [nblocks][C] workspace;
  * ABI 11: nblocks * 256 must be a multiple of C (the tensor is walked as a flat array and a thread keeps its channel) */

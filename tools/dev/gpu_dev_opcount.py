@@ -18,6 +18,8 @@ def main():
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     tr = Trainer(Args(), dev, mode=mode, lpips="none")
+    if len(sys.argv) > 2 and sys.argv[2] == "tuned":
+        tr.tune_generator()
     g = torch.Generator().manual_seed(1)
     real = (0.5 * torch.randn(B, 3, 256, 256, generator=g)).clamp(-1, 1).to(dev)
     params = torch.randn(B, 76, generator=g).to(dev)
@@ -39,6 +41,12 @@ def main():
         if e.key.startswith("aten::") and dev_us > 0:
             rows.append((e.count / n, dev_us / n, e.key))
     rows.sort(key=lambda r: -r[0])
+    kern = {}
+    for e in prof.events():
+        if getattr(e, "device_type", None) is not None and str(e.device_type).endswith("CUDA") and not e.name.startswith(("hfagp", "void hfagp", "Cijk")):
+            k = kern.setdefault(e.name[:90], [0, 0.0]); k[0] += 1; k[1] += e.device_time if hasattr(e, "device_time") else 0.0
+    for name, (c, us) in sorted(kern.items(), key=lambda kv: -kv[1][0])[:14]:
+        print(f"{c / n:10.1f} {us / n:15.1f}  kernel {name}")
     print(f"{'calls/step':>10s} {'device us/step':>15s}  op")
     for c, us, k in rows[:45]:
         print(f"{c:10.1f} {us:15.1f}  {k}")
