@@ -338,3 +338,55 @@ def test_raymarch_backward_sort_gather_ragged_planes_and_rays_leaving_the_box(de
     assert scale > 0 and torch.isfinite(out).all()
     assert (out - ref).abs().max().item() <= 2e-5 * scale
     assert rel_l2(out, ref) <= 2e-5
+
+
+# ----------------------------------------------------------------------------- batched small gradients (ABI 12)
+def test_bias_noise_and_affine_gradient_batches_equal_the_per_layer_forms(dev):
+    """`hfagp_bias_noise_grads` / `hfagp_affine_grad_batch` (one launch per block / per pass, accumulating into the .grad slices)
+    against the framework reductions and the per-layer `hfagp_affine_grad` they replace; more than 32 items (two launches),
+    items without a noise strength, accumulation into non-zero targets."""
+    from hfa_gp_amd import ops
+    g = torch.Generator(device=dev).manual_seed(3)
+    items, want = [], []
+    for i in range(35):
+        b, c = 2 + i % 3, (4, 32, 96, 512, 260)[i % 5]
+        sums = torch.randn(b, 10, c, device=dev, generator=g)
+        db = torch.randn(c, device=dev, generator=g)
+        dn = torch.randn(1, device=dev, generator=g) if i % 4 else None
+        want.append((db + sums[:, 4].sum(0), None if dn is None else dn + sums[:, 5].sum()))
+        items.append((sums, db, dn))
+    ops.bias_noise_grads(items)
+    for (sums, db, dn), (wb, wn) in zip(items, want):
+        assert (db - wb).abs().max().item() <= 1e-5 * max(1.0, wb.abs().max().item())
+        if dn is not None:
+            assert abs((dn - wn).item()) <= 1e-4 * max(1.0, abs(wn.item()))
+    ws = torch.randn(3, 14, 512, device=dev, generator=g)
+    aff, ref = [], []
+    for i in range(34):
+        cin = (512, 256, 64, 32, 3)[i % 5]
+        dstot = torch.randn(3, cin, device=dev, generator=g)
+        dA, dbb = torch.randn(cin, 512, device=dev, generator=g), torch.randn(cin, device=dev, generator=g)
+        rA, rb = dA.clone(), dbb.clone()
+        ops.affine_grad(dstot, ws[:, i % 14], rA, rb)
+        aff.append((dstot, ws[:, i % 14], dA, dbb))
+        ref.append((rA, rb))
+    ops.affine_grad_batch(aff)
+    for (_, _, dA, dbb), (rA, rb) in zip(aff, ref):
+        assert torch.equal(dA, rA) and torch.equal(dbb, rb)
+
+
+def test_weight_gradient_reads_dd_with_a_row_stride(dev):
+    """`HfagpWgradArgs::dd_stride`: row 3 of pointwise_bwd's sums [B][10][C] goes in as a view — same bits as the contiguous copy."""
+    from hfa_gp_amd import ops
+    g = torch.Generator(device=dev).manual_seed(9)
+    b, h, cin, cout = 2, 32, 64, 128
+    x = torch.randn(b, h, h, cin, device=dev, generator=g)
+    gy = torch.randn(b, h, h, cout, device=dev, generator=g)
+    w = torch.randn(cout, cin, 3, 3, device=dev, generator=g)
+    st = torch.randn(b, cin, device=dev, generator=g)
+    sums = torch.randn(b, 10, cout, device=dev, generator=g)
+    dcoef = torch.rand(b, cout, device=dev, generator=g) + 0.5
+    for prec in ("bf16x3", "fp32"):
+        a = ops.conv_wgrad(x, st, gy, w, ops.CONV3X3, dd=sums[:, 3], dcoef=dcoef, precision=prec)
+        c = ops.conv_wgrad(x, st, gy, w, ops.CONV3X3, dd=sums[:, 3].contiguous(), dcoef=dcoef, precision=prec)
+        assert torch.equal(a, c)

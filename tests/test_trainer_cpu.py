@@ -659,3 +659,25 @@ def test_trainable_basis_is_never_served_from_the_q_cache():
         a = gen._orthonormal(gen.bases)
         b = gen._orthonormal(gen.bases)
     assert a is b
+
+
+def test_equal_linear_with_the_scale_folded_into_the_gemm_matches_the_plain_expression():
+    """encoder3d._EqualLinearFn (the 3DMM driver's layers: `F.linear(x, W * scale, b * lr_mul)` without the four scalar-multiply
+    kernels per layer and step): values and all three gradients in fp64, lr_mul = 1 and != 1; 3-D inputs keep the plain path."""
+    import torch.nn.functional as F
+    from hfa_gp_amd.encoder3d import EqualLinear
+    torch.manual_seed(0)
+    for lr in (1, 0.01):
+        lin = EqualLinear(50, 70, lr_mul=lr).double()
+        lin.bias.data.normal_()
+        x = torch.randn(3, 50, dtype=torch.float64, requires_grad=True)
+        y = lin(x)
+        gy = torch.randn_like(y)
+        got = torch.autograd.grad(y, (x, lin.weight, lin.bias), gy)
+        ref_y = F.linear(x, lin.weight * lin.scale, bias=lin.bias * lin.lr_mul)
+        ref = torch.autograd.grad(ref_y, (x, lin.weight, lin.bias), gy)
+        assert (y - ref_y).abs().max().item() < 1e-12
+        for a, b in zip(got, ref):
+            assert (a - b).abs().max().item() < 1e-12
+        x3 = torch.randn(2, 3, 50, dtype=torch.float64)
+        assert (lin(x3) - F.linear(x3, lin.weight * lin.scale, bias=lin.bias * lin.lr_mul)).abs().max().item() < 1e-12
