@@ -30,8 +30,41 @@ SQRT2 = math.sqrt(2.0)
 FWD_PREC = "bf16x6"        # forward and data-gradient GEMMs (see the module docstring)
 
 
-def _image(w: torch.Tensor, up: bool = False) -> torch.Tensor:
-    """B-operand image of a conv weight [Cout, Cin, k, k] for the kernel that will run it."""
+# B-operand images of the trunk's (scaled) weights of the CURRENT step: {(data_ptr, transposed): image}, filled by ONE
+# hfagp_weight_prep_batch launch at the start of forward_app — the forward image and the image of the Cin/Cout transpose (the
+# data-gradient GEMMs) of every weight from a single read of it.  Per use the step ran 21 split launches + 12 transposing copies.
+_IMAGES: dict = {}
+
+
+def _prepare_images(pairs) -> None:
+    """pairs: [(scaled weight [Cout,Cin,3,3], its transpose runs an up-sampling kernel?)]"""
+    _IMAGES.clear()
+    items, keys = [], []
+    for w, t_up in pairs:
+        cout, cin = w.shape[:2]
+        if not (w.is_contiguous() and ops.weight_prep_batch_supported(w)):
+            continue
+        fwd = FWD_PREC if ops.split_supported(cin, cout, up=False) else None
+        bwd = FWD_PREC if ops.split_supported(cout, cin, up=t_up) else None
+        if fwd is None and bwd is None:
+            continue
+        items.append((w, fwd, bwd, False))
+        keys.append(w.data_ptr())
+    if items:
+        for key, (img, img_t, _) in zip(keys, ops.weight_prep_batch(items)):
+            if img is not None:
+                _IMAGES[(key, False)] = img
+            if img_t is not None:
+                _IMAGES[(key, True)] = img_t
+
+
+def _image(w: torch.Tensor, up: bool = False, transposed: bool = False) -> torch.Tensor:
+    """B-operand image of a conv weight [Cout, Cin, k, k] (`transposed`: of its Cin/Cout transpose) for the kernel that will run it."""
+    hit = _IMAGES.get((w.data_ptr(), transposed))
+    if hit is not None:
+        return hit
+    if transposed:
+        w = w.transpose(0, 1)
     cout, cin = w.shape[:2]
     w = w.contiguous()
     if ops.split_supported(cin, cout, up=up):
@@ -61,7 +94,7 @@ class _Conv3x3Act(torch.autograd.Function):
         db = g.sum((0, 1, 2))
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = ops.modconv(g, _image(w.transpose(0, 1)), cin, ops.CONV3X3_BWD)
+            dx = ops.modconv(g, _image(w, transposed=True), cin, ops.CONV3X3_BWD)
         dw = ops.conv_wgrad(x, None, g, w, ops.CONV3X3, precision=_wprec(cin, cout))
         return dx, dw, db
 
@@ -107,7 +140,7 @@ class _BlurConvDown(torch.autograd.Function):
         dy = dy.contiguous()
         dx = None
         if ctx.needs_input_grad[0]:
-            yt = ops.modconv(dy, _image(w.transpose(0, 1), up=True), cin, ops.CONVT3X3_UP2)
+            yt = ops.modconv(dy, _image(w, up=True, transposed=True), cin, ops.CONVT3X3_UP2)
             dx = ops.upfir_epilogue(yt, None, None, 0.0, None, "linear", 0.2, 1.0, None)
         like = torch.empty(cin, cout, 3, 3, device=w.device, dtype=torch.float32)
         dw = ops.conv_wgrad(dy, None, gph, like, ops.CONVT3X3_UP2, precision=_wprec(cout, cin)).transpose(0, 1)
@@ -167,6 +200,7 @@ def forward_app(net_app, x: torch.Tensor) -> torch.Tensor:
     ws.append(last.weight)
     scales.append(float(last.scale))
     scaled = _ScaleAll.apply(scales, *ws)
+    _prepare_images([(scaled[1 + 3 * k + j], j == 1) for k in range(len(blocks)) for j in (0, 1)])
     h = _InputConvAct.apply(x4, scaled[0], act.bias.reshape(-1))
     for k, blk in enumerate(blocks):
         w1, w2, wsk = scaled[1 + 3 * k: 4 + 3 * k]
