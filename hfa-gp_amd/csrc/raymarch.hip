@@ -102,8 +102,20 @@ __global__ void __launch_bounds__(256, 2) raymarch_kernel(const RayParams p) {
         const int b = __builtin_amdgcn_readlane(b_l, k), ray = __builtin_amdgcn_readlane(ray_l, k);    // wave-uniform -> scalar registers
         if constexpr (FROM_STATE) {
             const float* st = a.state + (size_t)ray * kStateFloats;
-#pragma unroll 4
-            for (int i = lane; i < S * 32; i += 64) lds.col[(i >> 5) * CS + (i & 31)] = st[i];
+            // 16-byte loads, ALL of the ray's colours in flight at once (12 per lane at 48 + 48 samples): with 4-byte loads, four in
+            // flight, a ray cost twelve memory round trips and this pass ran at a third of the rate the 440 MB of state allow
+            {
+                constexpr int NV = S * 8 / 64;
+                float4 v[NV];
+                const float4* st4 = reinterpret_cast<const float4*>(st);
+#pragma unroll
+                for (int k = 0; k < NV; ++k) v[k] = st4[lane + 64 * k];
+#pragma unroll
+                for (int k = 0; k < NV; ++k) {
+                    const int i = lane + 64 * k;
+                    *reinterpret_cast<float4*>(&lds.col[(i >> 3) * CS + 4 * (i & 7)]) = v[k];
+                }
+            }
             for (int i = lane; i < S; i += 64) {
                 lds.ts[i] = st[S * 32 + i];
                 lds.ss[i] = st[S * 33 + i];
@@ -303,7 +315,8 @@ __global__ void __launch_bounds__(256, 2) raymarch_kernel(const RayParams p) {
             if (a.state) {                          // forward of a step that will be differentiated: leave the state behind
                 float* st = a.state + (size_t)ray * kStateFloats;
 #pragma unroll 4
-                for (int i = lane; i < S * 32; i += 64) st[i] = lds.col[(i >> 5) * CS + (i & 31)];
+                for (int i = lane; i < S * 8; i += 64)           // 16 bytes per lane (the row stride CS keeps them aligned)
+                    reinterpret_cast<float4*>(st)[i] = *reinterpret_cast<const float4*>(&lds.col[(i >> 3) * CS + 4 * (i & 7)]);
                 for (int i = lane; i < S; i += 64) {
                     st[S * 32 + i] = lds.ts[i];
                     st[S * 33 + i] = lds.ss[i];
