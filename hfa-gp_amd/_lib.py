@@ -158,6 +158,9 @@ SYMBOLS = {
     "hfagp_weight_prep": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "hfagp_qr_gram_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "hfagp_qr_refine_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "hfagp_tall_gram_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "hfagp_tall_gram": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
+                                  C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
     "hfagp_style_batch_fwd": (C.c_int, [C.POINTER(StyleArgs), C.c_int32, C.c_void_p]),
     "hfagp_weight_prep_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "hfagp_weight_prep_prec": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),

@@ -184,9 +184,105 @@ __global__ void __launch_bounds__(256) qr_refine_kernel(const float* __restrict_
     }
 }
 
+// out[n][n] = X^T Y for two tall-skinny matrices [m x n], n <= 64 (the Gram matrices of the QR above and X = -Q^T dQ of its
+// backward): K = 7168, M = N = 50 is a shape the GEMM library answers with one 32 x 32 x 256 macro-tile kernel of 48 us; here 64
+// rows per block (112 blocks), a 4 x 4 register tile per thread, partial sums in a fixed order, then one small reduction.
+// Either operand may be row- or column-major (element (k, i) at k * rs + i * cs): the basis arrives as the transpose of [n][m].
+constexpr int kGramRows = 64;
+__global__ void __launch_bounds__(256) tall_gram_kernel(const float* __restrict__ X, long long xrs, long long xcs,
+                                                        const float* __restrict__ Y, long long yrs, long long ycs,
+                                                        float* __restrict__ partial, int m, int n) {
+    __shared__ __attribute__((aligned(16))) float Xs[kGramRows][kQrMax + 4], Ys[kGramRows][kQrMax + 4];
+    const int tid = threadIdx.x, k0 = blockIdx.x * kGramRows;
+    // (all 2 x 16 loads of a thread go out before the first LDS write: one memory round trip per block, not sixteen)
+    constexpr int NE = kGramRows * kQrMax / 256;
+    float xv[NE], yv[NE];
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+        const int e = tid + 256 * u;
+        // consecutive threads along the unit-stride direction of the operand
+        const int kx = xcs == 1 ? e / kQrMax : e % kGramRows, ix = xcs == 1 ? e % kQrMax : e / kGramRows;
+        const bool okx = k0 + kx < m && ix < n;
+        xv[u] = X[okx ? (long long)(k0 + kx) * xrs + ix * xcs : 0];
+        xv[u] = okx ? xv[u] : 0.f;
+        const int ky = ycs == 1 ? e / kQrMax : e % kGramRows, iy = ycs == 1 ? e % kQrMax : e / kGramRows;
+        const bool oky = k0 + ky < m && iy < n;
+        yv[u] = Y[oky ? (long long)(k0 + ky) * yrs + iy * ycs : 0];
+        yv[u] = oky ? yv[u] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+        const int e = tid + 256 * u;
+        Xs[xcs == 1 ? e / kQrMax : e % kGramRows][xcs == 1 ? e % kQrMax : e / kGramRows] = xv[u];
+        Ys[ycs == 1 ? e / kQrMax : e % kGramRows][ycs == 1 ? e % kQrMax : e / kGramRows] = yv[u];
+    }
+    __syncthreads();
+    const int ti = tid >> 4, tj = tid & 15;
+    float acc[4][4] = {};
+#pragma unroll 8
+    for (int k = 0; k < kGramRows; ++k) {
+        const float4 a = *reinterpret_cast<const float4*>(&Xs[k][4 * ti]), b = *reinterpret_cast<const float4*>(&Ys[k][4 * tj]);
+        const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+    }
+    float* dst = partial + (size_t)blockIdx.x * n * n;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (4 * ti + i < n && 4 * tj + j < n) dst[(4 * ti + i) * n + 4 * tj + j] = acc[i][j];
+}
+
+// block = 16 consecutive outputs x 16 partial lanes: lane q sums partials q, q + 16, ... (all loads in flight), then a fixed tree
+__global__ void __launch_bounds__(256) tall_gram_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out, int nblocks,
+                                                               int nn, float scale) {
+    __shared__ float red[16][17];
+    const int kk = threadIdx.x & 15, q = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + kk;
+    float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (e < nn) {
+        for (int b = q; b < nblocks; b += 8 * 16) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (b + 16 * u < nblocks) p[u] += partial[(size_t)(b + 16 * u) * nn + e];
+        }
+    }
+    red[q][kk] = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+    __syncthreads();
+    if (q == 0 && e < nn) {
+        float t[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) t[u] = red[u][kk];
+#pragma unroll
+        for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (u < w) t[u] += t[u + w];
+        out[e] = t[0] * scale;
+    }
+}
+
 }  // namespace hfagp
 
 using namespace hfagp;
+
+extern "C" size_t hfagp_tall_gram_workspace_bytes(int32_t m, int32_t n) {
+    return (size_t)((m + kGramRows - 1) / kGramRows) * n * n * sizeof(float);
+}
+
+extern "C" int hfagp_tall_gram(const float* X, int64_t x_rs, int64_t x_cs, const float* Y, int64_t y_rs, int64_t y_cs, float* workspace,
+                               float* out, int32_t m, int32_t n, float scale, void* stream) {
+    HFAGP_REQUIRE(X && Y && workspace && out, HFAGP_EBADARG, "tall_gram: null pointer");
+    HFAGP_REQUIRE(m >= 1 && n >= 1 && n <= kQrMax, HFAGP_EUNSUPPORTED, "tall_gram: n=%d must be in 1..%d", n, kQrMax);
+    const int nblocks = (m + kGramRows - 1) / kGramRows;
+    hipStream_t s = (hipStream_t)stream;
+    tall_gram_kernel<<<nblocks, 256, 0, s>>>(X, x_rs, x_cs, Y, y_rs, y_cs, workspace, m, n);
+    tall_gram_reduce_kernel<<<(n * n + 15) / 16, 256, 0, s>>>(workspace, out, nblocks, n * n, scale);
+    return check_launch("tall_gram");
+}
 
 extern "C" int hfagp_qr_refine_fwd(const float* gram, float* R, float* Rinv, float* status, int32_t n, void* stream) {
     HFAGP_REQUIRE(gram && R && Rinv, HFAGP_EBADARG, "qr_refine_fwd: null pointer");

@@ -226,6 +226,19 @@ def qr_refine(gram: torch.Tensor, status: Optional[torch.Tensor] = None) -> Tupl
     return r, rinv
 
 
+def tall_gram(x: torch.Tensor, y: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+    """scale * x^T y [n, n] for tall-skinny fp32 matrices [m, n <= 64], row- or column-major views (hfagp_tall_gram)."""
+    m, n = x.shape
+    for t in (x, y):
+        if t.shape != (m, n) or t.dtype != torch.float32 or not t.is_cuda or 1 not in (t.stride(0), t.stride(1)):
+            raise RuntimeError("tall_gram: operands must be fp32 device matrices of one shape with a unit stride")
+    out = torch.empty(n, n, device=x.device, dtype=torch.float32)
+    ws = torch.empty(L.lib().hfagp_tall_gram_workspace_bytes(m, n) // 4, device=x.device, dtype=torch.float32)
+    L.check(L.lib().hfagp_tall_gram(x.data_ptr(), x.stride(0), x.stride(1), y.data_ptr(), y.stride(0), y.stride(1), _ptr(ws),
+                                    _ptr(out), m, n, scale, _stream()), "tall_gram")
+    return out
+
+
 class TallSkinnyQR(torch.autograd.Function):
     """Q of the reduced QR of a tall-skinny fp32 CUDA matrix A [m, n <= 64] with torch.linalg.qr's (LAPACK's) sign
     convention; backward = the standard QR adjoint for dR = 0:
@@ -237,10 +250,10 @@ class TallSkinnyQR(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a: torch.Tensor, status: Optional[torch.Tensor] = None) -> torch.Tensor:
         n = a.shape[1]
-        gram = (a.T @ a).contiguous()
+        gram = tall_gram(a, a)
         _, rinv1 = qr_gram(gram, a[:n, :n].contiguous())
         q1 = a @ rinv1
-        _, rinv2 = qr_refine((q1.T @ q1).contiguous(), status)
+        _, rinv2 = qr_refine(tall_gram(q1, q1), status)
         rinv = rinv1 @ rinv2
         q = q1 @ rinv2
         ctx.save_for_backward(q, rinv)
@@ -249,7 +262,9 @@ class TallSkinnyQR(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gq: torch.Tensor):
         q, rinv = ctx.saved_tensors
-        x = torch.triu(-(q.T @ gq))
+        if gq.stride(0) != 1 and gq.stride(1) != 1:
+            gq = gq.contiguous()
+        x = torch.triu(tall_gram(q, gq, -1.0))
         s = x + x.T - torch.diag(torch.diagonal(x))
         return (gq + q @ s) @ rinv.T, None
 

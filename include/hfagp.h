@@ -141,6 +141,12 @@ int hfagp_qr_gram_fwd(const float* gram, const float* top, float* R, float* Rinv
  * HeadNeRF_* falls back to a library Householder QR when it grows), [1] = 1 when a pivot was not positive — the
  * outputs are then NaN, never silently wrong.                                                                   */
 int hfagp_qr_refine_fwd(const float* gram, float* R, float* Rinv, float* status, int32_t n, void* stream);
+/* ABI 12: out[n][n] = scale * X^T Y for tall-skinny X, Y [m x n], n <= 64, element (k, i) at k * rs + i * cs (row- or
+ * column-major operands): the Gram matrices of the two passes above (A^T A, Q1^T Q1) and -Q^T dQ of the QR's backward, where a
+ * GEMM library runs one macro-tile.  workspace: hfagp_tall_gram_workspace_bytes(m, n); fixed summation order.                */
+size_t hfagp_tall_gram_workspace_bytes(int32_t m, int32_t n);
+int hfagp_tall_gram(const float* X, int64_t x_rs, int64_t x_cs, const float* Y, int64_t y_rs, int64_t y_cs, float* workspace,
+                    float* out, int32_t m, int32_t n, float scale, void* stream);
 
 /* FullyConnectedLayer (mapping network): y = act((x . W^T) * lr_mul/sqrt(In) + bias*lr_mul) * gain   [B][Out] */
 int hfagp_fc_fwd(const float* x, const float* weight, const float* bias, float* y, int32_t B, int32_t In, int32_t Out,

@@ -7,6 +7,7 @@ gradients for a white-noise cotangent; this file checks the TRAINER's composed s
 HIP generator -> fused pool + MSE -> backward with the weight-gradient GEMMs, the decoder-gradient pass and the bucketed
 gradient sink of the multi-GPU path active (1-rank RCCL group, small buckets) — against the identical step through the CPU
 oracle under autograd.  Needs an MI355X:  python -m pytest tests -m gpu"""
+import math
 import os
 
 import pytest
@@ -390,3 +391,21 @@ def test_weight_gradient_reads_dd_with_a_row_stride(dev):
         a = ops.conv_wgrad(x, st, gy, w, ops.CONV3X3, dd=sums[:, 3], dcoef=dcoef, precision=prec)
         c = ops.conv_wgrad(x, st, gy, w, ops.CONV3X3, dd=sums[:, 3].contiguous(), dcoef=dcoef, precision=prec)
         assert torch.equal(a, c)
+
+
+@pytest.mark.parametrize("m,n", [(7168, 50), (7168, 64), (1000, 3), (64, 17), (65, 1)])
+def test_tall_gram_matches_the_matrix_product(dev, m, n):
+    """`hfagp_tall_gram` (X^T Y of tall-skinny operands in 64-row blocks + a fixed-order reduction; the three K = 7168 products of the
+    latent basis' QR and its backward) against fp64, with row-major, column-major (the basis arrives as the transpose of [n, m]) and
+    mixed operands, a scale, ragged m."""
+    from hfa_gp_amd import ops
+    g = torch.Generator(device=dev).manual_seed(m + n)
+    x = torch.randn(m, n, device=dev, generator=g)
+    yt = torch.randn(n, m, device=dev, generator=g)
+    for a, b, sc in ((x, x, 1.0), (yt.T, yt.T, 1.0), (x, yt.T, -1.0), (yt.T, x, 0.5)):
+        got = ops.tall_gram(a, b, sc)
+        ref = (sc * (a.double().T @ b.double())).float()
+        assert got.shape == (n, n)
+        assert (got - ref).abs().max().item() <= 2e-6 * math.sqrt(m) * max(1.0, ref.abs().max().item() / math.sqrt(m))
+    again = ops.tall_gram(x, x)
+    assert torch.equal(again, ops.tall_gram(x, x))          # fixed summation order

@@ -35,11 +35,12 @@ def main():
     for i in range(iters):
         l2 = step()[-3]
         evs[i + 1].record()
+    t_enq = (time.perf_counter() - t) / iters           # host time to ENQUEUE a step (nothing synchronised yet)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t) / iters
     per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(iters))
     print(f"train step B={B}: {dt*1e3:.2f} ms/step ({dt/B*1e3:.2f} ms/frame), per-step HIP events median {per[len(per)//2]:.2f} "
-          f"min {per[0]:.2f} max {per[-1]:.2f} ms, l2={float(l2):.4f}, mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB")
+          f"min {per[0]:.2f} max {per[-1]:.2f} ms, host enqueue {t_enq*1e3:.2f} ms/step, l2={float(l2):.4f}, mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB")
 
 
 if __name__ == "__main__":
