@@ -71,7 +71,7 @@ __global__ void __launch_bounds__(256) pointwise_bwd_kernel(const HfagpPointwise
 #pragma unroll
             for (int k = 0; k < 4; ++k) { gx[k] += gv[k] * sv[k]; acc[0][k] += gv[k] * xv[k]; }
         }
-        if (a.dxs_rgb) {
+        if (!SMALL && a.dxs_rgb) {
             const float gv[4] = {gr.x, gr.y, gr.z, gr.w}, sv[4] = {s_r.x, s_r.y, s_r.z, s_r.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) { gx[k] += gv[k] * sv[k]; acc[1][k] += gv[k] * xv[k]; }
@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(256) pointwise_bwd_kernel(const HfagpPointwise
         const float4 z4 = make_float4(0, 0, 0, 0);
         const float4* X = reinterpret_cast<const float4*>(a.x);
         const float4* GC = reinterpret_cast<const float4*>(a.dxs_conv);
-        const float4* GR = reinterpret_cast<const float4*>(a.dxs_rgb);
+        const float4* GR = SMALL ? nullptr : reinterpret_cast<const float4*>(a.dxs_rgb);
         const float4* GD = reinterpret_cast<const float4*>(a.g_direct);
         // (the small toRGB's clamp mask [|y| < clamp] applied here when the caller hands over y: three framework kernels less)
         const bool mask_small = a.y_rgb_small != nullptr && a.clamp_rgb_small >= 0.f;
@@ -469,6 +469,9 @@ int hfagp_pointwise_bwd(const HfagpPointwiseBwdArgs* a, void* stream) {
     HFAGP_REQUIRE(!a->g_rgb_small || (a->Co >= 1 && a->Co <= 4 && a->w_rgb_small && a->s_small), HFAGP_EBADARG,
                   "pointwise_bwd: small toRGB needs 1..4 channels, weights and styles");
     HFAGP_REQUIRE(a->nchunks >= 1, HFAGP_EBADARG, "pointwise_bwd: nchunks");
+    // (a layer has ONE toRGB: the 96-channel one arrives as dxs_rgb, the 1 .. 4-channel one as g_rgb_small; the small variants are
+    // compiled without the dxs_rgb operand: 18 registers, three resident workgroups per CU instead of two with parameter gradients)
+    HFAGP_REQUIRE(!(a->g_rgb_small && a->dxs_rgb), HFAGP_EUNSUPPORTED, "pointwise_bwd: dxs_rgb and g_rgb_small are exclusive");
     const int HW = a->H * a->W;
     const int rows = (HW + a->nchunks - 1) / a->nchunks;
     const int npl = 256 / (a->C / 4);

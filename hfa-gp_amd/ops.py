@@ -822,10 +822,10 @@ def pointwise_bwd(x: torch.Tensor, dxs_conv=None, s_conv=None, dxs_rgb=None, s_r
     # walking 64 pixels of 512 channels took 45 us), at most 256 (the partial sums are reduced by a second kernel)
     npl = max(1, 256 // (c // 4))
     # ... and enough blocks to fill the chip: a workgroup waits out one memory round trip per two pixels of its threads, so what
-    # counts is how many are RESIDENT — registers allow 5 / 3 / 4 / 2 per CU for the (small toRGB, parameter gradients) variants
+    # counts is how many are RESIDENT — registers allow 5 / 3 / 4 / 3 per CU for the (small toRGB, parameter gradients) variants
     # (the LDS scratch is sized by the rows a variant reduces since round 5; ten rows for all = 40 KB capped it at 4, and 512
     # blocks in total left two per CU: the 512^2 x 64 launches of the fitting step ran at 1.4 - 2.7 TB/s)
-    per_cu = {(False, False): 5, (True, False): 3, (False, True): 4, (True, True): 2}[(g_rgb_small is not None, bool(param_grads))]
+    per_cu = {(False, False): 5, (True, False): 3, (False, True): 4, (True, True): 3}[(g_rgb_small is not None, bool(param_grads))]
     nchunks = max(1, min(max(256, per_cu * 256 // b), -(-(h * w) // (npl * 4))))
     if _DEV_PW_CHUNKS:                                  # developer sweep (tools/dev/pointwise_sweep.py)
         nchunks = max(1, min(int(_DEV_PW_CHUNKS), h * w))

@@ -389,7 +389,7 @@ typedef struct {
     const float* s_conv;      /* [B][C] */
     const float* dxs_rgb;     /* [B][H][W][C] or NULL */
     const float* s_rgb;       /* [B][C] */
-    const float* g_rgb_small; /* NCHW [B][Co][H][W] (already clamp-masked) or NULL */
+    const float* g_rgb_small; /* NCHW [B][Co][H][W] (already clamp-masked) or NULL; ABI 12: exclusive with dxs_rgb (a layer has one toRGB) */
     const float* w_rgb_small; /* [Co][C] */
     const float* s_small;     /* [B][C] */
     const float* g_direct;    /* [B][H][W][C] extra gradient added as is, or NULL */
