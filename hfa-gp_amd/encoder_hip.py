@@ -33,6 +33,8 @@ FWD_PREC = "bf16x6"        # forward and data-gradient GEMMs (see the module doc
 # B-operand images of the trunk's (scaled) weights of the CURRENT step: {(data_ptr, transposed): image}, filled by ONE
 # hfagp_weight_prep_batch launch at the start of forward_app — the forward image and the image of the Cin/Cout transpose (the
 # data-gradient GEMMs) of every weight from a single read of it.  Per use the step ran 21 split launches + 12 transposing copies.
+# The key is the weight's ADDRESS (autograd hands the backward pass a different tensor object over the same storage), so every entry
+# holds a reference to its weight: while the entry lives no other tensor can be allocated at that address.
 _IMAGES: dict = {}
 
 
@@ -51,18 +53,18 @@ def _prepare_images(pairs) -> None:
         items.append((w, fwd, bwd, False))
         keys.append(w.data_ptr())
     if items:
-        for key, (img, img_t, _) in zip(keys, ops.weight_prep_batch(items)):
+        for (w, _, _, _), key, (img, img_t, _) in zip(items, keys, ops.weight_prep_batch(items)):
             if img is not None:
-                _IMAGES[(key, False)] = img
+                _IMAGES[(key, False)] = (img, w)
             if img_t is not None:
-                _IMAGES[(key, True)] = img_t
+                _IMAGES[(key, True)] = (img_t, w)
 
 
 def _image(w: torch.Tensor, up: bool = False, transposed: bool = False) -> torch.Tensor:
     """B-operand image of a conv weight [Cout, Cin, k, k] (`transposed`: of its Cin/Cout transpose) for the kernel that will run it."""
     hit = _IMAGES.get((w.data_ptr(), transposed))
-    if hit is not None:
-        return hit
+    if hit is not None and hit[1].shape == w.shape and hit[1]._version == w._version:
+        return hit[0]
     if transposed:
         w = w.transpose(0, 1)
     cout, cin = w.shape[:2]
