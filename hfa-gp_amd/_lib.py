@@ -126,6 +126,10 @@ class AffineGradItem(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("dstot", "w", "dA", "db")] + [(n, C.c_int32) for n in ("B", "Cin", "w_dim", "w_stride")]
 
 
+class ReducePartialsItem(C.Structure):
+    _fields_ = [("partial", C.c_void_p), ("sums", C.c_void_p)] + [(n, C.c_int32) for n in ("B", "nchunks", "n")]
+
+
 class BiasNoiseGradItem(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("sums", "dbias", "dnoise")] + [(n, C.c_int32) for n in ("B", "C")]
 
@@ -193,6 +197,7 @@ SYMBOLS = {
     "hfagp_affine_grad": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 4 + [C.c_void_p]),
     "hfagp_affine_grad_batch": (C.c_int, [C.POINTER(AffineGradItem), C.c_int32, C.c_void_p]),
     "hfagp_bias_noise_grads": (C.c_int, [C.POINTER(BiasNoiseGradItem), C.c_int32, C.c_void_p]),
+    "hfagp_reduce_partials_batch": (C.c_int, [C.POINTER(ReducePartialsItem), C.c_int32, C.c_void_p]),
     "hfagp_channel_sum": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "hfagp_pool_mse_workspace_bytes": (C.c_size_t, []),
     "hfagp_pool_mse_fwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 4 + [C.c_void_p]),

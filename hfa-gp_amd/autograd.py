@@ -41,6 +41,7 @@ class _Backward:
         # tuned step spent ~140 launches of 2-3 us + 370 MB of traffic on AccumulateGrad's per-tensor adds)
         self.inplace = bool(getattr(gen, "_grad_inplace", False))
         self.pending = []          # style gradients of the whole pass: (item for ops.style_bwd_batch, affine module)
+        self.deferred = []         # (partial, sums) of the fused passes whose reduction waits for flush_styles (generator frozen)
         self.direct_ready = []     # parameters whose .grad a kernel has accumulated into since the last release
         self.small = []            # in-place mode: (sums, bias.grad, noise_strength.grad) of the block's layers, one launch per block
 
@@ -60,6 +61,8 @@ class _Backward:
         return self.gen._timed(key, flops, ops.modconv, g, self.wt_t(weight), cin, mode)
 
     def pointwise(self, x: torch.Tensor, **kw):
+        if not self.pg:                     # generator frozen: the sums are needed only by flush_styles — reduced there, all at once
+            kw["deferred"] = self.deferred
         if self.gen.timing is None:
             return ops.pointwise_bwd(x, **kw)
         nbytes = 4.0 * (2 * x.numel() + sum(kw[k].numel() for k in ("dxs_conv", "dxs_rgb", "g_direct", "g_nchw3_a", "g_nchw3_b")
@@ -296,6 +299,8 @@ class _Backward:
                               rec["row"], 1.0), rec["layer"].affine))
 
     def flush_styles(self):
+        if self.deferred:
+            ops.reduce_partials_batch(self.deferred)
         dstots = ops.style_bwd_batch([it for it, _ in self.pending], self.d_ws)
         if self.pg and all(self._direct(affine.weight) and self._direct(affine.bias) for _, affine in self.pending) \
                 and len({id(affine) for _, affine in self.pending}) == len(self.pending):

@@ -203,6 +203,40 @@ __global__ void __launch_bounds__(256) reduce_partials_kernel(const float* __res
     }
 }
 
+// the same for the partial sums of SEVERAL fused passes in one launch (hfagp_reduce_partials_batch: a backward pass with the
+// generator frozen needs its 19 sets of sums only at the very end, for the style gradients: 19 launches of 5 us -> 1)
+constexpr int kRedBatchMax = 32;
+struct RedBatch { HfagpReducePartialsItem it[kRedBatchMax]; };
+__global__ void __launch_bounds__(256) reduce_partials_batch_kernel(const RedBatch t) {
+    __shared__ float red[16][17];
+    const HfagpReducePartialsItem& a = t.it[blockIdx.z];
+    const int kk = threadIdx.x & 15, q0 = threadIdx.x >> 4;
+    const int k = blockIdx.x * 16 + kk, b = blockIdx.y;
+    if (b >= a.B || blockIdx.x * 16 >= a.n) return;              // (uniform per workgroup)
+    float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (k < a.n) {
+        const float* src = a.partial + (size_t)b * a.nchunks * a.n + k;
+        for (int q = q0; q < a.nchunks; q += 8 * 16) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (q + 16 * u < a.nchunks) part[u] += src[(size_t)(q + 16 * u) * a.n];
+        }
+    }
+    red[q0][kk] = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
+    __syncthreads();
+    if (q0 == 0 && k < a.n) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = red[u][kk];
+#pragma unroll
+        for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (u < w) v[u] += v[u + w];
+        a.sums[(size_t)b * a.n + k] = v[0];
+    }
+}
+
 // depth[i] = clamp(depth[i], min_j t[j].x, max_j t[j].y) for the whole batch in one launch (hfagp_depth_clamp): every block
 // reduces ALL min / max pairs itself (they stay in L2: 256 KB at two frames, 4 MB at 32) and clamps its own slice
 __global__ void __launch_bounds__(1024) depth_clamp_kernel(float* __restrict__ depth, const float2* __restrict__ t, int n) {
@@ -462,7 +496,7 @@ using namespace hfagp;
 extern "C" {
 
 int hfagp_pointwise_bwd(const HfagpPointwiseBwdArgs* a, void* stream) {
-    HFAGP_REQUIRE(a && a->x && a->g_out && a->partial && a->sums, HFAGP_EBADARG, "pointwise_bwd: null pointer");
+    HFAGP_REQUIRE(a && a->x && a->g_out && a->partial, HFAGP_EBADARG, "pointwise_bwd: null pointer");
     HFAGP_REQUIRE(a->C % 4 == 0 && a->C / 4 <= 256 && a->B > 0 && a->H > 0 && a->W > 0, HFAGP_EUNSUPPORTED,
                   "pointwise_bwd: C=%d must be a multiple of 4 and <= 1024", a->C);
     HFAGP_REQUIRE(a->noise_strength_p == a->noise_strength_p, HFAGP_EBADARG, "pointwise_bwd: NaN noise strength");
@@ -487,8 +521,24 @@ int hfagp_pointwise_bwd(const HfagpPointwiseBwdArgs* a, void* stream) {
         else pointwise_bwd_kernel<false, false><<<grid, 256, lds, s>>>(*a, rows);
     }
     const int n = kRed * a->C;
-    reduce_partials_kernel<<<dim3((n + 15) / 16, a->B), 256, 0, s>>>(a->partial, a->sums, a->B, a->nchunks, n);
+    // (sums NULL, ABI 12: the caller reduces `partial` later, with other passes' in one launch: hfagp_reduce_partials_batch)
+    if (a->sums) reduce_partials_kernel<<<dim3((n + 15) / 16, a->B), 256, 0, s>>>(a->partial, a->sums, a->B, a->nchunks, n);
     return check_launch("pointwise_bwd");
+}
+
+int hfagp_reduce_partials_batch(const HfagpReducePartialsItem* items, int32_t n, void* stream) {
+    HFAGP_REQUIRE(items && n >= 1 && n <= kRedBatchMax, HFAGP_EBADARG, "reduce_partials_batch: 1..%d items", kRedBatchMax);
+    RedBatch t;
+    int most_n = 0, most_b = 0;
+    for (int i = 0; i < n; ++i) {
+        const HfagpReducePartialsItem& a = items[i];
+        HFAGP_REQUIRE(a.partial && a.sums && a.B > 0 && a.nchunks > 0 && a.n > 0, HFAGP_EBADARG, "reduce_partials_batch: item %d", i);
+        t.it[i] = a;
+        most_n = std::max(most_n, a.n);
+        most_b = std::max(most_b, a.B);
+    }
+    reduce_partials_batch_kernel<<<dim3((unsigned)((most_n + 15) / 16), (unsigned)most_b, (unsigned)n), 256, 0, (hipStream_t)stream>>>(t);
+    return check_launch("reduce_partials_batch");
 }
 
 int hfagp_depth_clamp(float* depth, const float* tminmax, int64_t n, void* stream) {

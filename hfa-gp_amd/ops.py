@@ -812,7 +812,7 @@ _DEV_PW_CHUNKS = os.environ.get("HFAGP_DEV_PW_CHUNKS")
 def pointwise_bwd(x: torch.Tensor, dxs_conv=None, s_conv=None, dxs_rgb=None, s_rgb=None, g_rgb_small=None,
                   w_rgb_small=None, s_small=None, g_direct=None, producer: Optional[dict] = None,
                   param_grads: bool = False, y_rgb_small=None, clamp_rgb_small: Optional[float] = None,
-                  g_nchw3_a=None, g_nchw3_b=None):
+                  g_nchw3_a=None, g_nchw3_b=None, deferred: Optional[list] = None):
     """Fused streaming pass over the saved activation x [B,H,W,C] (see include/hfagp.h).  `producer` =
     dict(dcoef, bias, noise, noise_strength, act, alpha, gain, clamp) of the layer that produced x, or None.
     Returns (g_out [B,H,W,C], sums [B,10,C])."""
@@ -833,7 +833,11 @@ def pointwise_bwd(x: torch.Tensor, dxs_conv=None, s_conv=None, dxs_rgb=None, s_r
     g_out = torch.empty_like(x)
     partial = torch.empty(b, nchunks, 10, c, device=x.device, dtype=torch.float32)
     sums = torch.empty(b, 10, c, device=x.device, dtype=torch.float32)
-    a.x, a.g_out, a.partial, a.sums = _ptr(x), _ptr(g_out), _ptr(partial), _ptr(sums)
+    # `deferred` (a list): the partial sums stay un-reduced and (partial, sums) is appended — `reduce_partials_batch(deferred)`
+    # fills every `sums` of the list in one launch (its views may be handed around before that)
+    a.x, a.g_out, a.partial, a.sums = _ptr(x), _ptr(g_out), _ptr(partial), (None if deferred is not None else _ptr(sums))
+    if deferred is not None:
+        deferred.append((partial, sums))
     a.dxs_conv, a.s_conv, a.dxs_rgb, a.s_rgb = _ptr(dxs_conv), _ptr(s_conv), _ptr(dxs_rgb), _ptr(s_rgb)
     a.g_rgb_small, a.w_rgb_small, a.s_small, a.g_direct = _ptr(g_rgb_small), _ptr(w_rgb_small), _ptr(s_small), _ptr(g_direct)
     a.B, a.H, a.W, a.C, a.nchunks = b, h, w, c, nchunks
@@ -990,6 +994,18 @@ def affine_grad(dstot: torch.Tensor, w: torch.Tensor, dA: torch.Tensor, db: torc
     b, cin = dstot.shape
     L.check(L.lib().hfagp_affine_grad(_ptr(dstot), w.data_ptr(), _ptr(dA), _ptr(db), b, cin, w.shape[1], w.stride(0),
                                       _stream()), "affine_grad")
+
+
+def reduce_partials_batch(items) -> None:
+    """items: (partial [B,nchunks,10,C], sums [B,10,C]) pairs of `pointwise_bwd(..., deferred=list)` calls: one launch per 32."""
+    for i0 in range(0, len(items), 32):
+        chunk = items[i0:i0 + 32]
+        arr = (L.ReducePartialsItem * len(chunk))()
+        for a, (partial, sums) in zip(arr, chunk):
+            a.partial, a.sums = _ptr(_chk(partial, "partial")), _ptr(_chk(sums, "sums"))
+            a.B, a.nchunks, a.n = partial.shape[0], partial.shape[1], partial.shape[2] * partial.shape[3]
+        L.check(L.lib().hfagp_reduce_partials_batch(arr, len(chunk), _stream()), "reduce_partials_batch")
+    items.clear()
 
 
 def affine_grad_batch(items) -> None:

@@ -415,6 +415,16 @@ typedef struct {
 
 int hfagp_pointwise_bwd(const HfagpPointwiseBwdArgs* a, void* stream);
 
+/* ABI 12: hfagp_pointwise_bwd with sums = NULL leaves its per-chunk partial sums un-reduced; this reduces up to 32 such buffers in
+ * one launch: sums[b][k] = sum over chunks of partial[b][chunk][k], k < n = 10 * C, in the fixed order of the single-pass reducer
+ * (a backward pass with the generator frozen consumes the sums only at its end: 19 launches -> 1).                               */
+typedef struct {
+    const float* partial;     /* [B][nchunks][n] */
+    float*       sums;        /* [B][n] */
+    int32_t B, nchunks, n;
+} HfagpReducePartialsItem;
+int hfagp_reduce_partials_batch(const HfagpReducePartialsItem* items, int32_t n, void* stream);
+
 /* MipRayMarcher2's depth clamp (EG3D: `torch.clamp(depth, min(sample depths), max(sample depths))` over the WHOLE batch) in one
  * launch: depth [n] is clamped in place to [min_i tminmax[i][0], max_i tminmax[i][1]] (tminmax as hfagp_raymarch_fwd writes it).
  * Up to 64 workgroups, each reducing all of tminmax itself (L2-resident) and clamping its slice; any batch since ABI 11. */

@@ -409,3 +409,27 @@ def test_tall_gram_matches_the_matrix_product(dev, m, n):
         assert (got - ref).abs().max().item() <= 2e-6 * math.sqrt(m) * max(1.0, ref.abs().max().item() / math.sqrt(m))
     again = ops.tall_gram(x, x)
     assert torch.equal(again, ops.tall_gram(x, x))          # fixed summation order
+
+
+def test_deferred_partial_sum_reduction_equals_the_immediate_one(dev):
+    """`hfagp_pointwise_bwd` with sums = NULL + `hfagp_reduce_partials_batch` (all fused passes of a frozen-generator backward reduced
+    in ONE launch at its end) gives the bits of the per-pass reducer, for passes of different batch / channel / chunk counts."""
+    from hfa_gp_amd import ops
+    g = torch.Generator(device=dev).manual_seed(21)
+    cases, deferred, ref = [(2, 64, 128), (1, 16, 512), (3, 8, 40), (2, 128, 64)], [], []
+    for b, h, c in cases:
+        x = torch.randn(b, h, h, c, device=dev, generator=g)
+        d = torch.randn(b, h, h, c, device=dev, generator=g)
+        s = torch.randn(b, c, device=dev, generator=g)
+        prod = dict(dcoef=torch.rand(b, c, device=dev, generator=g) + 0.5, bias=torch.randn(c, device=dev, generator=g),
+                    noise=torch.randn(h, h, device=dev, generator=g), noise_strength=0.1, act="lrelu", alpha=0.2, gain=math.sqrt(2.0),
+                    clamp=256.0)
+        g0, s0 = ops.pointwise_bwd(x, dxs_conv=d, s_conv=s, producer=prod)
+        g1, s1 = ops.pointwise_bwd(x, dxs_conv=d, s_conv=s, producer=prod, deferred=deferred)
+        assert torch.equal(g0, g1)
+        ref.append((s0, s1))
+    assert len(deferred) == len(cases)
+    ops.reduce_partials_batch(deferred)
+    assert not deferred
+    for s0, s1 in ref:
+        assert torch.equal(s0, s1)
