@@ -20,8 +20,8 @@ constexpr int kRed = 10;
 // SMALL: the small (1 .. 4-channel) toRGB's adjoint is part of the pass; PG: parameter-gradient reductions (rows 4 .. 9).
 // Round 5: compile-time variants — the generic kernel carried all ten reduction rows (40 registers) and the small-toRGB operands
 // through every launch: 181 registers, two waves per SIMD; the common (frozen generator, 96-channel toRGB) instance needs three rows.
-template <bool SMALL, bool PG>
-__global__ void __launch_bounds__(256) pointwise_bwd_kernel(const HfagpPointwiseBwdArgs a, int rows_per_block) {
+template <bool SMALL, bool PG, bool PACKED = false>
+__global__ void __launch_bounds__(256, (SMALL && PACKED && !PG) ? 4 : 1) pointwise_bwd_kernel(const HfagpPointwiseBwdArgs a, int rows_per_block) {
     // block = (chunk of pixel rows, sample b); thread = (pixel lane, 4-channel group)
     // rows the variant really accumulates: 0 .. 3 without the parameter gradients (the LDS scratch of all ten rows was 40 KB per
     // workgroup: four workgroups per CU whatever the register count)
@@ -135,6 +135,32 @@ __global__ void __launch_bounds__(256) pointwise_bwd_kernel(const HfagpPointwise
             const float g = a.g_rgb_small[q];
             return (mask_small && !(fabsf(a.y_rgb_small[q]) < a.clamp_rgb_small)) ? 0.f : g;
         };
+        // the four (gradient, mask) pairs of a pixel are the same for all C / 4 lanes on it: with a power-of-two lane group lanes
+        // 0 .. 3 of the group load the gradients, 4 .. 7 the masked outputs, and eight shuffles hand them round — instead of eight
+        // scalar loads (and their 64-bit addresses: 18 registers) in every lane
+        // (PACKED: the host checked that C / 4 is a power of two >= 8)
+        constexpr bool packed = SMALL && PACKED;
+        const int lane = threadIdx.x & 63, gbase = lane & ~(min(C4, 64) - 1), kq = lane & 7;
+        auto small4 = [&](int p, float sv[4]) __attribute__((always_inline)) {
+            if (!SMALL) { sv[0] = sv[1] = sv[2] = sv[3] = 0.f; return; }
+            if constexpr (packed) {
+                float v = 0.f;
+                const int c = kq & 3;
+                if (c < a.Co) {
+                    const size_t q = ((size_t)b * a.Co + c) * HW + p;
+                    if (kq < 4) v = a.g_rgb_small[q];
+                    else if (mask_small) v = a.y_rgb_small[q];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float g = __shfl(v, gbase + k), y = __shfl(v, gbase + 4 + k);
+                    sv[k] = (k < a.Co && !(mask_small && !(fabsf(y) < a.clamp_rgb_small))) ? g : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sv[k] = small(p, k);
+            }
+        };
         int p = p_begin + pl;
         for (; p + npl < p_end; p += 2 * npl) {
             const int q = p + npl;
@@ -144,15 +170,18 @@ __global__ void __launch_bounds__(256) pointwise_bwd_kernel(const HfagpPointwise
             const float4 r0 = GR ? GR[e0] : z4, r1 = GR ? GR[e1] : z4;
             const float4 d0 = GD ? GD[e0] : z4, d1 = GD ? GD[e1] : z4;
             const float n0 = a.noise_p ? a.noise_p[p] : 0.f, n1 = a.noise_p ? a.noise_p[q] : 0.f;
-            const float s00 = small(p, 0), s01 = small(p, 1), s02 = small(p, 2), s03 = small(p, 3);
-            const float s10 = small(q, 0), s11 = small(q, 1), s12 = small(q, 2), s13 = small(q, 3);
-            pixel(p, x0, c0, r0, d0, n0, s00, s01, s02, s03);
-            pixel(q, x1, c1, r1, d1, n1, s10, s11, s12, s13);
+            float s0[4], s1[4];
+            small4(p, s0);
+            small4(q, s1);
+            pixel(p, x0, c0, r0, d0, n0, s0[0], s0[1], s0[2], s0[3]);
+            pixel(q, x1, c1, r1, d1, n1, s1[0], s1[1], s1[2], s1[3]);
         }
         if (p < p_end) {
             const size_t e0 = base + (size_t)p * C4 + c4;
+            float s0[4];
+            small4(p, s0);
             pixel(p, X[e0], GC ? GC[e0] : z4, GR ? GR[e0] : z4, GD ? GD[e0] : z4, a.noise_p ? a.noise_p[p] : 0.f,
-                  small(p, 0), small(p, 1), small(p, 2), small(p, 3));
+                  s0[0], s0[1], s0[2], s0[3]);
         }
     }
     // ---- block reduction over the pixel lanes, then one deterministic partial per (b, chunk)
@@ -208,32 +237,31 @@ __global__ void __launch_bounds__(256) reduce_partials_kernel(const float* __res
 constexpr int kRedBatchMax = 32;
 struct RedBatch { HfagpReducePartialsItem it[kRedBatchMax]; };
 __global__ void __launch_bounds__(256) reduce_partials_batch_kernel(const RedBatch t) {
-    __shared__ float red[16][17];
+    // block = 32 consecutive outputs x 8 chunk lanes (128-byte rows; eight loads in flight per lane)
+    __shared__ float red[8][33];
     const HfagpReducePartialsItem& a = t.it[blockIdx.z];
-    const int kk = threadIdx.x & 15, q0 = threadIdx.x >> 4;
-    const int k = blockIdx.x * 16 + kk, b = blockIdx.y;
-    if (b >= a.B || blockIdx.x * 16 >= a.n) return;              // (uniform per workgroup)
+    const int kk = threadIdx.x & 31, q0 = threadIdx.x >> 5;
+    const int k = blockIdx.x * 32 + kk, b = blockIdx.y;
+    if (b >= a.B || blockIdx.x * 32 >= a.n) return;              // (uniform per workgroup)
+    // (32 loads in flight per lane: with 8 a lane's 80 chunks of the 512^2 passes were ten memory round trips — 50 us for 40 MB)
     float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (k < a.n) {
         const float* src = a.partial + (size_t)b * a.nchunks * a.n + k;
-        for (int q = q0; q < a.nchunks; q += 8 * 16) {
+        for (int q = q0; q < a.nchunks; q += 8 * 32) {
+            float v[32];
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (q + 16 * u < a.nchunks) part[u] += src[(size_t)(q + 16 * u) * a.n];
+            for (int u = 0; u < 32; ++u) v[u] = q + 8 * u < a.nchunks ? src[(size_t)(q + 8 * u) * a.n] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 32; ++u) part[u & 7] += v[u];
         }
     }
     red[q0][kk] = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
     __syncthreads();
     if (q0 == 0 && k < a.n) {
-        float v[16];
+        float v[8];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = red[u][kk];
-#pragma unroll
-        for (int w = 8; w >= 1; w >>= 1)
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (u < w) v[u] += v[u + w];
-        a.sums[(size_t)b * a.n + k] = v[0];
+        for (int u = 0; u < 8; ++u) v[u] = red[u][kk];
+        a.sums[(size_t)b * a.n + k] = ((v[0] + v[4]) + (v[2] + v[6])) + ((v[1] + v[5]) + (v[3] + v[7]));
     }
 }
 
@@ -514,8 +542,15 @@ int hfagp_pointwise_bwd(const HfagpPointwiseBwdArgs* a, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(a->nchunks, a->B);
     if (a->g_rgb_small) {
-        if (a->param_grads) pointwise_bwd_kernel<true, true><<<grid, 256, lds, s>>>(*a, rows);
-        else pointwise_bwd_kernel<true, false><<<grid, 256, lds, s>>>(*a, rows);
+        const int c4 = a->C / 4;
+        const bool packed = c4 >= 8 && (c4 & (c4 - 1)) == 0;
+        if (a->param_grads) {
+            if (packed) pointwise_bwd_kernel<true, true, true><<<grid, 256, lds, s>>>(*a, rows);
+            else pointwise_bwd_kernel<true, true><<<grid, 256, lds, s>>>(*a, rows);
+        } else {
+            if (packed) pointwise_bwd_kernel<true, false, true><<<grid, 256, lds, s>>>(*a, rows);
+            else pointwise_bwd_kernel<true, false><<<grid, 256, lds, s>>>(*a, rows);
+        }
     } else {
         if (a->param_grads) pointwise_bwd_kernel<false, true><<<grid, 256, lds, s>>>(*a, rows);
         else pointwise_bwd_kernel<false, false><<<grid, 256, lds, s>>>(*a, rows);
@@ -537,7 +572,7 @@ int hfagp_reduce_partials_batch(const HfagpReducePartialsItem* items, int32_t n,
         most_n = std::max(most_n, a.n);
         most_b = std::max(most_b, a.B);
     }
-    reduce_partials_batch_kernel<<<dim3((unsigned)((most_n + 15) / 16), (unsigned)most_b, (unsigned)n), 256, 0, (hipStream_t)stream>>>(t);
+    reduce_partials_batch_kernel<<<dim3((unsigned)((most_n + 31) / 32), (unsigned)most_b, (unsigned)n), 256, 0, (hipStream_t)stream>>>(t);
     return check_launch("reduce_partials_batch");
 }
 

@@ -826,6 +826,9 @@ def pointwise_bwd(x: torch.Tensor, dxs_conv=None, s_conv=None, dxs_rgb=None, s_r
     # (the LDS scratch is sized by the rows a variant reduces since round 5; ten rows for all = 40 KB capped it at 4, and 512
     # blocks in total left two per CU: the 512^2 x 64 launches of the fitting step ran at 1.4 - 2.7 TB/s)
     per_cu = {(False, False): 5, (True, False): 3, (False, True): 4, (True, True): 3}[(g_rgb_small is not None, bool(param_grads))]
+    c4 = c // 4
+    if g_rgb_small is not None and not param_grads and c4 >= 8 and c4 & (c4 - 1) == 0:
+        per_cu = 4                     # (the small-toRGB operands shared by shuffles: 128 registers)
     nchunks = max(1, min(max(256, per_cu * 256 // b), -(-(h * w) // (npl * 4))))
     if _DEV_PW_CHUNKS:                                  # developer sweep (tools/dev/pointwise_sweep.py)
         nchunks = max(1, min(int(_DEV_PW_CHUNKS), h * w))

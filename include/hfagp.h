@@ -416,8 +416,8 @@ typedef struct {
 int hfagp_pointwise_bwd(const HfagpPointwiseBwdArgs* a, void* stream);
 
 /* ABI 12: hfagp_pointwise_bwd with sums = NULL leaves its per-chunk partial sums un-reduced; this reduces up to 32 such buffers in
- * one launch: sums[b][k] = sum over chunks of partial[b][chunk][k], k < n = 10 * C, in the fixed order of the single-pass reducer
- * (a backward pass with the generator frozen consumes the sums only at its end: 19 launches -> 1).                               */
+ * one launch: sums[b][k] = sum over chunks of partial[b][chunk][k], k < n = 10 * C, in a fixed order (not the single-pass reducer's: the last bits may
+ * differ) (a backward pass with the generator frozen consumes the sums only at its end: 19 launches -> 1).                               */
 typedef struct {
     const float* partial;     /* [B][nchunks][n] */
     float*       sums;        /* [B][n] */
