@@ -1,0 +1,13 @@
+cd $GRAFT_REPO_ROOT
+python -m pytest tests/test_gpu_backward.py -x -q 2>&1 | grep -E "passed|failed|Error|assert|error" | head -12
+cd /tmp && export TMPDIR=/tmp
+out=/tmp/pw; rm -rf $out; mkdir -p $out
+rocprofv3 --kernel-trace --stats --output-format csv -d $out -o t -- python $GRAFT_REPO_ROOT/tools/dev/bench_train.py 2 8 3dmm > $out/log.txt 2>&1
+tail -1 $out/log.txt
+python - $out <<'PY'
+import csv, glob, sys
+for f in glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "upsample2d" in r["Name"]:
+            print(f'   {r["Name"][:80]:80s} calls={r["Calls"]:>4s} avg_us={float(r["AverageNs"])/1e3:9.1f} total_ms/step={float(r["TotalDurationNs"])/1e6/10:.3f}')
+PY
