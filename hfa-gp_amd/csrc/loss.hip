@@ -3,6 +3,7 @@
 //   l2        = MSELoss(reduction='mean')(real, generated)
 // as ONE pass over the image (pooled image + per-block partial sums, reduced in a fixed order -> deterministic) and
 // ONE pass for the adjoint d image = g * 2 (pooled - real) / (N f^2).  SURVEY.md section 8f rank 3.  gfx950 only.
+#include <cmath>
 #include "common.h"
 
 namespace hfagp {
@@ -86,7 +87,8 @@ __global__ void __launch_bounds__(256) adam_advance_kernel(const long long* __re
 }
 
 __global__ void __launch_bounds__(256) adam_update_kernel(const long long* __restrict__ tensors, const int2* __restrict__ chunks,
-                                                          double lr, double beta1d, double beta2d, float eps) {
+                                                          double lr, double beta1d, double beta2d, float eps, double ln_b1,
+                                                          double ln_b2) {
     __shared__ float bc[2];
     const int2 ch = chunks[blockIdx.x];
     const long long* t = tensors + 6 * (long long)ch.x;
@@ -97,8 +99,10 @@ __global__ void __launch_bounds__(256) adam_update_kernel(const long long* __res
     const long long numel = t[5];
     if (threadIdx.x == 0) {
         const double step = (double)*reinterpret_cast<const float*>(t[4]);
-        bc[0] = (float)(lr / (1.0 - pow(beta1d, step)));                  // lr / bias_correction1
-        bc[1] = (float)(1.0 / sqrt(1.0 - pow(beta2d, step)));             // 1 / sqrt(bias_correction2)
+        // beta^step = exp(step ln beta), ln beta from the host: the generic double pow() on ONE thread, with the other 255 waiting at
+        // the barrier, was most of this kernel whenever the step covers few parameters (84 us for the 110 chunks of driver + basis)
+        bc[0] = (float)(lr / (1.0 - exp(step * ln_b1)));                  // lr / bias_correction1
+        bc[1] = (float)(1.0 / sqrt(1.0 - exp(step * ln_b2)));             // 1 / sqrt(bias_correction2)
     }
     __syncthreads();
     // (1 - beta in DOUBLE, then rounded: 1.f - 0.999f is 1.3e-5 off the factor torch multiplies with)
@@ -109,12 +113,17 @@ __global__ void __launch_bounds__(256) adam_update_kernel(const long long* __res
         vv = vv * beta2 + gg * gg * omb2;
         pp -= step_size * mm / (sqrtf(vv) * rs2 + eps);
     };
-    const bool vec = (((unsigned long long)t[0] | (unsigned long long)t[1] | (unsigned long long)t[2] | (unsigned long long)t[3]) & 15ull) == 0 && (e0 & 3) == 0;
+    // (p, m, v 16-byte aligned; the gradient is a slice of the trainer's flat buffer, packed without padding: after the first
+    // parameter whose element count is not a multiple of 4 every slice is only 4-byte aligned — global 16-byte loads take that, and
+    // demanding 16 sent every later tensor down the scalar loop: 64 dependent rounds per thread, 84 us for driver + basis)
+    const bool vec = (((unsigned long long)t[0] | (unsigned long long)t[2] | (unsigned long long)t[3]) & 15ull) == 0 &&
+                     ((unsigned long long)t[1] & 3ull) == 0 && (e0 & 3) == 0;
     if (vec) {
         const long long ev = e0 + ((e1 - e0) & ~3ll);            // end of the whole float4s
         for (long long i = e0 + 4 * threadIdx.x; i < ev; i += 1024) {
             float4 pp = *reinterpret_cast<float4*>(p + i), mm = *reinterpret_cast<float4*>(m + i), vv = *reinterpret_cast<float4*>(v + i);
-            const float4 gg = *reinterpret_cast<const float4*>(g + i);
+            float4 gg;
+            __builtin_memcpy(&gg, g + i, 16);            // (4-byte aligned: the compiler must not assume more)
             one(pp.x, gg.x, mm.x, vv.x); one(pp.y, gg.y, mm.y, vv.y); one(pp.z, gg.z, mm.z, vv.z); one(pp.w, gg.w, mm.w, vv.w);
             *reinterpret_cast<float4*>(p + i) = pp; *reinterpret_cast<float4*>(m + i) = mm; *reinterpret_cast<float4*>(v + i) = vv;
         }
@@ -165,7 +174,7 @@ extern "C" int hfagp_adam_step(const void* tensor_table, const void* chunk_table
     hipStream_t s = (hipStream_t)stream;
     adam_advance_kernel<<<(ntensors + 255) / 256, 256, 0, s>>>(static_cast<const long long*>(tensor_table), ntensors);
     adam_update_kernel<<<(unsigned)nchunks, 256, 0, s>>>(static_cast<const long long*>(tensor_table), static_cast<const int2*>(chunk_table),
-                                                         lr, beta1, beta2, (float)eps);
+                                                         lr, beta1, beta2, (float)eps, log(beta1), log(beta2));
     return check_launch("adam_step");
 }
 
