@@ -15,6 +15,7 @@ GEMM-shaped adjoints (conv bwd-data) run on the forward MFMA kernel with transpo
 from __future__ import annotations
 
 import math
+import os
 from typing import List, Optional
 
 import torch
@@ -377,7 +378,10 @@ class SynthesisFn(torch.autograd.Function):
         res = cfg.neural_rendering_resolution
         net = gen.decoder.net
         dec_prm = (net["0"].weight, net["0"].bias, net["2"].weight, net["2"].bias)
-        dec_direct = ctx.pg and all(bw._direct(p) for p in dec_prm)       # the kernel's atomics land in the .grad slices themselves
+        # (the kernel's ~9 M end-of-kernel atomics landing in the .grad slices themselves — `dec_out` — instead of four fresh zeroed
+        # tensors was measured: the pass takes 1.17 ms instead of 0.98; the slices of the flat buffer are not line-aligned and the
+        # optimiser's state neighbours them.  HFAGP_DEV_DEC_DIRECT=1 re-enables it for A/B timing)
+        dec_direct = ctx.pg and os.environ.get("HFAGP_DEV_DEC_DIRECT", "0") == "1" and all(bw._direct(p) for p in dec_prm)
         rb = gen._timed("raymarch_bwd", float(b), ops.raymarch_bwd, g_feat.view(b, res * res, 32), tape["planes"],
                         u_strat=tape["u_strat"], u_imp=tape["u_imp"], decoder_grads=ctx.pg,
                         planes_absmax=tape.get("planes_absmax"), state=tape.get("ray_state"),
