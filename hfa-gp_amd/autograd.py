@@ -379,8 +379,9 @@ class SynthesisFn(torch.autograd.Function):
         net = gen.decoder.net
         dec_prm = (net["0"].weight, net["0"].bias, net["2"].weight, net["2"].bias)
         # (the kernel's ~9 M end-of-kernel atomics landing in the .grad slices themselves — `dec_out` — instead of four fresh zeroed
-        # tensors was measured: the pass takes 1.17 ms instead of 0.98; the slices of the flat buffer are not line-aligned and the
-        # optimiser's state neighbours them.  HFAGP_DEV_DEC_DIRECT=1 re-enables it for A/B timing)
+        # tensors was measured: the pass takes 1.17 - 1.20 ms instead of 0.98 - 0.99, and still does with the atomics cut to one set
+        # per workgroup (an LDS reduction over its eight waves: no change either way) — it is WHERE they land, not how many.
+        # HFAGP_DEV_DEC_DIRECT=1 re-enables it for A/B timing)
         dec_direct = ctx.pg and os.environ.get("HFAGP_DEV_DEC_DIRECT", "0") == "1" and all(bw._direct(p) for p in dec_prm)
         rb = gen._timed("raymarch_bwd", float(b), ops.raymarch_bwd, g_feat.view(b, res * res, 32), tape["planes"],
                         u_strat=tape["u_strat"], u_imp=tape["u_imp"], decoder_grads=ctx.pg,
