@@ -106,14 +106,14 @@ __global__ void __launch_bounds__(256, 2) raymarch_kernel(const RayParams p) {
             // flight, a ray cost twelve memory round trips and this pass ran at a third of the rate the 440 MB of state allow
             {
                 constexpr int NV = S * 8 / 64;
-                float4 v[NV];
-                const float4* st4 = reinterpret_cast<const float4*>(st);
+                f32x4 v[NV];
+                const f32x4* st4 = reinterpret_cast<const f32x4*>(st);
 #pragma unroll
-                for (int k = 0; k < NV; ++k) v[k] = st4[lane + 64 * k];
+                for (int k = 0; k < NV; ++k) v[k] = __builtin_nontemporal_load(st4 + lane + 64 * k);
 #pragma unroll
                 for (int k = 0; k < NV; ++k) {
                     const int i = lane + 64 * k;
-                    *reinterpret_cast<float4*>(&lds.col[(i >> 3) * CS + 4 * (i & 7)]) = v[k];
+                    *reinterpret_cast<f32x4*>(&lds.col[(i >> 3) * CS + 4 * (i & 7)]) = v[k];
                 }
             }
             for (int i = lane; i < S; i += 64) {
@@ -315,8 +315,9 @@ __global__ void __launch_bounds__(256, 2) raymarch_kernel(const RayParams p) {
             if (a.state) {                          // forward of a step that will be differentiated: leave the state behind
                 float* st = a.state + (size_t)ray * kStateFloats;
 #pragma unroll 4
-                for (int i = lane; i < S * 8; i += 64)           // 16 bytes per lane (the row stride CS keeps them aligned)
-                    reinterpret_cast<float4*>(st)[i] = *reinterpret_cast<const float4*>(&lds.col[(i >> 3) * CS + 4 * (i & 7)]);
+                for (int i = lane; i < S * 8; i += 64)           // 16 bytes per lane (the row stride CS keeps them aligned); streaming:
+                    __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(&lds.col[(i >> 3) * CS + 4 * (i & 7)]),      // 13 KB per ray
+                                                reinterpret_cast<f32x4*>(st) + i);                                          // must not evict the plane bands
                 for (int i = lane; i < S; i += 64) {
                     st[S * 32 + i] = lds.ts[i];
                     st[S * 33 + i] = lds.ss[i];
