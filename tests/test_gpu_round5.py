@@ -440,3 +440,19 @@ def test_deferred_partial_sum_reduction_equals_the_immediate_one(dev):
         _, t1 = ops.pointwise_bwd(x, dxs_conv=x, s_conv=torch.ones(b, c, device=dev), deferred=again)
     ops.reduce_partials_batch(again)
     assert torch.equal(t0, t1)                                                     # deterministic
+
+
+@pytest.mark.parametrize("b", [1, 4])
+def test_raymarch_backward_sort_gather_other_batches(dev, b):
+    """One frame (fewer bins than the scan tile) and four (16 448 bins: the scan kernel walks two LDS tiles with a carry) at
+    BASELINE's plane / ray sizes: sort + gather against the scatter kernels."""
+    from hfa_gp_amd import ops
+    from hfa_gp_amd.config import ffhq512_128
+    g, planes, kw = _raybwd_case(dev, ffhq512_128(), b, 30 + b)
+    with torch.no_grad():
+        ref = ops.raymarch_bwd(g, planes, rows=False, **kw)
+        out = ops.raymarch_bwd(g, planes, rows=True, **kw)
+    scale = ref.abs().max().item()
+    assert scale > 0 and torch.isfinite(out).all()
+    assert (out - ref).abs().max().item() <= 2e-5 * scale
+    assert rel_l2(out, ref) <= 2e-5
