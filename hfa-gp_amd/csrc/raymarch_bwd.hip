@@ -9,6 +9,11 @@
 //             dF^T[32x16] = W0^T . (dH * sigmoid(Hpre))^T       (32 MFMA)
 //           -> dF transposed through LDS so that each half-wave owns the 32 channels of ONE texel line ->
 //           fp32 atomic adds of full 128-byte lines into d_planes (12 taps per sample).
+//   pass 2 since round 5, whenever the caller provides HfagpRaymarchBwdArgs::rows_scratch: SORT + GATHER (raymarch_rows.hip) — the
+//           samples are counting-sorted by (plane, column strip, texel row); raymarch_bwd_df_kernel<.., SORTED> below (generator
+//           frozen) or raymarch_bwd_tiles_kernel<PG, .., SCATTER = false, WIDE> (tuned: with the decoder gradients) write dL/dF to
+//           the sorted slots; raymarch_bwd_rows_kernel forms every row tile of d_planes as a dense product.  The scatter kernels
+//           of this file (tiles: atomics; cols: LDS line cache) remain the fallback for shapes the sort does not take.
 //   The importance depths carry no gradient (EG3D: no_grad + detach), neither do the camera / depths.
 #include <algorithm>
 #include <cstdlib>
