@@ -1,5 +1,6 @@
 """bench.py's launcher path (no GPU needed): `--gpus N` without a launcher must start N ranks itself, and a mismatch
 between --gpus and the launcher's world size must be refused instead of silently running one rank."""
+import importlib.util
 import os
 import subprocess
 import sys
@@ -58,3 +59,37 @@ def test_rccl_choice_parser(tmp_path):
     log.write_text("h:1:2 [0] NCCL INFO RCCL version 2.26.6-HEAD\n")
     assert "one rank" in bench.rccl_choices(str(log), 1)["note"]
     assert "no RCCL log" in bench.rccl_choices(str(tmp_path / "absent.log"), 2)["note"]
+
+
+def _bench_module():
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    return bench
+
+
+def test_the_printed_line_stays_parseable_and_short():
+    """round 5's line had grown to 21.6 KB and the driver recorded `parsed: null`.  `compact_line` turns the full result
+    object of a real run (canned: profiles/r05_bench_line.json, the 21.6 KB one) into the line that is printed: valid JSON, at most
+    LINE_BYTE_BUDGET (6000) bytes, every contract key present, `roofline` and `cpu_baseline` with their required members."""
+    import json
+    bench = _bench_module()
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_line.json")))
+    assert len(json.dumps(full)) > 20000
+    text = json.dumps(bench.compact_line(full))
+    assert len(text) <= bench.LINE_BYTE_BUDGET == 6000, len(text)
+    line = json.loads(text)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert abs(line["value"] - full["value"]) < 1e-3 * full["value"] and line["steps"] == 20 and line["warmup"] == 5
+    assert set(line["roofline"]) == {"bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "launches"}
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(line["cpu_baseline"])
+    assert "workload" in line["config"] and "model" not in line["config"]
+    assert line["train_step_ms_3dmm_generator_tuned"] > 0 and line["roofline_train_frac_ms"]["tuned_3dmm"]["wgrad_gemms"][0] > 0
+    # an 8-rank line carries the per-rank rates and still fits; a pathological one sheds its optional groups instead of growing
+    full8 = dict(full, n_gpus=8, per_rank_frames_per_s=[830.0 + i for i in range(8)], per_rank_spread=0.01)
+    assert len(json.dumps(bench.compact_line(full8))) <= 6000
+    huge = dict(full, leg_seconds={f"leg{i}": 1.0 for i in range(600)})
+    small = bench.compact_line(huge)
+    assert len(json.dumps(small)) <= 6000 and "leg_seconds" not in small and "roofline" in small
