@@ -453,8 +453,11 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
 // channels per block and two waves per SIMD (256 registers each) — the patch is staged once for twice the MFMA
 // work and the second wave of a SIMD covers the barrier / staging bubbles of the first; used when the layer
 // still fills the chip with the larger tile (make_plan).
+#ifndef HFAGP_UP4_OCC
+#define HFAGP_UP4_OCC 2
+#endif
 template <int KD, int NW, int IO = 0>
-__global__ void __launch_bounds__(NW * 64, 1) upconv_bf16_kernel(const ConvParams p) {
+__global__ void __launch_bounds__(NW * 64, (NW == 4 && KD != 3) ? HFAGP_UP4_OCC : 1) upconv_bf16_kernel(const ConvParams p) {
     constexpr int NP = kind_parts_a(KD), NPB = kind_parts(KD);    // parts of the activations (LDS patch) / of the weight image
     constexpr bool F16 = kind_f16(KD);
     constexpr bool XH = (IO & 1) != 0, YH = (IO & 2) != 0;       // fp16 storage of x / y_t (see modconv_bf16_kernel)
@@ -474,14 +477,27 @@ __global__ void __launch_bounds__(NW * 64, 1) upconv_bf16_kernel(const ConvParam
     char* As = lds_raw;
     float* Ss = reinterpret_cast<float*>(lds_raw + 2 * A_BUF);
 
+    // ---- tiling (round 6).  The position grid of the even parity is (H+1) x (W+1): tiling it per sample in 8 x 16 tiles rounds BOTH
+    // extents up (257 -> 33 x 17 tiles instead of 32 x 16: 1.10 x the MFMA work at 256^2, 1.41 x at 64^2, 1.88 x at 32^2).  Now:
+    //   * the rows of all samples are STACKED with pitch RP = H+1 (row r = b RP + m; row m = H of a sample is the zero padding
+    //     below its image, which is also what the tap (-1, .) of row 0 of the next sample has to see): B (H+1) rows tile in 8s
+    //     without a remainder per sample; a tile may straddle samples (styles / range-guard scales of up to `up_ns` samples);
+    //   * the columns 0 .. W-1 are tiled in 16s exactly (W % 16 == 0) and the one remaining column n = W (only x[.][W-1] reaches
+    //     it: taps (0,-1), (-1,-1)) goes to FRINGE tiles: the same 8 x 16 tile and K loop, but tile column j stands for
+    //     (row block j >> 1, image column W-1 + (j & 1)) — eight two-column pieces of eight different 8-row blocks, of which the odd
+    //     columns are stored.  64 useful positions per fringe tile; B (H+1) / 64 of them per layer (0.8 % of the tiles at 256^2).
     unsigned id = blockIdx.x;
     const int tiles_nu = p.Cout / BNU;
     const int tn_blk = __builtin_amdgcn_readfirstlane(id % tiles_nu);  id /= tiles_nu;
-    const int tw = __builtin_amdgcn_readfirstlane(id % p.tiles_w);     id /= p.tiles_w;
-    const int th = __builtin_amdgcn_readfirstlane(id % p.tiles_h);     id /= p.tiles_h;
-    const int b = __builtin_amdgcn_readfirstlane(id % p.B);            id /= p.B;
+    const int n_reg = p.up_tr * p.up_tw, n_tile = n_reg + p.up_nf;
+    const int T = __builtin_amdgcn_readfirstlane(id % n_tile);         id /= n_tile;
     const int ks = __builtin_amdgcn_readfirstlane(id);
-    const int m0 = th * PH, n0 = tw * PW, co0 = tn_blk * BNU;
+    const bool fringe = T >= n_reg;                                    // block-uniform
+    const int RP = p.up_rp, R_total = p.up_rows;
+    // regular tile: rows r0 .. r0+7, columns n0 .. n0+15; fringe tile: rows r0 .. r0+63
+    const int r0 = fringe ? (T - n_reg) * 64 : (T / p.up_tw) * PH, n0 = fringe ? 0 : (T % p.up_tw) * PW;
+    const int co0 = tn_blk * BNU;
+    const int b_lo = min(max(r0 - 1, 0) / RP, p.B - 1);                // first sample the patch touches
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -489,15 +505,26 @@ __global__ void __launch_bounds__(NW * 64, 1) upconv_bf16_kernel(const ConvParam
     const int c_begin = __builtin_amdgcn_readfirstlane((int)(((long long)p.nchunks * ks) / p.ksplit));
     const int c_end = __builtin_amdgcn_readfirstlane((int)(((long long)p.nchunks * (ks + 1)) / p.ksplit));
 
-    // ---- A staging (as in modconv_bf16_kernel): patch rows m0-1 .. m0+PH-1, columns n0-1 .. n0+PW-1
+    // ---- A staging (as in modconv_bf16_kernel): patch rows r0-1 .. r0+PH-1, columns n0-1 .. n0+PW-1 (fringe: see above)
     const int npatch = p.ph * p.pw;
     constexpr int A_PER_T = ((PH + 2) * (PW + 2) * 4 + NTH - 1) / NTH;
     static_assert(A_PER_T == 2 || A_PER_T == 3, "staging schedule: two or three slots per thread");
     float4 ra[A_PER_T];
-    const char* xb = reinterpret_cast<const char*>(p.x) + (long long)b * p.x_batch_stride * XB;
-    for (int i = tid; i < p.Cin; i += NTH) Ss[i] = p.styles ? p.styles[(size_t)b * p.Cin + i] : 1.f;
-    float sback = 1.f, sdown = 1.f;
-    if constexpr (F16) sdown = style_range_guard(p.styles ? p.styles + (size_t)b * p.Cin : nullptr, p.Cin, lane, &sback, p.x_absmax);
+    const char* xb = reinterpret_cast<const char*>(p.x) + (long long)b_lo * p.x_batch_stride * XB;
+    // styles of the up_ns samples from b_lo on (ones past the batch), then the fp16 range-guard scales 2^-e | 2^e per sample
+    float* Gd = Ss + p.up_ns * p.Cin;                              // [up_ns] 2^-e, then [up_ns] 2^e
+    {
+        const long long s_lo = (long long)b_lo * p.Cin, s_n = (long long)p.B * p.Cin;
+        for (int i = tid; i < p.up_ns * p.Cin; i += NTH) Ss[i] = (p.styles && s_lo + i < s_n) ? p.styles[s_lo + i] : 1.f;
+        for (int sI = 0; sI < p.up_ns; ++sI) {
+            float bk = 1.f, dn = 1.f;
+            if constexpr (F16)
+                dn = style_range_guard((p.styles && b_lo + sI < p.B) ? p.styles + (size_t)(b_lo + sI) * p.Cin : nullptr, p.Cin, lane, &bk,
+                                       p.x_absmax);
+            if (tid == 0) { Gd[sI] = dn; Gd[p.up_ns + sI] = bk; }
+        }
+    }
+    __syncthreads();
     unsigned aoff[A_PER_T];
     int lds_a[A_PER_T], soff[A_PER_T];
     float amask[A_PER_T];
@@ -505,12 +532,18 @@ __global__ void __launch_bounds__(NW * 64, 1) upconv_bf16_kernel(const ConvParam
     for (int k = 0; k < A_PER_T; ++k) {
         const int idx = min(tid + k * NTH, npatch * 4 - 1);
         const int pix = idx >> 2, q = idx & 3;
-        lds_a[k] = ((pix / p.pw) * LPWB + pix % p.pw) * APITCH + 8 * q;
-        const int iy = m0 - 1 + pix / p.pw, ix = n0 - 1 + pix % p.pw;
-        const bool inside = iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
-        aoff[k] = inside ? (unsigned)((iy * p.in_w + ix) * p.Cin + 4 * q) * (unsigned)XB : 0u;
-        amask[k] = inside ? sdown : 0.f;          // zero padding and the fp16 range guard in one factor
-        soff[k] = 4 * q;
+        const int pi = pix / p.pw, pj = pix % p.pw;
+        lds_a[k] = (pi * LPWB + pj) * APITCH + 8 * q;
+        int r, n;
+        if (!fringe) { r = r0 - 1 + pi; n = n0 - 1 + pj; }
+        else { r = pj == 0 ? -1 : r0 + 8 * ((pj - 1) >> 1) + pi - 1; n = p.W - 1 + ((pj - 1) & 1); }
+        const bool row_ok = r >= 0 && r < R_total;
+        const int bb = row_ok ? r / RP : b_lo, m = r - bb * RP;
+        const bool inside = row_ok && m < p.H && n >= 0 && n < p.W;
+        const int sel = inside ? bb - b_lo : 0;
+        aoff[k] = inside ? (unsigned)(((long long)sel * p.x_batch_stride + (long long)(m * p.W + n) * p.Cin + 4 * q) * XB) : 0u;
+        amask[k] = inside ? Gd[sel] : 0.f;          // zero padding and the fp16 range guard in one factor
+        soff[k] = sel * p.Cin + 4 * q;
     }
     auto load_a = [&](int chunk) __attribute__((always_inline)) {
         const char* xc = xb + (long long)chunk * (CKB * XB);
@@ -657,32 +690,74 @@ __global__ void __launch_bounds__(NW * 64, 1) upconv_bf16_kernel(const ConvParam
     // ---- raw stores of the four phases: y_t[2m + (f>>1)][2n + (f&1)], extents (H+1-(f>>1)) x (W+1-(f&1));
     // one 64-bit row pointer per (phase, tile, patch row), 32-bit column offsets
     float* out = p.out + (size_t)ks * p.slab;
+    if (!fringe) {
+        // the four patch rows of this wave (wave-uniform): sample, image row, range-guard scale
+        int rb[2 * TM], rm[2 * TM];
+        float rs[2 * TM];
 #pragma unroll
-    for (int f = 0; f < 4; ++f) {
-        const int mh = p.H + 1 - (f >> 1), mw = p.W + 1 - (f & 1);
+        for (int i = 0; i < 2 * TM; ++i) {
+            const int r = r0 + 2 * (wm * TM + (i >> 1)) + (i & 1);
+            const bool ok = r < R_total;
+            rb[i] = ok ? r / RP : 0;
+            rm[i] = ok ? r - rb[i] * RP : (1 << 30);
+            rs[i] = F16 ? Gd[p.up_ns + min(max(rb[i] - b_lo, 0), p.up_ns - 1)] : 1.f;
+        }
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            const int co = co0 + (wn * TN + tn) * 32 + l31;
+        for (int f = 0; f < 4; ++f) {
+            const int mh = p.H + 1 - (f >> 1), mw = p.W + 1 - (f & 1);
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
+            for (int tn = 0; tn < TN; ++tn) {
+                const int co = co0 + (wn * TN + tn) * 32 + l31;
 #pragma unroll
-                for (int rw = 0; rw < 2; ++rw) {
-                    const int m = m0 + 2 * (wm * TM + tm) + rw;
-                    if (m >= mh) continue;
-                    const size_t rowoff = (((size_t)b * p.Ho + 2 * m + (f >> 1)) * p.Wo + (f & 1)) * p.Cout + co;
-                    float* rowp = out + rowoff;
-                    _Float16* rowh = reinterpret_cast<_Float16*>(p.out) + rowoff;
+                for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const int n = n0 + 8 * (q >> 2) + 4 * h + (q & 3);
-                        if (n >= mw) continue;
-                        {
-                            const float v = F16 ? acc[f][tm][tn][8 * rw + q] * sback : acc[f][tm][tn][8 * rw + q];
-                            if constexpr (YH) rowh[2 * n * p.Cout] = (_Float16)v;
-                            else rowp[2 * n * p.Cout] = v;
+                    for (int rw = 0; rw < 2; ++rw) {
+                        const int m = rm[2 * tm + rw];
+                        if (m >= mh) continue;
+                        const size_t rowoff = (((size_t)rb[2 * tm + rw] * p.Ho + 2 * m + (f >> 1)) * p.Wo + (f & 1)) * p.Cout + co;
+                        float* rowp = out + rowoff;
+                        _Float16* rowh = reinterpret_cast<_Float16*>(p.out) + rowoff;
+                        const float sb = rs[2 * tm + rw];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const int n = n0 + 8 * (q >> 2) + 4 * h + (q & 3);
+                            if (n >= mw) continue;
+                            {
+                                const float v = F16 ? acc[f][tm][tn][8 * rw + q] * sb : acc[f][tm][tn][8 * rw + q];
+                                if constexpr (YH) rowh[2 * n * p.Cout] = (_Float16)v;
+                                else rowp[2 * n * p.Cout] = v;
+                            }
                         }
                     }
-                }
+            }
+        }
+    } else {
+        // fringe tile: tile column j = 8 (q >> 2) + 4 h + (q & 3) is odd exactly for odd q; it is image column W of row
+        // r0 + 8 (j >> 1) + patch row -> y_t[2m + fy][2W] of the two even-column parities (f = 0, 2)
+#pragma unroll
+        for (int f = 0; f < 4; f += 2) {
+            const int mh = p.H + 1 - (f >> 1);
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const int co = co0 + (wn * TN + tn) * 32 + l31;
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int rw = 0; rw < 2; ++rw)
+#pragma unroll
+                        for (int q = 1; q < 8; q += 2) {
+                            const int j = 8 * (q >> 2) + 4 * h + (q & 3);
+                            const int r = r0 + 8 * (j >> 1) + 2 * (wm * TM + tm) + rw;
+                            if (r >= R_total) continue;
+                            const int bb = r / RP, m = r - bb * RP;
+                            if (m >= mh) continue;
+                            const size_t off = (((size_t)bb * p.Ho + 2 * m + (f >> 1)) * p.Wo + 2 * p.W) * p.Cout + co;
+                            const float v = F16 ? acc[f][tm][tn][8 * rw + q] * Gd[p.up_ns + min(bb - b_lo, p.up_ns - 1)]
+                                                : acc[f][tm][tn][8 * rw + q];
+                            if constexpr (YH) reinterpret_cast<_Float16*>(p.out)[off] = (_Float16)v;
+                            else out[off] = v;
+                        }
+            }
         }
     }
 }
@@ -711,27 +786,39 @@ static void launch_s2_merged(const Plan& pl, int cin, hipStream_t s) {
     modconv_bf16_kernel<KD, 2, 0><<<pl.grid, 256, bf16_lds_bytes<kind_parts_a(KD), 2>(cin), s>>>(pl.p, 0);
 }
 
+// LDS of the merged up-conv: the two patch buffers + styles and range-guard scales of up_ns samples; beyond the 64 KB default the
+// kernel's dynamic-LDS limit is raised once per instantiation
+template <int KD, int NW, int IO>
+static void launch_up_one(const Plan& pl, int cin, hipStream_t s) {
+    const size_t lds = bf16_lds_bytes<kind_parts_a(KD), 2>(0) + (size_t)(pl.p.up_ns * (cin + 2)) * sizeof(float);
+    static bool raised = false;
+    if (lds > 64 * 1024 && !raised) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&upconv_bf16_kernel<KD, NW, IO>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        raised = true;
+    }
+    upconv_bf16_kernel<KD, NW, IO><<<pl.grid, NW * 64, lds, s>>>(pl.p);
+}
+
 // fp16-storage variants (KD = 1 only): io = x_f16 | y_f16 << 1
 static void launch_up_io(const Plan& pl, int cin, int io, hipStream_t s) {
-    const size_t lds = bf16_lds_bytes<1, 2>(cin);
     const bool w8 = pl.up_waves == 8;
     if (io == 2) {
-        if (w8) upconv_bf16_kernel<1, 8, 2><<<pl.grid, 512, lds, s>>>(pl.p); else upconv_bf16_kernel<1, 4, 2><<<pl.grid, 256, lds, s>>>(pl.p);
+        if (w8) launch_up_one<1, 8, 2>(pl, cin, s); else launch_up_one<1, 4, 2>(pl, cin, s);
     } else {
-        if (w8) upconv_bf16_kernel<1, 8, 3><<<pl.grid, 512, lds, s>>>(pl.p); else upconv_bf16_kernel<1, 4, 3><<<pl.grid, 256, lds, s>>>(pl.p);
+        if (w8) launch_up_one<1, 8, 3>(pl, cin, s); else launch_up_one<1, 4, 3>(pl, cin, s);
     }
 }
 
 template <int KD>
 static void launch_up(const Plan& pl, int cin, hipStream_t s) {
-    const size_t lds = bf16_lds_bytes<kind_parts_a(KD), 2>(cin);
     if constexpr (KD != 3) {            // (three parts: the 8-wave variant would spill; make_plan never asks for it)
         if (pl.up_waves == 8) {
-            upconv_bf16_kernel<KD, 8><<<pl.grid, 512, lds, s>>>(pl.p);
+            launch_up_one<KD, 8, 0>(pl, cin, s);
             return;
         }
     }
-    upconv_bf16_kernel<KD, 4><<<pl.grid, 256, lds, s>>>(pl.p);
+    launch_up_one<KD, 4, 0>(pl, cin, s);
 }
 
 int launch_modconv_bf16(const HfagpModconvArgs* a, Plan& pl, hipStream_t s) {

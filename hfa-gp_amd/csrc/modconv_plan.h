@@ -1,6 +1,8 @@
 // Planning shared by the modulated-conv kernels (fp32-exact modconv.hip, split-bf16 modconv_bf16.hip): the
 // phase/tap tables of the five conv modes, tiling, split-K choice.  gfx950 only.
 #pragma once
+#include <algorithm>
+#include <cstdlib>
 #include "common.h"
 
 namespace hfagp {
@@ -32,6 +34,10 @@ struct ConvParams {
     int wtaps;                   // taps of the weight image (9, or 1 for the 1x1 conv)
     int dymin, dxmin, ph, pw;    // patch origin offset and patch extent (pixels)
     int fused;                   // 1: apply the epilogue here, 0: store raw accumulators
+    // merged up-conv (upconv_bf16_kernel) tiling: rows of all samples stacked with pitch up_rp (up_rows = B up_rp rows in up_tr tiles
+    // of 8), up_tw column tiles of 16, up_nf fringe tiles for the column n = W (0: the regular tiles cover W+1 columns), styles /
+    // range-guard scales of up_ns consecutive samples per block
+    int up_rp, up_rows, up_tr, up_tw, up_nf, up_ns;
     int act; float noise_strength, alpha, gain, clamp;
     Phase phase[4];
 };
@@ -149,17 +155,38 @@ static inline int make_plan(const HfagpModconvArgs* a, Plan& pl, int ck) {
         p.nslab = 1;
         for (int q = 0; q < 4; ++q) p.phase[q].slab = 0;
     }
-    // the 8-wave up-conv block owns a whole CU: take it when N = 128 tiles alone give every CU two blocks
+    long long up_tiles = 0;
+    if (pl.merged_up) {
+        // see upconv_bf16_kernel: stacked rows, exact column tiles + fringe tiles.  A run of L consecutive stacked rows touches at
+        // most (L + RP - 2) / RP + 1 samples: 9 rows for a regular tile's patch, 65 for a fringe tile's.
+        const int xb = a->x_f16 ? 2 : 4;
+        auto span = [](int L, int rp) { return (L + rp - 2) / rp + 1; };
+        auto fits = [&](int ns) { return ns <= 8 && (ns <= 1 || (long long)ns * a->x_batch_stride * xb < (1ll << 32)); };
+        int rp = a->H + 1;
+        { static const char* dev = getenv("HFAGP_DEV_UP_LEGACY_TILES"); if (dev && atoi(dev) == 1) rp = -1; }
+        bool fr = rp > 0 && a->W % PW == 0;
+        { static const char* dev = getenv("HFAGP_DEV_UP_NO_FRINGE"); if (dev && atoi(dev) == 1) fr = false; }
+        int ns = rp > 0 ? std::min(a->B, std::max(span(PH + 1, rp), fr ? span(8 * PH + 1, rp) : 1)) : 99;
+        if (!fits(ns) && fr) { fr = false; ns = std::min(a->B, span(PH + 1, rp)); }
+        if (!fits(ns)) { rp = (a->H + 1 + PH - 1) / PH * PH; fr = false; ns = std::min(a->B, 2); }   // per-sample row tiles (rounds 2-5)
+        p.up_rp = rp; p.up_rows = a->B * rp; p.up_ns = ns;
+        p.up_tr = (p.up_rows + PH - 1) / PH;
+        p.up_tw = fr ? a->W / PW : (a->W + 1 + PW - 1) / PW;
+        p.up_nf = fr ? (p.up_rows + 8 * PH - 1) / (8 * PH) : 0;
+        up_tiles = (long long)p.up_tr * p.up_tw + p.up_nf;
+    }
+    // Round 6: FOUR waves (N = 64 per block) at <= 256 registers, so that TWO independent blocks share a CU — their prologues (styles,
+    // range guard, first patch from HBM) and store epilogues overlap the other block's K loop.  The 8-wave block (N = 128, patch staged
+    // once for twice the MFMA work, but one block per CU with all eight waves in lockstep) measured 1-16 % slower at every size and
+    // batch (profiles/r06_up_waves_ab.log); it stays for bf16x6 (three parts: the 4-wave kernel only fits one block per CU there,
+    // where the wider block at least halves the staging) behind the developer switch below.
     pl.up_waves = 4;
-#ifndef HFAGP_UP_WAVES8_MIN_BLOCKS
-#define HFAGP_UP_WAVES8_MIN_BLOCKS (2 * kNumCU)
-#endif
-    if (pl.merged_up && a->precision != HFAGP_PREC_BF16X6 &&      // (three parts: the 8-wave variant would spill)
-        (long long)p.tiles_h * p.tiles_w * a->B * (a->Cout / 128) >= HFAGP_UP_WAVES8_MIN_BLOCKS) pl.up_waves = 8;
+    (void)up_tiles;
     { static const char* dev = getenv("HFAGP_DEV_UP_WAVES"); if (dev && pl.merged_up) pl.up_waves = atoi(dev) == 8 && a->Cout % 128 == 0 ? 8 : 4; }
     const int grid_tiles_n = pl.merged_up ? a->Cout / (pl.up_waves == 8 ? 128 : 64) : p.tiles_n;
     const int grid_phases = (pl.merged_up || pl.merged_s2) ? 1 : p.nphase;
-    const long long base_blocks = (long long)p.tiles_h * p.tiles_w * a->B * grid_tiles_n * grid_phases;
+    const long long base_blocks = pl.merged_up ? up_tiles * grid_tiles_n
+                                               : (long long)p.tiles_h * p.tiles_w * a->B * grid_tiles_n * grid_phases;
     int ks = a->ksplit;
     if (ks <= 0) {
         // split K until every CU has ONE block, and no further (round 4 sweep, tools/dev/ksplit_sweep.py: the old target of two
@@ -178,7 +205,7 @@ static inline int make_plan(const HfagpModconvArgs* a, Plan& pl, int ck) {
     p.ksplit = ks;
     if (ks * p.nslab > 1) p.fused = 0;
     pl.ws_bytes = ks * p.nslab > 1 ? (size_t)ks * p.nslab * p.slab * sizeof(float) : 0;
-    pl.grid = dim3((unsigned)(p.tiles_h * p.tiles_w * a->B * grid_tiles_n * ks), (unsigned)grid_phases, 1);
+    pl.grid = dim3((unsigned)(base_blocks / grid_phases * ks), (unsigned)grid_phases, 1);
     return HFAGP_OK;
 }
 
@@ -207,7 +234,12 @@ static inline bool smallconv_takes(const HfagpModconvArgs* a) {
            (a->mode == HFAGP_CONV3X3 || a->mode == HFAGP_CONV1X1 || a->mode == HFAGP_CONV3X3_BWD) &&
            // (3x3 at 32^2 measured 58 us here against 33 + 6 us for the staged kernel: 9 taps re-read the activations from L2 nine
            // times; the 1x1 has no such re-read: 7.5 + 5.5 us against 22 + 6 us at 32^2)
-           (long long)a->H * a->W <= (a->mode == HFAGP_CONV1X1 ? 1024 : 256) && a->Cin % 16 == 0 && a->Cin <= 512 && a->Cout % 32 == 0 && !a->x_f16 && !a->y_f16 &&
+           (long long)a->H * a->W <= (a->mode == HFAGP_CONV1X1 ? 1024 : 256) &&
+           // (round 6, tools/dev/smallconv_ab.sh -> profiles/r06_smallconv_ab.log: the lean kernel is a SMALL-BATCH kernel.  With >= 1024
+           // positions in the batch the staged kernel at its own split-K choice wins on the 3x3 layers of 8^2 and 16^2: B = 32: 433 ->
+           // 122 us at 16^2, 111 -> 62 us at 8^2; B = 8 at 16^2: 113 -> 50 us; at 4^2 the lean kernel wins at every batch)
+           !(a->mode != HFAGP_CONV1X1 && (long long)a->H * a->W >= 64 && (long long)a->B * a->H * a->W >= 1024) &&
+           a->Cin % 16 == 0 && a->Cin <= 512 && a->Cout % 32 == 0 && !a->x_f16 && !a->y_f16 &&
            !a->rgb_w && !a->rgb_part && a->y != nullptr;
 }
 

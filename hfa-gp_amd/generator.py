@@ -171,6 +171,8 @@ class TriPlaneGenerator(nn.Module):
         self.timing: Optional[Dict[str, list]] = None   # bench.py: {'raymarch': [(ev0, ev1, units)], 'modconv': [...]}
         self.ignored_checkpoint_keys: list = []  # EG3D entries a loaded checkpoint carried that have no tensor here
         self._register_load_state_dict_pre_hook(self._drop_foreign_eg3d_keys)
+        # a loaded checkpoint replaces parameters AND buffers in place: every derived image goes (the flat noise image)
+        self.register_load_state_dict_post_hook(lambda module, incompatible_keys: module.invalidate_caches())
 
     # entries of an EG3D `G_ema.state_dict()` / HFA-GP `ckpt["gen"]["generator.*"]` that carry no parameter of the
     # path: version-dependent helper buffers of modules that are fused away here.  They are dropped (and listed in
@@ -214,9 +216,13 @@ class TriPlaneGenerator(nn.Module):
     # ----------------------------------------------------------------- caches
     def invalidate_caches(self) -> None:
         """Drop every derived image of the parameters (GEMM weight images, wsq, host copies of scalars, the NHWC
-        constant).  The caches are keyed by (id, `_version`, `data_ptr`) of the parameter, which catches optimiser
-        steps, `load_state_dict` and `.to()`; an in-place write through `.data` (EMA / PTI-style `.data.copy_`) changes
-        neither, so such callers must call this.  Also called by `_apply` (device / dtype moves) and `__deepcopy__`."""
+        constant, the flat noise image).  The caches are keyed by (id, `_version`, `data_ptr`) of the parameter, which catches
+        torch's own in-place ops, `load_state_dict` and `.to()` — and `MultiTensorAdam`, which bumps the versions itself; it does
+        NOT catch `torch.optim.Adam(fused=True)` (leaves `_version` alone: the round-5 stale-image find) nor an in-place write through
+        `.data` (EMA / PTI-style `.data.copy_`).  Hence: while any parameter requires grad every forward rebuilds the images
+        (`_refresh_tuned`), the tuned -> frozen transition of the same object drops everything once, and callers that write through
+        `.data` while frozen must call this.  Also called by `_apply` (device / dtype moves), `__deepcopy__` and after
+        `load_state_dict` (post hook).  DESIGN.md section 5.2 lists every cache and its regression test."""
         self._prep = {}
         self._scalars = {}
         self._const_nhwc = None
@@ -224,6 +230,7 @@ class TriPlaneGenerator(nn.Module):
         self._plist = None
         self._conv_weights = None
         self._noise_layers = None
+        self._noise_key = None
         self._scaled_noise = {}
 
     def _refresh_tuned(self, backward_follows: bool = True) -> None:
@@ -239,15 +246,24 @@ class TriPlaneGenerator(nn.Module):
             self._scalar_params = [p for p in plist if p.dim() == 0]
         if not any(p.requires_grad for p in plist):
             self._scaled_noise = {}
+            if getattr(self, "_was_tuned", False):
+                # tuned -> frozen on the SAME object: what the last tuned forward cached predates the last optimiser step,
+                # and the host copies of the noise strengths were never refreshed while tuned
+                self._was_tuned = False
+                self.invalidate_caches()
             return
+        self._was_tuned = True
         self._prep = {}
         self._const_nhwc = None
         # noise strengths: NO host copy while tuned (a device-to-host read per step stalls the launch queue: +1.1 ms per step measured).
         # The forward kernels take noise_const * strength as their noise image with strength 1 (one gather + multiply over the 830 k
         # noise values of all layers), the fused backward pass reads the strength from device memory (noise_strength_dev).
         nl = getattr(self, "_noise_layers", None)
-        if nl is None:
+        # (the flat copy of the noise buffers follows them: load_state_dict / Trainer.resume copy into the buffers in place)
+        nkey = None if nl is None else tuple((m.noise_const._version, m.noise_const.data_ptr()) for m in nl)
+        if nl is None or nkey != getattr(self, "_noise_key", None):
             nl = self._noise_layers = [m for m in self.modules() if isinstance(m, _SynthesisLayer) and getattr(m, "noise_const", None) is not None]
+            self._noise_key = tuple((m.noise_const._version, m.noise_const.data_ptr()) for m in nl)
             if nl:
                 self._noise_flat = torch.cat([m.noise_const.detach().reshape(-1) for m in nl])
                 self._noise_idx = torch.cat([torch.full((m.noise_const.numel(),), i, dtype=torch.long, device=self._noise_flat.device)
@@ -566,6 +582,8 @@ class TriPlaneGenerator(nn.Module):
     # ----------------------------------------------------------------- public API
     def backbone_planes(self, ws: torch.Tensor, tape=None) -> torch.Tensor:
         """ws [B, num_ws, 512] → tri-plane volume [B, 3, R, R, 32] (plane-major, channels-last)."""
+        if not getattr(self, "_in_forward", False):     # called directly (not through synthesis): the derived images follow the weights
+            self._refresh_tuned(tape is not None)
         cfg = self.cfg
         syn = self.backbone.synthesis
         b = ws.shape[0]
@@ -648,6 +666,8 @@ class TriPlaneGenerator(nn.Module):
                            planes_absmax=planes_absmax, state=state, **self._render_args(c))
 
     def superres(self, rgb_raw: torch.Tensor, feat_img: torch.Tensor, ws: torch.Tensor, tape=None) -> torch.Tensor:
+        if not getattr(self, "_in_forward", False):     # called directly: see backbone_planes
+            self._refresh_tuned(tape is not None)
         cfg = self.cfg
         b = ws.shape[0]
         last = cfg.num_ws - 1
@@ -697,10 +717,17 @@ class TriPlaneGenerator(nn.Module):
     def _forward_impl(self, ws, c, u_strat, u_imp, tape):
         """ws, c: detached contiguous fp32 CUDA tensors.  Returns image, image_raw, depth, planes, feat_img;
         when `tape` is a dict it is filled with everything the backward pass needs."""
+        self._refresh_tuned(tape is not None)
+        self._in_forward = True          # (backbone_planes / superres below must not rebuild the images a second time)
+        try:
+            return self._forward_body(ws, c, u_strat, u_imp, tape)
+        finally:
+            self._in_forward = False
+
+    def _forward_body(self, ws, c, u_strat, u_imp, tape):
         cfg = self.cfg
         b = ws.shape[0]
         res = cfg.neural_rendering_resolution
-        self._refresh_tuned(tape is not None)
         bb_tape = [] if tape is not None else None
         sr_tape = [] if tape is not None else None
         planes = self.backbone_planes(ws, bb_tape)

@@ -126,6 +126,7 @@ class _LatentBasis(nn.Module):
             q = self._qr((bases.detach() + 1e-8).T)
             self._q_cache = (key, q)
             return q
+        self._q_cache = None          # (trained, then frozen on the same object: the frozen branch must start from an empty cache)
         if not torch.is_grad_enabled():
             return self._qr((bases.detach() + 1e-8).T)
         return self._qr((bases + 1e-8).T)

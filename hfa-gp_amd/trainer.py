@@ -56,14 +56,15 @@ class MultiTensorAdam(torch.optim.Adam):
 
     @torch.no_grad()
     def step(self, closure=None):
+        # options the kernel does not implement: torch's own step — decided BEFORE the closure runs, so that its loss is torch's to return
+        for group in self.param_groups:
+            if (group["weight_decay"] != 0 or group["amsgrad"] or group["maximize"] or isinstance(group["lr"], torch.Tensor)
+                    or group.get("differentiable", False)):
+                return super().step(closure)
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        for group in self.param_groups:
-            if (group["weight_decay"] != 0 or group["amsgrad"] or group["maximize"] or isinstance(group["lr"], torch.Tensor)
-                    or group.get("differentiable", False)):
-                return super().step()
         from . import ops
         for gi, group in enumerate(self.param_groups):
             params = [p for p in group["params"] if p.grad is not None]
@@ -79,7 +80,7 @@ class MultiTensorAdam(torch.optim.Adam):
                     # (a checkpoint written by the non-fused torch.optim.Adam keeps `step` on the host)
                     st["step"] = st["step"].to(device=p.device, dtype=torch.float32)
             key = (gi,) + tuple((id(p), p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr(),
-                                 self.state[p]["step"].data_ptr()) for p in params)
+                                 self.state[p]["exp_avg_sq"].data_ptr(), self.state[p]["step"].data_ptr()) for p in params)
             tab = self._tables.get(key)
             if tab is None:
                 if len(self._tables) > 8:
@@ -88,7 +89,24 @@ class MultiTensorAdam(torch.optim.Adam):
                                                          [self.state[p]["exp_avg_sq"] for p in params], [self.state[p]["step"] for p in params])
             b1, b2 = group["betas"]
             ops.adam_step(tab, float(group["lr"]), float(b1), float(b2), float(group["eps"]))
+            # the kernel writes the parameters through raw pointers: tell autograd (and every cache keyed on `_version`: the
+            # generator's weight images, the encoder trunk's, the latent basis' Q) that they changed, as an in-place torch op would
+            _bump_versions(params)
         return loss
+
+
+def _bump_versions(params) -> None:
+    inc = getattr(torch.autograd.graph, "increment_version", None)
+    if inc is not None:
+        try:
+            inc(params)                     # (an iterable of tensors since torch 2.5)
+            return
+        except TypeError:
+            for p in params:
+                inc(p)
+            return
+    for p in params:                        # older torch: an in-place no-op that goes through the dispatcher
+        p.add_(0)
 
 
 def _adam(params, **kw) -> torch.optim.Adam:
@@ -150,14 +168,23 @@ class FlatGrads:
         self.numel = sum(p.numel() for p in self.params)
         self.flat: Optional[torch.Tensor] = None
         self.buckets: List[Tuple[int, int]] = []
+        # every slice starts on a 16-byte boundary (a 0-d noise strength in front of a conv weight left the weight's
+        # .grad 4-byte aligned, and the reducers / the Adam kernel access it with 16-byte loads): `offsets[i]` is where parameter
+        # i's slice starts, the padding floats in between stay zero and travel with the collectives
+        self.offsets: List[int] = []
+        off = 0
+        for p in self.params:
+            self.offsets.append(off)
+            off += (p.numel() + 3) // 4 * 4
+        self.size = off
         if self.params:
             p0 = self.params[0]
-            self.flat = torch.zeros(self.numel, device=p0.device, dtype=torch.float32)
-            off, b0 = 0, 0
-            for p in self.params:
+            self.flat = torch.zeros(self.size, device=p0.device, dtype=torch.float32)
+            b0 = 0
+            for p, o in zip(self.params, self.offsets):
                 n = p.numel()
-                p.grad = self.flat[off: off + n].view_as(p)
-                off += n
+                p.grad = self.flat[o: o + n].view_as(p)
+                off = o + (n + 3) // 4 * 4
                 if (off - b0) * 4 >= bucket_bytes:
                     self.buckets.append((b0, off))
                     b0 = off
@@ -170,12 +197,10 @@ class FlatGrads:
         want = [p for p in params if p.requires_grad]
         if len(want) != len(self.params) or any(a is not b for a, b in zip(want, self.params)):
             return False
-        off = 0
         base = self.flat.data_ptr() if self.flat is not None else 0
-        for p in self.params:
+        for p, off in zip(self.params, self.offsets):
             if p.grad is None or p.grad.data_ptr() != base + 4 * off:
                 return False
-            off += p.numel()
         return True
 
     def zero(self) -> None:
@@ -221,13 +246,12 @@ class BucketedAllReduce:
         self.avg = getattr(dist.ReduceOp, "AVG", None) if dist.get_backend(group) == "nccl" else None
         self.bucket_of = {}
         self.size = [0] * len(flat.buckets)
-        off, b = 0, 0
-        for p in flat.params:
+        b = 0
+        for p, off in zip(flat.params, flat.offsets):
             while off >= flat.buckets[b][1]:
                 b += 1
             self.bucket_of[id(p)] = b
             self.size[b] += 1
-            off += p.numel()
         self.active = False
         self.last_order: List[int] = []
         self.generator_ids = set()     # ids of generator parameters (`_StepScope`): their hook also fires without a write

@@ -661,6 +661,48 @@ def test_trainable_basis_is_never_served_from_the_q_cache():
     assert a is b
 
 
+def test_q_cache_of_a_basis_trained_and_then_frozen_on_the_same_object():
+    """The `_version` class of bug, latent-basis cache: a frozen basis is cached, then made trainable, moved by a
+    version-less update (what torch's fused Adam does), and frozen again — the cached Q of the first frozen phase has the same key
+    (id, `_version`, `data_ptr`) and would be served.  Any use while trainable empties the cache."""
+    torch.manual_seed(6)
+    gen = headnerf.HeadNeRF_3DMM(Args(), Args.size, "cpu", 512, Args.latent_dim_shape)
+    OracleGenerator.adopt(gen.generator)
+    gen.bases.requires_grad_(False)
+    with torch.no_grad():
+        q_frozen = gen._orthonormal(gen.bases)
+    gen.bases.requires_grad_(True)
+    gen._orthonormal(gen.bases)                                          # a training step's use
+    v0 = gen.bases._version
+    gen.bases.data.add_(0.05 * torch.randn_like(gen.bases))
+    assert gen.bases._version == v0
+    gen.bases.requires_grad_(False)
+    with torch.no_grad():
+        q_after = gen._orthonormal(gen.bases)
+    want = torch.linalg.qr((gen.bases.detach() + 1e-8).T, mode="reduced")[0]
+    assert torch.allclose(q_after, want, atol=1e-5) and (q_after - q_frozen).abs().max().item() > 1e-4
+
+
+def test_multi_tensor_adam_decides_its_fallback_before_the_closure_runs():
+    """with an option the one-launch kernel does not implement (weight decay) `MultiTensorAdam.step(closure)` used to
+    evaluate the closure, then call torch's step WITHOUT it and return None.  Now torch's own step gets the closure: one evaluation,
+    its loss returned.  (CPU tensors: the fallback path needs no GPU.)"""
+    from hfa_gp_amd.trainer import MultiTensorAdam
+    p = torch.nn.Parameter(torch.ones(4))
+    opt = MultiTensorAdam([p], lr=0.1, weight_decay=0.01)
+    calls = []
+
+    def closure():
+        opt.zero_grad()
+        loss = (p * p).sum()
+        loss.backward()
+        calls.append(1)
+        return loss
+    out = opt.step(closure)
+    assert len(calls) == 1 and out is not None and abs(float(out) - 4.0) < 1e-6
+    assert not torch.equal(p.detach(), torch.ones(4))
+
+
 def test_equal_linear_with_the_scale_folded_into_the_gemm_matches_the_plain_expression():
     """encoder3d._EqualLinearFn (the 3DMM driver's layers: `F.linear(x, W * scale, b * lr_mul)` without the four scalar-multiply
     kernels per layer and step): values and all three gradients in fp64, lr_mul = 1 and != 1; 3-D inputs keep the plain path."""
