@@ -1048,23 +1048,54 @@ def channel_sum(g: torch.Tensor, out: torch.Tensor, accumulate: bool = True) -> 
             "channel_sum")
 
 
+ROWS_STATS = {"bytes": 0, "chunks": 0, "path": None}      # of the last raymarch_bwd call (bench.py reports it)
+_WARNED = set()
+
+
+def _warn_once(key: str, msg: str) -> None:
+    if key not in _WARNED:
+        _WARNED.add(key)
+        import warnings
+        warnings.warn(msg, RuntimeWarning, stacklevel=3)
+
+
+def rows_scratch_cap(device=None) -> int:
+    """Bytes the sort + gather ray-march backward may take for its scratch in ONE call: HFAGP_RAYBWD_SCRATCH_GIB (default 16), and
+    never more than half of what the device has free right now (plus what torch's allocator already caches)."""
+    cap = int(float(os.environ.get("HFAGP_RAYBWD_SCRATCH_GIB", "16")) * (1 << 30))
+    try:
+        free, _ = torch.cuda.mem_get_info(device)
+        free += torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
+        cap = min(cap, max(free // 2, 1 << 28))
+    except Exception:  # noqa: BLE001 — no device query: the configured cap alone
+        pass
+    return cap
+
+
 def raymarch_bwd(g_feat: torch.Tensor, planes: torch.Tensor, cam2world, intrinsics, u_strat, u_imp, dec_w0, dec_b0,
                  dec_w1, dec_b1, res: int, ray_start: float, ray_end: float, box_warp: float,
                  decoder_lr_mul: float = 1.0, plane_axes: int = 0, white_back: bool = False,
                  return_rec: bool = False, decoder_grads: bool = False, decoder_precision: str = "f16x3",
                  planes_absmax: Optional[torch.Tensor] = None, state: Optional[torch.Tensor] = None,
-                 two_kernel: bool = False, rows: Optional[bool] = None, dec_out=None):
+                 two_kernel: bool = False, rows: Optional[bool] = None, dec_out=None, _out=None):
     """g_feat [B,R,32] → d planes [B,3,H,W,32].  ``state``: what the forward call of this step left behind
     (`raymarch(..., state=)`): the compositing adjoint reads it instead of recomputing.  ``rows``: pass 2 as sort + gather
-    (hfagp.h `rows_scratch`, csrc/raymarch_rows.hip) — None = whenever it applies and its scratch stays under 16 GiB
-    (HFAGP_RAYBWD_ROWS=0 turns the default off: A/B timing), False = the scatter kernels."""
+    (hfagp.h `rows_scratch`, csrc/raymarch_rows.hip) — None = whenever it applies (HFAGP_RAYBWD_ROWS=0 turns the default off: A/B
+    timing), False = the scatter kernels.  The sort's scratch (~0.9 GB per frame at 128^2 rays x 96 samples) is bounded by
+    `rows_scratch_cap()`: a batch that needs more is processed in frame chunks (round 6; rounds 5 fell back to the 2 x slower scatter
+    kernels above 16 GiB, i.e. from B = 19 on, without a word); where the sort does not apply at all (more than 8192 bins per frame)
+    or its scratch cannot be allocated, the scatter kernels run and say so once."""
     _chk(planes, "planes")
     _chk(g_feat, "g_feat")
     b, _, h, w, _ = planes.shape
     r = res * res
     sc, sf = u_strat.shape[-1], u_imp.shape[-1]
-    d_planes = torch.zeros_like(planes)
-    rec = torch.empty(b, r, sc + sf, 4, device=planes.device, dtype=torch.float32)
+    if _out is not None:
+        d_planes, rec = _out
+    else:
+        d_planes = torch.zeros_like(planes)
+        rec = torch.empty(b, r, sc + sf, 4, device=planes.device, dtype=torch.float32)
+    planes_absmax = _decoder_bound(planes, decoder_precision, planes_absmax)      # (one bound for every chunk of the batch)
     a = L.RaymarchBwdArgs()
     f = a.fwd
     f.planes, f.cam2world, f.intrinsics = _ptr(planes), _ptr(_chk(cam2world, "cam2world")), _ptr(_chk(intrinsics, "intrinsics"))
@@ -1073,7 +1104,7 @@ def raymarch_bwd(g_feat: torch.Tensor, planes: torch.Tensor, cam2world, intrinsi
     f.B, f.H, f.W, f.res, f.Sc, f.Sf = b, h, w, res, sc, sf
     f.plane_axes, f.white_back = plane_axes, int(white_back)
     f.ray_start, f.ray_end, f.box_warp, f.decoder_lr_mul = ray_start, ray_end, box_warp, decoder_lr_mul
-    f.planes_absmax = _ptr(_decoder_bound(planes, decoder_precision, planes_absmax))
+    f.planes_absmax = _ptr(planes_absmax)
     if state is not None:
         if state.shape != (b, r, (sc + sf) * 35):
             raise RuntimeError(f"raymarch_bwd: state must be [B, R, {(sc + sf) * 35}], got {tuple(state.shape)}")
@@ -1088,9 +1119,35 @@ def raymarch_bwd(g_feat: torch.Tensor, planes: torch.Tensor, cam2world, intrinsi
     scratch = None
     if rows:
         need = int(L.lib().hfagp_raymarch_bwd_rows_bytes(C.byref(f)))
-        if 0 < need <= (16 << 30):
-            scratch = torch.empty(need, device=planes.device, dtype=torch.uint8)
-            a.rows_scratch, a.rows_scratch_bytes = _ptr(scratch), need
+        cap = rows_scratch_cap(planes.device)
+        if need > cap and b > 1:
+            # frame chunks: every per-frame input / output is a contiguous slice of the batch; the decoder gradients accumulate
+            nb = max(1, min(b - 1, int(b * cap // need)))
+            if decoder_grads and dec_out is None:
+                dec_out = tuple(torch.zeros_like(t) for t in (dec_w0, dec_b0, dec_w1, dec_b1))
+            for b0 in range(0, b, nb):
+                b1 = min(b, b0 + nb)
+                raymarch_bwd(g_feat[b0:b1], planes[b0:b1], cam2world[b0:b1], intrinsics[b0:b1], u_strat[b0:b1], u_imp[b0 * r:b1 * r],
+                             dec_w0, dec_b0, dec_w1, dec_b1, res, ray_start, ray_end, box_warp, decoder_lr_mul, plane_axes, white_back,
+                             False, decoder_grads, decoder_precision, planes_absmax, None if state is None else state[b0:b1],
+                             two_kernel, rows, dec_out, _out=(d_planes[b0:b1], rec[b0:b1]))
+            ROWS_STATS.update(bytes=min(need, cap), chunks=-(-b // nb), path="rows")
+            if decoder_grads:
+                return d_planes, tuple(dec_out)
+            return (d_planes, rec) if return_rec else d_planes
+        if need > 0:
+            try:
+                scratch = torch.empty(need, device=planes.device, dtype=torch.uint8)
+                a.rows_scratch, a.rows_scratch_bytes = _ptr(scratch), need
+                ROWS_STATS.update(bytes=need, chunks=1, path="rows")
+            except torch.cuda.OutOfMemoryError:
+                _warn_once("rows_oom", f"raymarch_bwd: {need / 2**30:.2f} GiB of sort scratch could not be allocated: this call runs the "
+                                       f"(~2 x slower) scatter kernels")
+        else:
+            _warn_once("rows_unsupported", f"raymarch_bwd: the sort + gather backward does not take {h} x {w} planes at {res}^2 rays "
+                                           f"(more than 8192 bins per frame): the (~2 x slower) scatter kernels run")
+        if scratch is None:
+            ROWS_STATS.update(bytes=0, chunks=1, path="scatter")
     if scratch is None and two_kernel and plane_axes == 0 and h == w and h <= 256 and b * r * (sc + sf) * 128 <= (4 << 30):
         df = torch.empty(b, r, sc + sf, 32, device=planes.device, dtype=torch.float32)
         a.df_scratch = _ptr(df)
