@@ -1063,8 +1063,9 @@ def main():
             # super-resolution layer): the whole layer is one launch (+ two strip fix-ups), so this is the layer's rate
             ms_uf, flops_uf, n_uf = agg("modconv_split_upfir")
             if n_uf:
-                roof["up_layer_fused"] = {"kernel": f"upconv_fir_kernel<{kd}> + upfir_strip_kernel (transposed conv + FIR + demod / "
-                                                    "noise / bias / act in one pass)", "achieved": flops_uf / (ms_uf * 1e-3) / 1e12,
+                roof["up_layer_fused"] = {"kernel": f"upfir_lean_kernel<{kd}> (Cin = 32: transposed conv on 16x16x32 MFMAs with swapped "
+                                                    "operands, FIR in registers + DPP, demod / noise / bias / act, one pass, no scratch)",
+                                          "achieved": flops_uf / (ms_uf * 1e-3) / 1e12,
                                           "frac": flops_uf / (ms_uf * 1e-3) / 1e12 / peak, "avg_launch_ms": ms_uf / n_uf,
                                           "launches": n_uf}
         # ray march: the planes of a frame (25 MB) are cache resident, so the SURVEY 8d "algorithmic bytes" are a GATHER

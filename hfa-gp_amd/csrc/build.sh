@@ -26,7 +26,7 @@ FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -fn
 common_hash="$(cat "${here}"/*.h "${here}/../../include/hfagp.h" "${here}/build.sh" | sha256sum | cut -d' ' -f1)"
 objs=()
 built=0
-for src in elementwise modconv modconv_bf16 smallconv upconv_fir torgb_skip raymarch backward raymarch_bwd raymarch_rows wgrad wgrad_bf16 qr loss collective; do
+for src in elementwise modconv modconv_bf16 smallconv upconv_fir upfir_lean torgb_skip raymarch backward raymarch_bwd raymarch_rows wgrad wgrad_bf16 qr loss collective; do
     obj="${here}/${src}.o"
     extra=()
     want="$( (echo "${common_hash} ${FLAGS[*]} ${extra[*]:-} ${HFAGP_EXTRA_FLAGS:-}"; cat "${here}/${src}.hip") | sha256sum | cut -d' ' -f1)"

@@ -567,7 +567,16 @@ static int launch_fused(const FusePlan& fp, int cin, hipStream_t s) {
 
 using namespace hfagp;
 
+// the streaming kernel (upfir_lean.hip).  No fill-the-chip threshold: measured ahead of the two-kernel form at EVERY batch
+// (32 -> 256 @128^2 -> 256^2, profiles/r06_upfir_lean_ab.log: B = 32 0.73 ms against 1.58 / 1.40 (strip kernel), B = 1 42 us against 66)
+static bool lean_takes(const HfagpModconvArgs* a, LeanParams& lp) {
+    if (!a || a->B <= 0 || a->H <= 0 || a->W <= 0 || a->Cout <= 0) return false;
+    return upfir_lean_plan(a, lp, 1);
+}
+
 extern "C" size_t hfagp_upconv_fir_scratch_bytes(const HfagpModconvArgs* a) {
+    LeanParams lp;
+    if (lean_takes(a, lp)) return 256;             // (no scratch: any non-zero size says "supported")
     FusePlan fp;
     if (!a || fuse_plan(a, fp) != HFAGP_OK || !fp.ok) return 0;
     return fp.col_bytes + fp.row_bytes + 256;
@@ -575,6 +584,10 @@ extern "C" size_t hfagp_upconv_fir_scratch_bytes(const HfagpModconvArgs* a) {
 
 extern "C" int hfagp_upconv_fir_fwd(const HfagpModconvArgs* a, void* scratch, void* stream) {
     HFAGP_REQUIRE(a && a->x && a->wt && a->y && scratch, HFAGP_EBADARG, "upconv_fir: null pointer");
+    {
+        LeanParams lp;
+        if (lean_takes(a, lp)) return launch_upfir_lean(a, lp, (hipStream_t)stream);
+    }
     FusePlan fp;
     int rc = fuse_plan(a, fp);
     if (rc != HFAGP_OK) return rc;

@@ -442,7 +442,7 @@ def _fir_scratch_bytes(a, x_f16: bool) -> int:
     """hfagp_upconv_fir_scratch_bytes, memoised per layer shape: the library builds the whole launch plan to answer, and the
     generator asks twice per up-sampling layer call (supported? / how much scratch?)."""
     key = (a.B, a.H, a.W, a.Cin, a.Cout, a.precision, x_f16, a.x_batch_stride == 0,
-           os.environ.get("HFAGP_DEV_FIR_MIN_BLOCKS"), os.environ.get("HFAGP_DEV_FIR_NSEG"))
+           os.environ.get("HFAGP_DEV_FIR_MIN_BLOCKS"), os.environ.get("HFAGP_DEV_FIR_NSEG"), os.environ.get("HFAGP_DEV_FIR_LEAN"))
     n = _FIR_BYTES.get(key)
     if n is None:
         n = _FIR_BYTES[key] = int(L.lib().hfagp_upconv_fir_scratch_bytes(C.byref(a)))

@@ -275,15 +275,21 @@ def test_full_size_parameter_gradients_three_way(dev):
 
 
 # ----------------------------------------------------------------------------- fused up-sampling layer (csrc/upconv_fir.hip)
-@pytest.mark.parametrize("b,h,w,cin,cout,prec,nseg", [
+@pytest.mark.parametrize("b,h,w,cin,cout,prec,nseg,lean", [(*c, False) if len(c) == 7 else c for c in [
     (2, 24, 40, 32, 128, "f16x3", None),      # 3 strips, default segmentation
     (3, 37, 21, 32, 128, "f16x3", 2),         # ragged: 2W = 42 output columns, 5 tile rows in 2 segments
     (2, 16, 16, 64, 128, "bf16x3", 1),        # the second strip holds only y_t column 32; one segment (window all the way down)
     (2, 19, 33, 64, 256, "f16x3", 3),         # two 128-channel tiles, 3 segments of one tile each (no window)
     (1, 40, 24, 32, 128, "f16", 2),
     (4, 64, 64, 128, 128, "f16x3", None),
-])
-def test_upconv_fir_matches_two_kernel_form(dev, monkeypatch, b, h, w, cin, cout, prec, nseg):
+    # round 6: the Cin = 32 cases run the streaming kernel (csrc/upfir_lean.hip) when `lean`, the strip kernel otherwise
+    (2, 24, 40, 32, 128, "f16x3", None, True),
+    (3, 37, 21, 32, 128, "f16x3", 2, True),   # 42 output columns = 1.5 strips of 28, 10 steps in 2 segments (carry pre-step)
+    (1, 40, 24, 32, 64, "f16", 3, True),      # one 64-channel block
+    (2, 16, 56, 32, 256, "bf16x3", 1, True),  # 112 output columns = exactly four strips; one segment
+    (5, 9, 7, 32, 192, "f16x3", 2, True),     # tiny ragged image, three channel blocks
+]])
+def test_upconv_fir_matches_two_kernel_form(dev, monkeypatch, b, h, w, cin, cout, prec, nseg, lean):
     """hfagp_upconv_fir_fwd (transposed conv + FIR + demod / noise / bias / leaky ReLU / clamp in one pass, strips finished by
     the fix-up kernel) against the two-kernel form it replaces and against the oracle's conv2d_resample path: every output
     pixel, including the strip / segment boundary columns and rows, image borders, ragged extents, the published max |y|."""
@@ -291,6 +297,7 @@ def test_upconv_fir_matches_two_kernel_form(dev, monkeypatch, b, h, w, cin, cout
     from hfa_gp_amd import ops
     from oracle import eg3d_oracle as O
     monkeypatch.setenv("HFAGP_DEV_FIR_MIN_BLOCKS", "1")
+    monkeypatch.setenv("HFAGP_DEV_FIR_LEAN", "1" if lean else "0")
     if nseg is not None:
         monkeypatch.setenv("HFAGP_DEV_FIR_NSEG", str(nseg))
     g = torch.Generator().manual_seed(b * 1000 + h * 10 + w)
@@ -306,16 +313,19 @@ def test_upconv_fir_matches_two_kernel_form(dev, monkeypatch, b, h, w, cin, cout
     assert ops.upconv_fir_supported(xd, wt, cout)
     am1, am2 = ops.absmax_slots(1, dev)[0], ops.absmax_slots(1, dev)[0]
     y = ops.upconv_fir(xd, wt, cout, sd, dd, nd, ns, bd, "lrelu", 0.2, math.sqrt(2.0), clamp, y_absmax=am1)
-    yt = ops.modconv(xd, wt, cout, ops.CONVT3X3_UP2, styles=sd)
-    want = ops.upfir_epilogue(yt, dd, nd, ns, bd, "lrelu", 0.2, math.sqrt(2.0), clamp, y_absmax=am2)
-    assert y.shape == want.shape == (b, 2 * h, 2 * w, cout)
-    err = (y - want).abs()
-    assert err.max().item() <= 2e-6 * max(1.0, want.abs().max().item()), (err.max().item(), err.argmax().item())
-    assert abs(am1.max().item() - am2.max().item()) <= 2e-6 * am2.max().item()
+    assert y.shape == (b, 2 * h, 2 * w, cout)
+    if cout % 128 == 0:           # (the two-kernel form needs 128-channel tiles; the 64- and 192-channel cases check against the oracle only)
+        yt = ops.modconv(xd, wt, cout, ops.CONVT3X3_UP2, styles=sd)
+        want = ops.upfir_epilogue(yt, dd, nd, ns, bd, "lrelu", 0.2, math.sqrt(2.0), clamp, y_absmax=am2)
+        err = (y - want).abs()
+        assert err.max().item() <= 2e-6 * max(1.0, want.abs().max().item()), (err.max().item(), err.argmax().item())
+        assert abs(am1.max().item() - am2.max().item()) <= 2e-6 * am2.max().item()
+    else:
+        assert abs(am1.max().item() - y.abs().max().item()) <= 1e-6 * y.abs().max().item()
     # and against the oracle's own up-sampling layer (fp32 conv_transpose2d + upfirdn2d)
     ref = O._conv_up2(x * s[:, :, None, None], wgt, O.fir_kernel()) * dco[:, :, None, None] + noise * ns
     ref = O.bias_act(ref, bias, act="lrelu", clamp=clamp)
-    tol = {"f16x3": 2e-5, "bf16x3": 2e-4, "f16": 2e-2}[prec]
+    tol = {"f16x3": 2e-5, "bf16x3": 2e-4, "f16": 2e-2, "f16x2": 1e-2}[prec]
     assert (ops.nhwc_to_nchw(y).cpu() - ref).abs().max().item() <= tol
 
 

@@ -20,6 +20,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     ("smallconv.hip", [r"smallconv_kernelILi[1245]E"]),
     ("wgrad_bf16.hip", [r"wgrad_bf16_kernelI"]),
     ("wgrad.hip", [r"wgrad_kernelI"]),
+    ("upfir_lean.hip", [r"upfir_lean_kernelI"]),      # round 6: the streaming first-SR-layer kernel: <= 256 registers, scratch 0
 ])
 def test_conv_kernels_do_not_spill(tmp_path, src, patterns):
     out = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-c",     # (build.sh's flags)
@@ -93,7 +94,7 @@ def test_torgb_skip_is_built_without_packed_fp32_fma(tmp_path):
             assert not m or int(m.group(1)) >= 3, f"{name}: occupancy {m.group(1)}"
 
 
-UNITS = ["elementwise", "modconv", "modconv_bf16", "smallconv", "upconv_fir", "torgb_skip", "raymarch", "backward", "raymarch_bwd", "raymarch_rows",
+UNITS = ["elementwise", "modconv", "modconv_bf16", "smallconv", "upconv_fir", "upfir_lean", "torgb_skip", "raymarch", "backward", "raymarch_bwd", "raymarch_rows",
          "wgrad", "wgrad_bf16", "qr", "loss", "collective"]
 
 
