@@ -60,6 +60,13 @@ def _sig(v, digits=5):
     return v
 
 
+def _rows_stats() -> dict:
+    """Scratch bytes / frame chunks / path (sort + gather rows or scatter fallback) of the LAST ray-march backward call of this
+    process (hfa_gp_amd.ops.ROWS_STATS)."""
+    from hfa_gp_amd import ops
+    return ops.ROWS_STATS
+
+
 def compact_line(full: dict) -> dict:
     """The ONE line rank 0 prints: the contract's keys, the dominant kernel's `roofline`, `cpu_baseline`, and a few dozen scalars
     (fitting steps, family roofline fractions, the other legs' headline numbers).  Everything else `main` measured — per-layer
@@ -1267,7 +1274,9 @@ def main():
                     # two planes (the third is the mirror) and read back once, through HBM
                     stream = fr * r * s_tot * 2 * (128 + 8) * 2.0
                     floor = (gb / (L2_PEAK_GBS * 1e9) + 2.0 * fl / (MFMA_BF16_PEAK_TFLOPS / 3 * 1e12) + stream / (HBM_PEAK_GBS * 1e9)) * 1e3
-                    tr = [train_traffic(k, mode_) for k in ("raymarch_bwd_df_kernel", "raymarch_bwd_rows_kernel", "raymarch_bwd_bins_kernel")]
+                    # (generator tuned: the decoder-gradient pass raymarch_bwd_tiles_kernel IS the dL/dF producer, there is no df kernel)
+                    producer = "raymarch_bwd_tiles_kernel" if mode_.endswith("_tuned") else "raymarch_bwd_df_kernel"
+                    tr = [train_traffic(k, mode_) for k in (producer, "raymarch_bwd_rows_kernel", "raymarch_bwd_bins_kernel")]
                     res_["raymarch_bwd"] = {"bound": "l2+mfma+hbm",
                                             "kernel": "raymarch_kernel<GRADS> (compositing adjoint from the saved state) + sort (bins, scan, "
                                                       "place) + raymarch_bwd_df_kernel (dL/dF to sorted slots; tuned: the decoder-gradient "
@@ -1275,6 +1284,7 @@ def main():
                                             "ms_per_step": ms, "ms_per_frame": ms / max(fr, 1), "floor_ms_per_step": floor,
                                             "frac": floor / ms, "share_of_step": ms / step_ms,
                                             "sorted_entries_per_frame": r * s_tot * 2, "stream_bytes_per_step": stream,
+                                            "rows_scratch": dict(_rows_stats()),
                                             "traffic": sum(tr) if all(t is not None for t in tr) else None}
                 if "raymarch" in ev:
                     res_["raymarch_fwd_ms_per_step"] = ev["raymarch"][0]

@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(256, 2) modconv_bf16_kernel(const ConvParams p
     // (readfirstlane: the divisions by run-time values are done on the vector ALU; without it every index derived
     // from the block coordinates stays in VGPRs and the uniform address arithmetic of the K loop — chunk x Cout
     // products, clamps — is issued as quarter-rate vector multiplies between the MFMAs)
-    unsigned id = blockIdx.x;
+    unsigned id = p.xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
     const int tn_blk = __builtin_amdgcn_readfirstlane(id % p.tiles_n); id /= p.tiles_n;
     const int tw = __builtin_amdgcn_readfirstlane(id % p.tiles_w);     id /= p.tiles_w;
     const int th = __builtin_amdgcn_readfirstlane(id % p.tiles_h);     id /= p.tiles_h;
@@ -486,7 +486,7 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && KD != 3) ? HFAGP_UP4_OCC 
     //     it: taps (0,-1), (-1,-1)) goes to FRINGE tiles: the same 8 x 16 tile and K loop, but tile column j stands for
     //     (row block j >> 1, image column W-1 + (j & 1)) — eight two-column pieces of eight different 8-row blocks, of which the odd
     //     columns are stored.  64 useful positions per fringe tile; B (H+1) / 64 of them per layer (0.8 % of the tiles at 256^2).
-    unsigned id = blockIdx.x;
+    unsigned id = p.xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
     const int tiles_nu = p.Cout / BNU;
     const int tn_blk = __builtin_amdgcn_readfirstlane(id % tiles_nu);  id /= tiles_nu;
     const int n_reg = p.up_tr * p.up_tw, n_tile = n_reg + p.up_nf;

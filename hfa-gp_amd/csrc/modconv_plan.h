@@ -38,6 +38,7 @@ struct ConvParams {
     // of 8), up_tw column tiles of 16, up_nf fringe tiles for the column n = W (0: the regular tiles cover W+1 columns), styles /
     // range-guard scales of up_ns consecutive samples per block
     int up_rp, up_rows, up_tr, up_tw, up_nf, up_ns;
+    int xcd;                     // 1: logical block id = xcd_remap(blockIdx.x) (contiguous tile ranges per XCD: siblings and neighbours share an L2)
     int act; float noise_strength, alpha, gain, clamp;
     Phase phase[4];
 };
@@ -74,6 +75,7 @@ static inline int make_plan(const HfagpModconvArgs* a, Plan& pl, int ck) {
     p.B = a->B; p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.Cout = a->Cout;
     p.act = a->act; p.noise_strength = a->noise_strength; p.alpha = a->alpha; p.gain = a->gain; p.clamp = a->clamp;
     p.nchunks = a->Cin / ck;
+    { static const char* dev = getenv("HFAGP_DEV_XCD_REMAP"); p.xcd = dev ? atoi(dev) : 0; }
     p.nslab = 1;
     int in_h = a->H, in_w = a->W;      // extent of the image(s) the patches are read from
 

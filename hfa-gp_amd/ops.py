@@ -1119,7 +1119,8 @@ def raymarch_bwd(g_feat: torch.Tensor, planes: torch.Tensor, cam2world, intrinsi
     scratch = None
     if rows:
         need = int(L.lib().hfagp_raymarch_bwd_rows_bytes(C.byref(f)))
-        cap = rows_scratch_cap(planes.device)
+        # (the free-memory query is a driver call: only batches that could matter pay it — a fitting step's 1.8 GB does not)
+        cap = rows_scratch_cap(planes.device) if need > (4 << 30) or "HFAGP_RAYBWD_SCRATCH_GIB" in os.environ else (16 << 30)
         if need > cap and b > 1:
             # frame chunks: every per-frame input / output is a contiguous slice of the batch; the decoder gradients accumulate
             nb = max(1, min(b - 1, int(b * cap // need)))

@@ -10,14 +10,14 @@ keep="$R/gpurun_out/prof_$tag"
 out="/tmp/prof_$tag"
 rm -rf "$out"; mkdir -p "$out" "$keep"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o bench -- python "$R/bench.py" "${args[@]}" > "$out/trace.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o bench -- python "$R/bench.py" "${args[@]}" --detail "$out/bench_detail_profiled.json" > "$out/trace.log" 2>&1
 grep '^{' "$out/trace.log" > "$out/bench_line_profiled.json" || true
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/pmc_fetch" -o bench -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-train --no-sweep --audio-frames 0 > "$out/pmc_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/pmc_write" -o bench -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-train --no-sweep --audio-frames 0 > "$out/pmc_write.log" 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$out/pmc_mfma" -o bench -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-train --no-sweep --audio-frames 0 > "$out/pmc_mfma.log" 2>&1
-python "$R/bench.py" "${args[@]}" > "$out/bench_unprofiled.log" 2>&1
+python "$R/bench.py" "${args[@]}" --detail "$out/bench_detail_unprofiled.json" > "$out/bench_unprofiled.log" 2>&1
 find "$out" -name "*.csv" | head -20
 python "$R/profiles/summarize.py" "$out" "$tag" > "$out/summary_$tag.md" 2>&1 || true
-cp "$out/summary_$tag.md" "$out/traffic.json" "$out/bench_unprofiled.log" "$out/bench_line_profiled.json" "$keep/" 2>/dev/null
+cp "$out/summary_$tag.md" "$out/traffic.json" "$out/bench_unprofiled.log" "$out/bench_line_profiled.json" "$out/bench_detail_unprofiled.json" "$keep/" 2>/dev/null
 cp "$(find "$out/trace" -name "*kernel_stats.csv" | head -1)" "$keep/kernel_stats.csv" 2>/dev/null
 tail -40 "$out/summary_$tag.md"

@@ -21,10 +21,13 @@ def main():
     out, tag = sys.argv[1], sys.argv[2]
     print(f"# rocprofv3 summary {tag}\n")
     js = os.path.join(out, "bench_unprofiled.log")
+    detail = os.path.join(out, "bench_detail_unprofiled.json")      # (round 6: the printed line is compact, the tables live here)
     if os.path.exists(js):
         for line in open(js):
             if line.startswith("{"):
                 d = json.loads(line)
+                if os.path.exists(detail):
+                    d = json.load(open(detail))
                 r32 = d.get("roofline_fp32_exact")
                 extra = (f"; exact-fp32 leg {d['value_fp32_exact']:.1f} frames/s, modconv_kernel {r32['achieved']:.1f} "
                          f"TFLOP/s ({r32['frac']:.3f} of 157.3)") if r32 else ""
@@ -83,7 +86,7 @@ def main():
              "the kernel in one synthesis"}
     for k, v in traffic.items():
         if k.startswith(("modconv_kernel<2, 2, 2, 2>", "modconv_bf16_kernel<2, 2, 9", "modconv_bf16_kernel<4, 2, 9", "upconv_bf16_kernel",
-                         "raymarch_kernel")):
+                         "upfir_lean_kernel", "upfir_epilogue_kernel", "torgb_skip_kernel", "raymarch_kernel")):
             out_t[k] = {"fetch_raw": v.get("FETCH_SIZE"), "write": v.get("WRITE_SIZE"),
                         "hbm_bytes": 2 * v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)}
     json.dump(out_t, open(os.path.join(out, "traffic.json"), "w"), indent=1)

@@ -477,12 +477,16 @@ def test_trained_weight_statistics_stress(dev, preset):
 
 # ----------------------------------------------------------------------------- run-to-run bit repeatability (the v_pk_fma_f32 hazard)
 def test_forward_and_backward_repeat_bit_for_bit(dev):
-    """A code-generation / hardware hazard once dropped one upsample tap in ~1e-5 of the outputs of ONE kernel, at different
-    positions every run (csrc/torgb_skip.hip, compiled without the SLP vectoriser since); its root cause is not established and
-    every other translation unit still uses packed fp32 arithmetic.  The symptom is run-to-run differences, so the whole
-    full-size forward path — every precision / storage setting the bench times — and the backward pass (the ray marcher's
-    atomically accumulated scatter replaced by a fixed tensor) must repeat BIT FOR BIT: planes, feature image, raw image, image,
-    d ws and every parameter gradient."""
+    """A hardware hazard once dropped one upsample tap in ~1e-5 of the outputs of ONE kernel, at different positions every run
+    (csrc/torgb_skip.hip: a packed-fp32 result lost while a vector-memory return is in flight — classified in round 5,
+    profiles/r05_lanes48_repro.txt; since then NO unit of the library contains packed fp32 arithmetic: build.sh's -fno-slp-vectorize
+    -fno-vectorize, checked statically by tests/test_kernel_resources.py).  The symptom is run-to-run differences, so the whole
+    full-size forward path — every precision / storage setting the bench times — and the backward pass must repeat BIT FOR BIT:
+    planes, feature image, raw image, image, d ws and every parameter gradient.  The ray march backward is the one exception and is
+    replaced by a fixed tensor here: its sort ranks the samples of a bin in arrival order and its row tiles are ADDED to d planes
+    with atomics (two addends per element and bin chunk), so two calls agree to ~1e-5 of the gradient's scale, not to the bit
+    (tests/test_gpu_round5.py::test_raymarch_backward_sort_gather_equals_the_scatter_kernels asserts that bound) — as PyTorch's
+    grid_sampler_2d_backward, which the reference runs, accumulates with atomics too."""
     from hfa_gp_amd import ops
     from hfa_gp_amd.config import ffhq512_128
     from hfa_gp_amd.generator import TriPlaneGenerator
