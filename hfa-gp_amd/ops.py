@@ -975,6 +975,10 @@ def conv_wgrad(x: torch.Tensor, styles: Optional[torch.Tensor], g: torch.Tensor,
     if out is not None:
         if out.shape != weight.shape or out.dtype != torch.float32 or not out.is_contiguous():
             raise RuntimeError("conv_wgrad: `out` must be a contiguous fp32 tensor of the weight's shape")
+        if out.data_ptr() % 16 != 0:
+            # (the reducers read and write dW with 16-byte accesses; FlatGrads aligns every slice, a caller's own view
+            # may not be)
+            raise RuntimeError("conv_wgrad: `out` must be 16-byte aligned (trainer.FlatGrads slices are)")
         a.accumulate = 1
     dweight = torch.empty_like(weight) if out is None else out
     a.x, a.styles, a.g = _ptr(x), _ptr(styles), _ptr(g)
