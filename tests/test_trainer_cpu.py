@@ -190,20 +190,23 @@ def test_flat_grads_alias_and_rebuild():
     real, label, params = frame(2)
     tr.gen_update(real, label, params)
     assert tr.flat_grads() is flat                                        # still aliased after a step
-    off = 0
-    for p in shared:
+    for p, off in zip(shared, flat.offsets):
         assert p.grad.data_ptr() == flat.flat.data_ptr() + 4 * off
         assert torch.equal(p.grad.reshape(-1), flat.flat[off: off + p.numel()])
-        off += p.numel()
     assert flat.flat.abs().sum() > 0
     flat.zero()
     assert tr.gen.bases.grad.abs().sum() == 0
     tr.tune_generator()
     flat2 = tr.flat_grads()
     assert flat2 is not flat and flat2.numel > flat.numel
+    # round 6: every slice starts on a 16-byte boundary — the generator's 0-d noise strengths sit between conv weights —
+    # the padding stays zero and is part of the buckets
+    assert any(p.dim() == 0 for p in flat2.params) and flat2.size > flat2.numel
+    assert all(off % 4 == 0 and p.grad.data_ptr() % 16 == flat2.flat.data_ptr() % 16 for p, off in zip(flat2.params, flat2.offsets))
+    assert flat2.buckets[-1][1] == flat2.size
     # buckets tile the buffer
     fb = FlatGrads(shared, bucket_bytes=1 << 20)
-    assert fb.buckets[0][0] == 0 and fb.buckets[-1][1] == fb.numel
+    assert fb.buckets[0][0] == 0 and fb.buckets[-1][1] == fb.size
     assert all(a[1] == b[0] for a, b in zip(fb.buckets[:-1], fb.buckets[1:])) and len(fb.buckets) > 1
 
 
