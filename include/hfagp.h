@@ -297,8 +297,10 @@ int hfagp_upfir_epilogue_fwd(const HfagpUpfirEpilogueArgs* a, void* stream);
  * alpha / gain / clamp / y_absmax apply (as in HfagpUpfirEpilogueArgs), workspace and ksplit are ignored and there is no
  * fused toRGB.  Precisions BF16X3, F16X3, F16 (x_f16 / y_f16 storage allowed with F16); Cin % 16 == 0, Cin <= 512,
  * Cout % 128 == 0; the launch must fill the chip (B * ceil((W+1)/16) * Cout/128 >= 256 strips).
- * hfagp_upconv_fir_scratch_bytes(): bytes of `scratch` the call needs, or 0 when the shape is not supported — the caller
- * then uses the two-call form.                                                                                      */
+ * Cin == 32 (the first super-resolution layer; Cout % 64 == 0, fp32 storage, precisions F16 / BF16X3 / F16X3 / F16X2) takes a
+ * STREAMING kernel instead (round 6, csrc/upfir_lean.hip: FIR in registers, no scratch use, no strip kernel) at any batch.
+ * hfagp_upconv_fir_scratch_bytes(): bytes of `scratch` the call needs (a non-zero token size where the streaming kernel runs:
+ * the pointer must still be non-NULL), or 0 when the shape is not supported — the caller then uses the two-call form.        */
 size_t hfagp_upconv_fir_scratch_bytes(const HfagpModconvArgs* a);
 int hfagp_upconv_fir_fwd(const HfagpModconvArgs* a, void* scratch, void* stream);
 
