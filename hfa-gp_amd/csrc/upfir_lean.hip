@@ -206,10 +206,12 @@ __global__ void __launch_bounds__(256, 2) upfir_lean_kernel(const LeanParams p) 
 #pragma unroll
                 for (int pt = 0; pt < NP; ++pt)
                     xf[g][pt] = *reinterpret_cast<const u32x4*>(Ab + pt * LPART + pr * LPW * LSLOT + G_OFF[g] + bpos);
+            // (product outer, tap inner: consecutive MFMAs then write DIFFERENT accumulators — phases 0 1 2 3 0 1 0 2 0 — instead of
+            // three dependent ones per tap)
 #pragma unroll
-            for (int t = 0; t < NITEM; ++t)
+            for (int k = 0; k < NPROD; ++k)
 #pragma unroll
-                for (int k = 0; k < NPROD; ++k)
+                for (int t = 0; t < NITEM; ++t)
                     acc[pr][I_PHASE[t]] = mfma16x32<F16>(wf[t][PB[k]], xf[I_GRP[t]][PA[k]], acc[pr][I_PHASE[t]]);
         }
         if (s + 1 < s_end) {
