@@ -244,8 +244,10 @@ __global__ void __launch_bounds__(256, 2) upfir_lean_kernel(const LeanParams p) 
                 const float nb0 = nz.x * ng, nb1 = nz.y * ng;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    // every shifted value has ONE use, so that the row shift rides on the consuming add (v_add_f32_dpp):
                     //   h0 = v1 + 3 (v0 + v1)(p+1) + v0(p+2),   h1 = (v0 + 3 v1)(p+1) + (3 v0 + v1)(p+2)
+                    // (the four row shifts stay v_mov_b32_dpp: hipcc sinks the arithmetic into the `if (row_ok)` block below, away from
+                    // the moves.  Measured alternative: branch-free stores through a buffer resource, out-of-range offsets for the
+                    // masked lanes — three of the four shifts then fold into v_add_f32_dpp, but the kernel ran 0.626 ms instead of 0.600)
                     const float s01 = v[0][r] + v[1][r];
                     const float t1 = fmaf(3.f, v[1][r], v[0][r]), t2 = fmaf(3.f, v[0][r], v[1][r]);
                     const float h0 = fmaf(3.f, row_shl<1>(s01), v[1][r]) + row_shl<2>(v[0][r]);
