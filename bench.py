@@ -920,7 +920,7 @@ def main():
     # one-off stall (wall 42.1 ms/step against 39.2 ms/step by HIP events).  The contract's W warm-up steps follow as asked.
     def settle():
         gen.conv_precision, gen.sr_conv_precision, gen.sr_storage = prec, None, "f32"
-        prev = None
+        prev, n_settled = None, 0
         for _ in range(12):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -928,9 +928,12 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             cur = e0.elapsed_time(e1)
-            if prev is not None and abs(cur - prev) <= 0.01 * prev:
+            # (at least six steps: two agreeing steps right after start-up have been followed by a one-off 60 ms stall inside the timed
+            # region — a run taken straight after the GPU test suite, round 6: 95.8 ms for one step of 35.5)
+            if n_settled >= 5 and prev is not None and abs(cur - prev) <= 0.01 * prev:
                 break
             prev = cur
+            n_settled += 1
     timed_leg("settle", settle)
     # the headline leg first, exactly as the contract words it (W warm-up steps, then K timed steps), WITHOUT the
     # per-kernel timing events (they cost host time per launch); a second pass of the same leg collects the events
@@ -1168,6 +1171,7 @@ def main():
             out["value_fp32_exact"] = frames / dt32
             out["roofline_fp32_exact"] = f32_roofline(timing32)
         out["step_ms"] = _pct(timing["step"])       # per-step HIP event pairs of the timed region (this rank)
+        out["step_ms"]["argmax"] = max(range(len(timing["step"])), key=lambda i: timing["step"][i])      # (which step a stall hit)
         if sweep is not None:
             out["batch_sweep"] = sweep
         if train is not None:
