@@ -840,6 +840,9 @@ int launch_modconv_bf16(const HfagpModconvArgs* a, Plan& pl, hipStream_t s) {
         if (a->mode == HFAGP_CONVT3X3_UP2) {
             HFAGP_REQUIRE(pl.merged_up, HFAGP_EUNSUPPORTED, "modconv: fp16 storage of the up-conv needs the merged four-phase "
                                                             "kernel (grids >= 32x32 at Cin <= 512)");
+            HFAGP_REQUIRE(q.up_ns <= 1 || (long long)q.up_ns * a->x_batch_stride * (a->x_f16 ? 2 : 4) < (1ll << 32), HFAGP_EUNSUPPORTED,
+                          "modconv (merged up-conv): %d samples of %lld elements exceed the 32-bit patch offsets", q.up_ns,
+                          (long long)a->x_batch_stride);
             launch_up_io(pl, a->Cin, io, s);
             return check_launch("modconv_fwd (fp16 storage, merged up-conv)");
         }
@@ -851,6 +854,10 @@ int launch_modconv_bf16(const HfagpModconvArgs* a, Plan& pl, hipStream_t s) {
     // (3x3: one; stride-2 transposed conv and its adjoint: 4 | 2, 2 | 1)
     const ConvParams& p = pl.p;
     if (pl.merged_up) {                 // one block for the four phases (grid.y = 1)
+        // (a block addresses the up_ns samples its tile can touch with 32-bit byte offsets from the first one)
+        HFAGP_REQUIRE(p.up_ns <= 1 || (long long)p.up_ns * a->x_batch_stride * (a->x_f16 ? 2 : 4) < (1ll << 32), HFAGP_EUNSUPPORTED,
+                      "modconv (merged up-conv): %d samples of %lld elements exceed the 32-bit patch offsets", p.up_ns,
+                      (long long)a->x_batch_stride);
         switch (kd) {
             case 1: launch_up<1>(pl, a->Cin, s); break;
             case 2: launch_up<2>(pl, a->Cin, s); break;
